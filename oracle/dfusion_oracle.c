@@ -1,0 +1,616 @@
+/*
+ * dfusion_oracle.c -- CPU restatement of the DynamicFusion per-frame hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path is the HIP library
+ * (dynamicfusion_amd/csrc) and never routes through anything in oracle/.
+ *
+ * What is restated (all citations relative to /root/reference):
+ *   compute_dists        kfusion/src/cuda/imgproc.cu:259-272, host imgproc.cpp:87-91
+ *   pack/unpack          kfusion/src/cuda/device.hpp:53-61
+ *   voxel indexing       kfusion/src/cuda/device.hpp:17-27
+ *   clear                kfusion/src/cuda/tsdf_volume.cu:15-28
+ *   integrate (rigid)    kfusion/src/cuda/tsdf_volume.cu:51-112, host :141-161
+ *   raycast              kfusion/src/cuda/tsdf_volume.cu:202-474
+ *   k-NN                 kfusion/src/warp_field.cpp:247-251 + knn_point_cloud.hpp:16-32
+ *                        (nanoflann v1.2.3 exact L2, ascending; brute force here)
+ *   weighting            kfusion/src/warp_field.cpp:238-241
+ *   DQB                  kfusion/src/warp_field.cpp:203-217
+ *   DualQuaternion math  kfusion/src/utils/dual_quaternion.hpp:59-63,120-125,204-210
+ *   Quaternion math      kfusion/src/utils/quaternion.hpp:124-130,172-194,211-228
+ *   warp                 kfusion/src/warp_field.cpp:180-195
+ *   warped integrate     composition DQB o TsdfIntegrator (the reference has
+ *                        no per-voxel warped integrate -- its oracle IS this composition)
+ *
+ * Arithmetic policy: IEEE fp32, explicit fmaf exactly where the reference
+ * writes __fmaf_rn / dot(), IEEE '/' and sqrtf for __fdividef / __fsqrt_rn / rsqrt,
+ * F16C for __float2half_rn / __half2float, lrintf (RN-even) for __float2int_rn, floorf for
+ * __float2int_rd.  Build with -ffp-contract=off so nothing else is fused.
+ *
+ * Parity pinning: the reference has NO tests for integrate / raycast / dists / clear, so that
+ * part is "parity unpinned" by golden vectors (pinned by source restatement only).  The
+ * quaternion / dual-quaternion / k-NN / DQB part is pinned against the reference's own
+ * headers compiled unmodified (oracle/_ref, built by oracle/Makefile) and against the
+ * known-answer vectors of tests/utils/test_quaternion.cc and test_dual_quaternion.cc.
+ *
+ * Deliberate deviations (each is also a documented policy of the HIP path):
+ *   - NaN pixel coordinates in integrate => skip (reference relies on texture border).
+ *   - fetch_tsdf index is clamped to the stored range (reference reads unchecked).
+ *   - k-NN ties: lower node index first (nanoflann: first found in tree order).
+ *   - exp() in weighting is the double overload (what gcc 5 / Ubuntu 16.04, the
+ *     reference's platform, resolves `exp(float)` to with <cmath> only), then cast to float.
+ *   - (ushort)(z*1000) in the depth raycast saturates to [0,65535].
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <immintrin.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+typedef struct OrcVolume {
+    void *data;          /* ushort2 voxels, first stored plane = slab z_store0 */
+    int dims[3];         /* GLOBAL dims (x,y,z) */
+    float voxel_size[3];
+    float trunc_dist;
+    int max_weight;
+} OrcVolume;             /* field-for-field device::TsdfVolume, kfusion/src/internal.hpp:29-49 */
+
+typedef struct OrcSlab {
+    int z_store0, z_store_n;   /* planes physically present behind data */
+    int z_own0, z_own_n;       /* planes this shard integrates / owns ray steps for */
+} OrcSlab;
+
+typedef struct { float x, y, z; } f3;
+
+/* ---------------------------------------------------------------- half <-> float */
+static inline uint16_t f2h(float f) { return (uint16_t)_cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT); }
+static inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
+
+ORC_API uint16_t orc_float2half(float f) { return f2h(f); }
+ORC_API float orc_half2float(uint16_t h) { return h2f(h); }
+
+/* ---------------------------------------------------------------- vector helpers
+ * temp_utils.hpp:27-30 : dot = fma(x1,x2, fma(y1,y2, z1*z2))
+ * device.hpp:71-74     : Mat3f*v = three dots ; Aff3f*v = R*v + t                      */
+static inline float dot3(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+static inline f3 mk3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+static inline f3 mat3_mul(const float *R, f3 v)
+{
+    return mk3(dot3(mk3(R[0], R[1], R[2]), v), dot3(mk3(R[3], R[4], R[5]), v), dot3(mk3(R[6], R[7], R[8]), v));
+}
+/* aff = R[9] row-major then t[3] (internal.hpp:26-27 via device_cast precomp.hpp:19-28) */
+static inline f3 aff_mul(const float *A, f3 v) { return add3(mat3_mul(A, v), mk3(A[9], A[10], A[11])); }
+/* temp_utils.hpp:97-100 : v * rsqrt(dot(v,v)) ; rsqrt -> 1/sqrtf (IEEE) */
+static inline f3 normalized3(f3 v) { float r = 1.0f / sqrtf(dot3(v, v)); return scale3(v, r); }
+
+static inline float qnanf(void) { union { uint32_t u; float f; } c; c.u = 0x7fffffffu; return c.f; } /* temp_utils.hpp:16 */
+
+static inline void slab_or_full(const OrcVolume *v, const OrcSlab *s, OrcSlab *out)
+{
+    if (s) { *out = *s; }
+    else { out->z_store0 = 0; out->z_store_n = v->dims[2]; out->z_own0 = 0; out->z_own_n = v->dims[2]; }
+}
+
+/* ---------------------------------------------------------------- compute_dists
+ * imgproc.cu:259-272.  finv = 1/f on the host (imgproc.cu:292).  The reference guard is
+ * `x<cols || y<rows` (bug, harmless when the grid divides evenly); restated as &&.        */
+ORC_API void orc_compute_dists(const uint16_t *depth, size_t depth_pitch, uint16_t *dists, size_t dists_pitch,
+                               int cols, int rows, const float intr[4] /* fx fy cx cy */)
+{
+    const float finvx = 1.f / intr[0], finvy = 1.f / intr[1], cx = intr[2], cy = intr[3];
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y) {
+        const uint16_t *drow = (const uint16_t *)((const char *)depth + (size_t)y * depth_pitch);
+        uint16_t *orow = (uint16_t *)((char *)dists + (size_t)y * dists_pitch);
+        for (int x = 0; x < cols; ++x) {
+            float xl = ((float)x - cx) * finvx;
+            float yl = ((float)y - cy) * finvy;
+            float lambda = sqrtf(xl * xl + yl * yl + 1);
+            orow[x] = f2h((float)drow[x] * lambda * 0.001f);
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- clear
+ * tsdf_volume.cu:15-28 : every voxel <- pack_tsdf(0,0) == 0x00000000                        */
+ORC_API void orc_clear(OrcVolume v, const OrcSlab *slab)
+{
+    OrcSlab s; slab_or_full(&v, slab, &s);
+    memset(v.data, 0, (size_t)v.dims[0] * v.dims[1] * s.z_store_n * 4);
+}
+
+/* ---------------------------------------------------------------- shared TSDF update
+ * tsdf_volume.cu:77-104 starting at the projection line; vc is the camera-frame position. */
+static inline int tsdf_update(uint16_t *vox /* [0]=half tsdf, [1]=weight */, f3 vc, const uint16_t *dists,
+                              size_t pitch, int cols, int rows, const float proj[4], float trunc,
+                              float trunc_inv, int max_weight)
+{
+    float u = fmaf(proj[0], vc.x / vc.z, proj[2]);      /* device.hpp:35 */
+    float w = fmaf(proj[1], vc.y / vc.z, proj[3]);      /* device.hpp:36 */
+    /* :82 ; written so that NaN coordinates are skipped (policy, see header) */
+    if (!(u >= 0 && w >= 0 && u < (float)cols && w < (float)rows)) return 0;
+    const uint16_t *row = (const uint16_t *)((const char *)dists + (size_t)(int)w * pitch);
+    float Dp = h2f(row[(int)u]);                         /* :85 point filter */
+    if (Dp == 0 || vc.z <= 0) return 0;                  /* :86 */
+    float sdf = Dp - sqrtf(dot3(vc, vc));                /* :89 */
+    if (sdf >= -trunc) {                                 /* :91 */
+        float tsdf = fminf(1.f, sdf * trunc_inv);        /* :93 */
+        int weight_prev = vox[1];
+        float tsdf_prev = h2f(vox[0]);                   /* :97 */
+        float tsdf_new = fmaf(tsdf_prev, (float)weight_prev, tsdf) / (float)(weight_prev + 1); /* :99 */
+        int weight_new = weight_prev + 1 < max_weight ? weight_prev + 1 : max_weight;          /* :100 */
+        vox[0] = f2h(tsdf_new);
+        vox[1] = (uint16_t)weight_new;                   /* :103 */
+        return 1;
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- integrate (rigid)
+ * tsdf_volume.cu:60-106.  vc accumulates `vc += zstep` from z = 0 for every plane, including
+ * skipped ones; a slab starting at z0 replays the first z0 additions so that it is bit-identical
+ * with the unsharded sweep.  Returns the number of voxels whose update branch (:91) was taken.  */
+ORC_API uint64_t orc_integrate(const uint16_t *dists, size_t pitch, int cols, int rows, OrcVolume v,
+                               const OrcSlab *slab, const float vol2cam[12], const float proj[4])
+{
+    OrcSlab s; slab_or_full(&v, slab, &s);
+    const int X = v.dims[0], Y = v.dims[1];
+    const float trunc_inv = 1.f / v.trunc_dist;          /* :147 */
+    const f3 zstep = scale3(mk3(vol2cam[2], vol2cam[5], vol2cam[8]), v.voxel_size[2]); /* :69 */
+    uint16_t *base = (uint16_t *)v.data;
+    uint64_t n_upd = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_upd)
+    for (int y = 0; y < Y; ++y)
+        for (int x = 0; x < X; ++x) {
+            f3 vx = mk3((float)x * v.voxel_size[0], (float)y * v.voxel_size[1], 0.f);   /* :71 */
+            f3 vc = aff_mul(vol2cam, vx);                                                 /* :72 */
+            for (int z = 0; z < s.z_own0 + s.z_own_n; ++z, vc = add3(vc, zstep)) {       /* :75 */
+                if (z < s.z_own0) continue;                                               /* replay only */
+                uint16_t *vox = base + 2 * ((size_t)x + (size_t)y * X + (size_t)(z - s.z_store0) * X * Y);
+                n_upd += tsdf_update(vox, vc, dists, pitch, cols, rows, proj, v.trunc_dist, trunc_inv, v.max_weight);
+            }
+        }
+    return n_upd;
+}
+
+/* ================================================================ quaternion math
+ * Quaternion<float> = (w,x,y,z).  quaternion.hpp.                                           */
+typedef struct { float w, x, y, z; } quat;
+
+/* quaternion.hpp:186-194 (left-associated float sums, no fusion) */
+static inline quat q_mul(quat a, quat b)
+{
+    quat r;
+    r.w = ((a.w * b.w) - (a.x * b.x) - (a.y * b.y) - (a.z * b.z));
+    r.x = ((a.w * b.x) + (a.x * b.w) + (a.y * b.z) - (a.z * b.y));
+    r.y = ((a.w * b.y) - (a.x * b.z) + (a.y * b.w) + (a.z * b.x));
+    r.z = ((a.w * b.z) + (a.x * b.y) - (a.y * b.x) + (a.z * b.w));
+    return r;
+}
+static inline quat q_conj(quat a) { quat r = {a.w, -a.x, -a.y, -a.z}; return r; }       /* :206-209 */
+static inline float q_norm(quat a) { return sqrtf((a.w * a.w) + (a.x * a.x) + (a.y * a.y) + (a.z * a.z)); } /* :211-214 */
+/* :220-228 : (*this) = (1.0/theNorm) * (*this) ; scalar is double, product rounded per component */
+static inline quat q_normalize(quat a)
+{
+    double inv = 1.0 / (double)q_norm(a);
+    quat r = {(float)(inv * (double)a.w), (float)(inv * (double)a.x), (float)(inv * (double)a.y), (float)(inv * (double)a.z)};
+    return r;
+}
+static inline quat q_scale_f(float s, quat a) { quat r = {s * a.w, s * a.x, s * a.y, s * a.z}; return r; } /* :172-178, U=float */
+static inline quat q_add(quat a, quat b) { quat r = {a.w + b.w, a.x + b.x, a.y + b.y, a.z + b.z}; return r; } /* :138-144 */
+
+/* dual_quaternion.hpp:120-125 : 2 * translation_ * normalize(rotation_).conjugate() */
+static inline quat dq_get_translation(quat rot, quat dual)
+{
+    quat rn = q_normalize(rot);
+    return q_mul(q_scale_f(2.f, dual), q_conj(rn));   /* int 2 * float == exact doubling */
+}
+
+ORC_API void orc_quat_mul(const float a[4], const float b[4], float out[4])
+{
+    quat r = q_mul(*(const quat *)a, *(const quat *)b); memcpy(out, &r, 16);
+}
+ORC_API void orc_quat_normalize(const float a[4], float out[4])
+{
+    quat r = q_normalize(*(const quat *)a); memcpy(out, &r, 16);
+}
+/* quaternion.hpp:75-83 encodeRotation(theta,x,y,z) with T=float (sin/cos resolve to the double
+ * overloads under <cmath> only, results narrowed to float on assignment). */
+ORC_API void orc_quat_encode_rotation(float theta, float x, float y, float z, float out[4])
+{
+    double sin_half = sin((double)(theta / 2));
+    quat q; q.w = (float)cos((double)(theta / 2));
+    q.x = (float)((double)x * sin_half); q.y = (float)((double)y * sin_half); q.z = (float)((double)z * sin_half);
+    q = q_normalize(q); memcpy(out, &q, 16);
+}
+/* quaternion.hpp:108-117 rotate(x,y,z) = q * (0,x,y,z) * q.conjugate() (NOT normalised) */
+ORC_API void orc_quat_rotate_xyz(const float q[4], float v[3])
+{
+    quat a = *(const quat *)q; quat p = {0.f, v[0], v[1], v[2]};
+    quat r = q_mul(q_mul(a, p), q_conj(a)); v[0] = r.x; v[1] = r.y; v[2] = r.z;
+}
+/* node translation quaternion t_i (w kept: it feeds rounding of the blended dual part) */
+ORC_API void orc_node_translation(const float dq[8], float out[4])
+{
+    quat t = dq_get_translation(*(const quat *)dq, *(const quat *)(dq + 4)); memcpy(out, &t, 16);
+}
+/* dual_quaternion.hpp:212-229 from_twist -> DualQuaternion(Quaternion(0,x,y,z), rotation) */
+ORC_API void orc_dq_from_twist(const float r[3], const float t[3], float dq_out[8])
+{
+    float norm = (float)sqrt((double)(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]));
+    quat rot;
+    if (norm > 1e-6f) {
+        float cosNorm = (float)cos((double)norm);
+        float sign = (float)((cosNorm > 0.f) - (cosNorm < 0.f));
+        cosNorm *= sign;
+        float sinNorm_norm = (float)((double)sign * sin((double)norm) / (double)norm);
+        rot.w = cosNorm; rot.x = r[0] * sinNorm_norm; rot.y = r[1] * sinNorm_norm; rot.z = r[2] * sinNorm_norm;
+    } else { rot.w = 1; rot.x = rot.y = rot.z = 0; }
+    quat tq = {0.f, t[0], t[1], t[2]};
+    quat half = {0.5f * tq.w, 0.5f * tq.x, 0.5f * tq.y, 0.5f * tq.z};     /* 0.5 * translation (exact) */
+    quat dual = q_mul(half, rot);                                          /* :59-63 */
+    memcpy(dq_out, &rot, 16); memcpy(dq_out + 4, &dual, 16);
+}
+
+/* ================================================================ k-NN + DQB
+ * Node arrays: pos[M*3], dq[M*8] = {rotation (w,x,y,z), translation_/dual (w,x,y,z)}
+ * (the first 8 floats of utils::DualQuaternion<float>), sigma[M] = deformation_node::weight.  */
+
+/* knn_point_cloud.hpp:25-31 : d0*d0+d1*d1+d2*d2 with d = query - node */
+static inline float knn_dist2(const float *q, const float *p)
+{
+    const float d0 = q[0] - p[0], d1 = q[1] - p[1], d2 = q[2] - p[2];
+    return d0 * d0 + d1 * d1 + d2 * d2;
+}
+
+/* exact k smallest, ascending; ties -> lower index first (strict < insertion, index order scan);
+ * nanoflann.hpp:110-131 addPoint semantics minus tree order. */
+static inline void knn_brute(const float *pos, int M, const float q[3], int k, int *idx, float *d2)
+{
+    int count = 0;
+    for (int j = 0; j < M; ++j) {
+        float d = knn_dist2(q, pos + 3 * j);
+        if (count == k && !(d < d2[k - 1])) continue;
+        int i = count < k ? count : k - 1;
+        while (i > 0 && d2[i - 1] > d) { d2[i] = d2[i - 1]; idx[i] = idx[i - 1]; --i; }
+        d2[i] = d; idx[i] = j;
+        if (count < k) ++count;
+    }
+}
+
+ORC_API void orc_knn(const float *pos, int M, const float *queries, int N, int k, int *idx_out, float *d2_out)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) knn_brute(pos, M, queries + 3 * i, k, idx_out + (size_t)i * k, d2_out + (size_t)i * k);
+}
+
+/* warp_field.cpp:238-241 */
+static inline float dqb_weight(float d2, float sigma) { return (float)exp((double)(-d2 / (2 * sigma * sigma))); }
+
+/* warp_field.cpp:203-217 + dual_quaternion.hpp:59-63.  node_t = per-node getTranslation().   */
+static inline void dqb_blend(const float *dq, const float *node_t, const float *sigma, int k, const int *idx,
+                             const float *d2, quat *rot_out, quat *dual_out)
+{
+    quat tsum = {0, 0, 0, 0}, rsum = {0, 0, 0, 0};
+    for (int i = 0; i < k; ++i) {
+        int j = idx[i];
+        float w = dqb_weight(d2[i], sigma[j]);
+        tsum = q_add(tsum, q_scale_f(w, *(const quat *)(node_t + 4 * j)));   /* :211 */
+        rsum = q_add(rsum, q_scale_f(w, *(const quat *)(dq + 8 * j)));       /* :212 */
+    }
+    rsum = q_normalize(rsum);                                                 /* :214 */
+    quat half = {0.5f * tsum.w, 0.5f * tsum.x, 0.5f * tsum.y, 0.5f * tsum.z};
+    *rot_out = rsum;
+    *dual_out = q_mul(half, rsum);                                            /* dq ctor :59-63 */
+}
+
+/* dual_quaternion.hpp:204-210 transform ; quaternion.hpp:124-130 rotate(Vec3f&) with cv::Vec3f
+ * semantics: cross = (a1*b2-a2*b1, a2*b0-a0*b2, a0*b1-a1*b0), component-wise float ops.      */
+static inline f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline f3 dq_transform(quat rot, quat dual, f3 p)
+{
+    quat t = dq_get_translation(rot, dual);                    /* :206-207 */
+    quat rn = q_normalize(rot);                                /* rotate(): rot.normalize() */
+    f3 qv = mk3(rn.x, rn.y, rn.z);
+    f3 inner = add3(cross3(qv, p), scale3(p, rn.w));           /* q_vec.cross(v) + v*rot.w_ */
+    p = add3(p, cross3(scale3(qv, 2.f), inner));               /* v += (q_vec*2.f).cross(...) */
+    return add3(p, mk3(t.x, t.y, t.z));                        /* point += translation */
+}
+
+static void node_translations(const float *dq, int M, float *node_t)
+{
+    for (int j = 0; j < M; ++j) orc_node_translation(dq + 8 * j, node_t + 4 * j);
+}
+
+/* DQB-warp one point (warp_field.cpp:187-188): returns DQB(p).transform(p) */
+static inline f3 warp_point(const float *pos, const float *dq, const float *node_t, const float *sigma, int M, int k, f3 p)
+{
+    int idx[16]; float d2[16]; float q[3] = {p.x, p.y, p.z};
+    knn_brute(pos, M, q, k, idx, d2);
+    quat rot, dual; dqb_blend(dq, node_t, sigma, k, idx, d2, &rot, &dual);
+    return dq_transform(rot, dual, p);
+}
+
+/* cv::Affine3f * Vec3f : m0*x + m1*y + m2*z + m3, left-associated floats (opencv affine.hpp) */
+static inline f3 cv_affine_mul(const float *A /* R[9], t[3] */, f3 v)
+{
+    return mk3(A[0] * v.x + A[1] * v.y + A[2] * v.z + A[9], A[3] * v.x + A[4] * v.y + A[5] * v.z + A[10],
+               A[6] * v.x + A[7] * v.y + A[8] * v.z + A[11]);
+}
+
+/* warp_field.cpp:180-195 WarpField::warp.  points/normals are N x 3 floats.  The reference's
+ * `i++`-skipped-on-NaN index drift is FIXED (index by position); normals are
+ * transformed like points (translation included), as the reference does.                     */
+ORC_API void orc_warp_points(const float *pos, const float *dq, const float *sigma, int M, int k, float *points,
+                             float *normals, int N, const float warp_to_live[12])
+{
+    float *node_t = (float *)malloc((size_t)M * 16);
+    node_translations(dq, M, node_t);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        float *p = points + 3 * (size_t)i;
+        float *n = normals ? normals + 3 * (size_t)i : 0;
+        if (isnan(p[0]) || (n && isnan(n[0]))) continue;
+        int idx[16]; float d2[16];
+        knn_brute(pos, M, p, k, idx, d2);
+        quat rot, dual; dqb_blend(dq, node_t, sigma, k, idx, d2, &rot, &dual);
+        f3 pw = cv_affine_mul(warp_to_live, dq_transform(rot, dual, mk3(p[0], p[1], p[2])));
+        p[0] = pw.x; p[1] = pw.y; p[2] = pw.z;
+        if (n) {
+            f3 nw = cv_affine_mul(warp_to_live, dq_transform(rot, dual, mk3(n[0], n[1], n[2])));
+            n[0] = nw.x; n[1] = nw.y; n[2] = nw.z;
+        }
+    }
+    free(node_t);
+}
+
+/* DQB only (for direct parity tests): out_dq[N*8] = {rot, dual} of DQB(p) */
+ORC_API void orc_dqb(const float *pos, const float *dq, const float *sigma, int M, int k, const float *points, int N,
+                     float *out_dq)
+{
+    float *node_t = (float *)malloc((size_t)M * 16);
+    node_translations(dq, M, node_t);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        int idx[16]; float d2[16];
+        knn_brute(pos, M, points + 3 * (size_t)i, k, idx, d2);
+        quat rot, dual; dqb_blend(dq, node_t, sigma, k, idx, d2, &rot, &dual);
+        memcpy(out_dq + 8 * (size_t)i, &rot, 16); memcpy(out_dq + 8 * (size_t)i + 4, &dual, 16);
+    }
+    free(node_t);
+}
+
+/* ---------------------------------------------------------------- integrate (warped)
+ * x_c = vol2world*(i*vsx, j*vsy, k*vsz) ; x_w = DQB(x_c).transform(x_c) ;
+ * vc = world2cam * x_w ; continue at tsdf_volume.cu:77.  No incremental zstep.              */
+ORC_API uint64_t orc_integrate_warped(const uint16_t *dists, size_t pitch, int cols, int rows, OrcVolume v,
+                                      const OrcSlab *slab, const float vol2world[12], const float world2cam[12],
+                                      const float proj[4], const float *pos, const float *dq, const float *sigma,
+                                      int M, int k)
+{
+    OrcSlab s; slab_or_full(&v, slab, &s);
+    const int X = v.dims[0], Y = v.dims[1];
+    const float trunc_inv = 1.f / v.trunc_dist;
+    uint16_t *base = (uint16_t *)v.data;
+    float *node_t = (float *)malloc((size_t)M * 16);
+    node_translations(dq, M, node_t);
+    uint64_t n_upd = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : n_upd)
+    for (int z = s.z_own0; z < s.z_own0 + s.z_own_n; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+                f3 vx = mk3((float)x * v.voxel_size[0], (float)y * v.voxel_size[1], (float)z * v.voxel_size[2]);
+                f3 xc = aff_mul(vol2world, vx);
+                f3 xw = warp_point(pos, dq, node_t, sigma, M, k, xc);
+                f3 vc = aff_mul(world2cam, xw);
+                uint16_t *vox = base + 2 * ((size_t)x + (size_t)y * X + (size_t)(z - s.z_store0) * X * Y);
+                n_upd += tsdf_update(vox, vc, dists, pitch, cols, rows, proj, v.trunc_dist, trunc_inv, v.max_weight);
+            }
+    free(node_t);
+    return n_upd;
+}
+
+/* ================================================================ raycast
+ * tsdf_volume.cu:202-474                                                                     */
+typedef struct {
+    const uint16_t *data; int X, Y, Z; OrcSlab s;
+    f3 vs, vsi, gd, volume_size; float time_step;
+} rc_ctx;
+
+static inline float vox_tsdf(const rc_ctx *c, int x, int y, int z)
+{   /* device.hpp:17-18 index ; clamped to the stored range (policy) */
+    x = x < 0 ? 0 : (x >= c->X ? c->X - 1 : x);
+    y = y < 0 ? 0 : (y >= c->Y ? c->Y - 1 : y);
+    int zl = z - c->s.z_store0; zl = zl < 0 ? 0 : (zl >= c->s.z_store_n ? c->s.z_store_n - 1 : zl);
+    return h2f(c->data[2 * ((size_t)x + (size_t)y * c->X + (size_t)zl * c->X * c->Y)]);
+}
+/* :262-270 */
+static inline float fetch_tsdf(const rc_ctx *c, f3 p, int *zi)
+{
+    int x = (int)lrintf(p.x * c->vsi.x), y = (int)lrintf(p.y * c->vsi.y), z = (int)lrintf(p.z * c->vsi.z);
+    if (zi) *zi = z;
+    return vox_tsdf(c, x, y, z);
+}
+/* :220-245 */
+static inline float interpolate(const rc_ctx *c, f3 cf)
+{
+    int gx = (int)floorf(cf.x), gy = (int)floorf(cf.y), gz = (int)floorf(cf.z);
+    if (gx < 0 || gx >= c->X - 1 || gy < 0 || gy >= c->Y - 1 || gz < 0 || gz >= c->Z - 1) return qnanf();
+    float a = cf.x - gx, b = cf.y - gy, cc = cf.z - gz;
+    float t = 0.f;
+    t += vox_tsdf(c, gx + 0, gy + 0, gz + 0) * (1 - a) * (1 - b) * (1 - cc);
+    t += vox_tsdf(c, gx + 0, gy + 0, gz + 1) * (1 - a) * (1 - b) * cc;
+    t += vox_tsdf(c, gx + 0, gy + 1, gz + 0) * (1 - a) * b * (1 - cc);
+    t += vox_tsdf(c, gx + 0, gy + 1, gz + 1) * (1 - a) * b * cc;
+    t += vox_tsdf(c, gx + 1, gy + 0, gz + 0) * a * (1 - b) * (1 - cc);
+    t += vox_tsdf(c, gx + 1, gy + 0, gz + 1) * a * (1 - b) * cc;
+    t += vox_tsdf(c, gx + 1, gy + 1, gz + 0) * a * b * (1 - cc);
+    t += vox_tsdf(c, gx + 1, gy + 1, gz + 1) * a * b * cc;
+    return t;
+}
+/* :408-426 */
+static inline f3 compute_normal(const rc_ctx *c, f3 p)
+{
+    f3 n;
+    float Fx1 = interpolate(c, mul3(mk3(p.x + c->gd.x, p.y, p.z), c->vsi));
+    float Fx2 = interpolate(c, mul3(mk3(p.x - c->gd.x, p.y, p.z), c->vsi));
+    n.x = (Fx1 - Fx2) / c->gd.x;
+    float Fy1 = interpolate(c, mul3(mk3(p.x, p.y + c->gd.y, p.z), c->vsi));
+    float Fy2 = interpolate(c, mul3(mk3(p.x, p.y - c->gd.y, p.z), c->vsi));
+    n.y = (Fy1 - Fy2) / c->gd.y;
+    float Fz1 = interpolate(c, mul3(mk3(p.x, p.y, p.z + c->gd.z), c->vsi));
+    float Fz2 = interpolate(c, mul3(mk3(p.x, p.y, p.z - c->gd.z), c->vsi));
+    n.z = (Fz1 - Fz2) / c->gd.z;
+    return normalized3(n);
+}
+/* :202-218 */
+static inline void intersect(f3 org, f3 dir, f3 box_max, float *tnear, float *tfar)
+{
+    f3 invR = mk3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
+    f3 tbot = mul3(invR, sub3(mk3(0.f, 0.f, 0.f), org));
+    f3 ttop = mul3(invR, sub3(box_max, org));
+    f3 tmin = mk3(fminf(ttop.x, tbot.x), fminf(ttop.y, tbot.y), fminf(ttop.z, tbot.z));
+    f3 tmax = mk3(fmaxf(ttop.x, tbot.x), fmaxf(ttop.y, tbot.y), fmaxf(ttop.z, tbot.z));
+    *tnear = fmaxf(fmaxf(tmin.x, tmin.y), fmaxf(tmin.x, tmin.z));
+    *tfar = fminf(fminf(tmax.x, tmax.y), fminf(tmax.x, tmax.z));
+}
+
+#define ORC_RC_NO_EVENT 0xffffffffu
+/* One ray.  Returns the event key: (step index k << 1) | kind, kind 1 = +->- hit, 0 = -->+ break;
+ * ORC_RC_NO_EVENT if no event on a step this slab owns.  A step is owned when the nearest-voxel
+ * plane of its `curr` sample lies in [z_own0, z_own0+z_own_n).  On a hit with a finite normal,
+ * vertex/normal (camera frame, :394-401) are written and *valid = 1.                          */
+static inline uint32_t cast_ray(const rc_ctx *c, const float aff[12], const float Rinv[9], const float reproj[4],
+                                int x, int y, f3 *vertex_out, f3 *normal_out, int *valid, uint32_t *n_steps)
+{
+    *valid = 0; if (n_steps) *n_steps = 0;
+    const f3 org = mk3(aff[9], aff[10], aff[11]);
+    /* device.hpp:43-48 : x = z*(u-cx)*finvx with z = 1.f */
+    f3 rp = mk3(1.f * ((float)x - reproj[2]) * reproj[0], 1.f * ((float)y - reproj[3]) * reproj[1], 1.f);
+    f3 dir = normalized3(mat3_mul(aff, rp));                                   /* :354 */
+    f3 box_max = sub3(c->volume_size, c->vs);                                  /* :359 */
+    float tmin, tmax; intersect(org, dir, box_max, &tmin, &tmax);
+    tmin = fmaxf(0.f, tmin);                                                   /* :364-365 */
+    if (tmin >= tmax) return ORC_RC_NO_EVENT;                                  /* :366 */
+    tmax -= c->time_step;                                                      /* :369 */
+    f3 vstep = scale3(dir, c->time_step);
+    f3 next = add3(org, scale3(dir, tmin));
+    int zn; float tsdf_next = fetch_tsdf(c, next, &zn);                        /* :373 */
+    uint32_t k = 0;
+    for (float tcurr = tmin; tcurr < tmax; tcurr += c->time_step, ++k) {       /* :374 */
+        float tsdf_curr = tsdf_next; f3 curr = next; int zc = zn;
+        next = add3(next, vstep);
+        tsdf_next = fetch_tsdf(c, next, &zn);                                  /* :380 */
+        if (zc < c->s.z_own0 || zc >= c->s.z_own0 + c->s.z_own_n) continue;   /* not this slab's step */
+        if (n_steps) ++*n_steps;
+        if (tsdf_curr < 0.f && tsdf_next > 0.f) return (k << 1) | 0u;          /* :381 */
+        if (tsdf_curr > 0.f && tsdf_next < 0.f) {                              /* :384 */
+            float Ft = interpolate(c, mul3(curr, c->vsi));
+            float Ftdt = interpolate(c, mul3(next, c->vsi));
+            float Ts = tcurr - (c->time_step * Ft) / (Ftdt - Ft);              /* :389 */
+            f3 vertex = add3(org, scale3(dir, Ts));
+            f3 normal = compute_normal(c, vertex);
+            if (!isnan(normal.x * normal.y * normal.z)) {                      /* :394 */
+                *normal_out = mat3_mul(Rinv, normal);
+                *vertex_out = mat3_mul(Rinv, sub3(vertex, org));
+                *valid = 1;
+            }
+            return (k << 1) | 1u;
+        }
+    }
+    return ORC_RC_NO_EVENT;
+}
+
+static void rc_setup(rc_ctx *c, const OrcVolume *v, const OrcSlab *slab, float step_factor, float delta_factor)
+{
+    c->data = (const uint16_t *)v->data; c->X = v->dims[0]; c->Y = v->dims[1]; c->Z = v->dims[2];
+    slab_or_full(v, slab, &c->s);
+    c->vs = mk3(v->voxel_size[0], v->voxel_size[1], v->voxel_size[2]);
+    c->volume_size = mk3(c->vs.x * (float)c->X, c->vs.y * (float)c->Y, c->vs.z * (float)c->Z);   /* :464 */
+    c->time_step = v->trunc_dist * step_factor;                                                  /* :465 */
+    c->gd = scale3(c->vs, delta_factor);                                                         /* :466 */
+    c->vsi = mk3(1.f / c->vs.x, 1.f / c->vs.y, 1.f / c->vs.z);                                   /* :467 */
+}
+
+/* Points variant, :340-405.  points/normals are float4 rows with byte pitches; misses = all-NaN.
+ * keys (optional, cols*rows uint32) receives the per-pixel event key for sharded merging.
+ * stats (optional): [0] = sum of owned steps, [1] = number of valid hits.                     */
+ORC_API void orc_raycast_points(OrcVolume v, const OrcSlab *slab, const float cam2vol[12], const float Rinv[9],
+                                const float reproj[4] /* finvx finvy cx cy */, float *points, size_t ppitch,
+                                float *normals, size_t npitch, int cols, int rows, float step_factor,
+                                float delta_factor, uint32_t *keys, uint64_t *stats)
+{
+    rc_ctx c; rc_setup(&c, &v, slab, step_factor, delta_factor);
+    uint64_t steps = 0, hits = 0;
+    const float qn = qnanf();
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : steps, hits)
+    for (int y = 0; y < rows; ++y) {
+        float *prow = (float *)((char *)points + (size_t)y * ppitch);
+        float *nrow = (float *)((char *)normals + (size_t)y * npitch);
+        for (int x = 0; x < cols; ++x) {
+            for (int i = 0; i < 4; ++i) { prow[4 * x + i] = qn; nrow[4 * x + i] = qn; }   /* :351 */
+            f3 vtx, nrm; int valid; uint32_t ns;
+            uint32_t key = cast_ray(&c, cam2vol, Rinv, reproj, x, y, &vtx, &nrm, &valid, &ns);
+            if (keys) keys[(size_t)y * cols + x] = key;
+            steps += ns;
+            if (valid) {
+                ++hits;
+                nrow[4 * x] = nrm.x; nrow[4 * x + 1] = nrm.y; nrow[4 * x + 2] = nrm.z; nrow[4 * x + 3] = 0.f;
+                prow[4 * x] = vtx.x; prow[4 * x + 1] = vtx.y; prow[4 * x + 2] = vtx.z; prow[4 * x + 3] = 0.f;
+            }
+        }
+    }
+    if (stats) { stats[0] = steps; stats[1] = hits; }
+}
+
+/* Depth variant, :272-338 : depth = (ushort)(vertex.z*1000), zero-filled; normals NaN-filled. */
+ORC_API void orc_raycast_depth(OrcVolume v, const OrcSlab *slab, const float cam2vol[12], const float Rinv[9],
+                               const float reproj[4], uint16_t *depth, size_t dpitch, float *normals, size_t npitch,
+                               int cols, int rows, float step_factor, float delta_factor)
+{
+    rc_ctx c; rc_setup(&c, &v, slab, step_factor, delta_factor);
+    const float qn = qnanf();
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < rows; ++y) {
+        uint16_t *drow = (uint16_t *)((char *)depth + (size_t)y * dpitch);
+        float *nrow = (float *)((char *)normals + (size_t)y * npitch);
+        for (int x = 0; x < cols; ++x) {
+            drow[x] = 0;                                                                  /* :283 */
+            for (int i = 0; i < 4; ++i) nrow[4 * x + i] = qn;
+            f3 vtx, nrm; int valid;
+            cast_ray(&c, cam2vol, Rinv, reproj, x, y, &vtx, &nrm, &valid, 0);
+            if (valid) {
+                nrow[4 * x] = nrm.x; nrow[4 * x + 1] = nrm.y; nrow[4 * x + 2] = nrm.z; nrow[4 * x + 3] = 0.f;
+                float mm = vtx.z * 1000;                                                  /* :333 */
+                drow[x] = (uint16_t)(mm <= 0.f ? 0 : (mm >= 65535.f ? 65535 : (int)mm));
+            }
+        }
+    }
+}
+
+ORC_API int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+ORC_API void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

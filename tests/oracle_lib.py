@@ -1,0 +1,228 @@
+"""ctypes bindings for the parity checkers in oracle/ (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+The product package (dynamicfusion_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+
+
+class Volume(C.Structure):
+    """device::TsdfVolume, kfusion/src/internal.hpp:29-49 (same layout as DfVolume)."""
+    _fields_ = [("data", C.c_void_p), ("dims", C.c_int * 3), ("voxel_size", C.c_float * 3),
+                ("trunc_dist", C.c_float), ("max_weight", C.c_int)]
+
+
+class Slab(C.Structure):
+    _fields_ = [("z_store0", C.c_int), ("z_store_n", C.c_int), ("z_own0", C.c_int), ("z_own_n", C.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    src = os.path.join(ORACLE_DIR, "dfusion_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    ref = os.path.join(ORACLE_DIR, "_ref", "libdfref.so")
+    glue = os.path.join(ORACLE_DIR, "ref_glue.cpp")
+    if os.path.isdir("/root/reference/kfusion/src/utils") and (
+            force or not os.path.exists(ref) or os.path.getmtime(ref) < os.path.getmtime(glue)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(os.path.join(ORACLE_DIR, "liboracle.so"))
+        L.orc_float2half.restype = C.c_uint16
+        L.orc_float2half.argtypes = [C.c_float]
+        L.orc_half2float.restype = C.c_float
+        L.orc_half2float.argtypes = [C.c_uint16]
+        L.orc_compute_dists.restype = None
+        L.orc_compute_dists.argtypes = [u16p, C.c_size_t, u16p, C.c_size_t, C.c_int, C.c_int, f32p]
+        L.orc_clear.restype = None
+        L.orc_clear.argtypes = [Volume, C.POINTER(Slab)]
+        L.orc_integrate.restype = C.c_uint64
+        L.orc_integrate.argtypes = [u16p, C.c_size_t, C.c_int, C.c_int, Volume, C.POINTER(Slab), f32p, f32p]
+        L.orc_integrate_warped.restype = C.c_uint64
+        L.orc_integrate_warped.argtypes = [u16p, C.c_size_t, C.c_int, C.c_int, Volume, C.POINTER(Slab), f32p, f32p,
+                                           f32p, f32p, f32p, f32p, C.c_int, C.c_int]
+        L.orc_knn.restype = None
+        L.orc_knn.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p, f32p]
+        L.orc_dqb.restype = None
+        L.orc_dqb.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_int, f32p]
+        L.orc_warp_points.restype = None
+        L.orc_warp_points.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_void_p, C.c_int, f32p]
+        L.orc_raycast_points.restype = None
+        L.orc_raycast_points.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, f32p, C.c_size_t, f32p,
+                                         C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_raycast_depth.restype = None
+        L.orc_raycast_depth.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, u16p, C.c_size_t, f32p,
+                                        C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float]
+        for name in ("orc_quat_mul",):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [f32p, f32p, f32p]
+        L.orc_quat_normalize.restype = None
+        L.orc_quat_normalize.argtypes = [f32p, f32p]
+        L.orc_quat_encode_rotation.restype = None
+        L.orc_quat_encode_rotation.argtypes = [C.c_float] * 4 + [f32p]
+        L.orc_quat_rotate_xyz.restype = None
+        L.orc_quat_rotate_xyz.argtypes = [f32p, f32p]
+        L.orc_node_translation.restype = None
+        L.orc_node_translation.argtypes = [f32p, f32p]
+        L.orc_dq_from_twist.restype = None
+        L.orc_dq_from_twist.argtypes = [f32p, f32p, f32p]
+        L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def have_ref():
+    build()
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libdfref.so"))
+
+
+def ref():
+    """The reference's own headers compiled here (oracle/_ref/libdfref.so)."""
+    global _ref
+    if _ref is None:
+        build()
+        R = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libdfref.so"))
+        R.ref_knn.restype = None
+        R.ref_knn.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p, f32p]
+        R.ref_dqb.restype = None
+        R.ref_dqb.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_int, f32p]
+        R.ref_warp_points.restype = None
+        R.ref_warp_points.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_void_p, C.c_int]
+        R.ref_quat_encode_rotation.restype = None
+        R.ref_quat_encode_rotation.argtypes = [C.c_float] * 4 + [f32p]
+        R.ref_quat_rotate_xyz.restype = None
+        R.ref_quat_rotate_xyz.argtypes = [f32p, f32p]
+        R.ref_quat_mul.restype = None
+        R.ref_quat_mul.argtypes = [f32p, f32p, f32p]
+        R.ref_quat_dot.restype = C.c_float
+        R.ref_quat_dot.argtypes = [f32p, f32p]
+        R.ref_quat_normalize.restype = None
+        R.ref_quat_normalize.argtypes = [f32p, f32p]
+        R.ref_dq_euler.restype = None
+        R.ref_dq_euler.argtypes = [C.c_float] * 6 + [f32p, f32p]
+        R.ref_dq_from_twist.restype = None
+        R.ref_dq_from_twist.argtypes = [f32p, f32p, f32p]
+        R.ref_dq_get_translation.restype = None
+        R.ref_dq_get_translation.argtypes = [f32p, f32p]
+        R.ref_dq_transform.restype = None
+        R.ref_dq_transform.argtypes = [f32p, f32p]
+        R.ref_nanoflann_version.restype = C.c_int
+        _ref = R
+    return _ref
+
+
+# ------------------------------------------------------------------ numpy-level helpers
+def make_volume(vol_u32, dims, voxel_size, trunc_dist, max_weight):
+    """vol_u32: C-contiguous uint32 array [nz_store, Y, X] (lo16 = half tsdf, hi16 = weight)."""
+    v = Volume()
+    v.data = vol_u32.ctypes.data
+    v.dims[:] = [int(d) for d in dims]
+    v.voxel_size[:] = [float(np.float32(s)) for s in voxel_size]
+    v.trunc_dist = float(np.float32(trunc_dist))
+    v.max_weight = int(max_weight)
+    return v
+
+
+def make_slab(z_store0, z_store_n, z_own0, z_own_n):
+    return Slab(int(z_store0), int(z_store_n), int(z_own0), int(z_own_n))
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def compute_dists(depth_u16, intr):
+    rows, cols = depth_u16.shape
+    out = np.zeros_like(depth_u16)
+    lib().orc_compute_dists(np.ascontiguousarray(depth_u16), cols * 2, out, cols * 2, cols, rows, f32(intr))
+    return out
+
+
+def integrate(dists, vol_u32, volume, vol2cam, proj, slab=None):
+    rows, cols = dists.shape
+    return int(lib().orc_integrate(dists, cols * 2, cols, rows, volume, C.byref(slab) if slab else None,
+                                   f32(vol2cam).reshape(-1), f32(proj)))
+
+
+def integrate_warped(dists, vol_u32, volume, vol2world, world2cam, proj, pos, dq, sigma, k, slab=None):
+    rows, cols = dists.shape
+    pos, dq, sigma = f32(pos), f32(dq), f32(sigma)
+    return int(lib().orc_integrate_warped(dists, cols * 2, cols, rows, volume, C.byref(slab) if slab else None,
+                                          f32(vol2world).reshape(-1), f32(world2cam).reshape(-1), f32(proj),
+                                          pos.reshape(-1), dq.reshape(-1), sigma, pos.shape[0], k))
+
+
+def raycast_points(volume, cam2vol, Rinv, reproj, cols, rows, step_factor, delta_factor, slab=None, want_keys=False):
+    pts = np.empty((rows, cols, 4), np.float32)
+    nrm = np.empty((rows, cols, 4), np.float32)
+    keys = np.empty((rows, cols), np.uint32) if want_keys else None
+    stats = np.zeros(2, np.uint64)
+    lib().orc_raycast_points(volume, C.byref(slab) if slab else None, f32(cam2vol).reshape(-1), f32(Rinv).reshape(-1),
+                             f32(reproj), pts.reshape(-1), cols * 16, nrm.reshape(-1), cols * 16, cols, rows,
+                             step_factor, delta_factor, keys.ctypes.data if want_keys else None, stats.ctypes.data)
+    return pts, nrm, keys, stats
+
+
+def raycast_depth(volume, cam2vol, Rinv, reproj, cols, rows, step_factor, delta_factor, slab=None):
+    dep = np.empty((rows, cols), np.uint16)
+    nrm = np.empty((rows, cols, 4), np.float32)
+    lib().orc_raycast_depth(volume, C.byref(slab) if slab else None, f32(cam2vol).reshape(-1), f32(Rinv).reshape(-1),
+                            f32(reproj), dep, cols * 2, nrm.reshape(-1), cols * 16, cols, rows, step_factor,
+                            delta_factor)
+    return dep, nrm
+
+
+def knn(pos, queries, k, use_ref=False):
+    pos, queries = f32(pos), f32(queries)
+    n = queries.shape[0]
+    idx = np.empty((n, k), np.int32)
+    d2 = np.empty((n, k), np.float32)
+    fn = ref().ref_knn if use_ref else lib().orc_knn
+    fn(pos.reshape(-1), pos.shape[0], queries.reshape(-1), n, k, idx.reshape(-1), d2.reshape(-1))
+    return idx, d2
+
+
+def dqb(pos, dq, sigma, points, k, use_ref=False):
+    pos, dq, sigma, points = f32(pos), f32(dq), f32(sigma), f32(points)
+    out = np.empty((points.shape[0], 8), np.float32)
+    fn = ref().ref_dqb if use_ref else lib().orc_dqb
+    fn(pos.reshape(-1), dq.reshape(-1), sigma, pos.shape[0], k, points.reshape(-1), points.shape[0], out.reshape(-1))
+    return out
+
+
+def warp_points(pos, dq, sigma, points, normals, k, warp_to_live=None, use_ref=False):
+    pos, dq, sigma = f32(pos), f32(dq), f32(sigma)
+    pts = f32(points).copy()
+    nrm = f32(normals).copy() if normals is not None else None
+    nptr = nrm.ctypes.data if nrm is not None else None
+    if use_ref:
+        ref().ref_warp_points(pos.reshape(-1), dq.reshape(-1), sigma, pos.shape[0], k, pts.reshape(-1), nptr, pts.shape[0])
+    else:
+        if warp_to_live is None:
+            warp_to_live = np.concatenate([np.eye(3, dtype=np.float32).reshape(-1), np.zeros(3, np.float32)])
+        lib().orc_warp_points(pos.reshape(-1), dq.reshape(-1), sigma, pos.shape[0], k, pts.reshape(-1), nptr,
+                              pts.shape[0], f32(warp_to_live).reshape(-1))
+    return pts, nrm
