@@ -1,0 +1,53 @@
+"""In-tree build of the gfx950 HIP library (libdfusion_hip.so) with hipcc.
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot, so a box without
+the sources' mtimes changing never rebuilds.  hipcc cross-compiles without a GPU.
+"""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libdfusion_hip.so")
+
+SOURCES = ["dfusion_volume.hip", "dfusion_warp.hip", "dfusion_raycast.hip"]
+HEADERS = ["dfusion_device.h", "dfusion_internal.h", os.path.join(REPO_DIR, "include", "dfusion.h")]
+
+# -ffp-contract=off: fused multiply-adds only where the reference writes __fmaf_rn (explicit fmaf);
+# that is what makes the kernels bit-comparable with the IEEE CPU oracle.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-fno-fast-math", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the dynamicfusion_amd HIP library cannot be built")
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into dynamicfusion_amd/libdfusion_hip.so."""
+    if not force and not _stale():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(REPO_DIR, "include"), "-I", CSRC]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,97 @@
+"""ctypes binding of the C-ABI in include/dfusion.h (libdfusion_hip.so).
+
+There is NO fallback: if the HIP library is missing or an entry point fails, this raises.  The
+product path never touches oracle/.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_lib = None
+
+
+class DfVolume(C.Structure):
+    """include/dfusion.h DfVolume == device::TsdfVolume (kfusion/src/internal.hpp:29-49)."""
+    _fields_ = [("data", C.c_void_p), ("dims", C.c_int * 3), ("voxel_size", C.c_float * 3),
+                ("trunc_dist", C.c_float), ("max_weight", C.c_int)]
+
+
+class DfSlab(C.Structure):
+    _fields_ = [("z_store0", C.c_int), ("z_store_n", C.c_int), ("z_own0", C.c_int), ("z_own_n", C.c_int)]
+
+
+DF_WARP_NO_CULL = 1
+
+# every symbol include/dfusion.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "dfusion_abi_version", "dfusion_error_string", "dfusion_clear", "dfusion_compute_dists", "dfusion_integrate",
+    "dfusion_raycast_points", "dfusion_raycast_depth", "dfusion_warp_create", "dfusion_warp_destroy",
+    "dfusion_warp_set_nodes", "dfusion_warp_set_transforms", "dfusion_warp_build_index", "dfusion_knn",
+    "dfusion_warp_points", "dfusion_integrate_warped", "dfusion_copy_bandwidth_probe",
+]
+
+
+class DfusionError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def lib():
+    """Load (building if stale and hipcc is present) libdfusion_hip.so.  Raises if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        import torch  # noqa: F401  -- load torch's libamdhip64 first so one HIP runtime serves both
+    except Exception:  # pragma: no cover
+        pass
+    path = _build.LIB_PATH
+    try:
+        path = _build.build_library()
+    except Exception as e:
+        if not os.path.exists(path):
+            raise DfusionError("libdfusion_hip.so is missing and could not be built: %s" % e)
+    L = C.CDLL(path)
+    fp = C.POINTER(C.c_float)
+    vp = C.c_void_p
+    L.dfusion_abi_version.restype = C.c_int
+    L.dfusion_error_string.restype = C.c_char_p
+    L.dfusion_error_string.argtypes = [C.c_int]
+    L.dfusion_clear.argtypes = [DfVolume, C.POINTER(DfSlab), vp]
+    L.dfusion_compute_dists.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, fp, vp]
+    L.dfusion_integrate.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, DfVolume, C.POINTER(DfSlab), fp, fp, vp, vp]
+    L.dfusion_raycast_points.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, C.c_size_t, vp, C.c_size_t,
+                                         C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]
+    L.dfusion_raycast_depth.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, C.c_size_t, vp, C.c_size_t,
+                                        C.c_int, C.c_int, C.c_float, C.c_float, vp]
+    L.dfusion_warp_create.argtypes = [C.POINTER(vp)]
+    L.dfusion_warp_destroy.argtypes = [vp]
+    L.dfusion_warp_set_nodes.argtypes = [vp, vp, vp, vp, C.c_int, vp]
+    L.dfusion_warp_set_transforms.argtypes = [vp, vp, vp]
+    L.dfusion_warp_build_index.argtypes = [vp, DfVolume, fp, C.c_int, vp]
+    L.dfusion_knn.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.dfusion_warp_points.argtypes = [vp, C.c_int, vp, vp, C.c_int, fp, vp]
+    L.dfusion_integrate_warped.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, DfVolume, C.POINTER(DfSlab), fp, fp, fp,
+                                           vp, C.c_int, C.c_uint, vp, vp]
+    L.dfusion_copy_bandwidth_probe.argtypes = [vp, vp, C.c_size_t, vp]
+    for s in SYMBOLS:
+        if s not in ("dfusion_error_string",):
+            getattr(L, s).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().dfusion_error_string(rc)
+        raise DfusionError("%s failed: %s (code %d)" % (what or "dfusion call", msg.decode() if msg else "?", rc))
+
+
+def floats(seq):
+    """Host float block (affines, intrinsics) -> C float array."""
+    seq = [float(x) for x in seq]
+    return (C.c_float * len(seq))(*seq)

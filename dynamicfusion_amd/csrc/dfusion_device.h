@@ -1,0 +1,131 @@
+// dfusion_device.h -- device-side arithmetic shared by the gfx950 kernels.
+//
+// Every routine states the reference line it reproduces.  The whole library is compiled with
+// -ffp-contract=off: a fused multiply-add appears ONLY where the reference writes __fmaf_rn / dot()
+// (explicit fmaf below); '/' and sqrtf are hipcc's correctly rounded fp32 forms; f32 denormals are
+// preserved (hipcc default on gfx950).  That makes the kernels bit-compatible with the IEEE CPU
+// restatement in oracle/dfusion_oracle.c, which is how parity is tested.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dfusion.h"
+
+#pragma clang fp contract(off)
+
+#define DF_WAVE 64
+
+struct f3 { float x, y, z; };
+struct quat { float w, x, y, z; };      // utils::Quaternion<float> (w_, x_, y_, z_)
+
+struct DfAff { float R[9]; float t[3]; };   // device::Aff3f, internal.hpp:26-27
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+// temp_utils.hpp:27-30
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+// device.hpp:71-72
+__device__ __forceinline__ f3 mat3_mul(const float* R, f3 v)
+{
+    return mk3(dot3(mk3(R[0], R[1], R[2]), v), dot3(mk3(R[3], R[4], R[5]), v), dot3(mk3(R[6], R[7], R[8]), v));
+}
+// device.hpp:74
+__device__ __forceinline__ f3 aff_mul(const DfAff& A, f3 v) { return add3(mat3_mul(A.R, v), mk3(A.t[0], A.t[1], A.t[2])); }
+// temp_utils.hpp:97-100 (rsqrt -> IEEE 1/sqrt)
+__device__ __forceinline__ f3 normalized3(f3 v) { float r = 1.0f / sqrtf(dot3(v, v)); return scale3(v, r); }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ float qnanf_() { return __uint_as_float(0x7fffffffu); }   // temp_utils.hpp:16
+
+// device.hpp:53-61 : __float2half_rn / __half2float
+__device__ __forceinline__ uint32_t f2h_bits(float f) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ float h2f_bits(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu)); }
+
+// ---------------------------------------------------------------- quaternion.hpp / dual_quaternion.hpp
+// quaternion.hpp:186-194
+__device__ __forceinline__ quat q_mul(quat a, quat b)
+{
+    quat r;
+    r.w = ((a.w * b.w) - (a.x * b.x) - (a.y * b.y) - (a.z * b.z));
+    r.x = ((a.w * b.x) + (a.x * b.w) + (a.y * b.z) - (a.z * b.y));
+    r.y = ((a.w * b.y) - (a.x * b.z) + (a.y * b.w) + (a.z * b.x));
+    r.z = ((a.w * b.z) + (a.x * b.y) - (a.y * b.x) + (a.z * b.w));
+    return r;
+}
+__device__ __forceinline__ quat q_conj(quat a) { quat r; r.w = a.w; r.x = -a.x; r.y = -a.y; r.z = -a.z; return r; }
+// quaternion.hpp:211-228 : (1.0/norm) * q with a double scalar, rounded per component
+__device__ __forceinline__ quat q_normalize(quat a)
+{
+    float n = sqrtf((a.w * a.w) + (a.x * a.x) + (a.y * a.y) + (a.z * a.z));
+    double inv = 1.0 / (double)n;
+    quat r;
+    r.w = (float)(inv * (double)a.w); r.x = (float)(inv * (double)a.x);
+    r.y = (float)(inv * (double)a.y); r.z = (float)(inv * (double)a.z);
+    return r;
+}
+__device__ __forceinline__ quat q_scale(float s, quat a) { quat r; r.w = s * a.w; r.x = s * a.x; r.y = s * a.y; r.z = s * a.z; return r; }
+__device__ __forceinline__ quat q_add(quat a, quat b) { quat r; r.w = a.w + b.w; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; return r; }
+// dual_quaternion.hpp:120-125
+__device__ __forceinline__ quat dq_get_translation(quat rot, quat dual) { return q_mul(q_scale(2.f, dual), q_conj(q_normalize(rot))); }
+// dual_quaternion.hpp:204-210 + quaternion.hpp:124-130
+__device__ __forceinline__ f3 dq_transform(quat rot, quat dual, f3 p)
+{
+    quat rn = q_normalize(rot);                       // shared by getTranslation() and rotate()
+    quat t = q_mul(q_scale(2.f, dual), q_conj(rn));
+    f3 qv = mk3(rn.x, rn.y, rn.z);
+    f3 inner = add3(cross3(qv, p), scale3(p, rn.w));
+    p = add3(p, cross3(scale3(qv, 2.f), inner));
+    return add3(p, mk3(t.x, t.y, t.z));
+}
+// warp_field.cpp:238-241 (double exp overload, see oracle header)
+__device__ __forceinline__ float dqb_weight(float d2, float sigma) { return (float)exp((double)(-d2 / (2 * sigma * sigma))); }
+// knn_point_cloud.hpp:25-31
+__device__ __forceinline__ float knn_dist2(f3 q, float px, float py, float pz)
+{
+    const float d0 = q.x - px, d1 = q.y - py, d2 = q.z - pz;
+    return d0 * d0 + d1 * d1 + d2 * d2;
+}
+
+// ---------------------------------------------------------------- projective TSDF update
+// tsdf_volume.cu:77-104 from the projection on.  Returns the new packed voxel in `vox` and true
+// if the update branch (:91) was taken.  `vox_in` is only meaningful when it is.
+struct DfIntegrateParams {
+    const uint16_t* dists; size_t pitch; int cols, rows;
+    float fx, fy, cx, cy;
+    float trunc, trunc_inv; int max_weight;
+};
+
+// Decide whether voxel at camera-frame vc updates; returns tsdf sample in *tsdf_out.
+__device__ __forceinline__ bool tsdf_sample(const DfIntegrateParams& P, f3 vc, float* tsdf_out)
+{
+    if (!(vc.z > 0.f)) return false;                      // :86 (second half); order-independent skip
+    float u = fmaf(P.fx, vc.x / vc.z, P.cx);              // device.hpp:35
+    float v = fmaf(P.fy, vc.y / vc.z, P.cy);              // device.hpp:36
+    if (!(u >= 0.f && v >= 0.f && u < (float)P.cols && v < (float)P.rows)) return false;   // :82 (+NaN => skip)
+    const uint16_t* row = (const uint16_t*)((const char*)P.dists + (size_t)(int)v * P.pitch);
+    float Dp = h2f_bits(row[(int)u]);                     // :85
+    if (Dp == 0.f) return false;                          // :86
+    float sdf = Dp - sqrtf(dot3(vc, vc));                 // :89
+    if (!(sdf >= -P.trunc)) return false;                 // :91
+    *tsdf_out = fminf(1.f, sdf * P.trunc_inv);            // :93
+    return true;
+}
+// :97-103
+__device__ __forceinline__ uint32_t tsdf_fuse(uint32_t vox, float tsdf, int max_weight)
+{
+    int weight_prev = (int)(vox >> 16);
+    float tsdf_prev = h2f_bits(vox);
+    float tsdf_new = fmaf(tsdf_prev, (float)weight_prev, tsdf) / (float)(weight_prev + 1);
+    int weight_new = min(weight_prev + 1, max_weight);
+    return f2h_bits(tsdf_new) | ((uint32_t)weight_new << 16);
+}
+
+// ---------------------------------------------------------------- wave64 helpers
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned long long lane_mask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }

@@ -1,0 +1,56 @@
+// dfusion_internal.h -- host-side internals shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "dfusion.h"
+#include "dfusion_device.h"
+
+#define DF_BRICK 8                    // k-NN index brick edge (voxels)
+
+#define DF_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (int)e__; } while (0)
+#define DF_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+static inline DfSlab df_slab_or_full(const DfVolume& v, const DfSlab* s)
+{
+    if (s) return *s;
+    DfSlab f; f.z_store0 = 0; f.z_store_n = v.dims[2]; f.z_own0 = 0; f.z_own_n = v.dims[2]; return f;
+}
+static inline bool df_slab_valid(const DfVolume& v, const DfSlab& s)
+{
+    return s.z_store_n > 0 && s.z_own_n >= 0 && s.z_store0 >= 0 && s.z_store0 + s.z_store_n <= v.dims[2] &&
+           s.z_own0 >= s.z_store0 && s.z_own0 + s.z_own_n <= s.z_store0 + s.z_store_n;
+}
+static inline bool df_volume_valid(const DfVolume& v)
+{
+    return v.data && v.dims[0] > 0 && v.dims[1] > 0 && v.dims[2] > 0 && (v.dims[0] % 4) == 0 &&
+           v.voxel_size[0] > 0 && v.voxel_size[1] > 0 && v.voxel_size[2] > 0 && v.trunc_dist > 0;
+}
+static inline DfAff df_aff(const float a[12]) { DfAff r; memcpy(r.R, a, 36); memcpy(r.t, a + 9, 12); return r; }
+
+// Device-side view of the warp field + brick index (passed to kernels by value).
+struct DfWarpView {
+    const float4* pos_sigma;   // [M] xyz = vertex, w = dg_w
+    const float4* rot;         // [M] rotation_ (w,x,y,z)
+    const float4* dual;        // [M] translation_ (w,x,y,z)
+    const float4* node_t;      // [M] getTranslation() of the node (w,x,y,z), dual_quaternion.hpp:120-125
+    int M;
+    // brick index
+    const uint32_t* brick_off; // [nb+1]
+    const uint16_t* brick_list;
+    int bx, by, bz;            // brick grid over the GLOBAL volume
+};
+
+struct DfWarpField {
+    int device;
+    int M, cap;
+    float4 *pos_sigma, *rot, *dual, *node_t;
+    // index
+    uint32_t* brick_off; uint32_t* brick_cnt; uint16_t* brick_list;
+    size_t off_cap, list_cap;
+    int bx, by, bz, k_built;
+    int geom_dims[3]; float geom_vs[3]; float geom_aff[12];
+    bool index_valid;
+    // device scalars for the conservative brick cull: [0] max |t_i|, [1] max sin(theta_i/2), [2] max dists
+    float* bounds_dev;
+};

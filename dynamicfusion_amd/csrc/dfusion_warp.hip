@@ -1,0 +1,630 @@
+// dfusion_warp.hip -- warp-field nodes on device, exact k-NN brick index, per-point warp, and the
+// north-star kernel: per-voxel dual-quaternion blend fused into the projective TSDF update.
+//
+// Replaces (on device) /root/reference/kfusion/src/warp_field.cpp:180-251 (KNN / weighting / DQB /
+// warp), the nanoflann kd-tree it queries (warp_field.cpp:275-282), and composes them with
+// kfusion/src/cuda/tsdf_volume.cu:77-104.
+//
+// MI355X design notes
+//   * k-NN: a kd-tree walk is pointer-chasing and divergent.  Instead, for every 8^3 voxel brick
+//     the index stores the EXACT candidate set {n : |n - c_B| <= D_k(c_B) + 2 r_B} (c_B brick
+//     centre, r_B half diagonal, D_k distance to the k-th nearest node).  Any node among the k
+//     nearest of any voxel of the brick is in that set, so a brute-force top-k over the list is
+//     the exact nanoflann answer.  Lists depend only on canonical node positions: they are
+//     rebuilt when nodes are inserted, not per frame.  Built on the GPU, one wave per brick,
+//     with wave-level k-th-smallest selection and ballot/popcount-prefix compaction.
+//   * integrate_warped: one 256-thread workgroup per brick; candidate positions (+sigma) are
+//     staged in LDS once per brick and read back with broadcast ds_read_b128; each lane keeps the
+//     running top-k of its voxel in registers.
+#include "dfusion_internal.h"
+#include <stdlib.h>
+#include <math.h>
+
+// ====================================================================================== nodes
+__global__ __launch_bounds__(256) void df_pack_nodes_kernel(const float* __restrict__ pos, const float* __restrict__ dq,
+                                                            const float* __restrict__ sigma, int M,
+                                                            float4* __restrict__ pos_sigma, float4* __restrict__ rot,
+                                                            float4* __restrict__ dual, float4* __restrict__ node_t)
+{
+    int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    if (pos) pos_sigma[j] = make_float4(pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], sigma[j]);
+    quat r, d;
+    r.w = dq[8 * j]; r.x = dq[8 * j + 1]; r.y = dq[8 * j + 2]; r.z = dq[8 * j + 3];
+    d.w = dq[8 * j + 4]; d.x = dq[8 * j + 5]; d.y = dq[8 * j + 6]; d.z = dq[8 * j + 7];
+    quat t = dq_get_translation(r, d);                 // DualQuaternion::getTranslation, dual_quaternion.hpp:120-125
+    rot[j] = make_float4(r.w, r.x, r.y, r.z);
+    dual[j] = make_float4(d.w, d.x, d.y, d.z);
+    node_t[j] = make_float4(t.w, t.x, t.y, t.z);
+}
+
+// Conservative per-node displacement ingredients for brick culling: max |t_i| and max sin(theta_i/2)
+// over nodes.  bounds[0] = max |t|, bounds[1] = max sin(half angle), bounds[1] = 2 (=> no culling) if
+// any rotation has w < 0 or is not finite (the hemisphere argument of the bound needs w >= 0).
+__global__ __launch_bounds__(256) void df_node_bounds_kernel(const float4* __restrict__ rot, const float4* __restrict__ node_t,
+                                                             int M, float* __restrict__ bounds)
+{
+    int j = blockIdx.x * 256 + threadIdx.x;
+    float tn = 0.f, sh = 0.f;
+    if (j < M) {
+        float4 t = node_t[j], r = rot[j];
+        tn = sqrtf(t.y * t.y + t.z * t.z + t.w * t.w);          // (x,y,z) of the quaternion are .y .z .w of the float4
+        float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+        float vn = sqrtf(r.y * r.y + r.z * r.z + r.w * r.w);
+        sh = vn / n;
+        if (!(r.x >= 0.f) || !(n > 0.f) || !(sh == sh) || !(tn == tn)) { sh = 2.f; }
+        if (!(tn == tn)) tn = 3.0e38f;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { tn = fmaxf(tn, __shfl_xor(tn, o, 64)); sh = fmaxf(sh, __shfl_xor(sh, o, 64)); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax((unsigned int*)&bounds[0], __float_as_uint(tn));   // non-negative floats order as uints
+        atomicMax((unsigned int*)&bounds[1], __float_as_uint(sh));
+    }
+}
+
+extern "C" int dfusion_warp_create(DfWarpField** out)
+{
+    if (!out) return DF_E_INVALID;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return DF_E_NO_DEVICE;
+    DfWarpField* wf = (DfWarpField*)calloc(1, sizeof(DfWarpField));
+    if (!wf) return DF_E_INVALID;
+    wf->device = dev;
+    *out = wf;
+    return DF_OK;
+}
+
+extern "C" int dfusion_warp_destroy(DfWarpField* wf)
+{
+    if (!wf) return DF_OK;
+    (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
+    (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev);
+    free(wf);
+    return DF_OK;
+}
+
+static int df_warp_reserve(DfWarpField* wf, int M)
+{
+    if (M <= wf->cap) return DF_OK;
+    (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
+    wf->pos_sigma = wf->rot = wf->dual = wf->node_t = nullptr; wf->cap = 0;
+    size_t bytes = (size_t)M * sizeof(float4);
+    DF_HIP(hipMalloc((void**)&wf->pos_sigma, bytes));
+    DF_HIP(hipMalloc((void**)&wf->rot, bytes));
+    DF_HIP(hipMalloc((void**)&wf->dual, bytes));
+    DF_HIP(hipMalloc((void**)&wf->node_t, bytes));
+    if (!wf->bounds_dev) DF_HIP(hipMalloc((void**)&wf->bounds_dev, 4 * sizeof(float)));
+    wf->cap = M;
+    return DF_OK;
+}
+
+static int df_warp_pack(DfWarpField* wf, const float* pos, const float* dq, const float* sigma, hipStream_t st)
+{
+    hipLaunchKernelGGL(df_pack_nodes_kernel, dim3((wf->M + 255) / 256), dim3(256), 0, st, pos, dq, sigma, wf->M,
+                       wf->pos_sigma, wf->rot, wf->dual, wf->node_t);
+    DF_LAUNCH_CHECK();
+    DF_HIP(hipMemsetAsync(wf->bounds_dev, 0, 2 * sizeof(float), st));
+    hipLaunchKernelGGL(df_node_bounds_kernel, dim3((wf->M + 255) / 256), dim3(256), 0, st, wf->rot, wf->node_t, wf->M,
+                       wf->bounds_dev);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+extern "C" int dfusion_warp_set_nodes(DfWarpField* wf, const float* pos, const float* dq, const float* sigma, int M,
+                                      dfStream stream)
+{
+    if (!wf || !pos || !dq || !sigma || M <= 0 || M > 65535) return DF_E_INVALID;
+    int rc = df_warp_reserve(wf, M);
+    if (rc) return rc;
+    wf->M = M;
+    wf->index_valid = false;
+    return df_warp_pack(wf, pos, dq, sigma, (hipStream_t)stream);
+}
+
+extern "C" int dfusion_warp_set_transforms(DfWarpField* wf, const float* dq, dfStream stream)
+{
+    if (!wf || !dq || wf->M <= 0) return DF_E_INVALID;
+    return df_warp_pack(wf, nullptr, dq, nullptr, (hipStream_t)stream);
+}
+
+// ====================================================================================== top-k in registers
+// Sorted insert with strict '<' so equal distances keep scan (= node index) order:
+// nanoflann KNNResultSet::addPoint (nanoflann.hpp:110-131) minus tree order.
+template <int K>
+__device__ __forceinline__ void topk_insert(float (&bd)[K], int (&bi)[K], float d, int j)
+{
+    if (d < bd[K - 1]) {
+        bd[K - 1] = d; bi[K - 1] = j;
+#pragma unroll
+        for (int i = K - 1; i > 0; --i) {
+            if (bd[i] < bd[i - 1]) {
+                float td = bd[i]; bd[i] = bd[i - 1]; bd[i - 1] = td;
+                int ti = bi[i]; bi[i] = bi[i - 1]; bi[i - 1] = ti;
+            }
+        }
+    }
+}
+template <int K>
+__device__ __forceinline__ void topk_init(float (&bd)[K], int (&bi)[K])
+{
+#pragma unroll
+    for (int i = 0; i < K; ++i) { bd[i] = __uint_as_float(0x7f800000u); bi[i] = 0; }   // +inf
+}
+
+// WarpField::DQB (warp_field.cpp:203-217) from a finished top-k, then DualQuaternion ctor :59-63.
+template <int K>
+__device__ __forceinline__ void dqb_blend(const DfWarpView& W, const float (&bd)[K], const int (&bi)[K], quat* rot_out,
+                                          quat* dual_out)
+{
+    quat tsum, rsum;
+    tsum.w = tsum.x = tsum.y = tsum.z = 0.f;
+    rsum.w = rsum.x = rsum.y = rsum.z = 0.f;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int j = bi[i];
+        const float sigma = W.pos_sigma[j].w;
+        const float w = dqb_weight(bd[i], sigma);
+        const float4 t4 = W.node_t[j], r4 = W.rot[j];
+        quat t, r;
+        t.w = t4.x; t.x = t4.y; t.y = t4.z; t.z = t4.w;
+        r.w = r4.x; r.x = r4.y; r.y = r4.z; r.z = r4.w;
+        tsum = q_add(tsum, q_scale(w, t));            // :211
+        rsum = q_add(rsum, q_scale(w, r));            // :212
+    }
+    rsum = q_normalize(rsum);                         // :214
+    quat half;
+    half.w = 0.5f * tsum.w; half.x = 0.5f * tsum.x; half.y = 0.5f * tsum.y; half.z = 0.5f * tsum.z;
+    *rot_out = rsum;
+    *dual_out = q_mul(half, rsum);                    // dual_quaternion.hpp:59-63
+}
+
+// ====================================================================================== brute-force k-NN / warp of points
+// One lane per query point; all M node positions stream through LDS in chunks (broadcast reads).
+#define DF_PT_CHUNK 1024
+
+template <int K, int MODE /* 0 = knn out, 1 = warp points */>
+__global__ __launch_bounds__(256) void df_points_kernel(DfWarpView W, const float* __restrict__ queries, int N,
+                                                        int* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                        float* __restrict__ points, float* __restrict__ normals,
+                                                        DfAff to_live)
+{
+    __shared__ float4 s_pos[DF_PT_CHUNK];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < N;
+    f3 q = mk3(0.f, 0.f, 0.f);
+    const float* src = MODE == 0 ? queries : points;
+    if (active) q = mk3(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2]);
+    float bd[K]; int bi[K];
+    topk_init<K>(bd, bi);
+    for (int base = 0; base < W.M; base += DF_PT_CHUNK) {
+        const int n = min(DF_PT_CHUNK, W.M - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < n; t += 256) s_pos[t] = W.pos_sigma[base + t];
+        __syncthreads();
+        for (int c = 0; c < n; ++c) {
+            const float4 p = s_pos[c];
+            topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), base + c);
+        }
+    }
+    if (!active) return;
+    if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) { idx_out[(size_t)i * K + j] = bi[j]; d2_out[(size_t)i * K + j] = bd[j]; }
+    } else {
+        // warp_field.cpp:185-192 (index drift fixed: SURVEY.md 9.6)
+        bool skip = q.x != q.x;
+        f3 nq = mk3(0.f, 0.f, 0.f);
+        if (normals) { nq = mk3(normals[3 * (size_t)i], normals[3 * (size_t)i + 1], normals[3 * (size_t)i + 2]); skip = skip || (nq.x != nq.x); }
+        if (skip) return;
+        quat rot, dual;
+        dqb_blend<K>(W, bd, bi, &rot, &dual);
+        f3 p = dq_transform(rot, dual, q);
+        // cv::Affine3f * Vec3f : left-associated, no fma (opencv affine.hpp)
+        const float* A = to_live.R; const float* T = to_live.t;
+        points[3 * (size_t)i]     = A[0] * p.x + A[1] * p.y + A[2] * p.z + T[0];
+        points[3 * (size_t)i + 1] = A[3] * p.x + A[4] * p.y + A[5] * p.z + T[1];
+        points[3 * (size_t)i + 2] = A[6] * p.x + A[7] * p.y + A[8] * p.z + T[2];
+        if (normals) {
+            f3 nn = dq_transform(rot, dual, nq);      // reference translates normals too (warp_field.cpp:191)
+            normals[3 * (size_t)i]     = A[0] * nn.x + A[1] * nn.y + A[2] * nn.z + T[0];
+            normals[3 * (size_t)i + 1] = A[3] * nn.x + A[4] * nn.y + A[5] * nn.z + T[1];
+            normals[3 * (size_t)i + 2] = A[6] * nn.x + A[7] * nn.y + A[8] * nn.z + T[2];
+        }
+    }
+}
+
+static DfWarpView df_view(const DfWarpField* wf)
+{
+    DfWarpView W;
+    W.pos_sigma = wf->pos_sigma; W.rot = wf->rot; W.dual = wf->dual; W.node_t = wf->node_t; W.M = wf->M;
+    W.brick_off = wf->brick_off; W.brick_list = wf->brick_list; W.bx = wf->bx; W.by = wf->by; W.bz = wf->bz;
+    return W;
+}
+
+#define DF_DISPATCH_K(k, ...)                             \
+    switch (k) {                                          \
+        case 1: { constexpr int K = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int K = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int K = 3; __VA_ARGS__; } break; \
+        case 4: { constexpr int K = 4; __VA_ARGS__; } break; \
+        case 5: { constexpr int K = 5; __VA_ARGS__; } break; \
+        case 6: { constexpr int K = 6; __VA_ARGS__; } break; \
+        case 7: { constexpr int K = 7; __VA_ARGS__; } break; \
+        case 8: { constexpr int K = 8; __VA_ARGS__; } break; \
+        default: return DF_E_INVALID;                     \
+    }
+
+extern "C" int dfusion_knn(DfWarpField* wf, int k, const float* queries, int N, int* idx, float* d2, dfStream stream)
+{
+    if (!wf || !queries || !idx || !d2 || N < 0 || wf->M < k || k < 1) return DF_E_INVALID;
+    if (N == 0) return DF_OK;
+    DfWarpView W = df_view(wf);
+    DfAff ident; memset(&ident, 0, sizeof(ident));
+    DF_DISPATCH_K(k, df_points_kernel<K, 0><<<dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+                         W, queries, N, idx, d2, (float*)nullptr, (float*)nullptr, ident));
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+extern "C" int dfusion_warp_points(DfWarpField* wf, int k, float* points, float* normals, int N, const float warp_to_live[12],
+                                   dfStream stream)
+{
+    if (!wf || !points || !warp_to_live || N < 0 || wf->M < k || k < 1) return DF_E_INVALID;
+    if (N == 0) return DF_OK;
+    DfWarpView W = df_view(wf);
+    DfAff live = df_aff(warp_to_live);
+    DF_DISPATCH_K(k, df_points_kernel<K, 1><<<dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+                         W, (const float*)nullptr, N, (int*)nullptr, (float*)nullptr, points, normals, live));
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+// ====================================================================================== brick index build
+struct DfIndexGeom {
+    int X, Y, Z; int bx, by, bz;
+    float vsx, vsy, vsz;
+    DfAff vol2world;
+    float r2x;            // 2 * half-diagonal of the voxel-centre lattice of a brick (metres), inflated
+};
+
+// One wave per brick.  FILL = false: cnt[b] = |candidates| ; FILL = true: write list at off[b].
+template <int K, bool FILL>
+__global__ __launch_bounds__(256) void df_brick_index_kernel(const float4* __restrict__ pos_sigma, int M, DfIndexGeom g,
+                                                             uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                                             uint16_t* __restrict__ list)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nb = g.bx * g.by * g.bz;
+    if (b >= nb) return;                                   // whole wave exits together
+    const int bzz = b / (g.bx * g.by);
+    const int rem = b - bzz * g.bx * g.by;
+    const int byy = rem / g.bx, bxx = rem - byy * g.bx;
+    // centre of the brick's voxel-centre lattice (voxel (i,j,k) sits at (i*vsx, j*vsy, k*vsz), tsdf_volume.cu:71)
+    const f3 c = aff_mul(g.vol2world, mk3(((float)(bxx * DF_BRICK) + 3.5f) * g.vsx, ((float)(byy * DF_BRICK) + 3.5f) * g.vsy,
+                                          ((float)(bzz * DF_BRICK) + 3.5f) * g.vsz));
+    // pass 1: D_k(c)^2 -- per-lane top-K over a strided share of the nodes, then K wave-min pops
+    float bd[K]; int bi[K];
+    topk_init<K>(bd, bi);
+    for (int j = lane; j < M; j += 64) {
+        const float4 p = pos_sigma[j];
+        topk_insert<K>(bd, bi, knn_dist2(c, p.x, p.y, p.z), j);
+    }
+    float dk2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const float m = wave_min_f32(bd[0]);
+        dk2 = m;
+        const unsigned long long who = __ballot(bd[0] == m);
+        const int first = __ffsll((long long)who) - 1;
+        if (lane == first) {                               // pop this lane's head
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) bd[i] = bd[i + 1];
+            bd[K - 1] = __uint_as_float(0x7f800000u);
+        }
+    }
+    // inclusion radius (squared), inflated for rounding: any node that can be in the k-NN of ANY voxel of
+    // the brick satisfies |n - c| <= D_k(c) + 2 r_B.
+    const float thr = (sqrtf(dk2) + g.r2x) * 1.0001f + 1e-6f;
+    const float thr2 = thr * thr;
+    // pass 2: ballot / popcount-prefix compaction in node-index order
+    uint32_t total = 0;
+    const uint32_t o = FILL ? off[b] : 0u;
+    for (int base = 0; base < M; base += 64) {
+        const int j = base + lane;
+        bool in = false;
+        if (j < M) { const float4 p = pos_sigma[j]; in = knn_dist2(c, p.x, p.y, p.z) <= thr2; }
+        const unsigned long long m = __ballot(in);
+        if (FILL && in) list[o + total + (uint32_t)__popcll(m & lane_mask_lt())] = (uint16_t)j;
+        total += (uint32_t)__popcll(m);
+    }
+    if (!FILL && lane == 0) cnt[b] = total;
+}
+
+// Exclusive scan of n counts into off[0..n] with ONE 1024-thread block (n <= a few million).
+__global__ __launch_bounds__(1024) void df_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, int n)
+{
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = t * per, e = min(b + per, n);
+    uint32_t s = 0;
+    for (int i = b; i < e; ++i) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                    // Hillis-Steele inclusive scan
+        uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0u;
+    for (int i = b; i < e; ++i) { off[i] = run; run += cnt[i]; }
+    if (t == 1023) off[n] = part[1023];
+}
+
+extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const float vol2world[12], int k, dfStream stream)
+{
+    if (!wf || !vol2world || wf->M <= 0 || k < 1 || k > 8 || wf->M < k) return DF_E_INVALID;
+    if (v.dims[0] <= 0 || v.dims[1] <= 0 || v.dims[2] <= 0) return DF_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    DfIndexGeom g;
+    g.X = v.dims[0]; g.Y = v.dims[1]; g.Z = v.dims[2];
+    g.bx = (g.X + DF_BRICK - 1) / DF_BRICK; g.by = (g.Y + DF_BRICK - 1) / DF_BRICK; g.bz = (g.Z + DF_BRICK - 1) / DF_BRICK;
+    g.vsx = v.voxel_size[0]; g.vsy = v.voxel_size[1]; g.vsz = v.voxel_size[2];
+    g.vol2world = df_aff(vol2world);
+    {   // half diagonal of the 8x8x8 lattice of voxel CENTRES under vol2world (allowing a non-orthonormal R)
+        double r = 0.0;
+        for (int sx = -1; sx <= 1; sx += 2) for (int sy = -1; sy <= 1; sy += 2) for (int sz = -1; sz <= 1; sz += 2) {
+            double ex = sx * 3.5 * g.vsx, ey = sy * 3.5 * g.vsy, ez = sz * 3.5 * g.vsz;
+            double wx = vol2world[0] * ex + vol2world[1] * ey + vol2world[2] * ez;
+            double wy = vol2world[3] * ex + vol2world[4] * ey + vol2world[5] * ez;
+            double wz = vol2world[6] * ex + vol2world[7] * ey + vol2world[8] * ez;
+            double d = sqrt(wx * wx + wy * wy + wz * wz);
+            if (d > r) r = d;
+        }
+        g.r2x = (float)(2.0 * r * 1.0001 + 1e-6);
+    }
+    const size_t nb = (size_t)g.bx * g.by * g.bz;
+    if (nb + 1 > wf->off_cap) {
+        (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); wf->brick_off = wf->brick_cnt = nullptr; wf->off_cap = 0;
+        DF_HIP(hipMalloc((void**)&wf->brick_off, (nb + 1) * sizeof(uint32_t)));
+        DF_HIP(hipMalloc((void**)&wf->brick_cnt, (nb + 1) * sizeof(uint32_t)));
+        wf->off_cap = nb + 1;
+    }
+    const dim3 grid((unsigned)((nb + 3) / 4));
+    DF_DISPATCH_K(k, df_brick_index_kernel<K, false><<<grid, dim3(256), 0, st>>>(wf->pos_sigma, wf->M, g, wf->brick_cnt,
+                                                                                 (const uint32_t*)nullptr, (uint16_t*)nullptr));
+    DF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(df_scan_kernel, dim3(1), dim3(1024), 0, st, wf->brick_cnt, wf->brick_off, (int)nb);
+    DF_LAUNCH_CHECK();
+    uint32_t total = 0;
+    DF_HIP(hipMemcpyAsync(&total, wf->brick_off + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    DF_HIP(hipStreamSynchronize(st));
+    if ((size_t)total > wf->list_cap) {
+        (void)hipFree(wf->brick_list); wf->brick_list = nullptr; wf->list_cap = 0;
+        size_t cap = (size_t)total + (size_t)total / 8 + 1024;
+        DF_HIP(hipMalloc((void**)&wf->brick_list, cap * sizeof(uint16_t)));
+        wf->list_cap = cap;
+    }
+    DF_DISPATCH_K(k, df_brick_index_kernel<K, true><<<grid, dim3(256), 0, st>>>(wf->pos_sigma, wf->M, g, (uint32_t*)nullptr,
+                                                                                (const uint32_t*)wf->brick_off, wf->brick_list));
+    DF_LAUNCH_CHECK();
+    DF_HIP(hipStreamSynchronize(st));
+    wf->bx = g.bx; wf->by = g.by; wf->bz = g.bz; wf->k_built = k;
+    memcpy(wf->geom_dims, v.dims, sizeof(wf->geom_dims));
+    memcpy(wf->geom_vs, v.voxel_size, sizeof(wf->geom_vs));
+    memcpy(wf->geom_aff, vol2world, sizeof(wf->geom_aff));
+    wf->index_valid = true;
+    return DF_OK;
+}
+
+// ====================================================================================== integrate (warped)
+struct DfWarpedArgs {
+    uint32_t* vol; int X, Y, Z;
+    int z_store0, z_own0, z_own_n;
+    int bz0;                       // first brick layer of this launch
+    float vsx, vsy, vsz;
+    DfAff vol2world, world2cam;
+    DfIntegrateParams P;
+    unsigned long long* n_upd;
+    // conservative cull (disabled when cull == null).  cull[0] = max |t_i|, cull[1] = max sin(theta_i/2)
+    // (> 1 => bound unavailable), cull[2] = max dists value of this frame; all produced on the stream, so the
+    // frame needs no host round trip.
+    const float* cull;
+    float kf;                      // (float)k
+    float brick_r;                 // half diagonal of a brick's voxel-centre lattice (world metres), inflated
+    float cam_scale;               // >= operator norm of world2cam.R (1 for a rigid pose), inflated
+};
+
+#define DF_CAND_CHUNK 256
+
+template <int K>
+__global__ __launch_bounds__(256) void df_integrate_warped_kernel(const DfWarpedArgs a, const DfWarpView W)
+{
+    __shared__ float4 s_pos[DF_CAND_CHUNK];
+    __shared__ uint16_t s_idx[DF_CAND_CHUNK];
+
+    // brick coordinates; blockIdx.x enumerates bricks x-fastest so that the 4 waves of neighbouring
+    // workgroups touch neighbouring 32-byte row segments (same 128-byte lines, same XCD L2 via b % 8
+    // striding only 8 bricks = 256 B apart).
+    const int bxx = blockIdx.x % W.bx;
+    const int byy = blockIdx.x / W.bx;
+    const int bzz = a.bz0 + blockIdx.y;
+    const int b = (bzz * W.by + byy) * W.bx + bxx;
+
+    const int t = threadIdx.x;
+    const int lx = t & 7, ly = (t >> 3) & 7, lz = t >> 6;           // lz in 0..3 ; each thread does z = lz and lz+4
+    const int x = bxx * DF_BRICK + lx, y = byy * DF_BRICK + ly;
+    const int z0 = bzz * DF_BRICK + lz, z1 = z0 + 4;
+
+    if (a.cull) {
+        // Conservative, result-identical brick rejection.  Every voxel of the brick has canonical position
+        // within brick_r of the brick centre c; its warped position is within
+        //   delta = 2 sin(theta_max/2) * (|c| + brick_r) + k * max|t_i|
+        // of its canonical one: the blend of unit quaternions with w >= 0 and weights >= 0 rotates (about the
+        // origin) by at most theta_max, and |T| = |sum w_i t_i| <= k max|t_i| because w_i = exp(-..) <= 1.
+        // So its camera-frame position lies within rho = cam_scale*(brick_r + delta) of cc = world2cam * c.
+        // No voxel of the brick can update if that ball is entirely behind the camera, entirely outside one
+        // image-frustum side plane, or entirely farther than max_dist + trunc from the camera centre.
+        const float max_t = a.cull[0], sin_half = a.cull[1], max_dist = a.cull[2];
+        if (sin_half <= 1.0f && max_t < 1.0e30f) {
+            const f3 c = aff_mul(a.vol2world, mk3(((float)(bxx * DF_BRICK) + 3.5f) * a.vsx, ((float)(byy * DF_BRICK) + 3.5f) * a.vsy,
+                                                  ((float)(bzz * DF_BRICK) + 3.5f) * a.vsz));
+            const float cn = sqrtf(dot3(c, c));
+            const float delta = 2.f * sin_half * (cn + a.brick_r) + a.kf * max_t;
+            const float rho = a.cam_scale * (a.brick_r + delta) * 1.002f + 1e-3f;
+            const f3 cc = aff_mul(a.world2cam, c);
+            bool out = false;
+            if (cc.z + rho <= 0.f) out = true;                                           // behind the camera
+            if (sqrtf(dot3(cc, cc)) - rho > max_dist * 1.002f + a.P.trunc) out = true;   // sdf < -trunc everywhere
+            // side planes through the camera centre: u >= 0 <=> fx*x + cx*z >= 0 ; u < cols <=> -fx*x + (cols-cx)*z > 0
+            const float nl = sqrtf(a.P.fx * a.P.fx + a.P.cx * a.P.cx);
+            if ((a.P.fx * cc.x + a.P.cx * cc.z) / nl < -rho) out = true;
+            const float cr = (float)a.P.cols - a.P.cx;
+            const float nr = sqrtf(a.P.fx * a.P.fx + cr * cr);
+            if ((-a.P.fx * cc.x + cr * cc.z) / nr < -rho) out = true;
+            const float nt = sqrtf(a.P.fy * a.P.fy + a.P.cy * a.P.cy);
+            if ((a.P.fy * cc.y + a.P.cy * cc.z) / nt < -rho) out = true;
+            const float cb = (float)a.P.rows - a.P.cy;
+            const float nbt = sqrtf(a.P.fy * a.P.fy + cb * cb);
+            if ((-a.P.fy * cc.y + cb * cc.z) / nbt < -rho) out = true;
+            if (out) return;                                                             // block-uniform
+        }
+    }
+
+    const bool in_xy = x < a.X && y < a.Y;
+    const bool act0 = in_xy && z0 >= a.z_own0 && z0 < a.z_own0 + a.z_own_n && z0 < a.Z;
+    const bool act1 = in_xy && z1 >= a.z_own0 && z1 < a.z_own0 + a.z_own_n && z1 < a.Z;
+
+    // canonical positions
+    const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
+    const f3 q0 = aff_mul(a.vol2world, mk3(fxv, fyv, (float)z0 * a.vsz));
+    const f3 q1 = aff_mul(a.vol2world, mk3(fxv, fyv, (float)z1 * a.vsz));
+
+    float bd0[K], bd1[K]; int bi0[K], bi1[K];
+    topk_init<K>(bd0, bi0);
+    topk_init<K>(bd1, bi1);
+
+    const uint32_t off = W.brick_off[b];
+    const uint32_t cnt = W.brick_off[b + 1] - off;
+    for (uint32_t base = 0; base < cnt; base += DF_CAND_CHUNK) {
+        const int n = (int)min((uint32_t)DF_CAND_CHUNK, cnt - base);
+        __syncthreads();
+        if (t < n) {
+            const uint16_t j = W.brick_list[off + base + t];
+            s_idx[t] = j;
+            s_pos[t] = W.pos_sigma[j];
+        }
+        __syncthreads();
+        for (int c = 0; c < n; ++c) {
+            const float4 p = s_pos[c];                 // broadcast ds_read_b128
+            const int j = s_idx[c];
+            topk_insert<K>(bd0, bi0, knn_dist2(q0, p.x, p.y, p.z), j);
+            topk_insert<K>(bd1, bi1, knn_dist2(q1, p.x, p.y, p.z), j);
+        }
+    }
+
+    unsigned int my_upd = 0;
+    const size_t plane = (size_t)a.X * a.Y;
+    if (act0) {
+        quat rot, dual;
+        dqb_blend<K>(W, bd0, bi0, &rot, &dual);
+        const f3 vc = aff_mul(a.world2cam, dq_transform(rot, dual, q0));
+        float ts;
+        if (tsdf_sample(a.P, vc, &ts)) {
+            uint32_t* p = a.vol + (size_t)(z0 - a.z_store0) * plane + (size_t)y * a.X + x;
+            *p = tsdf_fuse(*p, ts, a.P.max_weight);
+            ++my_upd;
+        }
+    }
+    if (act1) {
+        quat rot, dual;
+        dqb_blend<K>(W, bd1, bi1, &rot, &dual);
+        const f3 vc = aff_mul(a.world2cam, dq_transform(rot, dual, q1));
+        float ts;
+        if (tsdf_sample(a.P, vc, &ts)) {
+            uint32_t* p = a.vol + (size_t)(z1 - a.z_store0) * plane + (size_t)y * a.X + x;
+            *p = tsdf_fuse(*p, ts, a.P.max_weight);
+            ++my_upd;
+        }
+    }
+    if (a.n_upd) {
+        unsigned int s = my_upd;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((t & 63) == 0 && s) atomicAdd(a.n_upd, (unsigned long long)s);
+    }
+}
+
+// max dists value over the image (for the cull's depth test); `out` zeroed on the stream first.
+__global__ __launch_bounds__(256) void df_dists_max_kernel(const uint16_t* __restrict__ dists, size_t pitch, int cols, int rows,
+                                                           float* __restrict__ out)
+{
+    float m = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cols * rows; i += gridDim.x * 256) {
+        const int y = i / cols, x = i - y * cols;
+        const float d = h2f_bits(*(const uint16_t*)((const char*)dists + (size_t)y * pitch + 2 * (size_t)x));
+        if (!(d <= 3.0e38f)) m = 3.0e38f;              // inf / NaN distances: make the depth test vacuous
+        else m = fmaxf(m, d);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(m));
+}
+
+extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
+                                        const float vol2world[12], const float world2cam[12], const float proj[4],
+                                        DfWarpField* wf, int k, unsigned flags, unsigned long long* n_updated, dfStream stream)
+{
+    if (!dists || !vol2world || !world2cam || !proj || !wf || cols <= 0 || rows <= 0 || !df_volume_valid(v)) return DF_E_INVALID;
+    if (k < 1 || k > 8 || wf->M < k) return DF_E_INVALID;
+    DfSlab s = df_slab_or_full(v, slab);
+    if (!df_slab_valid(v, s)) return DF_E_INVALID;
+    if (!wf->index_valid || wf->k_built < k || memcmp(wf->geom_dims, v.dims, sizeof(wf->geom_dims)) ||
+        memcmp(wf->geom_vs, v.voxel_size, sizeof(wf->geom_vs)) || memcmp(wf->geom_aff, vol2world, sizeof(wf->geom_aff)))
+        return DF_E_NO_INDEX;
+    if (s.z_own_n == 0) return DF_OK;
+    hipStream_t st = (hipStream_t)stream;
+
+    DfWarpedArgs a;
+    a.vol = (uint32_t*)v.data; a.X = v.dims[0]; a.Y = v.dims[1]; a.Z = v.dims[2];
+    a.z_store0 = s.z_store0; a.z_own0 = s.z_own0; a.z_own_n = s.z_own_n;
+    a.vsx = v.voxel_size[0]; a.vsy = v.voxel_size[1]; a.vsz = v.voxel_size[2];
+    a.vol2world = df_aff(vol2world); a.world2cam = df_aff(world2cam);
+    a.P.dists = dists; a.P.pitch = pitch; a.P.cols = cols; a.P.rows = rows;
+    a.P.fx = proj[0]; a.P.fy = proj[1]; a.P.cx = proj[2]; a.P.cy = proj[3];
+    a.P.trunc = v.trunc_dist; a.P.trunc_inv = 1.f / v.trunc_dist; a.P.max_weight = v.max_weight;
+    a.n_upd = n_updated;
+    a.cull = nullptr; a.kf = (float)k; a.brick_r = 0.f; a.cam_scale = 1.f;
+
+    if (!(flags & DF_WARP_NO_CULL) && proj[0] > 0.f && proj[1] > 0.f) {
+        DF_HIP(hipMemsetAsync(wf->bounds_dev + 2, 0, sizeof(float), st));
+        hipLaunchKernelGGL(df_dists_max_kernel, dim3(64), dim3(256), 0, st, dists, pitch, cols, rows, wf->bounds_dev + 2);
+        DF_LAUNCH_CHECK();
+        double r = 0.0;      // half diagonal of the brick's voxel-centre lattice under vol2world
+        for (int sx = -1; sx <= 1; sx += 2) for (int sy = -1; sy <= 1; sy += 2) for (int sz = -1; sz <= 1; sz += 2) {
+            double ex = sx * 3.5 * a.vsx, ey = sy * 3.5 * a.vsy, ez = sz * 3.5 * a.vsz;
+            double wx = vol2world[0] * ex + vol2world[1] * ey + vol2world[2] * ez;
+            double wy = vol2world[3] * ex + vol2world[4] * ey + vol2world[5] * ez;
+            double wz = vol2world[6] * ex + vol2world[7] * ey + vol2world[8] * ez;
+            double d = sqrt(wx * wx + wy * wy + wz * wz);
+            if (d > r) r = d;
+        }
+        double fro = 0.0;    // Frobenius norm of world2cam.R bounds its operator norm; == sqrt(3) for a rotation
+        for (int i = 0; i < 9; ++i) fro += (double)world2cam[i] * world2cam[i];
+        fro = sqrt(fro);
+        a.cam_scale = (float)((fabs(fro - 1.7320508075688772) < 1e-3) ? 1.001 : fro * 1.001);
+        a.brick_r = (float)(r * 1.001 + 1e-6);
+        a.cull = wf->bounds_dev;
+    }
+
+    DfWarpView W = df_view(wf);
+    const int bz_lo = s.z_own0 / DF_BRICK, bz_hi = (s.z_own0 + s.z_own_n - 1) / DF_BRICK;
+    a.bz0 = bz_lo;
+    dim3 grid((unsigned)(W.bx * W.by), (unsigned)(bz_hi - bz_lo + 1));
+    DF_DISPATCH_K(k, df_integrate_warped_kernel<K><<<grid, dim3(256), 0, st>>>(a, W));
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}

@@ -1,0 +1,80 @@
+"""Z-slab sharding of the TSDF volume over the GPUs of one node (one process per GPU, RCCL via
+torch.distributed).  The reference is single-GPU; this is the only parallelism of the path
+(SURVEY.md 8e):
+
+  integrate   embarrassingly parallel per voxel: each rank updates the planes it owns; inputs (depth,
+              node transforms) are broadcast from rank 0; no exchange.
+  halo        after integrate every rank sends its H boundary planes to each Z neighbour
+              (paired isend/irecv = ncclSend/ncclRecv over one xGMI link per neighbour).
+  raycast     every rank marches ALL rays on the same global step lattice but only evaluates steps
+              whose `curr` sample lies in a plane it owns, emitting per pixel its first event key
+              (step<<1 | hit).  Merge = per-pixel MIN over ranks (all_reduce MIN on int64
+              key<<8 | rank); the winning rank's vertex/normal bits are summed to rank 0 (every other
+              rank contributes integer zero, so the result is bit-identical with the unsharded cast).
+
+The collectives go through `torch.distributed`, so the same code runs over RCCL on GPUs and over gloo
+in the world_size-2 CPU tests (tests/test_sharded_cpu.py), where a stand-in backend supplies the
+per-slab kernels.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+NO_EVENT = 0xFFFFFFFF
+
+
+def slab_range(Z, rank, world):
+    """Planes owned by `rank`: contiguous, multiples of 8 where possible (brick-aligned)."""
+    per = (Z // 8 + world - 1) // world * 8 if Z % 8 == 0 else (Z + world - 1) // world
+    lo = min(Z, rank * per)
+    hi = min(Z, lo + per)
+    return lo, hi - lo
+
+
+def halo_planes(trunc_dist, step_factor, delta_factor, voxel_z):
+    """Planes of the neighbour a slab must hold: the march's `next` sample can be one time_step beyond
+    `curr` (tsdf_volume.cu:378-380), trilinear taps read g+1 (:236-243), gradient probes reach
+    +-gradient_delta (:413-423)."""
+    return int(math.ceil(trunc_dist * step_factor / voxel_z + delta_factor)) + 2
+
+
+def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, group=None):
+    """vol_tensor: [z_store_n, Y, X] int32 (own planes + halos).  Sends own boundary planes to both Z
+    neighbours and receives theirs into the halo planes."""
+    if world == 1:
+        return
+    ops = []
+    lo_local = z_own0 - z_store0
+    if rank > 0:                       # lower neighbour: send my first `halo` own planes, receive its last ones
+        n_lo = z_own0 - z_store0       # halo planes I hold below
+        assert n_lo == halo and z_own_n >= halo, "slab thinner than the halo"
+        ops.append(dist.P2POp(dist.isend, vol_tensor[lo_local:lo_local + halo], rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, vol_tensor[0:n_lo], rank - 1, group))
+    if rank < world - 1:
+        hi_local = lo_local + z_own_n
+        n_hi = vol_tensor.shape[0] - hi_local
+        assert n_hi == halo and z_own_n >= halo, "slab thinner than the halo"
+        ops.append(dist.P2POp(dist.isend, vol_tensor[hi_local - halo:hi_local], rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, vol_tensor[hi_local:hi_local + n_hi], rank + 1, group))
+    for r in dist.batch_isend_irecv(ops):
+        r.wait()
+
+
+def merge_raycast(points, normals, keys, rank, world, dst=0, group=None):
+    """points/normals: float32 [rows, cols, 4] of THIS rank's cast; keys: int32 [rows, cols] (uint32 bits).
+    Returns (points, normals) of the merged cast on rank `dst` (None elsewhere)."""
+    if world == 1:
+        return points, normals
+    k64 = ((keys.to(torch.int64) & 0xFFFFFFFF) << 8) | rank
+    dist.all_reduce(k64, op=dist.ReduceOp.MIN, group=group)
+    none = (k64 >> 8) == NO_EVENT
+    mine = ((k64 & 0xFF) == rank) & ~none
+    buf = torch.stack([points.view(torch.int32), normals.view(torch.int32)]) * mine[None, :, :, None].to(torch.int32)
+    dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if rank != dst:
+        return None, None
+    buf[:, none] = 0x7FFFFFFF            # the reference's miss fill, quiet NaN 0x7fffffff (temp_utils.hpp:16)
+    out = buf.view(torch.float32)
+    return out[0], out[1]

@@ -1,0 +1,90 @@
+"""Host-side mirror of kfusion::WarpField over the C-ABI (node store + k-NN + DQB on the GPU).
+
+Mirrors /root/reference/kfusion/include/kfusion/warp_field.hpp:41-88 for the hot-path methods:
+init / getNodes / KNN / warp / setWarpToLive / buildKDTree (here: the GPU brick index).
+Solver-side methods (energy*, Ceres) are out of scope.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .synth import aff12, identity_dq
+from .tsdf_volume import _ptr, _stream
+
+F32 = np.float32
+KNN_NEIGHBOURS = 8           # warp_field.hpp:10 (compile-time there, runtime here)
+
+
+class WarpField:
+    def __init__(self, k=KNN_NEIGHBOURS, device="cuda"):
+        self.k = int(k)
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        capi.check(capi.lib().dfusion_warp_create(C.byref(h)), "dfusion_warp_create")
+        self.handle = h
+        self.warp_to_live_ = np.eye(4, dtype=F32)      # warp_field.cpp:26
+        self.M = 0
+        self._index_key = None
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                capi.lib().dfusion_warp_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- WarpField::init(std::vector<Vec3f>) (warp_field.cpp:68-88): identity transforms, dg_w = sigma
+    def init(self, vertices, sigma=3.0, transforms=None):
+        pos = np.ascontiguousarray(vertices, F32).reshape(-1, 3)
+        M = pos.shape[0]
+        dq = identity_dq(M) if transforms is None else np.ascontiguousarray(transforms, F32).reshape(M, 8)
+        sig = np.full(M, sigma, F32) if np.isscalar(sigma) else np.ascontiguousarray(sigma, F32).reshape(M)
+        self.set_nodes(torch.from_numpy(pos).to(self.device), torch.from_numpy(dq).to(self.device),
+                       torch.from_numpy(sig).to(self.device))
+
+    def set_nodes(self, pos_dev, dq_dev, sigma_dev):
+        self.M = int(pos_dev.shape[0])
+        self._keep = [pos_dev, dq_dev, sigma_dev]
+        capi.check(capi.lib().dfusion_warp_set_nodes(self.handle, _ptr(pos_dev), _ptr(dq_dev), _ptr(sigma_dev), self.M,
+                                                     _stream()), "dfusion_warp_set_nodes")
+        self._index_key = None
+
+    def set_transforms(self, dq_dev):
+        """What the warp optimiser writes back every frame (CombinedSolver.h:189-197)."""
+        capi.check(capi.lib().dfusion_warp_set_transforms(self.handle, _ptr(dq_dev), _stream()),
+                   "dfusion_warp_set_transforms")
+
+    def setWarpToLive(self, pose):     # warp_field.cpp:302-305
+        self.warp_to_live_ = np.asarray(pose, F32).reshape(4, 4).copy()
+
+    # ---- buildKDTree (warp_field.cpp:275-282) -> exact k-NN brick index for one volume geometry
+    def ensure_index(self, volume, k):
+        key = (volume.getDims(), tuple(volume.getVoxelSize().tolist()), volume.getPose().tobytes(), int(k))
+        if self._index_key is not None and self._index_key[:3] == key[:3] and self._index_key[3] >= k:
+            return
+        capi.check(capi.lib().dfusion_warp_build_index(self.handle, volume.c_volume(), capi.floats(aff12(volume.getPose())),
+                                                       int(k), _stream()), "dfusion_warp_build_index")
+        self._index_key = key
+
+    # ---- WarpField::KNN (warp_field.cpp:247-251), batched
+    def KNN(self, queries_dev, k=None):
+        k = self.k if k is None else k
+        n = int(queries_dev.shape[0])
+        idx = torch.empty((n, k), dtype=torch.int32, device=self.device)
+        d2 = torch.empty((n, k), dtype=torch.float32, device=self.device)
+        capi.check(capi.lib().dfusion_knn(self.handle, k, _ptr(queries_dev), n, _ptr(idx), _ptr(d2), _stream()),
+                   "dfusion_knn")
+        return idx, d2
+
+    # ---- WarpField::warp (warp_field.cpp:180-195), in place on device [N,3] tensors
+    def warp(self, points_dev, normals_dev=None, k=None):
+        k = self.k if k is None else k
+        n = int(points_dev.shape[0])
+        capi.check(capi.lib().dfusion_warp_points(self.handle, k, _ptr(points_dev),
+                                                  _ptr(normals_dev) if normals_dev is not None else None, n,
+                                                  capi.floats(aff12(self.warp_to_live_)), _stream()),
+                   "dfusion_warp_points")

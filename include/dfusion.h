@@ -1,0 +1,154 @@
+/*
+ * dfusion.h -- C-ABI of the MI355X (gfx950) DynamicFusion hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its seam is the link-time set of
+ * free functions kfusion::device::* declared in the private header
+ * /root/reference/kfusion/src/internal.hpp:104-115 and called from the public class
+ * kfusion::cuda::TsdfVolume (kfusion/src/tsdf_volume.cpp).  Every entry point below names the
+ * reference interface it replaces.  Plain C types only: raw device pointers, byte pitches,
+ * row-major float arrays; no torch / OpenCV / HIP types in any signature (a stream is an opaque
+ * void* holding a hipStream_t; NULL = the default stream).
+ *
+ * Conventions
+ *   - every function returns 0 on success, otherwise a hipError_t value or a DF_E_* code;
+ *     nothing prints, nothing calls exit() (the reference's cudaSafeCall prints and exit(0)s,
+ *     kfusion/src/safe_call.hpp:13-27; the C++ wrapper maps non-zero to kfusion::cuda::error).
+ *   - pointers named *_dev are DEVICE pointers; small parameter blocks (affines, intrinsics)
+ *     are HOST pointers read before the call returns (the reference passes them by value).
+ *   - an affine is 12 floats: R row-major [9] then t [3]  (device::Aff3f, internal.hpp:26-27,
+ *     filled by device_cast, kfusion/src/precomp.hpp:19-28).
+ *   - kernels are enqueued on `stream` and NOT synchronised (the reference's integrate ends in
+ *     cudaDeviceSynchronize, tsdf_volume.cu:160; the C++ wrapper restores that behaviour).
+ *   - no global state: any number of volumes / warp fields / streams may be used concurrently
+ *     (the reference is not re-entrant: global texture ref tsdf_volume.cu:50, host globals
+ *     warp_field.cpp:11-15).
+ */
+#ifndef DFUSION_H
+#define DFUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFUSION_ABI_VERSION 1
+
+typedef void *dfStream; /* hipStream_t */
+
+/* device::TsdfVolume, kfusion/src/internal.hpp:29-49, field for field.
+ * Voxel = ushort2 {half tsdf, u16 weight} (device.hpp:53-61); linear index
+ * x + y*dims[0] + z*dims[0]*dims[1] (device.hpp:17-18).                                      */
+typedef struct DfVolume {
+    void *data;          /* DEVICE pointer to the first STORED plane (see DfSlab)            */
+    int dims[3];         /* global voxel counts (x, y, z); dims[0] % 4 == 0                  */
+    float voxel_size[3]; /* metres                                                            */
+    float trunc_dist;    /* metres                                                            */
+    int max_weight;
+} DfVolume;
+
+/* Z-slab view for multi-GPU sharding (no reference counterpart: the reference is single-GPU).
+ * `data` holds planes [z_store0, z_store0+z_store_n) (own planes + halos); this shard integrates
+ * and owns ray steps for planes [z_own0, z_own0+z_own_n).  NULL = the whole volume.           */
+typedef struct DfSlab {
+    int z_store0, z_store_n;
+    int z_own0, z_own_n;
+} DfSlab;
+
+/* Opaque warp-field handle: device copy of the deformation nodes (WarpField::nodes_,
+ * kfusion/include/kfusion/warp_field.hpp:35-40) plus the k-NN brick index that replaces the
+ * nanoflann kd-tree (warp_field.cpp:275-282).                                                 */
+typedef struct DfWarpField DfWarpField;
+
+enum {
+    DF_OK = 0,
+    DF_E_INVALID = 100001,   /* bad argument (null pointer, dims, k not in {1..8}, M < k, ...) */
+    DF_E_NO_INDEX = 100002,  /* dfusion_warp_build_index not called for this geometry / k       */
+    DF_E_NO_DEVICE = 100003  /* no HIP device / kernel image not loadable                       */
+};
+
+/* flags for dfusion_integrate_warped */
+#define DF_WARP_NO_CULL 1u   /* disable the (result-identical) conservative brick culling     */
+
+int dfusion_abi_version(void);
+const char *dfusion_error_string(int err);
+
+/* ---- volume -------------------------------------------------------------------------------
+ * device::clear_volume (internal.hpp:105; tsdf_volume.cu:15-41): every stored voxel <- 0.     */
+int dfusion_clear(DfVolume v, const DfSlab *slab, dfStream stream);
+
+/* device::compute_dists (internal.hpp:124; kfusion/src/cuda/imgproc.cu:259-294): depth mm (u16)
+ * -> ray length in metres as IEEE-half bits.  intr = {fx, fy, cx, cy}.                         */
+int dfusion_compute_dists(const uint16_t *depth_dev, size_t depth_pitch, uint16_t *dists_dev, size_t dists_pitch,
+                          int cols, int rows, const float intr[4], dfStream stream);
+
+/* device::integrate (internal.hpp:106; tsdf_volume.cu:51-112,141-161): rigid projective TSDF
+ * update.  proj = {fx, fy, cx, cy} (device::Projector).  n_updated_dev (nullable) is
+ * INCREMENTED by the number of voxels whose update branch (tsdf_volume.cu:91) was taken.       */
+int dfusion_integrate(const uint16_t *dists_dev, size_t dists_pitch, int cols, int rows, DfVolume v,
+                      const DfSlab *slab, const float vol2cam[12], const float proj[4],
+                      unsigned long long *n_updated_dev, dfStream stream);
+
+/* device::raycast, Points variant (internal.hpp:113-114; tsdf_volume.cu:340-405,459-474).
+ * points/normals: float4 per pixel, byte pitches, misses = all-NaN.  reproj = {1/fx, 1/fy, cx,
+ * cy} (device::Reprojector, precomp.cpp:55).  keys_dev (nullable, cols*rows uint32): per-pixel
+ * first-event key (step<<1 | hit) on steps this slab owns, 0xffffffff = none (sharded merge).  */
+int dfusion_raycast_points(DfVolume v, const DfSlab *slab, const float cam2vol[12], const float Rinv[9],
+                           const float reproj[4], float *points_dev, size_t points_pitch, float *normals_dev,
+                           size_t normals_pitch, int cols, int rows, float step_factor, float delta_factor,
+                           uint32_t *keys_dev, dfStream stream);
+
+/* device::raycast, Depth variant (internal.hpp:110-111; tsdf_volume.cu:272-338,441-456).       */
+int dfusion_raycast_depth(DfVolume v, const DfSlab *slab, const float cam2vol[12], const float Rinv[9],
+                          const float reproj[4], uint16_t *depth_dev, size_t depth_pitch, float *normals_dev,
+                          size_t normals_pitch, int cols, int rows, float step_factor, float delta_factor,
+                          dfStream stream);
+
+/* ---- warp field -----------------------------------------------------------------------------
+ * WarpField::WarpField / ~WarpField (warp_field.cpp:17-34).                                    */
+int dfusion_warp_create(DfWarpField **out);
+int dfusion_warp_destroy(DfWarpField *wf);
+
+/* WarpField::init + buildKDTree (warp_field.cpp:41-88,275-282): upload M nodes.
+ *   pos_dev[M*3]   deformation_node::vertex
+ *   dq_dev[M*8]    deformation_node::transform = {rotation_ (w,x,y,z), translation_ (w,x,y,z)},
+ *                  the first 32 bytes of utils::DualQuaternion<float> (dual_quaternion.hpp:231-232)
+ *   sigma_dev[M]   deformation_node::weight (dg_w)
+ * Invalidates the k-NN index (node positions changed).                                        */
+int dfusion_warp_set_nodes(DfWarpField *wf, const float *pos_dev, const float *dq_dev, const float *sigma_dev,
+                           int M, dfStream stream);
+
+/* Per-frame transform update (what WarpFieldOptimiser writes back, CombinedSolver.h:189-197);
+ * node positions, hence the k-NN index, are unchanged.                                        */
+int dfusion_warp_set_transforms(DfWarpField *wf, const float *dq_dev, dfStream stream);
+
+/* Builds the exact k-NN acceleration index for voxel queries of this volume geometry: for each
+ * 8x8x8 brick the list of nodes that can be among the k nearest of ANY of its voxels.  Replaces
+ * the kd-tree build (warp_field.cpp:275-282).  Blocks until the index is built.               */
+int dfusion_warp_build_index(DfWarpField *wf, DfVolume geometry, const float vol2world[12], int k, dfStream stream);
+
+/* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k],
+ * ascending distance, ties -> lower node index.                                               */
+int dfusion_knn(DfWarpField *wf, int k, const float *queries_dev, int N, int *idx_dev, float *d2_dev, dfStream stream);
+
+/* WarpField::warp (warp_field.cpp:180-195) on device: points/normals [N*3] in place
+ * (normals_dev nullable); NaN points are skipped; warp_to_live = WarpField::warp_to_live_.     */
+int dfusion_warp_points(DfWarpField *wf, int k, float *points_dev, float *normals_dev, int N,
+                        const float warp_to_live[12], dfStream stream);
+
+/* The north-star kernel: per-voxel DQB (WarpField::DQB, warp_field.cpp:203-217) composed with
+ * TsdfIntegrator (tsdf_volume.cu:77-104): x_c = vol2world*voxel, x_w = DQB(x_c).transform(x_c),
+ * vc = world2cam*x_w, then the projective update.  Requires dfusion_warp_build_index.         */
+int dfusion_integrate_warped(const uint16_t *dists_dev, size_t dists_pitch, int cols, int rows, DfVolume v,
+                             const DfSlab *slab, const float vol2world[12], const float world2cam[12],
+                             const float proj[4], DfWarpField *wf, int k, unsigned flags,
+                             unsigned long long *n_updated_dev, dfStream stream);
+
+/* ---- measurement helper: plain device copy used as the MEASURED HBM roofline denominator ---- */
+int dfusion_copy_bandwidth_probe(void *dst_dev, const void *src_dev, size_t bytes, dfStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFUSION_H */

@@ -1,0 +1,284 @@
+"""GPU parity tests: the HIP path (through the C-ABI, libdfusion_hip.so) against the CPU oracle on the
+same seeded inputs.  Run on the MI355X box with `pytest -m gpu`.
+
+Bar (BASELINE.json north_star / SURVEY.md 8d):
+  * integer voxel indexing and weights: bit-exact
+  * fused TSDF: |delta| <= 1e-4 after half decode (we additionally require identical half bits on
+    >= 99.99 % of voxels and report the rest)
+  * k-NN: identical index lists and distances (no exact ties in the seeded data)
+  * ray-cast: identical hit mask, vertex |delta| <= 1e-4 m, normal |delta| <= 1e-3
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from dynamicfusion_amd import Intr, TsdfVolume, WarpField, capi, compute_dists, download_u16, synth, upload_u16
+from scene import Scene, compare_volumes, decode
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+SMALL = synth.Config(64, 1.0, cols=160, rows=120, nodes=100, k=4, name="64^3 small")
+MID = synth.Config(128, 1.0, cols=640, rows=480, nodes=500, k=8, name="128^3 mid")
+
+
+def make_gpu_volume(sc, slab=None):
+    cfg = sc.cfg
+    vol = TsdfVolume(cfg.dims, slab=slab)
+    vol.setTruncDist(cfg.trunc_dist)          # KinFu::KinFu order, kinfu.cpp:102-107
+    vol.setMaxWeight(cfg.max_weight)
+    vol.setSize([cfg.size] * 3)
+    vol.setPose(sc.pose)
+    vol.setRaycastStepFactor(cfg.raycast_step_factor)
+    vol.setGradientDeltaFactor(cfg.gradient_delta_factor)
+    assert abs(vol.getTruncDist() - sc.trunc) == 0
+    return vol
+
+
+def make_gpu_warp(sc, f=0, k=None):
+    wf = WarpField(k=k or sc.cfg.k)
+    wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[f])
+    return wf
+
+
+def assert_volume_parity(gpu_u32, ref_u32, exact=True):
+    s = compare_volumes(gpu_u32, ref_u32)
+    print("volume parity:", s)
+    assert s["weight_mismatch"] == 0 if exact else s["weight_mismatch"] <= 1e-4 * s["n"], s
+    if exact:
+        assert s["bits_mismatch"] == 0, s
+    else:
+        assert s["bits_mismatch"] <= 1e-4 * s["n"], s
+        assert s["n_dtsdf_gt_1e-4"] <= 1e-4 * s["n"], s
+    return s
+
+
+def test_library_is_the_hip_build():
+    assert capi.lib().dfusion_abi_version() == 1
+    assert torch.cuda.is_available()
+
+
+def test_compute_dists_bit_exact():
+    sc = Scene(synth.Config(64, 1.0, nodes=0), n_frames=1, with_nodes=False)
+    intr = Intr(*sc.cfg.intr)
+    d = compute_dists(upload_u16(sc.depths[0]), intr)
+    torch.cuda.synchronize()
+    assert np.array_equal(download_u16(d), sc.dists[0])
+
+
+def test_clear_zeroes_every_voxel():
+    sc = Scene(SMALL, n_frames=1, with_nodes=False)
+    vol = make_gpu_volume(sc)
+    vol.data().fill_(0x12345678)
+    vol.clear()
+    torch.cuda.synchronize()
+    assert int(vol.data().abs().max()) == 0
+
+
+@pytest.mark.parametrize("cfg", [SMALL, synth.CONFIGS["cpu128"]], ids=["64", "128"])
+def test_integrate_rigid_bit_exact(cfg):
+    sc = Scene(cfg, n_frames=3, with_nodes=False)
+    intr = Intr(*cfg.intr)
+    vol = make_gpu_volume(sc)
+    ref = sc.new_volume()
+    n_upd = torch.zeros(1, dtype=torch.int64, device="cuda")
+    n_ref = 0
+    for f in range(3):
+        vol.integrate(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, n_updated=n_upd)
+        n_ref += O.integrate(sc.dists[f], ref, sc.ovol(ref), synth.aff12(sc.vol2cam(f)), sc.intr)
+    assert_volume_parity(vol.download(), ref)
+    assert int(n_upd.item()) == n_ref
+    _, w = decode(ref)
+    assert w.max() == 3
+
+
+def test_integrate_rigid_slabs_equal_full():
+    """Z-slab sharding of the rigid sweep replays vc += zstep and is bit-identical with the full sweep."""
+    sc = Scene(SMALL, n_frames=1, with_nodes=False)
+    intr = Intr(*SMALL.intr)
+    full = make_gpu_volume(sc)
+    full.integrate(upload_u16(sc.dists[0]), sc.cam_poses[0], intr)
+    parts = []
+    Z = SMALL.dims[2]
+    for g in range(4):
+        v = make_gpu_volume(sc, slab=(g * Z // 4, Z // 4, 0))
+        v.integrate(upload_u16(sc.dists[0]), sc.cam_poses[0], intr)
+        parts.append(v.download())
+    assert np.array_equal(np.concatenate(parts, 0), full.download())
+
+
+@pytest.mark.parametrize("k", [4, 8])
+def test_knn_matches_oracle(k):
+    sc = Scene(MID, n_frames=1)
+    wf = make_gpu_warp(sc, k=k)
+    rng = np.random.RandomState(5)
+    q = rng.uniform(-0.6, 0.6, (20000, 3)).astype(F32) + np.array([0, 0, 1.0], F32)
+    idx, d2 = wf.KNN(torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    ridx, rd2 = O.knn(sc.pos, q, k)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(d2.cpu().numpy().view(np.uint32), rd2.view(np.uint32))
+
+
+def test_knn_reference_fixture_cube_corners():
+    """tests/nanoflann_test.cpp:23-49 inputs: 8 cube corners, 5 queries, k = 8; sets must agree with the
+    oracle (exact ties only differ in order, which both sides resolve by node index)."""
+    pos = np.array([[1, 1, 1], [1, 1, -1], [1, -1, 1], [1, -1, -1], [-1, 1, 1], [-1, 1, -1], [-1, -1, 1], [-1, -1, -1]], F32)
+    q = np.array([[-1, -1, -1], [0, 0, 0], [1, 1, 1], [2, 2, 2], [3, 3, 3]], F32)
+    wf = WarpField(k=8)
+    wf.init(pos, sigma=3.0)
+    idx, d2 = wf.KNN(torch.from_numpy(q).cuda(), 8)
+    ridx, rd2 = O.knn(pos, q, 8)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(d2.cpu().numpy(), rd2)
+
+
+@pytest.mark.parametrize("sigma_mode", ["spacing", "reference"])
+def test_warp_points_matches_oracle(sigma_mode):
+    sc = Scene(MID, n_frames=1, sigma_mode=sigma_mode)
+    wf = make_gpu_warp(sc)
+    rng = np.random.RandomState(6)
+    p = (rng.uniform(-0.5, 0.5, (30000, 3)) + np.array([0, 0, 1.0])).astype(F32)
+    n = rng.normal(size=(30000, 3)).astype(F32)
+    p[17] = np.nan                                       # NaN points are skipped (warp_field.cpp:185)
+    live = synth.rot_y_about(0.01, (0, 0, 1))
+    wf.setWarpToLive(live)
+    pd, nd = torch.from_numpy(p).cuda(), torch.from_numpy(n).cuda()
+    wf.warp(pd, nd)
+    torch.cuda.synchronize()
+    rp, rn = O.warp_points(sc.pos, sc.dqs[0], sc.sigma, p, n, sc.cfg.k, synth.aff12(live))
+    gp, gn = pd.cpu().numpy(), nd.cpu().numpy()
+    same = np.array_equal(gp.view(np.uint32), rp.view(np.uint32)) and np.array_equal(gn.view(np.uint32), rn.view(np.uint32))
+    m = np.isfinite(rp)
+    print("warp_points bit-identical:", same, "max |d|", np.abs(gp[m] - rp[m]).max())
+    assert np.array_equal(np.isnan(gp), np.isnan(rp))
+    assert np.abs(gp[m] - rp[m]).max() <= 1e-6
+    assert np.abs(gn[m] - rn[m]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("cfg,sigma_mode", [(SMALL, "spacing"), (SMALL, "reference"), (MID, "spacing")],
+                         ids=["64-k4", "64-k4-sigma3", "128-k8"])
+def test_integrate_warped_matches_oracle(cfg, sigma_mode):
+    sc = Scene(cfg, n_frames=2, sigma_mode=sigma_mode)
+    intr = Intr(*cfg.intr)
+    vol = make_gpu_volume(sc)
+    wf = make_gpu_warp(sc)
+    ref = sc.new_volume()
+    n_upd = torch.zeros(1, dtype=torch.int64, device="cuda")
+    n_ref = 0
+    for f in range(2):
+        wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+        vol.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, wf, n_updated=n_upd)
+        n_ref += O.integrate_warped(sc.dists[f], ref, sc.ovol(ref), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)),
+                                    sc.intr, sc.pos, sc.dqs[f], sc.sigma, cfg.k)
+    s = assert_volume_parity(vol.download(), ref, exact=False)
+    print("n_upd gpu/oracle", int(n_upd.item()), n_ref)
+    assert abs(int(n_upd.item()) - n_ref) <= 1e-4 * n_ref + s["weight_mismatch"]
+
+
+def test_integrate_warped_cull_is_result_identical():
+    sc = Scene(MID, n_frames=1)
+    intr = Intr(*MID.intr)
+    wf = make_gpu_warp(sc)
+    a, b = make_gpu_volume(sc), make_gpu_volume(sc)
+    d = upload_u16(sc.dists[0])
+    a.integrate_warped(d, sc.cam_poses[0], intr, wf, cull=True)
+    b.integrate_warped(d, sc.cam_poses[0], intr, wf, cull=False)
+    assert torch.equal(a.data(), b.data())
+
+
+def test_integrate_warped_identity_nodes_close_to_rigid():
+    """Default-constructed node transforms (dual_quaternion.hpp:25-29) give x_w == x_c exactly; the warped
+    sweep then differs from the rigid one only by direct-vs-incremental vc rounding."""
+    sc = Scene(SMALL, n_frames=1, identity_warp=True)
+    intr = Intr(*SMALL.intr)
+    wf = make_gpu_warp(sc)
+    a, b = make_gpu_volume(sc), make_gpu_volume(sc)
+    d = upload_u16(sc.dists[0])
+    a.integrate_warped(d, sc.cam_poses[0], intr, wf)
+    b.integrate(d, sc.cam_poses[0], intr)
+    s = compare_volumes(a.download(), b.download())
+    print(s)
+    assert s["weight_mismatch"] <= 2e-3 * s["n"]
+
+
+def _raycast_both(sc, vol, ref, f, want_keys=False, depth_variant=False):
+    cfg = sc.cfg
+    intr = Intr(*cfg.intr)
+    nrm = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
+    if depth_variant:
+        out = torch.empty((cfg.rows, cfg.cols), dtype=torch.int16, device="cuda")
+        vol.raycast(sc.cam_poses[f], intr, out, nrm)
+        torch.cuda.synchronize()
+        rd, rn = O.raycast_depth(sc.ovol(ref), synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.reproj, cfg.cols, cfg.rows,
+                                 cfg.raycast_step_factor, cfg.gradient_delta_factor)
+        return download_u16(out), nrm.cpu().numpy(), rd, rn
+    pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
+    keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int32, device="cuda") if want_keys else None
+    vol.raycast(sc.cam_poses[f], intr, pts, nrm, keys=keys)
+    torch.cuda.synchronize()
+    rp, rn, rk, stats = O.raycast_points(sc.ovol(ref), synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.reproj, cfg.cols, cfg.rows,
+                                         cfg.raycast_step_factor, cfg.gradient_delta_factor, want_keys=want_keys)
+    return pts.cpu().numpy(), nrm.cpu().numpy(), rp, rn, (keys.cpu().numpy().view(np.uint32) if want_keys else None), rk, stats
+
+
+def _filled(sc, frames=2):
+    """Volume integrated on the CPU (oracle), uploaded to the GPU: isolates ray-cast parity."""
+    ref = sc.new_volume()
+    for f in range(frames):
+        O.integrate(sc.dists[f], ref, sc.ovol(ref), synth.aff12(sc.vol2cam(f)), sc.intr)
+    vol = make_gpu_volume(sc)
+    vol.upload(ref)
+    return vol, ref
+
+
+@pytest.mark.parametrize("cfg", [SMALL, synth.CONFIGS["cpu128"]], ids=["64", "128"])
+def test_raycast_points_matches_oracle(cfg):
+    sc = Scene(cfg, n_frames=2, with_nodes=False)
+    vol, ref = _filled(sc)
+    gp, gn, rp, rn, gk, rk, stats = _raycast_both(sc, vol, ref, 1, want_keys=True)
+    assert stats[1] > 0.2 * cfg.cols * cfg.rows          # plenty of hits
+    assert np.array_equal(gk, rk)                        # same first event on every ray (integer: exact)
+    assert np.array_equal(np.isnan(gp), np.isnan(rp))    # identical hit/miss mask
+    m = np.isfinite(rp)
+    bit_same = np.array_equal(gp.view(np.uint32), rp.view(np.uint32)) and np.array_equal(gn.view(np.uint32), rn.view(np.uint32))
+    print("raycast bit-identical:", bit_same, "max |dv|", np.abs(gp[m] - rp[m]).max(), "max |dn|", np.abs(gn[m] - rn[m]).max())
+    assert np.abs(gp[m] - rp[m]).max() <= 1e-4
+    assert np.abs(gn[m] - rn[m]).max() <= 1e-3
+
+
+def test_raycast_depth_matches_oracle():
+    sc = Scene(SMALL, n_frames=2, with_nodes=False)
+    vol, ref = _filled(sc)
+    gd, gn, rd, rn = _raycast_both(sc, vol, ref, 1, depth_variant=True)
+    assert (rd > 0).sum() > 0.2 * rd.size
+    assert np.array_equal(gd > 0, rd > 0)
+    assert np.abs(gd.astype(np.int32) - rd.astype(np.int32)).max() <= 1
+    m = np.isfinite(rn)
+    assert np.array_equal(np.isnan(gn), np.isnan(rn))
+    assert np.abs(gn[m] - rn[m]).max() <= 1e-3
+
+
+def test_raycast_empty_volume_is_all_nan():
+    sc = Scene(SMALL, n_frames=1, with_nodes=False)
+    vol = make_gpu_volume(sc)
+    pts = torch.zeros((SMALL.rows, SMALL.cols, 4), dtype=torch.float32, device="cuda")
+    nrm = torch.zeros_like(pts)
+    vol.raycast(sc.cam_poses[0], Intr(*SMALL.intr), pts, nrm)
+    assert bool(torch.isnan(pts).all()) and bool(torch.isnan(nrm).all())
+
+
+def test_errors_are_reported_not_swallowed():
+    sc = Scene(SMALL, n_frames=1)
+    vol = make_gpu_volume(sc)
+    wf = WarpField(k=4)
+    wf.init(sc.pos[:2], sigma=1.0)                       # M < k
+    with pytest.raises(capi.DfusionError):
+        wf.KNN(torch.zeros((4, 3), device="cuda"), 4)
+    wf2 = make_gpu_warp(sc)
+    rc = capi.lib().dfusion_integrate_warped(
+        upload_u16(sc.dists[0]).data_ptr(), SMALL.cols * 2, SMALL.cols, SMALL.rows, vol.c_volume(), None,
+        capi.floats(synth.aff12(sc.pose)), capi.floats(synth.aff12(sc.world2cam(0))), Intr(*SMALL.intr).as_proj(),
+        wf2.handle, 4, 0, None, None)
+    assert rc == 100002                                  # DF_E_NO_INDEX: index not built yet

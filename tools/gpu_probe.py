@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""One-process timing sweep of the hot-path kernels (HIP events), used to pick launch variants."""
+import os, sys, json, time
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from dynamicfusion_amd import Intr, TsdfVolume, WarpField, capi, compute_dists, synth, upload_u16
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "512"
+    cfg = synth.CONFIGS[name]; intr = Intr(*cfg.intr)
+    print("config", cfg.name, torch.cuda.get_device_name(0))
+    src = torch.zeros(1 << 30, dtype=torch.uint8, device="cuda"); dst = torch.empty_like(src)
+    st = torch.cuda.current_stream().cuda_stream
+    ms = timeit(lambda: capi.check(capi.lib().dfusion_copy_bandwidth_probe(dst.data_ptr(), src.data_ptr(), 1 << 30, st)))
+    print("copy probe: %.1f GB/s (r+w)" % (2 * (1 << 30) / ms / 1e6))
+    ms = timeit(lambda: dst.copy_(src)); print("torch copy: %.1f GB/s" % (2 * (1 << 30) / ms / 1e6))
+    del src, dst
+    depth = upload_u16(synth.depth_frame(cfg, 0)); dists = compute_dists(depth, intr)
+    cam = synth.camera_pose(cfg, 1)
+    vol = TsdfVolume(cfg.dims); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setSize([cfg.size]*3); vol.setPose(cfg.volume_pose)
+    vol.setRaycastStepFactor(cfg.raycast_step_factor); vol.setGradientDeltaFactor(cfg.gradient_delta_factor)
+    nvox = np.prod(cfg.dims)
+    ms = timeit(lambda: vol.clear()); print("clear: %.3f ms  %.1f GB/s" % (ms, 4 * nvox / ms / 1e6))
+    n = torch.zeros(1, dtype=torch.int64, device="cuda")
+    vol.integrate(dists, cam, intr, n_updated=n); nupd = int(n.item()); print("rigid n_upd", nupd, nupd / nvox)
+    for unroll in (1, 2, 4):
+        for zc in (0, 16, 32, 64, 128, 512):
+            os.environ["DFUSION_RIGID_UNROLL"] = str(unroll); os.environ["DFUSION_RIGID_ZCHUNK"] = str(zc)
+            ms = timeit(lambda: vol.integrate(dists, cam, intr, sync=False))
+            print("rigid unroll=%d zchunk=%-3d : %.3f ms  alg %.0f GB/s  sweep %.0f GB/s" % (unroll, zc, ms, 8 * nupd / ms / 1e6, 8 * nvox / ms / 1e6))
+    os.environ.pop("DFUSION_RIGID_UNROLL"); os.environ.pop("DFUSION_RIGID_ZCHUNK")
+    if cfg.nodes:
+        pos, sigma = synth.make_nodes(cfg); dq = synth.node_transforms(cfg, 1)
+        wf = WarpField(k=cfg.k); wf.init(pos, sigma=sigma, transforms=dq)
+        t0 = time.time(); wf.ensure_index(vol, cfg.k); torch.cuda.synchronize(); print("index build %.3f s" % (time.time() - t0))
+        vol.clear(); n.zero_()
+        vol.integrate_warped(dists, cam, intr, wf, n_updated=n); nw = int(n.item()); print("warped n_upd", nw, nw / nvox)
+        for cull in (True, False):
+            ms = timeit(lambda: vol.integrate_warped(dists, cam, intr, wf, cull=cull, sync=False), iters=5, warm=1)
+            print("warped cull=%s : %.3f ms  alg %.0f GB/s" % (cull, ms, 8 * nw / ms / 1e6))
+    pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
+    ms = timeit(lambda: vol.raycast(cam, intr, pts, nrm)); print("raycast: %.3f ms, hits %.3f" % (ms, float(torch.isfinite(pts[..., 0]).float().mean())))
+
+if __name__ == "__main__":
+    main()
