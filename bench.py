@@ -123,7 +123,7 @@ def main():
         vol = TsdfVolume(cfg.dims, device=dev, slab=(z_own0, z_own_n, halo))
     else:
         vol = TsdfVolume(cfg.dims, device=dev)
-    vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setSize([cfg.size] * 3)
+    vol.setSize([cfg.size] * 3); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight)
     vol.setPose(cfg.volume_pose)
     vol.setRaycastStepFactor(cfg.raycast_step_factor); vol.setGradientDeltaFactor(cfg.gradient_delta_factor)
     vol.clear()
@@ -207,7 +207,7 @@ def main():
     extra = {}
     if args.rigid and world == 1:
         vol2 = TsdfVolume(cfg.dims, device=dev)
-        vol2.setTruncDist(cfg.trunc_dist); vol2.setMaxWeight(cfg.max_weight); vol2.setSize([cfg.size] * 3); vol2.setPose(cfg.volume_pose)
+        vol2.setSize([cfg.size] * 3); vol2.setTruncDist(cfg.trunc_dist); vol2.setMaxWeight(cfg.max_weight); vol2.setPose(cfg.volume_pose)
         nr = torch.zeros(1, dtype=torch.int64, device=dev)
         for f in range(2):
             vol2.integrate(dists, cam_poses[f], intr, sync=False)

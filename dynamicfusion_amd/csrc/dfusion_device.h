@@ -38,8 +38,15 @@ __device__ __forceinline__ f3 normalized3(f3 v) { float r = 1.0f / sqrtf(dot3(v,
 __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 __device__ __forceinline__ float qnanf_() { return __uint_as_float(0x7fffffffu); }   // temp_utils.hpp:16
 
-// device.hpp:53-61 : __float2half_rn / __half2float
-__device__ __forceinline__ uint32_t f2h_bits(float f) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f); }
+// device.hpp:53-61 : __float2half_rn / __half2float.
+// The empty asm pins `f` as an already-rounded f32 value: without it the gfx950 backend folds
+// fptrunc(fmul a, b) into v_fma_mixlo_f16, which rounds the EXACT product once to f16 -- a different
+// result from __float2half_rn(a * b) (double rounding) on ties (measured: 8 of 307200 dists pixels).
+__device__ __forceinline__ uint32_t f2h_bits(float f)
+{
+    asm volatile("" : "+v"(f));
+    return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f);
+}
 __device__ __forceinline__ float h2f_bits(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu)); }
 
 // ---------------------------------------------------------------- quaternion.hpp / dual_quaternion.hpp
@@ -118,7 +125,7 @@ __device__ __forceinline__ uint32_t tsdf_fuse(uint32_t vox, float tsdf, int max_
     float tsdf_prev = h2f_bits(vox);
     float tsdf_new = fmaf(tsdf_prev, (float)weight_prev, tsdf) / (float)(weight_prev + 1);
     int weight_new = min(weight_prev + 1, max_weight);
-    return f2h_bits(tsdf_new) | ((uint32_t)weight_new << 16);
+    return f2h_bits(tsdf_new) | (((uint32_t)weight_new & 0xffffu) << 16);
 }
 
 // ---------------------------------------------------------------- wave64 helpers

@@ -26,7 +26,7 @@ def main():
     del src, dst
     depth = upload_u16(synth.depth_frame(cfg, 0)); dists = compute_dists(depth, intr)
     cam = synth.camera_pose(cfg, 1)
-    vol = TsdfVolume(cfg.dims); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setSize([cfg.size]*3); vol.setPose(cfg.volume_pose)
+    vol = TsdfVolume(cfg.dims); vol.setSize([cfg.size]*3); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setPose(cfg.volume_pose)
     vol.setRaycastStepFactor(cfg.raycast_step_factor); vol.setGradientDeltaFactor(cfg.gradient_delta_factor)
     nvox = np.prod(cfg.dims)
     ms = timeit(lambda: vol.clear()); print("clear: %.3f ms  %.1f GB/s" % (ms, 4 * nvox / ms / 1e6))
