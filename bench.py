@@ -150,7 +150,7 @@ def main():
         if world > 1:                                  # rank 0 owns the sensor frame and the solver output
             if rank == 0:
                 depth_in.copy_(depths[f]); dq_in.copy_(dqs[f])
-            dist.broadcast(depth_in, 0); dist.broadcast(dq_in, 0)
+            sharded.broadcast_bytes(depth_in, 0); sharded.broadcast_bytes(dq_in, 0)
             d_in, q_in = depth_in, dq_in
         else:
             d_in, q_in = depths[f], dqs[f]

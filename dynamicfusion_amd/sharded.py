@@ -40,6 +40,12 @@ def halo_planes(trunc_dist, step_factor, delta_factor, voxel_z):
     return int(math.ceil(trunc_dist * step_factor / voxel_z + delta_factor)) + 2
 
 
+def broadcast_bytes(t, src=0, group=None):
+    """Broadcast any contiguous tensor as raw bytes (RCCL/gloo have no 16-bit integer type; the depth image
+    is uint16)."""
+    dist.broadcast(t.view(torch.uint8), src, group=group)
+
+
 def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, group=None):
     """vol_tensor: [z_store_n, Y, X] int32 (own planes + halos).  Sends own boundary planes to both Z
     neighbours and receives theirs into the halo planes."""

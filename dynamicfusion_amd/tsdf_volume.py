@@ -62,7 +62,7 @@ class TsdfVolume:
     """kfusion::cuda::TsdfVolume.  `slab=(z_own0, z_own_n, halo)` makes this object one Z-slab shard
     (own planes + `halo` planes each side, clipped to the volume) of a larger volume."""
 
-    def __init__(self, dims, device="cuda", slab=None):
+    def __init__(self, dims, device="cuda", slab=None, allocate=True):
         # ctor defaults: tsdf_volume.cpp:7-14
         self.trunc_dist_ = float(F32(0.03))
         self.max_weight_ = 128
@@ -73,6 +73,7 @@ class TsdfVolume:
         self.device = torch.device(device)
         self.slab_ = slab
         self.data_ = None
+        self.allocate_ = allocate      # False: host parameter object only (no device blob; compute calls raise)
         self.create(dims)
 
     # ---- tsdf_volume.cpp:32-39
@@ -87,9 +88,10 @@ class TsdfVolume:
             z_own0, z_own_n, halo = self.slab_
             lo, hi = max(0, z_own0 - halo), min(Z, z_own0 + z_own_n + halo)
             self.z_store0, self.z_store_n, self.z_own0, self.z_own_n = lo, hi - lo, z_own0, z_own_n
-        self.data_ = torch.empty((self.z_store_n, Y, X), dtype=torch.int32, device=self.device)
         self.setTruncDist(self.trunc_dist_)
-        self.clear()
+        if self.allocate_:
+            self.data_ = torch.empty((self.z_store_n, Y, X), dtype=torch.int32, device=self.device)
+            self.clear()
 
     def getDims(self):
         return self.dims_
@@ -148,6 +150,8 @@ class TsdfVolume:
 
     # ---- C-ABI views
     def c_volume(self):
+        if self.data_ is None:
+            raise capi.DfusionError("TsdfVolume has no device blob (allocate=False)")
         v = capi.DfVolume()
         v.data = self.data_.data_ptr()
         v.dims[:] = self.dims_
