@@ -139,6 +139,7 @@ def main():
     pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev)
     nrm = torch.empty_like(pts)
     keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int32, device=dev) if world > 1 else None
+    vertex = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev) if world > 1 else None
     depth_in = torch.empty_like(depths[0])
     dq_in = torch.empty_like(dqs[0])
 
@@ -161,11 +162,15 @@ def main():
         if timed_idx is not None: ev[timed_idx][1].record()
         if world > 1:
             sharded.exchange_halos(vol.data(), vol.z_store0, vol.z_own0, vol.z_own_n, Z, halo, rank, world)
-        vol.raycast(cam_poses[f], intr, pts, nrm, keys=keys)
-        if timed_idx is not None: ev[timed_idx][2].record()
         if world > 1:
-            return sharded.merge_raycast(pts, nrm, keys, rank, world)
-        return pts, nrm
+            out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, vertex),
+                                          lambda mk, vx: vol.raycast_shade(cam_poses[f], intr, vx.contiguous(), mk.contiguous(), pts, nrm),
+                                          rank, world)
+        else:
+            vol.raycast(cam_poses[f], intr, pts, nrm)
+            out = (pts, nrm)
+        if timed_idx is not None: ev[timed_idx][2].record()
+        return out
 
     def barrier():
         if world > 1:

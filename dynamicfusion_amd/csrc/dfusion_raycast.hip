@@ -75,27 +75,20 @@ __device__ __forceinline__ f3 rc_normal(const DfRayArgs& a, f3 p)
     return normalized3(n);
 }
 
-template <int MODE /* 0 = Points (tsdf_volume.cu:340-405), 1 = Depth (:272-338) */>
-__global__ __launch_bounds__(256) void df_raycast_kernel(const DfRayArgs a)
-{
-    // XCD-aware, bijective renumbering: hardware block id b runs on XCD b % 8; give each XCD a contiguous
-    // run of logical tiles (row-major), i.e. a horizontal band of the image.
-    const int nwg = a.tiles_x * a.tiles_y;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int ty = wg / a.tiles_x, tx = wg - ty * a.tiles_x;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = tx * 16 + (w & 1) * 8 + (lane & 7);
-    const int y = ty * 16 + (w >> 1) * 8 + (lane >> 3);
-    if (x >= a.cols || y >= a.rows) return;
+// ---- the three stages of one ray: march (first event), locate (zero-crossing refinement), shade (normal).
+struct DfRayHit { uint32_t key; bool hit; float t_hit; f3 p_curr, p_next, org, dir; };
 
-    const float qn = qnanf_();
-    const f3 org = mk3(a.aff.t[0], a.aff.t[1], a.aff.t[2]);
+// :353-404 minus the refinement: first event on a step this slab owns.
+__device__ __forceinline__ DfRayHit rc_march(const DfRayArgs& a, int x, int y)
+{
+    DfRayHit h;
+    h.key = 0xffffffffu; h.hit = false; h.t_hit = 0.f;
+    h.org = mk3(a.aff.t[0], a.aff.t[1], a.aff.t[2]);
     // device.hpp:43-48 with z = 1.f
     const f3 rp = mk3(1.f * ((float)x - a.cx) * a.finvx, 1.f * ((float)y - a.cy) * a.finvy, 1.f);
-    const f3 dir = normalized3(mat3_mul(a.aff.R, rp));                                // :354
-    const f3 vsi = mk3(a.vsix, a.vsiy, a.vsiz);
+    h.dir = normalized3(mat3_mul(a.aff.R, rp));                                       // :354
+    h.p_curr = h.org; h.p_next = h.org;
+    const f3 org = h.org, dir = h.dir;
 
     // intersect, :202-218, box [0, volume_size - voxel_size] (:359)
     float tmin, tmax;
@@ -110,61 +103,130 @@ __global__ __launch_bounds__(256) void df_raycast_kernel(const DfRayArgs a)
         tmax = fminf(fminf(tmx.x, tmx.y), fminf(tmx.x, tmx.z));
     }
     tmin = fmaxf(0.f, tmin);                                                          // :364-365
-
-    uint32_t key = 0xffffffffu;
-    bool hit = false;
-    float t_hit = 0.f;
-    f3 p_curr = org, p_next = org;
-
-    if (tmin < tmax) {                                                                // :366
-        tmax -= a.time_step;                                                          // :369
-        const f3 vstep = scale3(dir, a.time_step);
-        f3 next = add3(org, scale3(dir, tmin));
-        // fetch_tsdf, :262-270 (__float2int_rn == rint, round-half-even)
-        int zn = (int)rintf(next.z * a.vsiz);
-        float tsdf_next = rc_vox(a, (int)rintf(next.x * a.vsix), (int)rintf(next.y * a.vsiy), zn);   // :373
-        uint32_t k = 0;
-        for (float tcurr = tmin; tcurr < tmax; tcurr += a.time_step, ++k) {           // :374
-            const float tsdf_curr = tsdf_next;
-            const f3 curr = next;
-            const int zc = zn;
-            next = add3(next, vstep);
-            zn = (int)rintf(next.z * a.vsiz);
-            const bool own_c = zc >= a.z_own0 && zc < a.z_own1;
-            // the sample is needed as `next` of this step or as `curr` of the following one
-            if (own_c || (zn >= a.z_own0 && zn < a.z_own1))
-                tsdf_next = rc_vox(a, (int)rintf(next.x * a.vsix), (int)rintf(next.y * a.vsiy), zn);   // :380
-            if (!own_c) continue;                                                     // another slab's step
-            if (tsdf_curr < 0.f && tsdf_next > 0.f) { key = k << 1; break; }          // :381
-            if (tsdf_curr > 0.f && tsdf_next < 0.f) {                                 // :384
-                key = (k << 1) | 1u; hit = true; t_hit = tcurr; p_curr = curr; p_next = next;
-                break;
-            }
+    if (!(tmin < tmax)) return h;                                                     // :366
+    tmax -= a.time_step;                                                              // :369
+    const f3 vstep = scale3(dir, a.time_step);
+    f3 next = add3(org, scale3(dir, tmin));
+    // fetch_tsdf, :262-270 (__float2int_rn == rint, round-half-even)
+    int zn = (int)rintf(next.z * a.vsiz);
+    float tsdf_next = rc_vox(a, (int)rintf(next.x * a.vsix), (int)rintf(next.y * a.vsiy), zn);   // :373
+    uint32_t k = 0;
+    for (float tcurr = tmin; tcurr < tmax; tcurr += a.time_step, ++k) {               // :374
+        const float tsdf_curr = tsdf_next;
+        const f3 curr = next;
+        const int zc = zn;
+        next = add3(next, vstep);
+        zn = (int)rintf(next.z * a.vsiz);
+        const bool own_c = zc >= a.z_own0 && zc < a.z_own1;
+        // the sample is needed as `next` of this step or as `curr` of the following one
+        if (own_c || (zn >= a.z_own0 && zn < a.z_own1))
+            tsdf_next = rc_vox(a, (int)rintf(next.x * a.vsix), (int)rintf(next.y * a.vsiy), zn);   // :380
+        if (!own_c) continue;                                                         // another slab's step
+        if (tsdf_curr < 0.f && tsdf_next > 0.f) { h.key = k << 1; break; }            // :381
+        if (tsdf_curr > 0.f && tsdf_next < 0.f) {                                     // :384
+            h.key = (k << 1) | 1u; h.hit = true; h.t_hit = tcurr; h.p_curr = curr; h.p_next = next;
+            break;
         }
     }
+    return h;
+}
 
+// :386-391 : vertex (volume frame) of a hit.  Reads only the trilinear neighbourhoods of curr and next.
+__device__ __forceinline__ f3 rc_locate(const DfRayArgs& a, const DfRayHit& h)
+{
+    const f3 vsi = mk3(a.vsix, a.vsiy, a.vsiz);
+    const float Ft = rc_interpolate(a, mul3(h.p_curr, vsi));                          // :386
+    const float Ftdt = rc_interpolate(a, mul3(h.p_next, vsi));                        // :387
+    const float Ts = h.t_hit - (a.time_step * Ft) / (Ftdt - Ft);                      // :389  (may extrapolate far!)
+    return add3(h.org, scale3(h.dir, Ts));
+}
+
+// :392-401 : normal at the vertex, validity test, camera-frame outputs.
+__device__ __forceinline__ bool rc_shade(const DfRayArgs& a, f3 vertex, float4* out_p, float4* out_n, uint16_t* out_d)
+{
+    const f3 normal = rc_normal(a, vertex);
+    const float chk = normal.x * normal.y * normal.z;
+    if (!(chk == chk)) return false;                                                  // :394 !isnan
+    const f3 org = mk3(a.aff.t[0], a.aff.t[1], a.aff.t[2]);
+    const f3 n = mat3_mul(a.Rinv, normal);
+    const f3 v = mat3_mul(a.Rinv, sub3(vertex, org));
+    *out_n = make_float4(n.x, n.y, n.z, 0.f);
+    *out_p = make_float4(v.x, v.y, v.z, 0.f);
+    const float mm = v.z * 1000;                                                      // :333
+    *out_d = (uint16_t)(mm <= 0.f ? 0 : (mm >= 65535.f ? 65535 : (int)mm));
+    return true;
+}
+
+// pixel of this thread: a wave64 owns an 8x8 tile, a workgroup 16x16; XCD-aware, bijective renumbering:
+// hardware block id b runs on XCD b % 8; each XCD gets a contiguous run of logical tiles (row-major).
+__device__ __forceinline__ bool rc_pixel(const DfRayArgs& a, int* px, int* py)
+{
+    const int nwg = a.tiles_x * a.tiles_y;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int ty = wg / a.tiles_x, tx = wg - ty * a.tiles_x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    *px = tx * 16 + (w & 1) * 8 + (lane & 7);
+    *py = ty * 16 + (w >> 1) * 8 + (lane >> 3);
+    return *px < a.cols && *py < a.rows;
+}
+
+template <int MODE /* 0 = Points (tsdf_volume.cu:340-405), 1 = Depth (:272-338) */>
+__global__ __launch_bounds__(256) void df_raycast_kernel(const DfRayArgs a)
+{
+    int x, y;
+    if (!rc_pixel(a, &x, &y)) return;
+    const float qn = qnanf_();
+    const DfRayHit h = rc_march(a, x, y);
     float4 out_p = make_float4(qn, qn, qn, qn), out_n = make_float4(qn, qn, qn, qn);   // :351
     uint16_t out_d = 0;                                                               // :283
-    if (hit) {                                                                        // refinement, wave reconverged
-        const float Ft = rc_interpolate(a, mul3(p_curr, vsi));                        // :386
-        const float Ftdt = rc_interpolate(a, mul3(p_next, vsi));                      // :387
-        const float Ts = t_hit - (a.time_step * Ft) / (Ftdt - Ft);                    // :389
-        const f3 vertex = add3(org, scale3(dir, Ts));
-        const f3 normal = rc_normal(a, vertex);
-        const float chk = normal.x * normal.y * normal.z;
-        if (chk == chk) {                                                             // :394 !isnan
-            const f3 n = mat3_mul(a.Rinv, normal);
-            const f3 v = mat3_mul(a.Rinv, sub3(vertex, org));
-            out_n = make_float4(n.x, n.y, n.z, 0.f);
-            out_p = make_float4(v.x, v.y, v.z, 0.f);
-            const float mm = v.z * 1000;                                              // :333
-            out_d = (uint16_t)(mm <= 0.f ? 0 : (mm >= 65535.f ? 65535 : (int)mm));
-        }
-    }
+    if (h.hit) rc_shade(a, rc_locate(a, h), &out_p, &out_n, &out_d);                   // refinement after the loop: wave reconverged
     *reinterpret_cast<float4*>((char*)a.nrm + (size_t)y * a.npitch + 16 * (size_t)x) = out_n;
     if (MODE == 0) *reinterpret_cast<float4*>((char*)a.pts + (size_t)y * a.ppitch + 16 * (size_t)x) = out_p;
     else *reinterpret_cast<uint16_t*>((char*)a.depth + (size_t)y * a.dpitch + 2 * (size_t)x) = out_d;
-    if (a.keys) a.keys[(size_t)y * a.cols + x] = key;
+    if (a.keys) a.keys[(size_t)y * a.cols + x] = h.key;
+}
+
+// ---- sharded cast, stage 1: first event on owned steps + located vertex (volume frame) of hits.
+__global__ __launch_bounds__(256) void df_raycast_march_kernel(const DfRayArgs a, float4* __restrict__ vertex)
+{
+    int x, y;
+    if (!rc_pixel(a, &x, &y)) return;
+    const DfRayHit h = rc_march(a, x, y);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h.hit) { const f3 p = rc_locate(a, h); v = make_float4(p.x, p.y, p.z, 0.f); }
+    vertex[(size_t)y * a.cols + x] = v;
+    a.keys[(size_t)y * a.cols + x] = h.key;
+}
+
+// ---- sharded cast, stage 2: after the per-pixel MIN merge of keys and the broadcast of the winners' vertices,
+// the slab that owns the vertex' plane computes the normal.  Pixels this slab does not resolve get all-zero
+// bits (the host sums integer views across ranks); resolved misses get the reference's NaN fill.
+__global__ __launch_bounds__(256) void df_raycast_shade_kernel(const DfRayArgs a, const float4* __restrict__ vertex,
+                                                               const uint32_t* __restrict__ merged_keys)
+{
+    int x, y;
+    if (!rc_pixel(a, &x, &y)) return;
+    const uint32_t key = merged_keys[(size_t)y * a.cols + x];
+    const float qn = qnanf_();
+    float4 out_p = make_float4(0.f, 0.f, 0.f, 0.f), out_n = out_p;
+    if (key != 0xffffffffu && (key & 1u)) {
+        const float4 v4 = vertex[(size_t)y * a.cols + x];
+        const f3 v = mk3(v4.x, v4.y, v4.z);
+        // owner of the vertex: the slab holding its nearest plane (clamped into the volume; NaN -> plane 0)
+        float zf = rintf(v.z * a.vsiz);
+        int pz = (zf == zf) ? (int)fminf(fmaxf(zf, 0.f), (float)(a.Z - 1)) : 0;
+        if (pz >= a.z_own0 && pz < a.z_own1) {
+            out_p = make_float4(qn, qn, qn, qn); out_n = out_p;
+            uint16_t d;
+            rc_shade(a, v, &out_p, &out_n, &d);
+        }
+    } else if (a.z_own0 == 0) {                       // misses / back-face breaks: filled once, by the slab owning plane 0
+        out_p = make_float4(qn, qn, qn, qn); out_n = out_p;
+    }
+    *reinterpret_cast<float4*>((char*)a.nrm + (size_t)y * a.npitch + 16 * (size_t)x) = out_n;
+    *reinterpret_cast<float4*>((char*)a.pts + (size_t)y * a.ppitch + 16 * (size_t)x) = out_p;
 }
 
 static int df_raycast_setup(DfRayArgs& a, const DfVolume& v, const DfSlab* slab, const float cam2vol[12], const float Rinv[9],
@@ -213,6 +275,37 @@ extern "C" int dfusion_raycast_depth(DfVolume v, const DfSlab* slab, const float
     if (rc) return rc;
     a.depth = depth; a.dpitch = dpitch; a.nrm = normals; a.npitch = npitch;
     hipLaunchKernelGGL(df_raycast_kernel<1>, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+// ---- sharded (Z-slab) cast in two stages; no reference counterpart (the reference is single-GPU).
+extern "C" int dfusion_raycast_march(DfVolume v, const DfSlab* slab, const float cam2vol[12], const float reproj[4], int cols,
+                                     int rows, float step_factor, uint32_t* keys, float* vertex, dfStream stream)
+{
+    if (!keys || !vertex) return DF_E_INVALID;
+    DfRayArgs a;
+    const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    int rc = df_raycast_setup(a, v, slab, cam2vol, ident, reproj, cols, rows, step_factor, 0.5f);
+    if (rc) return rc;
+    a.keys = keys;
+    hipLaunchKernelGGL(df_raycast_march_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, (float4*)vertex);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+extern "C" int dfusion_raycast_shade(DfVolume v, const DfSlab* slab, const float cam2vol[12], const float Rinv[9],
+                                     const float reproj[4], const float* vertex, const uint32_t* merged_keys, float* points,
+                                     size_t ppitch, float* normals, size_t npitch, int cols, int rows, float delta_factor,
+                                     dfStream stream)
+{
+    if (!vertex || !merged_keys || !points || !normals) return DF_E_INVALID;
+    DfRayArgs a;
+    int rc = df_raycast_setup(a, v, slab, cam2vol, Rinv, reproj, cols, rows, 0.75f, delta_factor);
+    if (rc) return rc;
+    a.pts = points; a.ppitch = ppitch; a.nrm = normals; a.npitch = npitch;
+    hipLaunchKernelGGL(df_raycast_shade_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a,
+                       (const float4*)vertex, merged_keys);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }

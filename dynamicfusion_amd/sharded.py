@@ -8,9 +8,12 @@ torch.distributed).  The reference is single-GPU; this is the only parallelism o
               (paired isend/irecv = ncclSend/ncclRecv over one xGMI link per neighbour).
   raycast     every rank marches ALL rays on the same global step lattice but only evaluates steps
               whose `curr` sample lies in a plane it owns, emitting per pixel its first event key
-              (step<<1 | hit).  Merge = per-pixel MIN over ranks (all_reduce MIN on int64
-              key<<8 | rank); the winning rank's vertex/normal bits are summed to rank 0 (every other
-              rank contributes integer zero, so the result is bit-identical with the unsharded cast).
+              (step<<1 | hit) and, for hits, the located vertex.  Merge = per-pixel MIN over ranks
+              (all_reduce MIN on int64 key<<8 | rank) + broadcast of the winner's vertex bits; the
+              zero-crossing refinement can extrapolate the vertex into ANOTHER rank's slab
+              (tsdf_volume.cu:389), so the normal is computed by the rank that owns the vertex and the
+              final point/normal bits are summed to rank 0 (every other rank contributes integer zero:
+              bit-identical with the unsharded cast).
 
 The collectives go through `torch.distributed`, so the same code runs over RCCL on GPUs and over gloo
 in the world_size-2 CPU tests (tests/test_sharded_cpu.py), where a stand-in backend supplies the
@@ -68,19 +71,29 @@ def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, 
         r.wait()
 
 
-def merge_raycast(points, normals, keys, rank, world, dst=0, group=None):
-    """points/normals: float32 [rows, cols, 4] of THIS rank's cast; keys: int32 [rows, cols] (uint32 bits).
-    Returns (points, normals) of the merged cast on rank `dst` (None elsewhere)."""
+def raycast_sharded(march_fn, shade_fn, rank, world, dst=0, group=None):
+    """Two-stage sharded ray-cast (see include/dfusion.h, dfusion_raycast_march / _shade).
+
+    march_fn() -> (keys int32 [rows, cols] (uint32 bits), vertex float32 [rows, cols, 4]) of THIS rank's slab;
+    shade_fn(merged_keys int32, vertex float32) -> (points, normals) float32 [rows, cols, 4], all-zero bits for
+    pixels this slab does not resolve.  Returns the merged (points, normals) on rank `dst`, (None, None) elsewhere.
+
+    Collectives per frame: all_reduce(MIN) of int64 keys (2.4 MB at 640x480), all_reduce(SUM) of the winners'
+    vertex bits (4.9 MB), reduce(SUM) of the final point/normal bits (9.8 MB) -- every summand but one is integer
+    zero, so the result is bit-identical with the unsharded cast."""
+    keys, vertex = march_fn()
     if world == 1:
-        return points, normals
+        return shade_fn(keys, vertex)
     k64 = ((keys.to(torch.int64) & 0xFFFFFFFF) << 8) | rank
     dist.all_reduce(k64, op=dist.ReduceOp.MIN, group=group)
-    none = (k64 >> 8) == NO_EVENT
-    mine = ((k64 & 0xFF) == rank) & ~none
-    buf = torch.stack([points.view(torch.int32), normals.view(torch.int32)]) * mine[None, :, :, None].to(torch.int32)
+    mine = (k64 & 0xFF) == rank
+    vbits = vertex.view(torch.int32) * mine[:, :, None].to(torch.int32)
+    dist.all_reduce(vbits, op=dist.ReduceOp.SUM, group=group)
+    merged = (k64 >> 8).to(torch.int32)                       # uint32 bits (0xffffffff wraps to -1)
+    pts, nrm = shade_fn(merged, vbits.view(torch.float32))
+    buf = torch.stack([pts.view(torch.int32), nrm.view(torch.int32)])
     dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM, group=group)
     if rank != dst:
         return None, None
-    buf[:, none] = 0x7FFFFFFF            # the reference's miss fill, quiet NaN 0x7fffffff (temp_utils.hpp:16)
     out = buf.view(torch.float32)
     return out[0], out[1]

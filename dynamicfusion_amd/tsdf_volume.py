@@ -216,6 +216,24 @@ class TsdfVolume:
                                                self.raycast_step_factor_, self.gradient_delta_factor_, _stream()),
                        "dfusion_raycast_depth")
 
+    # ---- Z-slab two-stage cast (dfusion_raycast_march / dfusion_raycast_shade; no reference counterpart)
+    def raycast_march(self, camera_pose, intr, keys, vertex):
+        aff, _ = self._raycast_args(camera_pose)
+        rows, cols = keys.shape
+        capi.check(capi.lib().dfusion_raycast_march(self.c_volume(), self.c_slab(), aff, intr.as_reproj(), cols, rows,
+                                                    self.raycast_step_factor_, _ptr(keys), _ptr(vertex), _stream()),
+                   "dfusion_raycast_march")
+        return keys, vertex
+
+    def raycast_shade(self, camera_pose, intr, vertex, merged_keys, points, normals):
+        aff, Rinv = self._raycast_args(camera_pose)
+        rows, cols = merged_keys.shape
+        capi.check(capi.lib().dfusion_raycast_shade(self.c_volume(), self.c_slab(), aff, Rinv, intr.as_reproj(),
+                                                    _ptr(vertex), _ptr(merged_keys), _ptr(points), cols * 16,
+                                                    _ptr(normals), cols * 16, cols, rows, self.gradient_delta_factor_,
+                                                    _stream()), "dfusion_raycast_shade")
+        return points, normals
+
     # ---- convenience for tests
     def download(self):
         """uint32 numpy [z_store_n, Y, X] : lo16 = half tsdf bits, hi16 = weight."""

@@ -105,6 +105,21 @@ int dfusion_raycast_depth(DfVolume v, const DfSlab *slab, const float cam2vol[12
                           size_t normals_pitch, int cols, int rows, float step_factor, float delta_factor,
                           dfStream stream);
 
+/* Z-slab (multi-GPU) cast in two stages; no reference counterpart.  The zero-crossing refinement
+ * Ts = t - step*Ft/(Ftdt-Ft) (tsdf_volume.cu:389) may EXTRAPOLATE arbitrarily far along the ray, so the
+ * vertex of a hit can lie in another GPU's slab: stage 1 finds, on the steps this slab owns, the first
+ * event key and (for hits) the located vertex in the VOLUME frame (float4 per pixel, zeros otherwise);
+ * the host MIN-merges the keys and broadcasts the winners' vertices; stage 2 lets the slab that owns the
+ * vertex' nearest plane compute the normal (needs a 2-plane halo) and write the final camera-frame
+ * point/normal.  Pixels a slab does not resolve are written as all-zero BITS (the slab owning plane 0
+ * writes the NaN fill of misses), so integer-summing the slabs' outputs equals the unsharded cast.      */
+int dfusion_raycast_march(DfVolume v, const DfSlab *slab, const float cam2vol[12], const float reproj[4], int cols,
+                          int rows, float step_factor, uint32_t *keys_dev, float *vertex_dev, dfStream stream);
+int dfusion_raycast_shade(DfVolume v, const DfSlab *slab, const float cam2vol[12], const float Rinv[9],
+                          const float reproj[4], const float *vertex_dev, const uint32_t *merged_keys_dev,
+                          float *points_dev, size_t points_pitch, float *normals_dev, size_t normals_pitch, int cols,
+                          int rows, float delta_factor, dfStream stream);
+
 /* ---- warp field -----------------------------------------------------------------------------
  * WarpField::WarpField / ~WarpField (warp_field.cpp:17-34).                                    */
 int dfusion_warp_create(DfWarpField **out);

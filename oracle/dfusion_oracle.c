@@ -486,22 +486,24 @@ static inline void intersect(f3 org, f3 dir, f3 box_max, float *tnear, float *tf
 }
 
 #define ORC_RC_NO_EVENT 0xffffffffu
-/* One ray.  Returns the event key: (step index k << 1) | kind, kind 1 = +->- hit, 0 = -->+ break;
- * ORC_RC_NO_EVENT if no event on a step this slab owns.  A step is owned when the nearest-voxel
- * plane of its `curr` sample lies in [z_own0, z_own0+z_own_n).  On a hit with a finite normal,
- * vertex/normal (camera frame, :394-401) are written and *valid = 1.                          */
-static inline uint32_t cast_ray(const rc_ctx *c, const float aff[12], const float Rinv[9], const float reproj[4],
-                                int x, int y, f3 *vertex_out, f3 *normal_out, int *valid, uint32_t *n_steps)
+typedef struct { uint32_t key; int hit; float t_hit; f3 p_curr, p_next, org, dir; uint32_t n_steps; } rc_hit;
+
+/* One ray, stage 1 (march): the event key is (step index k << 1) | kind, kind 1 = +->- hit, 0 = -->+ break;
+ * ORC_RC_NO_EVENT if no event on a step this slab owns.  A step is owned when the nearest-voxel plane of its
+ * `curr` sample lies in [z_own0, z_own0+z_own_n).                                                      */
+static inline rc_hit ray_march(const rc_ctx *c, const float aff[12], const float reproj[4], int x, int y)
 {
-    *valid = 0; if (n_steps) *n_steps = 0;
-    const f3 org = mk3(aff[9], aff[10], aff[11]);
+    rc_hit h; h.key = ORC_RC_NO_EVENT; h.hit = 0; h.t_hit = 0.f; h.n_steps = 0;
+    h.org = mk3(aff[9], aff[10], aff[11]);
     /* device.hpp:43-48 : x = z*(u-cx)*finvx with z = 1.f */
     f3 rp = mk3(1.f * ((float)x - reproj[2]) * reproj[0], 1.f * ((float)y - reproj[3]) * reproj[1], 1.f);
-    f3 dir = normalized3(mat3_mul(aff, rp));                                   /* :354 */
+    h.dir = normalized3(mat3_mul(aff, rp));                                    /* :354 */
+    h.p_curr = h.org; h.p_next = h.org;
+    const f3 org = h.org, dir = h.dir;
     f3 box_max = sub3(c->volume_size, c->vs);                                  /* :359 */
     float tmin, tmax; intersect(org, dir, box_max, &tmin, &tmax);
     tmin = fmaxf(0.f, tmin);                                                   /* :364-365 */
-    if (tmin >= tmax) return ORC_RC_NO_EVENT;                                  /* :366 */
+    if (!(tmin < tmax)) return h;                                              /* :366 */
     tmax -= c->time_step;                                                      /* :369 */
     f3 vstep = scale3(dir, c->time_step);
     f3 next = add3(org, scale3(dir, tmin));
@@ -512,23 +514,40 @@ static inline uint32_t cast_ray(const rc_ctx *c, const float aff[12], const floa
         next = add3(next, vstep);
         tsdf_next = fetch_tsdf(c, next, &zn);                                  /* :380 */
         if (zc < c->s.z_own0 || zc >= c->s.z_own0 + c->s.z_own_n) continue;   /* not this slab's step */
-        if (n_steps) ++*n_steps;
-        if (tsdf_curr < 0.f && tsdf_next > 0.f) return (k << 1) | 0u;          /* :381 */
+        ++h.n_steps;
+        if (tsdf_curr < 0.f && tsdf_next > 0.f) { h.key = (k << 1) | 0u; return h; }   /* :381 */
         if (tsdf_curr > 0.f && tsdf_next < 0.f) {                              /* :384 */
-            float Ft = interpolate(c, mul3(curr, c->vsi));
-            float Ftdt = interpolate(c, mul3(next, c->vsi));
-            float Ts = tcurr - (c->time_step * Ft) / (Ftdt - Ft);              /* :389 */
-            f3 vertex = add3(org, scale3(dir, Ts));
-            f3 normal = compute_normal(c, vertex);
-            if (!isnan(normal.x * normal.y * normal.z)) {                      /* :394 */
-                *normal_out = mat3_mul(Rinv, normal);
-                *vertex_out = mat3_mul(Rinv, sub3(vertex, org));
-                *valid = 1;
-            }
-            return (k << 1) | 1u;
+            h.key = (k << 1) | 1u; h.hit = 1; h.t_hit = tcurr; h.p_curr = curr; h.p_next = next;
+            return h;
         }
     }
-    return ORC_RC_NO_EVENT;
+    return h;
+}
+/* stage 2 (locate), :386-391 : vertex in the volume frame.  Ts may extrapolate far beyond [curr, next]. */
+static inline f3 ray_locate(const rc_ctx *c, const rc_hit *h)
+{
+    float Ft = interpolate(c, mul3(h->p_curr, c->vsi));
+    float Ftdt = interpolate(c, mul3(h->p_next, c->vsi));
+    float Ts = h->t_hit - (c->time_step * Ft) / (Ftdt - Ft);                   /* :389 */
+    return add3(h->org, scale3(h->dir, Ts));
+}
+/* stage 3 (shade), :392-401 : normal at the vertex; camera-frame outputs if the normal is finite. */
+static inline int ray_shade(const rc_ctx *c, const float aff[12], const float Rinv[9], f3 vertex, f3 *vertex_out, f3 *normal_out)
+{
+    f3 normal = compute_normal(c, vertex);
+    if (isnan(normal.x * normal.y * normal.z)) return 0;                       /* :394 */
+    *normal_out = mat3_mul(Rinv, normal);
+    *vertex_out = mat3_mul(Rinv, sub3(vertex, mk3(aff[9], aff[10], aff[11])));
+    return 1;
+}
+static inline uint32_t cast_ray(const rc_ctx *c, const float aff[12], const float Rinv[9], const float reproj[4],
+                                int x, int y, f3 *vertex_out, f3 *normal_out, int *valid, uint32_t *n_steps)
+{
+    rc_hit h = ray_march(c, aff, reproj, x, y);
+    *valid = 0;
+    if (n_steps) *n_steps = h.n_steps;
+    if (h.hit) *valid = ray_shade(c, aff, Rinv, ray_locate(c, &h), vertex_out, normal_out);
+    return h.key;
 }
 
 static void rc_setup(rc_ctx *c, const OrcVolume *v, const OrcSlab *slab, float step_factor, float delta_factor)
@@ -593,6 +612,57 @@ ORC_API void orc_raycast_depth(OrcVolume v, const OrcSlab *slab, const float cam
                 nrow[4 * x] = nrm.x; nrow[4 * x + 1] = nrm.y; nrow[4 * x + 2] = nrm.z; nrow[4 * x + 3] = 0.f;
                 float mm = vtx.z * 1000;                                                  /* :333 */
                 drow[x] = (uint16_t)(mm <= 0.f ? 0 : (mm >= 65535.f ? 65535 : (int)mm));
+            }
+        }
+    }
+}
+
+/* ---- Z-slab (multi-GPU) cast in two stages, mirroring dfusion_raycast_march / dfusion_raycast_shade.
+ * march: keys[cols*rows] + located vertex (float4, volume frame; zeros unless this slab found a hit).      */
+ORC_API void orc_raycast_march(OrcVolume v, const OrcSlab *slab, const float cam2vol[12], const float reproj[4],
+                               int cols, int rows, float step_factor, uint32_t *keys, float *vertex)
+{
+    rc_ctx c; rc_setup(&c, &v, slab, step_factor, 0.5f);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            rc_hit h = ray_march(&c, cam2vol, reproj, x, y);
+            float *o = vertex + 4 * ((size_t)y * cols + x);
+            o[0] = o[1] = o[2] = o[3] = 0.f;
+            if (h.hit) { f3 p = ray_locate(&c, &h); o[0] = p.x; o[1] = p.y; o[2] = p.z; }
+            keys[(size_t)y * cols + x] = h.key;
+        }
+}
+/* shade: given the MERGED keys and the winners' vertices, the slab owning the vertex' nearest plane writes the
+ * final point/normal (NaN if the normal is not finite); the slab owning plane 0 writes the NaN fill of misses;
+ * everything else is all-zero bits so that integer-summing the slabs' outputs reproduces the unsharded cast. */
+ORC_API void orc_raycast_shade(OrcVolume v, const OrcSlab *slab, const float cam2vol[12], const float Rinv[9],
+                               const float *vertex, const uint32_t *merged_keys, float *points, size_t ppitch,
+                               float *normals, size_t npitch, int cols, int rows, float delta_factor)
+{
+    rc_ctx c; rc_setup(&c, &v, slab, 0.75f, delta_factor);
+    const float qn = qnanf();
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < rows; ++y) {
+        float *prow = (float *)((char *)points + (size_t)y * ppitch);
+        float *nrow = (float *)((char *)normals + (size_t)y * npitch);
+        for (int x = 0; x < cols; ++x) {
+            uint32_t key = merged_keys[(size_t)y * cols + x];
+            float fill = 0.f;
+            int resolved = 0; f3 vtx, nrm;
+            if (key != ORC_RC_NO_EVENT && (key & 1u)) {
+                const float *vv = vertex + 4 * ((size_t)y * cols + x);
+                float zf = rintf(vv[2] * c.vsi.z);
+                int pz = (zf == zf) ? (int)fminf(fmaxf(zf, 0.f), (float)(c.Z - 1)) : 0;
+                if (pz >= c.s.z_own0 && pz < c.s.z_own0 + c.s.z_own_n) {
+                    fill = qn;
+                    resolved = ray_shade(&c, cam2vol, Rinv, mk3(vv[0], vv[1], vv[2]), &vtx, &nrm);
+                }
+            } else if (c.s.z_own0 == 0) fill = qn;
+            for (int i = 0; i < 4; ++i) { prow[4 * x + i] = fill; nrow[4 * x + i] = fill; }
+            if (resolved) {
+                nrow[4 * x] = nrm.x; nrow[4 * x + 1] = nrm.y; nrow[4 * x + 2] = nrm.z; nrow[4 * x + 3] = 0.f;
+                prow[4 * x] = vtx.x; prow[4 * x + 1] = vtx.y; prow[4 * x + 2] = vtx.z; prow[4 * x + 3] = 0.f;
             }
         }
     }

@@ -75,6 +75,11 @@ def lib():
         L.orc_raycast_depth.restype = None
         L.orc_raycast_depth.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, u16p, C.c_size_t, f32p,
                                         C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.orc_raycast_march.restype = None
+        L.orc_raycast_march.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, C.c_int, C.c_int, C.c_float, u32p, f32p]
+        L.orc_raycast_shade.restype = None
+        L.orc_raycast_shade.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, u32p, f32p, C.c_size_t, f32p, C.c_size_t,
+                                        C.c_int, C.c_int, C.c_float]
         for name in ("orc_quat_mul",):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = [f32p, f32p, f32p]
@@ -184,6 +189,23 @@ def raycast_points(volume, cam2vol, Rinv, reproj, cols, rows, step_factor, delta
                              f32(reproj), pts.reshape(-1), cols * 16, nrm.reshape(-1), cols * 16, cols, rows,
                              step_factor, delta_factor, keys.ctypes.data if want_keys else None, stats.ctypes.data)
     return pts, nrm, keys, stats
+
+
+def raycast_march(volume, cam2vol, reproj, cols, rows, step_factor, slab=None):
+    keys = np.empty((rows, cols), np.uint32)
+    vertex = np.empty((rows, cols, 4), np.float32)
+    lib().orc_raycast_march(volume, C.byref(slab) if slab else None, f32(cam2vol).reshape(-1), f32(reproj), cols, rows,
+                            step_factor, keys.reshape(-1), vertex.reshape(-1))
+    return keys, vertex
+
+
+def raycast_shade(volume, cam2vol, Rinv, vertex, merged_keys, cols, rows, delta_factor, slab=None):
+    pts = np.empty((rows, cols, 4), np.float32)
+    nrm = np.empty((rows, cols, 4), np.float32)
+    lib().orc_raycast_shade(volume, C.byref(slab) if slab else None, f32(cam2vol).reshape(-1), f32(Rinv).reshape(-1),
+                            np.ascontiguousarray(vertex, np.float32).reshape(-1), np.ascontiguousarray(merged_keys, np.uint32).reshape(-1),
+                            pts.reshape(-1), cols * 16, nrm.reshape(-1), cols * 16, cols, rows, delta_factor)
+    return pts, nrm
 
 
 def raycast_depth(volume, cam2vol, Rinv, reproj, cols, rows, step_factor, delta_factor, slab=None):

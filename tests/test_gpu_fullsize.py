@@ -1,0 +1,139 @@
+"""BASELINE.json full sizes (256^3 / 500 nodes / k=4 and the 512^3 / 2000 nodes / k=8 headline): the oracle
+cannot sweep these in seconds, so parity rests on (i) oracle checks on a bounded sample of planes / rays and
+(ii) size-independent properties: cull on == cull off, slab-sharded == unsharded, update counts consistent with
+weights, reference-header golden vectors reproduced by the HIP k-NN / warp kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from dynamicfusion_amd import Intr, TsdfVolume, WarpField, sharded, synth, upload_u16
+from scene import Scene, compare_volumes
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def setup(cfg, slab=None):
+    v = TsdfVolume(cfg.dims, slab=slab)
+    v.setSize([cfg.size] * 3); v.setTruncDist(cfg.trunc_dist); v.setMaxWeight(cfg.max_weight); v.setPose(cfg.volume_pose)
+    v.setRaycastStepFactor(cfg.raycast_step_factor); v.setGradientDeltaFactor(cfg.gradient_delta_factor)
+    return v
+
+
+def test_knn_and_warp_reproduce_reference_header_goldens():
+    g = np.load(os.path.join(GOLD, "knn.npz"))
+    wf = WarpField(k=8)
+    wf.init(g["pos"], sigma=3.0)
+    q = torch.from_numpy(g["queries"]).cuda()
+    for k, ki, kd in ((4, "idx4", "d2_4"), (8, "idx8", "d2_8")):
+        idx, d2 = wf.KNN(q, k)
+        assert np.array_equal(idx.cpu().numpy(), g[ki]) and np.array_equal(bits(d2.cpu().numpy()), bits(g[kd]))
+    w = np.load(os.path.join(GOLD, "dqb_warp.npz"))
+    for tag in ("s3", "s015"):
+        for k in (4, 8):
+            wf2 = WarpField(k=k)
+            wf2.init(w["pos"], sigma=w["sigma_" + tag], transforms=w["dq"])
+            p, n = torch.from_numpy(w["points"].copy()).cuda(), torch.from_numpy(w["normals"].copy()).cuda()
+            wf2.warp(p, n)
+            torch.cuda.synchronize()
+            assert np.array_equal(bits(p.cpu().numpy()), bits(w["warp_p_%s_k%d" % (tag, k)]))
+            assert np.array_equal(bits(n.cpu().numpy()), bits(w["warp_n_%s_k%d" % (tag, k)]))
+
+
+@pytest.mark.parametrize("name", ["256", "512"])
+def test_full_size_properties_and_sampled_oracle(name):
+    cfg = synth.CONFIGS[name]
+    intr = Intr(*cfg.intr)
+    sc = Scene(cfg, n_frames=2)
+    X, Y, Z = cfg.dims
+    wf = WarpField(k=cfg.k)
+    wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
+    dists = [upload_u16(d) for d in sc.dists]
+
+    # ---- warped integrate: cull on == cull off ; n_upd == sum of weights
+    a, b = setup(cfg), setup(cfg)
+    n_upd = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for f in range(2):
+        wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+        a.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, n_updated=n_upd, cull=True)
+        b.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, cull=False)
+    assert torch.equal(a.data(), b.data())
+    weights = (a.data() >> 16) & 0xFFFF
+    assert int(weights.sum()) == int(n_upd.item()) and int(weights.max()) == 2
+    del b
+
+    # ---- oracle on a bounded sample: 2 planes in the middle of the volume, both frames
+    z0 = Z // 2 - 1
+    ref = np.zeros((2, Y, X), np.uint32)
+    slab = O.make_slab(z0, 2, z0, 2)
+    for f in range(2):
+        O.integrate_warped(sc.dists[f], ref, sc.ovol(ref), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)), sc.intr,
+                           sc.pos, sc.dqs[f], sc.sigma, cfg.k, slab=slab)
+    s = compare_volumes(a.data()[z0:z0 + 2].cpu().numpy().view(np.uint32), ref)
+    print(name, "sampled-plane parity:", s)
+    assert s["weight_mismatch"] <= 1e-4 * s["n"] and s["n_dtsdf_gt_1e-4"] <= 1e-4 * s["n"]
+    assert (ref >> 16).max() == 2
+
+    # ---- slab-sharded (world = 8) integrate + raycast == unsharded
+    world = 8
+    halo = sharded.halo_planes(sc.trunc, cfg.raycast_step_factor, cfg.gradient_delta_factor, float(sc.vs[2]))
+    fp = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
+    fn = torch.empty_like(fp)
+    fk = torch.empty((cfg.rows, cfg.cols), dtype=torch.int32, device="cuda")
+    a.raycast(sc.cam_poses[1], intr, fp, fn, keys=fk)
+    best = torch.full((cfg.rows, cfg.cols), 0xFFFFFFFF, dtype=torch.int64, device="cuda")
+    vtx = torch.zeros_like(fp)
+    slabs = []
+    for r in range(world):
+        zs, zn = sharded.slab_range(Z, r, world)
+        v = setup(cfg, slab=(zs, zn, halo))
+        for f in range(2):
+            wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+            v.integrate_warped(dists[f], sc.cam_poses[f], intr, wf)
+        own = slice(v.z_own0 - v.z_store0, v.z_own0 - v.z_store0 + zn)
+        assert torch.equal(v.data()[own], a.data()[zs:zs + zn])
+        v.data().copy_(a.data()[v.z_store0:v.z_store0 + v.z_store_n])      # halos as the exchange would deliver them
+        k32, vx = torch.empty_like(fk), torch.empty_like(fp)
+        v.raycast_march(sc.cam_poses[1], intr, k32, vx)
+        k64 = k32.to(torch.int64) & 0xFFFFFFFF
+        better = k64 < best
+        best = torch.where(better, k64, best)
+        vtx[better] = vx[better]
+        slabs.append(v)
+    assert torch.equal(best, fk.to(torch.int64) & 0xFFFFFFFF)
+    merged = best.to(torch.int32)
+    acc = torch.zeros((2, cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
+    for v in slabs:
+        p, n = torch.empty_like(fp), torch.empty_like(fp)
+        v.raycast_shade(sc.cam_poses[1], intr, vtx, merged, p, n)
+        acc[0] += p.view(torch.int32)
+        acc[1] += n.view(torch.int32)
+    del slabs
+    assert (~torch.isnan(fp)).float().mean() > 0.3
+    assert torch.equal(acc[0], fp.view(torch.int32)) and torch.equal(acc[1], fn.view(torch.int32))
+
+    # ---- ray-cast vs the oracle on a sample of rows (oracle casts the full image on the downloaded volume only
+    # at 256^3; at 512^3 the download is 512 MiB -- still fine on the GPU box)
+    host = a.download()
+    rp, rn, rk, _ = O.raycast_points(sc.ovol(host), synth.aff12(sc.cam2vol(1)), sc.rinv(1), sc.reproj, cfg.cols, cfg.rows,
+                                     cfg.raycast_step_factor, cfg.gradient_delta_factor, want_keys=True)
+    assert np.array_equal(fk.cpu().numpy().view(np.uint32), rk)
+    gp, gn = fp.cpu().numpy(), fn.cpu().numpy()
+    assert np.array_equal(np.isnan(gp), np.isnan(rp))
+    m = np.isfinite(rp)
+    assert np.abs(gp[m] - rp[m]).max() <= 1e-4 and np.abs(gn[m] - rn[m]).max() <= 1e-3
+
+    # ---- rigid: slab-sharded == unsharded at full size (replayed vc accumulation)
+    r_full = setup(cfg)
+    r_full.integrate(dists[0], sc.cam_poses[0], intr)
+    zs, zn = sharded.slab_range(Z, 5, 8)
+    r_slab = setup(cfg, slab=(zs, zn, 0))
+    r_slab.integrate(dists[0], sc.cam_poses[0], intr)
+    assert torch.equal(r_slab.data(), r_full.data()[zs:zs + zn])

@@ -125,27 +125,47 @@ def test_raycast_hits_reproduce_depth():
     assert np.array_equal(dep[hit], (pts[..., 2][hit] * F32(1000)).astype(np.uint16))
 
 
-def test_raycast_slab_merge_equals_full():
-    """Per-slab casts (own planes + halo) merged by min event key reproduce the unsharded cast bit for bit."""
-    from dynamicfusion_amd import sharded
-    sc = Scene(CFG, n_frames=2, with_nodes=False)
-    vol, _ = _integrated(sc, 2)
-    args = (synth.aff12(sc.cam2vol(1)), sc.rinv(1), sc.reproj, CFG.cols, CFG.rows, CFG.raycast_step_factor, CFG.gradient_delta_factor)
-    fp, fn, fk, _ = O.raycast_points(sc.ovol(vol), *args, want_keys=True)
-    Z = CFG.dims[2]
-    halo = sharded.halo_planes(sc.trunc, CFG.raycast_step_factor, CFG.gradient_delta_factor, float(sc.vs[2]))
-    world = 3
-    best_k = np.full(fk.shape, 0xffffffff, np.uint64)
-    mp, mn = np.full_like(fp, np.nan), np.full_like(fn, np.nan)
+def _two_stage_cast(sc, vol, f, world, halo, cfg):
+    """march per slab -> MIN-merge keys + winner's vertex -> shade per slab -> integer-sum (what sharded.py does)."""
+    Z = cfg.dims[2]
+    slabs = []
     for r in range(world):
-        z0, zn = sharded.slab_range(Z, r, world)
+        z0, zn = sharded_mod().slab_range(Z, r, world)
         lo, hi = max(0, z0 - halo), min(Z, z0 + zn + halo)
-        part = np.ascontiguousarray(vol[lo:hi])
-        p, n, k, _ = O.raycast_points(sc.ovol(part), *args, slab=O.make_slab(lo, hi - lo, z0, zn), want_keys=True)
-        better = k.astype(np.uint64) < best_k
-        best_k[better] = k[better]
-        mp[better], mn[better] = p[better], n[better]
-    assert np.array_equal(best_k.astype(np.uint32), fk)
-    assert np.array_equal(np.isnan(mp), np.isnan(fp))
-    ok = np.isfinite(fp)
-    assert np.array_equal(mp[ok], fp[ok]) and np.array_equal(mn[ok], fn[ok])
+        slabs.append((np.ascontiguousarray(vol[lo:hi]), O.make_slab(lo, hi - lo, z0, zn)))
+    best = np.full((cfg.rows, cfg.cols), 0xffffffff, np.uint32)
+    vtx = np.zeros((cfg.rows, cfg.cols, 4), np.float32)
+    for part, slab in slabs:
+        k, v = O.raycast_march(sc.ovol(part), synth.aff12(sc.cam2vol(f)), sc.reproj, cfg.cols, cfg.rows, cfg.raycast_step_factor, slab=slab)
+        better = k < best
+        best[better] = k[better]
+        vtx[better] = v[better]
+    acc_p = np.zeros((cfg.rows, cfg.cols, 4), np.uint32)
+    acc_n = np.zeros_like(acc_p)
+    for part, slab in slabs:
+        p, n = O.raycast_shade(sc.ovol(part), synth.aff12(sc.cam2vol(f)), sc.rinv(f), vtx, best, cfg.cols, cfg.rows,
+                               cfg.gradient_delta_factor, slab=slab)
+        acc_p += p.view(np.uint32)
+        acc_n += n.view(np.uint32)
+    return best, acc_p, acc_n
+
+
+def sharded_mod():
+    from dynamicfusion_amd import sharded
+    return sharded
+
+
+def test_raycast_two_stage_slab_cast_equals_full():
+    """Per-slab march (own planes + halo), MIN-merge of event keys, shade by the slab owning the located vertex
+    (which the refinement may extrapolate into another slab, tsdf_volume.cu:389), integer-sum of the outputs:
+    reproduces the unsharded cast bit for bit."""
+    cfg = synth.Config(96, 1.0, cols=160, rows=120, nodes=0)
+    sc = Scene(cfg, n_frames=2, with_nodes=False)
+    vol, _ = _integrated(sc, 2)
+    fp, fn, fk, _ = O.raycast_points(sc.ovol(vol), synth.aff12(sc.cam2vol(1)), sc.rinv(1), sc.reproj, cfg.cols, cfg.rows,
+                                     cfg.raycast_step_factor, cfg.gradient_delta_factor, want_keys=True)
+    halo = sharded_mod().halo_planes(sc.trunc, cfg.raycast_step_factor, cfg.gradient_delta_factor, float(sc.vs[2]))
+    for world in (2, 6):
+        best, acc_p, acc_n = _two_stage_cast(sc, vol, 1, world, halo, cfg)
+        assert np.array_equal(best, fk)
+        assert np.array_equal(acc_p, fp.view(np.uint32)) and np.array_equal(acc_n, fn.view(np.uint32))

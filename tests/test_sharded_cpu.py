@@ -62,9 +62,18 @@ def _worker(rank, world, port):
             O.integrate_warped(dists, vol, sc.ovol(vol), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)), sc.intr,
                                sc.pos, dq.numpy(), sc.sigma, CFG.k, slab=slab)
             sharded.exchange_halos(vol_t, lo, z0, zn, Z, halo, rank, world)
-            p, n, k, _ = O.raycast_points(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.reproj, CFG.cols, CFG.rows,
-                                          CFG.raycast_step_factor, CFG.gradient_delta_factor, slab=slab, want_keys=True)
-            pts, nrm = sharded.merge_raycast(torch.from_numpy(p), torch.from_numpy(n), torch.from_numpy(k.view(np.int32)), rank, world)
+
+            def march():
+                k, vx = O.raycast_march(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.reproj, CFG.cols, CFG.rows,
+                                        CFG.raycast_step_factor, slab=slab)
+                return torch.from_numpy(k.view(np.int32)), torch.from_numpy(vx)
+
+            def shade(merged, vx):
+                p, n = O.raycast_shade(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.rinv(f), vx.numpy(),
+                                       merged.numpy().view(np.uint32), CFG.cols, CFG.rows, CFG.gradient_delta_factor, slab=slab)
+                return torch.from_numpy(p), torch.from_numpy(n)
+
+            pts, nrm = sharded.raycast_sharded(march, shade, rank, world)
         # every rank checks its slab (own + halo planes) against the unsharded volume; rank 0 checks the merged cast
         full, fp, fn = _unsharded(sc)
         assert np.array_equal(vol, full[lo:hi]), "rank %d: slab (incl. exchanged halos) differs from the unsharded volume" % rank
@@ -86,6 +95,6 @@ def test_zslab_pipeline_over_gloo(world):
 
 def test_single_rank_is_a_no_op_path():
     p = torch.zeros((4, 4, 4))
-    out = sharded.merge_raycast(p, p, None, 0, 1)
+    out = sharded.raycast_sharded(lambda: (None, None), lambda k, v: (p, p), 0, 1)
     assert out[0] is p
     sharded.exchange_halos(None, 0, 0, 4, 4, 2, 0, 1)
