@@ -22,6 +22,10 @@ class DfSlab(C.Structure):
 
 
 DF_WARP_NO_CULL = 1
+DF_WARP_NO_TABLE = 2
+DF_WARP_NO_WEIGHT_TABLE = 4
+DF_INDEX_VOXEL_TABLE = 1
+DF_INDEX_WEIGHT_TABLE = 2
 
 # every symbol include/dfusion.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -75,7 +79,7 @@ def lib():
     L.dfusion_warp_destroy.argtypes = [vp]
     L.dfusion_warp_set_nodes.argtypes = [vp, vp, vp, vp, C.c_int, vp]
     L.dfusion_warp_set_transforms.argtypes = [vp, vp, vp]
-    L.dfusion_warp_build_index.argtypes = [vp, DfVolume, fp, C.c_int, vp]
+    L.dfusion_warp_build_index.argtypes = [vp, DfVolume, C.POINTER(DfSlab), fp, C.c_int, C.c_uint, vp]
     L.dfusion_knn.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.dfusion_warp_points.argtypes = [vp, C.c_int, vp, vp, C.c_int, fp, vp]
     L.dfusion_integrate_warped.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, DfVolume, C.POINTER(DfSlab), fp, fp, fp,

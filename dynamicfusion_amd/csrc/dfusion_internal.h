@@ -51,6 +51,10 @@ struct DfWarpField {
     int bx, by, bz, k_built;
     int geom_dims[3]; float geom_vs[3]; float geom_aff[12];
     bool index_valid;
+    // per-voxel k-NN table (optional, DF_INDEX_VOXEL_TABLE)
+    uint16_t* knn_tab; size_t knn_tab_cap;      // elements (uint16)
+    int tab_z0, tab_zn, tab_k; bool tab_valid;
+    float* w_tab; size_t w_tab_cap; bool w_tab_valid;   // per-voxel blend weights (optional, DF_INDEX_WEIGHT_TABLE)
     // device scalars for the conservative brick cull: [0] max |t_i|, [1] max sin(theta_i/2), [2] max dists
     float* bounds_dev;
 };

@@ -80,6 +80,7 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     if (!wf) return DF_OK;
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev);
+    (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab);
     free(wf);
     return DF_OK;
 }
@@ -119,6 +120,7 @@ extern "C" int dfusion_warp_set_nodes(DfWarpField* wf, const float* pos, const f
     if (rc) return rc;
     wf->M = M;
     wf->index_valid = false;
+    wf->tab_valid = false; wf->w_tab_valid = false;
     return df_warp_pack(wf, pos, dq, sigma, (hipStream_t)stream);
 }
 
@@ -152,10 +154,10 @@ __device__ __forceinline__ void topk_init(float (&bd)[K], int (&bi)[K])
     for (int i = 0; i < K; ++i) { bd[i] = __uint_as_float(0x7f800000u); bi[i] = 0; }   // +inf
 }
 
-// WarpField::DQB (warp_field.cpp:203-217) from a finished top-k, then DualQuaternion ctor :59-63.
+// WarpField::DQB (warp_field.cpp:203-217) from the k weights + node indices, then DualQuaternion ctor :59-63.
 template <int K>
-__device__ __forceinline__ void dqb_blend(const DfWarpView& W, const float (&bd)[K], const int (&bi)[K], quat* rot_out,
-                                          quat* dual_out)
+__device__ __forceinline__ void dqb_blend_w(const DfWarpView& W, const float (&wt)[K], const int (&bi)[K], quat* rot_out,
+                                            quat* dual_out)
 {
     quat tsum, rsum;
     tsum.w = tsum.x = tsum.y = tsum.z = 0.f;
@@ -163,8 +165,7 @@ __device__ __forceinline__ void dqb_blend(const DfWarpView& W, const float (&bd)
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         const int j = bi[i];
-        const float sigma = W.pos_sigma[j].w;
-        const float w = dqb_weight(bd[i], sigma);
+        const float w = wt[i];
         const float4 t4 = W.node_t[j], r4 = W.rot[j];
         quat t, r;
         t.w = t4.x; t.x = t4.y; t.y = t4.z; t.z = t4.w;
@@ -177,6 +178,21 @@ __device__ __forceinline__ void dqb_blend(const DfWarpView& W, const float (&bd)
     half.w = 0.5f * tsum.w; half.x = 0.5f * tsum.x; half.y = 0.5f * tsum.y; half.z = 0.5f * tsum.z;
     *rot_out = rsum;
     *dual_out = q_mul(half, rsum);                    // dual_quaternion.hpp:59-63
+}
+// weights from squared distances: WarpField::weighting (warp_field.cpp:238-241) per neighbour
+template <int K>
+__device__ __forceinline__ void dqb_weights(const DfWarpView& W, const float (&bd)[K], const int (&bi)[K], float (&wt)[K])
+{
+#pragma unroll
+    for (int i = 0; i < K; ++i) wt[i] = dqb_weight(bd[i], W.pos_sigma[bi[i]].w);
+}
+template <int K>
+__device__ __forceinline__ void dqb_blend(const DfWarpView& W, const float (&bd)[K], const int (&bi)[K], quat* rot_out,
+                                          quat* dual_out)
+{
+    float wt[K];
+    dqb_weights<K>(W, bd, bi, wt);
+    dqb_blend_w<K>(W, wt, bi, rot_out, dual_out);
 }
 
 // ====================================================================================== brute-force k-NN / warp of points
@@ -364,10 +380,16 @@ __global__ __launch_bounds__(1024) void df_scan_kernel(const uint32_t* __restric
     if (t == 1023) off[n] = part[1023];
 }
 
-extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const float vol2world[12], int k, dfStream stream)
+static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab& s, const float vol2world[12], int k, bool weights,
+                                hipStream_t st);
+
+extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const DfSlab* slab, const float vol2world[12], int k,
+                                        unsigned flags, dfStream stream)
 {
     if (!wf || !vol2world || wf->M <= 0 || k < 1 || k > 8 || wf->M < k) return DF_E_INVALID;
     if (v.dims[0] <= 0 || v.dims[1] <= 0 || v.dims[2] <= 0) return DF_E_INVALID;
+    DfSlab sl = df_slab_or_full(v, slab);
+    if (sl.z_own_n < 0 || sl.z_own0 < 0 || sl.z_own0 + sl.z_own_n > v.dims[2]) return DF_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     DfIndexGeom g;
     g.X = v.dims[0]; g.Y = v.dims[1]; g.Z = v.dims[2];
@@ -417,6 +439,10 @@ extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const float
     memcpy(wf->geom_vs, v.voxel_size, sizeof(wf->geom_vs));
     memcpy(wf->geom_aff, vol2world, sizeof(wf->geom_aff));
     wf->index_valid = true;
+    wf->tab_valid = false;
+    wf->w_tab_valid = false;
+    if (flags & (DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE))
+        return df_build_voxel_table(wf, v, sl, vol2world, k, (flags & DF_INDEX_WEIGHT_TABLE) != 0, st);
     return DF_OK;
 }
 
@@ -424,7 +450,7 @@ extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const float
 struct DfWarpedArgs {
     uint32_t* vol; int X, Y, Z;
     int z_store0, z_own0, z_own_n;
-    int bz0;                       // first brick layer of this launch
+    int bz0;                       // first brick / tile layer of this launch
     float vsx, vsy, vsz;
     DfAff vol2world, world2cam;
     DfIntegrateParams P;
@@ -434,21 +460,142 @@ struct DfWarpedArgs {
     // frame needs no host round trip.
     const float* cull;
     float kf;                      // (float)k
-    float brick_r;                 // half diagonal of a brick's voxel-centre lattice (world metres), inflated
+    float tile_r;                  // half diagonal of a work tile's voxel-centre lattice (world metres), inflated
     float cam_scale;               // >= operator norm of world2cam.R (1 for a rigid pose), inflated
+    // per-voxel tables over planes [tab_z0, tab_z0 + tab_zn), x fastest (voxel = ((z-tab_z0)*Y + y)*X + x):
+    //   knn_tab  K uint16 node indices per voxel, ascending distance (16 B/voxel at K = 8: one dwordx4 per lane)
+    //   w_tab    K float weights per voxel, stored as K/4 float4 PLANES of tab_nvox entries each, so that a wave of
+    //            x-adjacent lanes reads 1 KiB contiguous per instruction
+    uint16_t* knn_tab; float* w_tab; int tab_z0; size_t tab_nvox;
 };
 
 #define DF_CAND_CHUNK 256
 
 template <int K>
-__global__ __launch_bounds__(256) void df_integrate_warped_kernel(const DfWarpedArgs a, const DfWarpView W)
+__device__ __forceinline__ void knn_tab_store(uint16_t* tab, size_t voxel, const int (&bi)[K])
+{
+    if constexpr (K == 8) {
+        uint4 v;
+        v.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 16); v.y = (uint32_t)bi[2] | ((uint32_t)bi[3] << 16);
+        v.z = (uint32_t)bi[4] | ((uint32_t)bi[5] << 16); v.w = (uint32_t)bi[6] | ((uint32_t)bi[7] << 16);
+        reinterpret_cast<uint4*>(tab)[voxel] = v;
+    } else if constexpr (K == 4) {
+        uint2 v;
+        v.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 16); v.y = (uint32_t)bi[2] | ((uint32_t)bi[3] << 16);
+        reinterpret_cast<uint2*>(tab)[voxel] = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) tab[voxel * K + i] = (uint16_t)bi[i];
+    }
+}
+template <int K>
+__device__ __forceinline__ void knn_tab_load(const uint16_t* tab, size_t voxel, int (&bi)[K])
+{
+    if constexpr (K == 8) {
+        const uint4 v = reinterpret_cast<const uint4*>(tab)[voxel];
+        bi[0] = v.x & 0xffff; bi[1] = v.x >> 16; bi[2] = v.y & 0xffff; bi[3] = v.y >> 16;
+        bi[4] = v.z & 0xffff; bi[5] = v.z >> 16; bi[6] = v.w & 0xffff; bi[7] = v.w >> 16;
+    } else if constexpr (K == 4) {
+        const uint2 v = reinterpret_cast<const uint2*>(tab)[voxel];
+        bi[0] = v.x & 0xffff; bi[1] = v.x >> 16; bi[2] = v.y & 0xffff; bi[3] = v.y >> 16;
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) bi[i] = tab[voxel * K + i];
+    }
+}
+template <int K>
+__device__ __forceinline__ void w_tab_store(float* tab, size_t nvox, size_t voxel, const float (&wt)[K])
+{
+    if constexpr (K % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < K / 4; ++i)
+            reinterpret_cast<float4*>(tab)[(size_t)i * nvox + voxel] = make_float4(wt[4 * i], wt[4 * i + 1], wt[4 * i + 2], wt[4 * i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) tab[(size_t)i * nvox + voxel] = wt[i];
+    }
+}
+template <int K>
+__device__ __forceinline__ void w_tab_load(const float* tab, size_t nvox, size_t voxel, float (&wt)[K])
+{
+    if constexpr (K % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < K / 4; ++i) {
+            const float4 v = reinterpret_cast<const float4*>(tab)[(size_t)i * nvox + voxel];
+            wt[4 * i] = v.x; wt[4 * i + 1] = v.y; wt[4 * i + 2] = v.z; wt[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) wt[i] = tab[(size_t)i * nvox + voxel];
+    }
+}
+
+// Conservative, result-identical rejection of a whole work tile (brick or row tile).  Every voxel of the tile has
+// canonical position within tile_r of the tile centre c; its warped position is within
+//   delta = 2 sin(theta_max/2) * (|c| + tile_r) + k * max|t_i|
+// of its canonical one: the blend of unit quaternions with w >= 0 and weights >= 0 rotates (about the origin) by at
+// most theta_max, and |T| = |sum w_i t_i| <= k max|t_i| because w_i = exp(-..) <= 1.  So its camera-frame position
+// lies within rho = cam_scale*(tile_r + delta) of cc = world2cam * c.  No voxel of the tile can update if that ball
+// is entirely behind the camera, entirely outside one image-frustum side plane, or entirely farther than
+// max_dist + trunc from the camera centre.
+__device__ __forceinline__ bool df_tile_culled(const DfWarpedArgs& a, f3 c)
+{
+    const float max_t = a.cull[0], sin_half = a.cull[1], max_dist = a.cull[2];
+    if (!(sin_half <= 1.0f && max_t < 1.0e30f)) return false;
+    const float cn = sqrtf(dot3(c, c));
+    const float delta = 2.f * sin_half * (cn + a.tile_r) + a.kf * max_t;
+    const float rho = a.cam_scale * (a.tile_r + delta) * 1.002f + 1e-3f;
+    const f3 cc = aff_mul(a.world2cam, c);
+    bool out = false;
+    if (cc.z + rho <= 0.f) out = true;                                           // behind the camera
+    if (sqrtf(dot3(cc, cc)) - rho > max_dist * 1.002f + a.P.trunc) out = true;   // sdf < -trunc everywhere
+    // side planes through the camera centre: u >= 0 <=> fx*x + cx*z >= 0 ; u < cols <=> -fx*x + (cols-cx)*z > 0
+    const float nl = sqrtf(a.P.fx * a.P.fx + a.P.cx * a.P.cx);
+    if ((a.P.fx * cc.x + a.P.cx * cc.z) / nl < -rho) out = true;
+    const float cr = (float)a.P.cols - a.P.cx;
+    const float nr = sqrtf(a.P.fx * a.P.fx + cr * cr);
+    if ((-a.P.fx * cc.x + cr * cc.z) / nr < -rho) out = true;
+    const float nt = sqrtf(a.P.fy * a.P.fy + a.P.cy * a.P.cy);
+    if ((a.P.fy * cc.y + a.P.cy * cc.z) / nt < -rho) out = true;
+    const float cb = (float)a.P.rows - a.P.cy;
+    const float nbt = sqrtf(a.P.fy * a.P.fy + cb * cb);
+    if ((-a.P.fy * cc.y + cb * cc.z) / nbt < -rho) out = true;
+    return out;
+}
+
+// blend -> transform -> project -> fuse for one voxel; returns 1 if the update branch was taken
+template <int K>
+__device__ __forceinline__ unsigned int df_warp_update(const DfWarpedArgs& a, const DfWarpView& W, f3 q, const float (&wt)[K],
+                                                       const int (&bi)[K], uint32_t* vox)
+{
+    quat rot, dual;
+    dqb_blend_w<K>(W, wt, bi, &rot, &dual);
+    const f3 vc = aff_mul(a.world2cam, dq_transform(rot, dual, q));
+    float ts;
+    if (!tsdf_sample(a.P, vc, &ts)) return 0u;
+    *vox = tsdf_fuse(*vox, ts, a.P.max_weight);
+    return 1u;
+}
+
+__device__ __forceinline__ void df_count_updates(const DfWarpedArgs& a, unsigned int my_upd)
+{
+    if (a.n_upd) {
+        unsigned int s = my_upd;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.n_upd, (unsigned long long)s);
+    }
+}
+
+// ---- brick kernel: exact k-NN from the brick candidate lists (through LDS), one 256-thread workgroup per 8^3 brick.
+// BUILD = false: fused with the TSDF update -- no per-voxel memory ("lean" path, re-ranks ~150 candidates per voxel per frame).
+// BUILD = true : writes the per-voxel k-NN (and weight) tables instead; run when node POSITIONS change, not per frame.
+template <int K, bool BUILD>
+__global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a, const DfWarpView W)
 {
     __shared__ float4 s_pos[DF_CAND_CHUNK];
     __shared__ uint16_t s_idx[DF_CAND_CHUNK];
 
-    // brick coordinates; blockIdx.x enumerates bricks x-fastest so that the 4 waves of neighbouring
-    // workgroups touch neighbouring 32-byte row segments (same 128-byte lines, same XCD L2 via b % 8
-    // striding only 8 bricks = 256 B apart).
     const int bxx = blockIdx.x % W.bx;
     const int byy = blockIdx.x / W.bx;
     const int bzz = a.bz0 + blockIdx.y;
@@ -459,39 +606,10 @@ __global__ __launch_bounds__(256) void df_integrate_warped_kernel(const DfWarped
     const int x = bxx * DF_BRICK + lx, y = byy * DF_BRICK + ly;
     const int z0 = bzz * DF_BRICK + lz, z1 = z0 + 4;
 
-    if (a.cull) {
-        // Conservative, result-identical brick rejection.  Every voxel of the brick has canonical position
-        // within brick_r of the brick centre c; its warped position is within
-        //   delta = 2 sin(theta_max/2) * (|c| + brick_r) + k * max|t_i|
-        // of its canonical one: the blend of unit quaternions with w >= 0 and weights >= 0 rotates (about the
-        // origin) by at most theta_max, and |T| = |sum w_i t_i| <= k max|t_i| because w_i = exp(-..) <= 1.
-        // So its camera-frame position lies within rho = cam_scale*(brick_r + delta) of cc = world2cam * c.
-        // No voxel of the brick can update if that ball is entirely behind the camera, entirely outside one
-        // image-frustum side plane, or entirely farther than max_dist + trunc from the camera centre.
-        const float max_t = a.cull[0], sin_half = a.cull[1], max_dist = a.cull[2];
-        if (sin_half <= 1.0f && max_t < 1.0e30f) {
-            const f3 c = aff_mul(a.vol2world, mk3(((float)(bxx * DF_BRICK) + 3.5f) * a.vsx, ((float)(byy * DF_BRICK) + 3.5f) * a.vsy,
-                                                  ((float)(bzz * DF_BRICK) + 3.5f) * a.vsz));
-            const float cn = sqrtf(dot3(c, c));
-            const float delta = 2.f * sin_half * (cn + a.brick_r) + a.kf * max_t;
-            const float rho = a.cam_scale * (a.brick_r + delta) * 1.002f + 1e-3f;
-            const f3 cc = aff_mul(a.world2cam, c);
-            bool out = false;
-            if (cc.z + rho <= 0.f) out = true;                                           // behind the camera
-            if (sqrtf(dot3(cc, cc)) - rho > max_dist * 1.002f + a.P.trunc) out = true;   // sdf < -trunc everywhere
-            // side planes through the camera centre: u >= 0 <=> fx*x + cx*z >= 0 ; u < cols <=> -fx*x + (cols-cx)*z > 0
-            const float nl = sqrtf(a.P.fx * a.P.fx + a.P.cx * a.P.cx);
-            if ((a.P.fx * cc.x + a.P.cx * cc.z) / nl < -rho) out = true;
-            const float cr = (float)a.P.cols - a.P.cx;
-            const float nr = sqrtf(a.P.fx * a.P.fx + cr * cr);
-            if ((-a.P.fx * cc.x + cr * cc.z) / nr < -rho) out = true;
-            const float nt = sqrtf(a.P.fy * a.P.fy + a.P.cy * a.P.cy);
-            if ((a.P.fy * cc.y + a.P.cy * cc.z) / nt < -rho) out = true;
-            const float cb = (float)a.P.rows - a.P.cy;
-            const float nbt = sqrtf(a.P.fy * a.P.fy + cb * cb);
-            if ((-a.P.fy * cc.y + cb * cc.z) / nbt < -rho) out = true;
-            if (out) return;                                                             // block-uniform
-        }
+    if (!BUILD && a.cull) {
+        const f3 c = aff_mul(a.vol2world, mk3(((float)(bxx * DF_BRICK) + 3.5f) * a.vsx, ((float)(byy * DF_BRICK) + 3.5f) * a.vsy,
+                                              ((float)(bzz * DF_BRICK) + 3.5f) * a.vsz));
+        if (df_tile_culled(a, c)) return;                           // block-uniform
     }
 
     const bool in_xy = x < a.X && y < a.Y;
@@ -506,7 +624,6 @@ __global__ __launch_bounds__(256) void df_integrate_warped_kernel(const DfWarped
     float bd0[K], bd1[K]; int bi0[K], bi1[K];
     topk_init<K>(bd0, bi0);
     topk_init<K>(bd1, bi1);
-
     const uint32_t off = W.brick_off[b];
     const uint32_t cnt = W.brick_off[b + 1] - off;
     for (uint32_t base = 0; base < cnt; base += DF_CAND_CHUNK) {
@@ -526,36 +643,72 @@ __global__ __launch_bounds__(256) void df_integrate_warped_kernel(const DfWarped
         }
     }
 
-    unsigned int my_upd = 0;
     const size_t plane = (size_t)a.X * a.Y;
-    if (act0) {
-        quat rot, dual;
-        dqb_blend<K>(W, bd0, bi0, &rot, &dual);
-        const f3 vc = aff_mul(a.world2cam, dq_transform(rot, dual, q0));
-        float ts;
-        if (tsdf_sample(a.P, vc, &ts)) {
-            uint32_t* p = a.vol + (size_t)(z0 - a.z_store0) * plane + (size_t)y * a.X + x;
-            *p = tsdf_fuse(*p, ts, a.P.max_weight);
-            ++my_upd;
+    float wt0[K], wt1[K];
+    if constexpr (BUILD) {
+        const size_t tv0 = (size_t)(z0 - a.tab_z0) * plane + (size_t)y * a.X + x, tv1 = tv0 + 4 * plane;
+        if (act0) { knn_tab_store<K>(a.knn_tab, tv0, bi0); if (a.w_tab) { dqb_weights<K>(W, bd0, bi0, wt0); w_tab_store<K>(a.w_tab, a.tab_nvox, tv0, wt0); } }
+        if (act1) { knn_tab_store<K>(a.knn_tab, tv1, bi1); if (a.w_tab) { dqb_weights<K>(W, bd1, bi1, wt1); w_tab_store<K>(a.w_tab, a.tab_nvox, tv1, wt1); } }
+    } else {
+        unsigned int my_upd = 0;
+        if (act0) {
+            dqb_weights<K>(W, bd0, bi0, wt0);
+            my_upd += df_warp_update<K>(a, W, q0, wt0, bi0, a.vol + (size_t)(z0 - a.z_store0) * plane + (size_t)y * a.X + x);
         }
-    }
-    if (act1) {
-        quat rot, dual;
-        dqb_blend<K>(W, bd1, bi1, &rot, &dual);
-        const f3 vc = aff_mul(a.world2cam, dq_transform(rot, dual, q1));
-        float ts;
-        if (tsdf_sample(a.P, vc, &ts)) {
-            uint32_t* p = a.vol + (size_t)(z1 - a.z_store0) * plane + (size_t)y * a.X + x;
-            *p = tsdf_fuse(*p, ts, a.P.max_weight);
-            ++my_upd;
+        if (act1) {
+            dqb_weights<K>(W, bd1, bi1, wt1);
+            my_upd += df_warp_update<K>(a, W, q1, wt1, bi1, a.vol + (size_t)(z1 - a.z_store0) * plane + (size_t)y * a.X + x);
         }
+        df_count_updates(a, my_upd);
     }
-    if (a.n_upd) {
-        unsigned int s = my_upd;
+}
+
+// ---- row-tile kernel: the per-frame sweep when the per-voxel tables are cached in HBM.
+// The exact k-NN of a voxel (and its k blend weights) depend only on canonical node positions, so with 288 GB of HBM
+// they are computed once per node set and streamed back every frame: 16 B (+32 B) per voxel at k = 8 instead of
+// re-ranking ~150 candidates (and 8 f32 divisions + 8 f64 exp) per voxel.  A workgroup owns a 32(x) x 8(y) x 8(z) tile:
+// a wave covers two 32-voxel rows, so every access is a run of >= 128 contiguous bytes (volume 4 B, k-NN 16 B, weights
+// 16 B per lane and plane); each lane walks the 8 planes of the tile.
+#define DF_ROW_TX 32
+#define DF_ROW_TY 8
+#define DF_ROW_TZ 8
+
+template <int K, bool HAS_W>
+__global__ __launch_bounds__(256) void df_warp_rows_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
+{
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int zt = a.bz0 + blockIdx.y;                                 // tile layer (DF_ROW_TZ planes)
+    if (a.cull) {
+        const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX) + 0.5f * (DF_ROW_TX - 1)) * a.vsx,
+                                              ((float)(ty * DF_ROW_TY) + 0.5f * (DF_ROW_TY - 1)) * a.vsy,
+                                              ((float)(zt * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
+        if (df_tile_culled(a, c)) return;                               // block-uniform
+    }
+    const int x = tx * DF_ROW_TX + (threadIdx.x & (DF_ROW_TX - 1));
+    const int y = ty * DF_ROW_TY + (threadIdx.x >> 5);
+    const bool in_xy = x < a.X && y < a.Y;
+    const size_t plane = (size_t)a.X * a.Y;
+    const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
+    const int zb = max(zt * DF_ROW_TZ, a.z_own0), ze = min(min((zt + 1) * DF_ROW_TZ, a.z_own0 + a.z_own_n), a.Z);
+    unsigned int my_upd = 0;
+    if (in_xy) {
+#pragma unroll 2
+        for (int z = zb; z < ze; ++z) {
+            const size_t tv = (size_t)(z - a.tab_z0) * plane + (size_t)y * a.X + x;
+            const f3 q = aff_mul(a.vol2world, mk3(fxv, fyv, (float)z * a.vsz));     // canonical position
+            int bi[K]; float wt[K];
+            knn_tab_load<K>(a.knn_tab, tv, bi);
+            if constexpr (HAS_W) {
+                w_tab_load<K>(a.w_tab, a.tab_nvox, tv, wt);
+            } else {
+                // distances recomputed with the expression the build used (knn_point_cloud.hpp:25-31): bit-identical
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-        if ((t & 63) == 0 && s) atomicAdd(a.n_upd, (unsigned long long)s);
+                for (int i = 0; i < K; ++i) { const float4 p = W.pos_sigma[bi[i]]; wt[i] = dqb_weight(knn_dist2(q, p.x, p.y, p.z), p.w); }
+            }
+            my_upd += df_warp_update<K>(a, W, q, wt, bi, a.vol + (size_t)(z - a.z_store0) * plane + (size_t)y * a.X + x);
+        }
     }
+    df_count_updates(a, my_upd);
 }
 
 // max dists value over the image (for the cull's depth test); `out` zeroed on the stream first.
@@ -574,6 +727,21 @@ __global__ __launch_bounds__(256) void df_dists_max_kernel(const uint16_t* __res
     if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(m));
 }
 
+// half diagonal (world metres) of the voxel-centre lattice of an nx x ny x nz tile under vol2world
+static double df_tile_radius(const float vol2world[12], double nx, double ny, double nz, const DfVolume& v)
+{
+    double r = 0.0;
+    for (int sx = -1; sx <= 1; sx += 2) for (int sy = -1; sy <= 1; sy += 2) for (int sz = -1; sz <= 1; sz += 2) {
+        double ex = sx * 0.5 * (nx - 1) * v.voxel_size[0], ey = sy * 0.5 * (ny - 1) * v.voxel_size[1], ez = sz * 0.5 * (nz - 1) * v.voxel_size[2];
+        double wx = vol2world[0] * ex + vol2world[1] * ey + vol2world[2] * ez;
+        double wy = vol2world[3] * ex + vol2world[4] * ey + vol2world[5] * ez;
+        double wz = vol2world[6] * ex + vol2world[7] * ey + vol2world[8] * ez;
+        double d = sqrt(wx * wx + wy * wy + wz * wz);
+        if (d > r) r = d;
+    }
+    return r;
+}
+
 extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
                                         const float vol2world[12], const float world2cam[12], const float proj[4],
                                         DfWarpField* wf, int k, unsigned flags, unsigned long long* n_updated, dfStream stream)
@@ -589,6 +757,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     hipStream_t st = (hipStream_t)stream;
 
     DfWarpedArgs a;
+    memset(&a, 0, sizeof(a));
     a.vol = (uint32_t*)v.data; a.X = v.dims[0]; a.Y = v.dims[1]; a.Z = v.dims[2];
     a.z_store0 = s.z_store0; a.z_own0 = s.z_own0; a.z_own_n = s.z_own_n;
     a.vsx = v.voxel_size[0]; a.vsy = v.voxel_size[1]; a.vsz = v.voxel_size[2];
@@ -597,34 +766,78 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     a.P.fx = proj[0]; a.P.fy = proj[1]; a.P.cx = proj[2]; a.P.cy = proj[3];
     a.P.trunc = v.trunc_dist; a.P.trunc_inv = 1.f / v.trunc_dist; a.P.max_weight = v.max_weight;
     a.n_upd = n_updated;
-    a.cull = nullptr; a.kf = (float)k; a.brick_r = 0.f; a.cam_scale = 1.f;
+    a.kf = (float)k; a.cam_scale = 1.f;
+    const bool use_tab = wf->tab_valid && wf->tab_k == k && !(flags & DF_WARP_NO_TABLE) && s.z_own0 >= wf->tab_z0 &&
+                         s.z_own0 + s.z_own_n <= wf->tab_z0 + wf->tab_zn;
+    const bool use_w = use_tab && wf->w_tab_valid && !(flags & DF_WARP_NO_WEIGHT_TABLE);
+    if (use_tab) { a.knn_tab = wf->knn_tab; a.tab_z0 = wf->tab_z0; a.tab_nvox = (size_t)a.X * a.Y * wf->tab_zn; }
+    if (use_w) a.w_tab = wf->w_tab;
 
     if (!(flags & DF_WARP_NO_CULL) && proj[0] > 0.f && proj[1] > 0.f) {
         DF_HIP(hipMemsetAsync(wf->bounds_dev + 2, 0, sizeof(float), st));
         hipLaunchKernelGGL(df_dists_max_kernel, dim3(64), dim3(256), 0, st, dists, pitch, cols, rows, wf->bounds_dev + 2);
         DF_LAUNCH_CHECK();
-        double r = 0.0;      // half diagonal of the brick's voxel-centre lattice under vol2world
-        for (int sx = -1; sx <= 1; sx += 2) for (int sy = -1; sy <= 1; sy += 2) for (int sz = -1; sz <= 1; sz += 2) {
-            double ex = sx * 3.5 * a.vsx, ey = sy * 3.5 * a.vsy, ez = sz * 3.5 * a.vsz;
-            double wx = vol2world[0] * ex + vol2world[1] * ey + vol2world[2] * ez;
-            double wy = vol2world[3] * ex + vol2world[4] * ey + vol2world[5] * ez;
-            double wz = vol2world[6] * ex + vol2world[7] * ey + vol2world[8] * ez;
-            double d = sqrt(wx * wx + wy * wy + wz * wz);
-            if (d > r) r = d;
-        }
+        const double r = use_tab ? df_tile_radius(vol2world, DF_ROW_TX, DF_ROW_TY, DF_ROW_TZ, v)
+                                 : df_tile_radius(vol2world, DF_BRICK, DF_BRICK, DF_BRICK, v);
         double fro = 0.0;    // Frobenius norm of world2cam.R bounds its operator norm; == sqrt(3) for a rotation
         for (int i = 0; i < 9; ++i) fro += (double)world2cam[i] * world2cam[i];
         fro = sqrt(fro);
         a.cam_scale = (float)((fabs(fro - 1.7320508075688772) < 1e-3) ? 1.001 : fro * 1.001);
-        a.brick_r = (float)(r * 1.001 + 1e-6);
+        a.tile_r = (float)(r * 1.001 + 1e-6);
         a.cull = wf->bounds_dev;
     }
 
     DfWarpView W = df_view(wf);
-    const int bz_lo = s.z_own0 / DF_BRICK, bz_hi = (s.z_own0 + s.z_own_n - 1) / DF_BRICK;
-    a.bz0 = bz_lo;
-    dim3 grid((unsigned)(W.bx * W.by), (unsigned)(bz_hi - bz_lo + 1));
-    DF_DISPATCH_K(k, df_integrate_warped_kernel<K><<<grid, dim3(256), 0, st>>>(a, W));
+    if (use_tab) {
+        const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_ROW_TY - 1) / DF_ROW_TY;
+        const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
+        a.bz0 = zt_lo;
+        dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(zt_hi - zt_lo + 1));
+        if (use_w) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
+        else { DF_DISPATCH_K(k, df_warp_rows_kernel<K, false><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
+    } else {
+        const int bz_lo = s.z_own0 / DF_BRICK, bz_hi = (s.z_own0 + s.z_own_n - 1) / DF_BRICK;
+        a.bz0 = bz_lo;
+        dim3 grid((unsigned)(W.bx * W.by), (unsigned)(bz_hi - bz_lo + 1));
+        DF_DISPATCH_K(k, df_warp_brick_kernel<K, false><<<grid, dim3(256), 0, st>>>(a, W));
+    }
     DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+// Per-voxel k-NN (and weight) tables for planes [z_own0, z_own0 + z_own_n) (this rank's slab).
+static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab& s, const float vol2world[12], int k, bool weights,
+                                hipStream_t st)
+{
+    if (s.z_own_n == 0) return DF_OK;
+    // table planes are brick-aligned so that both voxels of a build thread (z, z+4) index inside it
+    const int bz_lo = s.z_own0 / DF_BRICK, bz_hi = (s.z_own0 + s.z_own_n - 1) / DF_BRICK;
+    const int tz0 = bz_lo * DF_BRICK, tzn = (bz_hi - bz_lo + 1) * DF_BRICK;
+    const size_t nvox = (size_t)v.dims[0] * v.dims[1] * tzn;
+    const size_t need = nvox * k;
+    if (need > wf->knn_tab_cap) {
+        (void)hipFree(wf->knn_tab); wf->knn_tab = nullptr; wf->knn_tab_cap = 0;
+        DF_HIP(hipMalloc((void**)&wf->knn_tab, need * sizeof(uint16_t)));
+        wf->knn_tab_cap = need;
+    }
+    if (weights && need > wf->w_tab_cap) {
+        (void)hipFree(wf->w_tab); wf->w_tab = nullptr; wf->w_tab_cap = 0;
+        DF_HIP(hipMalloc((void**)&wf->w_tab, need * sizeof(float)));
+        wf->w_tab_cap = need;
+    }
+    DfWarpedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w_tab = weights ? wf->w_tab : nullptr;
+    a.X = v.dims[0]; a.Y = v.dims[1]; a.Z = v.dims[2];
+    a.z_store0 = tz0; a.z_own0 = tz0; a.z_own_n = tzn;        // every voxel of the covered bricks gets an entry
+    a.vsx = v.voxel_size[0]; a.vsy = v.voxel_size[1]; a.vsz = v.voxel_size[2];
+    a.vol2world = df_aff(vol2world);
+    a.knn_tab = wf->knn_tab; a.tab_z0 = tz0; a.tab_nvox = nvox; a.bz0 = bz_lo;
+    DfWarpView W = df_view(wf);
+    dim3 grid((unsigned)(W.bx * W.by), (unsigned)(bz_hi - bz_lo + 1));
+    DF_DISPATCH_K(k, df_warp_brick_kernel<K, true><<<grid, dim3(256), 0, st>>>(a, W));
+    DF_LAUNCH_CHECK();
+    DF_HIP(hipStreamSynchronize(st));
+    wf->tab_z0 = tz0; wf->tab_zn = tzn; wf->tab_k = k; wf->tab_valid = true; wf->w_tab_valid = weights;
     return DF_OK;
 }

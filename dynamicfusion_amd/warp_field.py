@@ -18,8 +18,10 @@ KNN_NEIGHBOURS = 8           # warp_field.hpp:10 (compile-time there, runtime he
 
 
 class WarpField:
-    def __init__(self, k=KNN_NEIGHBOURS, device="cuda"):
+    def __init__(self, k=KNN_NEIGHBOURS, device="cuda", voxel_table=True, weight_table=True):
         self.k = int(k)
+        self.voxel_table = bool(voxel_table)     # cache the per-voxel k-NN in HBM (k*2 B/voxel); False = re-rank per frame
+        self.weight_table = bool(weight_table) and self.voxel_table   # also cache the k blend weights (k*4 B/voxel)
         self.device = torch.device(device)
         h = C.c_void_p()
         capi.check(capi.lib().dfusion_warp_create(C.byref(h)), "dfusion_warp_create")
@@ -63,11 +65,16 @@ class WarpField:
 
     # ---- buildKDTree (warp_field.cpp:275-282) -> exact k-NN brick index for one volume geometry
     def ensure_index(self, volume, k):
-        key = (volume.getDims(), tuple(volume.getVoxelSize().tolist()), volume.getPose().tobytes(), int(k))
-        if self._index_key is not None and self._index_key[:3] == key[:3] and self._index_key[3] >= k:
+        key = (volume.getDims(), tuple(volume.getVoxelSize().tolist()), volume.getPose().tobytes(),
+               (volume.z_own0, volume.z_own_n), int(k))
+        if self._index_key is not None and self._index_key[:4] == key[:4] and (
+                self._index_key[4] == k or (not self.voxel_table and self._index_key[4] >= k)):
             return
-        capi.check(capi.lib().dfusion_warp_build_index(self.handle, volume.c_volume(), capi.floats(aff12(volume.getPose())),
-                                                       int(k), _stream()), "dfusion_warp_build_index")
+        capi.check(capi.lib().dfusion_warp_build_index(self.handle, volume.c_volume(), volume.c_slab(),
+                                                       capi.floats(aff12(volume.getPose())), int(k),
+                                                       (capi.DF_INDEX_VOXEL_TABLE if self.voxel_table else 0) |
+                                                       (capi.DF_INDEX_WEIGHT_TABLE if self.weight_table else 0), _stream()),
+                   "dfusion_warp_build_index")
         self._index_key = key
 
     # ---- WarpField::KNN (warp_field.cpp:247-251), batched

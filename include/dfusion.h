@@ -70,6 +70,15 @@ enum {
 
 /* flags for dfusion_integrate_warped */
 #define DF_WARP_NO_CULL 1u   /* disable the (result-identical) conservative brick culling     */
+#define DF_WARP_NO_TABLE 2u  /* ignore the per-voxel k-NN table even if built (re-rank per frame) */
+#define DF_WARP_NO_WEIGHT_TABLE 4u /* ignore the per-voxel weight table (recompute exp per frame)   */
+/* flags for dfusion_warp_build_index */
+#define DF_INDEX_VOXEL_TABLE 1u /* also cache the exact k-NN of EVERY voxel of the slab in HBM:
+                                   k * 2 bytes per voxel (2 GiB at 512^3, k = 8) -- the per-frame
+                                   sweep then streams it instead of re-running the k-NN search   */
+#define DF_INDEX_WEIGHT_TABLE 2u /* implies the above, and also caches the k blend weights
+                                   exp(-d^2/(2 dg_w^2)) of every voxel (k * 4 bytes per voxel, 4 GiB
+                                   at 512^3, k = 8): they too depend only on canonical geometry     */
 
 int dfusion_abi_version(void);
 const char *dfusion_error_string(int err);
@@ -139,9 +148,12 @@ int dfusion_warp_set_nodes(DfWarpField *wf, const float *pos_dev, const float *d
 int dfusion_warp_set_transforms(DfWarpField *wf, const float *dq_dev, dfStream stream);
 
 /* Builds the exact k-NN acceleration index for voxel queries of this volume geometry: for each
- * 8x8x8 brick the list of nodes that can be among the k nearest of ANY of its voxels.  Replaces
- * the kd-tree build (warp_field.cpp:275-282).  Blocks until the index is built.               */
-int dfusion_warp_build_index(DfWarpField *wf, DfVolume geometry, const float vol2world[12], int k, dfStream stream);
+ * 8x8x8 brick the list of nodes that can be among the k nearest of ANY of its voxels, and (flag
+ * DF_INDEX_VOXEL_TABLE) the per-voxel k-NN table of the slab's own planes.  Replaces the kd-tree
+ * build (warp_field.cpp:275-282); needed again only when node POSITIONS change (they do not between
+ * frames: only transforms are optimised).  `geometry.data` is not dereferenced.  Blocks until built. */
+int dfusion_warp_build_index(DfWarpField *wf, DfVolume geometry, const DfSlab *slab, const float vol2world[12], int k,
+                             unsigned flags, dfStream stream);
 
 /* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k],
  * ascending distance, ties -> lower node index.                                               */

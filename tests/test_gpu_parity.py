@@ -191,6 +191,27 @@ def test_integrate_warped_cull_is_result_identical():
     assert torch.equal(a.data(), b.data())
 
 
+@pytest.mark.parametrize("cfg", [SMALL, MID], ids=["64-k4", "128-k8"])
+def test_voxel_knn_table_equals_on_the_fly_search(cfg):
+    """The per-voxel k-NN table cached in HBM (DF_INDEX_VOXEL_TABLE) must give the same volume, bit for bit, as
+    re-running the brick-list k-NN every frame."""
+    sc = Scene(cfg, n_frames=2)
+    intr = Intr(*cfg.intr)
+    wf_tab = make_gpu_warp(sc)
+    wf_fly = WarpField(k=cfg.k, voxel_table=False)
+    wf_fly.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
+    a, b, c, e = make_gpu_volume(sc), make_gpu_volume(sc), make_gpu_volume(sc), make_gpu_volume(sc)
+    for f in range(2):
+        d = upload_u16(sc.dists[f])
+        for wf in (wf_tab, wf_fly):
+            wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+        a.integrate_warped(d, sc.cam_poses[f], intr, wf_tab)
+        b.integrate_warped(d, sc.cam_poses[f], intr, wf_fly)
+        c.integrate_warped(d, sc.cam_poses[f], intr, wf_tab, use_table=False)
+        e.integrate_warped(d, sc.cam_poses[f], intr, wf_tab, use_weights=False)
+    assert torch.equal(a.data(), b.data()) and torch.equal(a.data(), c.data()) and torch.equal(a.data(), e.data())
+
+
 def test_integrate_warped_identity_nodes_close_to_rigid():
     """Default-constructed node transforms (dual_quaternion.hpp:25-29) give x_w == x_c exactly; the warped
     sweep then differs from the rigid one only by direct-vs-incremental vc rounding."""

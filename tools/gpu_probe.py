@@ -44,9 +44,10 @@ def main():
         t0 = time.time(); wf.ensure_index(vol, cfg.k); torch.cuda.synchronize(); print("index build %.3f s" % (time.time() - t0))
         vol.clear(); n.zero_()
         vol.integrate_warped(dists, cam, intr, wf, n_updated=n); nw = int(n.item()); print("warped n_upd", nw, nw / nvox)
-        for cull in (True, False):
-            ms = timeit(lambda: vol.integrate_warped(dists, cam, intr, wf, cull=cull, sync=False), iters=5, warm=1)
-            print("warped cull=%s : %.3f ms  alg %.0f GB/s" % (cull, ms, 8 * nw / ms / 1e6))
+        for tab, wts in ((True, True), (True, False), (False, False)):
+            for cull in (True, False):
+                ms = timeit(lambda: vol.integrate_warped(dists, cam, intr, wf, cull=cull, use_table=tab, use_weights=wts, sync=False), iters=5, warm=1)
+                print("warped knn_table=%s w_table=%s cull=%s : %.3f ms  alg %.0f GB/s" % (tab, wts, cull, ms, 8 * nw / ms / 1e6))
     pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
     ms = timeit(lambda: vol.raycast(cam, intr, pts, nrm)); print("raycast: %.3f ms, hits %.3f" % (ms, float(torch.isfinite(pts[..., 0]).float().mean())))
 
