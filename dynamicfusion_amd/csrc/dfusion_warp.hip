@@ -179,6 +179,31 @@ __device__ __forceinline__ void dqb_blend_w(const DfWarpView& W, const float (&w
     *rot_out = rsum;
     *dual_out = q_mul(half, rsum);                    // dual_quaternion.hpp:59-63
 }
+// Same blend with the node transforms staged in LDS (s_rot / s_nt indexed by GLOBAL node id).
+template <int K>
+__device__ __forceinline__ void dqb_blend_lds(const float4* s_rot, const float4* s_nt, const float (&wt)[K], const int (&bi)[K],
+                                              quat* rot_out, quat* dual_out)
+{
+    quat tsum, rsum;
+    tsum.w = tsum.x = tsum.y = tsum.z = 0.f;
+    rsum.w = rsum.x = rsum.y = rsum.z = 0.f;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int j = bi[i];
+        const float w = wt[i];
+        const float4 t4 = s_nt[j], r4 = s_rot[j];
+        quat t, r;
+        t.w = t4.x; t.x = t4.y; t.y = t4.z; t.z = t4.w;
+        r.w = r4.x; r.x = r4.y; r.y = r4.z; r.z = r4.w;
+        tsum = q_add(tsum, q_scale(w, t));            // :211
+        rsum = q_add(rsum, q_scale(w, r));            // :212
+    }
+    rsum = q_normalize(rsum);                         // :214
+    quat half;
+    half.w = 0.5f * tsum.w; half.x = 0.5f * tsum.x; half.y = 0.5f * tsum.y; half.z = 0.5f * tsum.z;
+    *rot_out = rsum;
+    *dual_out = q_mul(half, rsum);                    // dual_quaternion.hpp:59-63
+}
 // weights from squared distances: WarpField::weighting (warp_field.cpp:238-241) per neighbour
 template <int K>
 __device__ __forceinline__ void dqb_weights(const DfWarpView& W, const float (&bd)[K], const int (&bi)[K], float (&wt)[K])
@@ -673,8 +698,8 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
 #define DF_ROW_TY 8
 #define DF_ROW_TZ 8
 
-template <int K, bool HAS_W>
-__global__ __launch_bounds__(256) void df_warp_rows_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
+template <int K, bool HAS_W, int UNROLL>
+__global__ __launch_bounds__(256, UNROLL) void df_warp_rows_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int zt = a.bz0 + blockIdx.y;                                 // tile layer (DF_ROW_TZ planes)
@@ -692,7 +717,6 @@ __global__ __launch_bounds__(256) void df_warp_rows_kernel(const DfWarpedArgs a,
     const int zb = max(zt * DF_ROW_TZ, a.z_own0), ze = min(min((zt + 1) * DF_ROW_TZ, a.z_own0 + a.z_own_n), a.Z);
     unsigned int my_upd = 0;
     if (in_xy) {
-#pragma unroll 2
         for (int z = zb; z < ze; ++z) {
             const size_t tv = (size_t)(z - a.tab_z0) * plane + (size_t)y * a.X + x;
             const f3 q = aff_mul(a.vol2world, mk3(fxv, fyv, (float)z * a.vsz));     // canonical position
@@ -706,6 +730,77 @@ __global__ __launch_bounds__(256) void df_warp_rows_kernel(const DfWarpedArgs a,
                 for (int i = 0; i < K; ++i) { const float4 p = W.pos_sigma[bi[i]]; wt[i] = dqb_weight(knn_dist2(q, p.x, p.y, p.z), p.w); }
             }
             my_upd += df_warp_update<K>(a, W, q, wt, bi, a.vol + (size_t)(z - a.z_store0) * plane + (size_t)y * a.X + x);
+        }
+    }
+    df_count_updates(a, my_upd);
+}
+
+// ---- row-tile kernel, node transforms in LDS.  PMC on the kernel above: ~116 vector-memory instructions per wave, 16 of
+// every 19 being 16-byte node gathers through the texture-address path (64 lanes x 16 B = 16 TA cycles each) -- on par
+// with the HBM time of the table stream.  When the whole node table fits (M * 32 B <= 128 KiB, i.e. M <= 4096), a
+// 512-thread workgroup stages rot + node_t of ALL nodes in LDS once and walks DF_LDS_ZT tile layers; gathers become
+// ds_read_b128 (256 B/clk/CU, identical addresses broadcast).  Two such workgroups fill a CU (160 KiB LDS, 16 waves).
+#define DF_LDS_TY 16
+#define DF_LDS_ZT 8          // tile layers (of DF_ROW_TZ planes) walked per workgroup
+
+template <int K, bool HAS_W, int NB>
+__global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [M] rot, then [M] node_t
+    float4* s_rot = s_nodes;
+    float4* s_nt = s_nodes + W.M;
+    for (int j = threadIdx.x; j < W.M; j += 512) { s_rot[j] = W.rot[j]; s_nt[j] = W.node_t[j]; }
+    __syncthreads();
+
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * DF_ROW_TX + (threadIdx.x & (DF_ROW_TX - 1));
+    const int y = ty * DF_LDS_TY + (threadIdx.x >> 5);
+    const bool in_xy = x < a.X && y < a.Y;
+    const size_t plane = (size_t)a.X * a.Y;
+    const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
+    unsigned int my_upd = 0;
+    for (int l = 0; l < DF_LDS_ZT; ++l) {
+        const int zt = a.bz0 + blockIdx.y * DF_LDS_ZT + l;                // tile layer (DF_ROW_TZ planes)
+        const int zb = max(zt * DF_ROW_TZ, a.z_own0), ze = min(min((zt + 1) * DF_ROW_TZ, a.z_own0 + a.z_own_n), a.Z);
+        if (zb >= ze) continue;
+        if (a.cull) {
+            const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX) + 0.5f * (DF_ROW_TX - 1)) * a.vsx,
+                                                  ((float)(ty * DF_LDS_TY) + 0.5f * (DF_LDS_TY - 1)) * a.vsy,
+                                                  ((float)(zt * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
+            if (df_tile_culled(a, c)) continue;                           // block-uniform
+        }
+        if (!in_xy) continue;
+        // NB planes per batch: all table loads of the batch are issued back to back (NB * 3 KiB in flight per wave),
+        // then the NB voxels are blended one after the other -- memory-level parallelism without more waves.
+        for (int z0 = zb; z0 < ze; z0 += NB) {
+            int bi[NB][K]; float wt[NB][K];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int z = min(z0 + u, ze - 1);                        // clamp: tail lanes re-read a valid entry
+                const size_t tv = (size_t)(z - a.tab_z0) * plane + (size_t)y * a.X + x;
+                knn_tab_load<K>(a.knn_tab, tv, bi[u]);
+                if constexpr (HAS_W) w_tab_load<K>(a.w_tab, a.tab_nvox, tv, wt[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int z = z0 + u;
+                if (z < ze) {
+                    const f3 q = aff_mul(a.vol2world, mk3(fxv, fyv, (float)z * a.vsz));     // canonical position
+                    if constexpr (!HAS_W) {
+#pragma unroll
+                        for (int i = 0; i < K; ++i) { const float4 p = W.pos_sigma[bi[u][i]]; wt[u][i] = dqb_weight(knn_dist2(q, p.x, p.y, p.z), p.w); }
+                    }
+                    quat rot, dual;
+                    dqb_blend_lds<K>(s_rot, s_nt, wt[u], bi[u], &rot, &dual);
+                    const f3 vc = aff_mul(a.world2cam, dq_transform(rot, dual, q));
+                    float ts;
+                    if (tsdf_sample(a.P, vc, &ts)) {
+                        uint32_t* vox = a.vol + (size_t)(z - a.z_store0) * plane + (size_t)y * a.X + x;
+                        *vox = tsdf_fuse(*vox, ts, a.P.max_weight);
+                        ++my_upd;
+                    }
+                }
+            }
         }
     }
     df_count_updates(a, my_upd);
@@ -788,13 +883,36 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     }
 
     DfWarpView W = df_view(wf);
-    if (use_tab) {
+    const char* evl = getenv("DFUSION_ROWS_LDS");
+    const bool lds_ok = (size_t)wf->M * 32 <= 128 * 1024 && !(evl && atoi(evl) == 0);
+    if (use_tab && lds_ok) {
+        const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_LDS_TY - 1) / DF_LDS_TY;
+        const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
+        a.bz0 = zt_lo;
+        if (!(flags & DF_WARP_NO_CULL) && a.cull) a.tile_r = (float)(df_tile_radius(vol2world, DF_ROW_TX, DF_LDS_TY, DF_ROW_TZ, v) * 1.001 + 1e-6);
+        dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + DF_LDS_ZT - 1) / DF_LDS_ZT));
+        const size_t lds = (size_t)wf->M * 32;
+        const char* evb = getenv("DFUSION_ROWS_NB");
+        const int nb = evb ? atoi(evb) : 2;
+#define DF_LAUNCH_LDS(HW, NBV)                                                                                                          \
+        DF_DISPATCH_K(k, { DF_HIP(hipFuncSetAttribute((const void*)df_warp_rows_lds_kernel<K, HW, NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                           df_warp_rows_lds_kernel<K, HW, NBV><<<grid, dim3(512), lds, st>>>(a, W, tiles_x); })
+        if (use_w) {
+            if (nb == 1) { DF_LAUNCH_LDS(true, 1); } else if (nb == 4) { DF_LAUNCH_LDS(true, 4); } else { DF_LAUNCH_LDS(true, 2); }
+        } else { DF_LAUNCH_LDS(false, 1); }
+#undef DF_LAUNCH_LDS
+    } else if (use_tab) {
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_ROW_TY - 1) / DF_ROW_TY;
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
         a.bz0 = zt_lo;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(zt_hi - zt_lo + 1));
-        if (use_w) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
-        else { DF_DISPATCH_K(k, df_warp_rows_kernel<K, false><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
+        const char* ev = getenv("DFUSION_ROWS_UNROLL");
+        const int unroll = ev ? atoi(ev) : 2;
+        if (use_w && unroll == 5) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true, 5><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
+        else if (use_w && unroll == 6) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true, 6><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
+        else if (use_w && unroll == 8) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true, 8><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
+        else if (use_w) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true, 4><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
+        else { DF_DISPATCH_K(k, df_warp_rows_kernel<K, false, 4><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
     } else {
         const int bz_lo = s.z_own0 / DF_BRICK, bz_hi = (s.z_own0 + s.z_own_n - 1) / DF_BRICK;
         a.bz0 = bz_lo;

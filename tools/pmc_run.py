@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Small fixed workload for rocprofv3 --pmc passes: N launches each of the hot kernels at one config."""
+import os, sys
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+from dynamicfusion_amd import Intr, TsdfVolume, WarpField, compute_dists, synth, upload_u16
+name = sys.argv[1] if len(sys.argv) > 1 else "512"; n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+mode = sys.argv[3] if len(sys.argv) > 3 else "tables"
+cfg = synth.CONFIGS[name]; intr = Intr(*cfg.intr)
+depth = upload_u16(synth.depth_frame(cfg, 0)); dists = compute_dists(depth, intr); cam = synth.camera_pose(cfg, 1)
+vol = TsdfVolume(cfg.dims); vol.setSize([cfg.size]*3); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setPose(cfg.volume_pose)
+vol.setRaycastStepFactor(cfg.raycast_step_factor); vol.setGradientDeltaFactor(cfg.gradient_delta_factor)
+pos, sigma = synth.make_nodes(cfg); dq = synth.node_transforms(cfg, 1)
+wf = WarpField(k=cfg.k, voxel_table=(mode != "lean"), weight_table=(mode == "tables")); wf.init(pos, sigma=sigma, transforms=dq)
+pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
+for _ in range(n):
+    vol.integrate_warped(dists, cam, intr, wf, sync=False)
+for _ in range(n):
+    vol.raycast(cam, intr, pts, nrm)
+for _ in range(n):
+    vol.integrate(dists, cam, intr, sync=False)
+torch.cuda.synchronize()
+print("done", cfg.name, mode)
