@@ -49,5 +49,33 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+HOST_DIR = os.path.join(PKG_DIR, "host")
+HOST_LIB = os.path.join(HOST_DIR, "libkfusion_hip.so")
+HOST_APP = os.path.join(HOST_DIR, "headless_frame")
+
+
+def build_host(force=False, verbose=False):
+    """C++ host mirror (kfusion::cuda::TsdfVolume / WarpField over the C-ABI) + the headless harness, with g++."""
+    build_library(force=False)
+    src = os.path.join(HOST_DIR, "src", "kfusion_hip.cpp")
+    app = os.path.join(HOST_DIR, "apps", "headless_frame.cpp")
+    deps = [src, app, LIB_PATH] + [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(HOST_DIR, "include")) for f in fs]
+    if not force and os.path.exists(HOST_LIB) and os.path.exists(HOST_APP) and \
+            min(os.path.getmtime(HOST_LIB), os.path.getmtime(HOST_APP)) >= max(os.path.getmtime(d) for d in deps):
+        return HOST_LIB, HOST_APP
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    common = ["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HOST_DIR, "include"),
+              "-I", os.path.join(REPO_DIR, "include"), "-I", os.path.join(rocm, "include")]
+    link = ["-L", PKG_DIR, "-ldfusion_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64"]
+    cmds = [common + ["-fPIC", "-shared", src, "-o", HOST_LIB] + link + ["-Wl,-rpath,$ORIGIN/.."],
+            common + [app, "-o", HOST_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
+    for c in cmds:
+        if verbose:
+            print(" ".join(c))
+        subprocess.check_call(c)
+    return HOST_LIB, HOST_APP
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

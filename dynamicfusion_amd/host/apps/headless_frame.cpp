@@ -1,0 +1,99 @@
+// headless_frame.cpp -- the hot-path call sequence of KinFu::operator() / KinFu::dynamicfusion
+// (/root/reference/kfusion/src/kinfu.cpp:226,248,297,351,385,391) through the source-compatible C++ API, without the GUI,
+// ICP or solver.  Inputs and outputs are raw binary files so that tests can drive it and diff against the oracle:
+//   headless_frame <dims> <size_m> <cols> <rows> <frames> <nodes> <k> <in.bin> <out.bin>
+// in.bin : per frame { depth u16[rows*cols], camera pose f32[12] (R row-major, t) } , then nodes { pos f32[3M], dq f32[8M]
+//          per frame, sigma f32[M] } ; intrinsics fx fy cx cy f32[4] ; volume pose f32[12] first of all.
+// out.bin: volume u32[dims^3], points f32[rows*cols*4], normals f32[rows*cols*4] of the last frame.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <kfusion/cuda/tsdf_volume.hpp>
+#include <kfusion/cuda/imgproc.hpp>
+#include <kfusion/warp_field.hpp>
+
+using namespace kfusion;
+
+static Affine3f read_affine(FILE* f)
+{
+    float a[12];
+    if (std::fread(a, 4, 12, f) != 12) { std::fprintf(stderr, "short read\n"); std::exit(2); }
+    Affine3f r;
+    for (int i = 0; i < 9; ++i) r.R.val[i] = a[i];
+    for (int i = 0; i < 3; ++i) r.t[i] = a[9 + i];
+    return r;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc != 10) { std::fprintf(stderr, "usage: %s dims size cols rows frames nodes k in.bin out.bin\n", argv[0]); return 2; }
+    const int dims = std::atoi(argv[1]); const float size = (float)std::atof(argv[2]);
+    const int cols = std::atoi(argv[3]), rows = std::atoi(argv[4]), frames = std::atoi(argv[5]), M = std::atoi(argv[6]), k = std::atoi(argv[7]);
+    FILE* in = std::fopen(argv[8], "rb");
+    if (!in) { std::perror("in"); return 2; }
+    const Affine3f volume_pose = read_affine(in);
+    float intr_v[4];
+    if (std::fread(intr_v, 4, 4, in) != 4) return 2;
+    const Intr intr(intr_v[0], intr_v[1], intr_v[2], intr_v[3]);
+
+    cuda::TsdfVolume volume(Vec3i(dims, dims, dims));        // KinFu::KinFu, kinfu.cpp:99-107 (size before trunc, see tests)
+    volume.setSize(Vec3f::all(size));
+    volume.setTruncDist(0.04f);
+    volume.setMaxWeight(64);
+    volume.setPose(volume_pose);
+    volume.setRaycastStepFactor(0.75f);
+    volume.setGradientDeltaFactor(0.5f);
+
+    std::vector<std::vector<unsigned short> > depth(frames, std::vector<unsigned short>((size_t)rows * cols));
+    std::vector<Affine3f> cam(frames);
+    for (int f = 0; f < frames; ++f) {
+        if (std::fread(depth[f].data(), 2, depth[f].size(), in) != depth[f].size()) return 2;
+        cam[f] = read_affine(in);
+    }
+    WarpField warp(k);
+    std::vector<std::vector<float> > dq(frames, std::vector<float>((size_t)M * 8));
+    if (M > 0) {
+        std::vector<float> pos((size_t)M * 3), sigma(M);
+        if (std::fread(pos.data(), 4, pos.size(), in) != pos.size()) return 2;
+        for (int f = 0; f < frames; ++f) if (std::fread(dq[f].data(), 4, dq[f].size(), in) != dq[f].size()) return 2;
+        if (std::fread(sigma.data(), 4, sigma.size(), in) != sigma.size()) return 2;
+        std::vector<Vec3f> pts(M);
+        for (int i = 0; i < M; ++i) pts[i] = Vec3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+        warp.init(pts);
+        for (int i = 0; i < M; ++i) (*warp.getNodes())[i].weight = sigma[i];
+        warp.commit(true);
+    }
+    std::fclose(in);
+
+    cuda::Depth depth_device;
+    cuda::Dists dists;
+    cuda::Cloud points; cuda::Normals normals;
+    points.create(rows, cols); normals.create(rows, cols);
+    for (int f = 0; f < frames; ++f) {
+        depth_device.upload(depth[f].data(), (size_t)cols * 2, rows, cols);          // demo.cpp:89
+        cuda::computeDists(depth_device, dists, intr);                               // kinfu.cpp:226
+        if (M > 0) {
+            for (int i = 0; i < M; ++i) std::memcpy((void*)(*warp.getNodes())[i].transform.raw(), &dq[f][8 * (size_t)i], 32);
+            warp.commit(false);                                                      // solver write-back stand-in (kinfu.cpp:387)
+            volume.integrate(dists, cam[f], intr, warp);                             // the north-star fusion (kinfu.cpp:391)
+        } else {
+            volume.integrate(dists, cam[f], intr);                                   // kinfu.cpp:248
+        }
+        volume.raycast(cam[f], intr, points, normals);                               // kinfu.cpp:297 / :351
+        cuda::waitAllDefaultStream();                                                // kinfu.cpp:301
+    }
+
+    FILE* out = std::fopen(argv[9], "wb");
+    if (!out) { std::perror("out"); return 2; }
+    std::vector<unsigned int> vol((size_t)dims * dims * dims);
+    volume.data().download(vol.data());
+    std::fwrite(vol.data(), 4, vol.size(), out);
+    std::vector<float> p((size_t)rows * cols * 4), n(p.size());
+    points.download(p.data(), (size_t)cols * 16);
+    normals.download(n.data(), (size_t)cols * 16);
+    std::fwrite(p.data(), 4, p.size(), out);
+    std::fwrite(n.data(), 4, n.size(), out);
+    std::fclose(out);
+    std::printf("headless_frame ok: %d frames, %d nodes\n", frames, M);
+    return 0;
+}

@@ -1,0 +1,90 @@
+"""The C++ drop-in boundary (dynamicfusion_amd/host: kfusion::cuda::TsdfVolume, DeviceArray2D, WarpField, computeDists)
+driven through the headless harness, which makes the hot-path calls of KinFu::operator() / dynamicfusion
+(kinfu.cpp:226,248,297,351,391) -- diffed against the oracle on the same inputs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from dynamicfusion_amd import build, synth
+from scene import Scene, compare_volumes
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+# ---- the harness derives vol2cam / cam2vol / Rinv with the arithmetic of host/include/kfusion/types.hpp
+def cxx_inv(m):
+    R = m[:3, :3].astype(np.float64)
+    d = np.array([R[1, 1] * R[2, 2] - R[1, 2] * R[2, 1], R[0, 2] * R[2, 1] - R[0, 1] * R[2, 2], R[0, 1] * R[1, 2] - R[0, 2] * R[1, 1],
+                  R[1, 2] * R[2, 0] - R[1, 0] * R[2, 2], R[0, 0] * R[2, 2] - R[0, 2] * R[2, 0], R[0, 2] * R[1, 0] - R[0, 0] * R[1, 2],
+                  R[1, 0] * R[2, 1] - R[1, 1] * R[2, 0], R[0, 1] * R[2, 0] - R[0, 0] * R[2, 1], R[0, 0] * R[1, 1] - R[0, 1] * R[1, 0]])
+    det = R[0, 0] * d[0] + R[0, 1] * d[3] + R[0, 2] * d[6]
+    Ri = (d / det).astype(F32).reshape(3, 3)
+    out = np.eye(4, dtype=F32)
+    out[:3, :3] = Ri
+    t = m[:3, 3].astype(np.float64)
+    out[:3, 3] = np.array([-(float(Ri[i, 0]) * t[0] + float(Ri[i, 1]) * t[1] + float(Ri[i, 2]) * t[2]) for i in range(3)], F32)
+    return out
+
+
+def cxx_mul(a, b):
+    out = np.eye(4, dtype=F32)
+    A, B = a.astype(np.float64), b.astype(np.float64)
+    for i in range(3):
+        for j in range(3):
+            out[i, j] = F32(A[i, 0] * B[0, j] + A[i, 1] * B[1, j] + A[i, 2] * B[2, j])
+        out[i, 3] = F32(A[i, 0] * B[0, 3] + A[i, 1] * B[1, 3] + A[i, 2] * B[2, 3] + A[i, 3])
+    return out
+
+
+def run_harness(tmp_path, cfg, sc, frames, with_nodes):
+    _, app = build.build_host()
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    M = cfg.nodes if with_nodes else 0
+    with open(fin, "wb") as f:
+        f.write(synth.aff12(sc.pose).tobytes())
+        f.write(np.asarray(cfg.intr, F32).tobytes())
+        for i in range(frames):
+            f.write(sc.depths[i].tobytes())
+            f.write(synth.aff12(sc.cam_poses[i]).tobytes())
+        if M:
+            f.write(sc.pos.astype(F32).tobytes())
+            for i in range(frames):
+                f.write(sc.dqs[i].astype(F32).tobytes())
+            f.write(sc.sigma.astype(F32).tobytes())
+    r = subprocess.run([app, str(cfg.dims[0]), str(cfg.size), str(cfg.cols), str(cfg.rows), str(frames), str(M), str(cfg.k), fin, fout],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(fout, np.uint8)
+    nv = int(np.prod(cfg.dims))
+    vol = raw[:4 * nv].view(np.uint32).reshape(cfg.dims[2], cfg.dims[1], cfg.dims[0])
+    img = raw[4 * nv:].view(np.float32).reshape(2, cfg.rows, cfg.cols, 4)
+    return vol, img[0], img[1]
+
+
+@pytest.mark.parametrize("with_nodes", [False, True], ids=["rigid", "warped"])
+def test_cxx_api_matches_oracle(tmp_path, with_nodes):
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=100, k=8)
+    frames = 2
+    sc = Scene(cfg, n_frames=frames)
+    vol, pts, nrm = run_harness(tmp_path, cfg, sc, frames, with_nodes)
+    ref = sc.new_volume()
+    for f in range(frames):
+        cam_inv = cxx_inv(sc.cam_poses[f])
+        if with_nodes:
+            O.integrate_warped(sc.dists[f], ref, sc.ovol(ref), synth.aff12(sc.pose), synth.aff12(cam_inv), sc.intr, sc.pos,
+                               sc.dqs[f], sc.sigma, cfg.k)
+        else:
+            O.integrate(sc.dists[f], ref, sc.ovol(ref), synth.aff12(cxx_mul(cam_inv, sc.pose)), sc.intr)
+    s = compare_volumes(vol, ref)
+    print(s)
+    assert s["bits_mismatch"] == 0, s
+    cam2vol = cxx_mul(cxx_inv(sc.pose), sc.cam_poses[frames - 1])
+    rinv = cxx_inv(cam2vol)[:3, :3]
+    rp, rn, _, stats = O.raycast_points(sc.ovol(ref), synth.aff12(cam2vol), rinv, sc.reproj, cfg.cols, cfg.rows,
+                                        cfg.raycast_step_factor, cfg.gradient_delta_factor)
+    assert stats[1] > 1000
+    assert np.array_equal(pts.view(np.uint32), rp.view(np.uint32)) and np.array_equal(nrm.view(np.uint32), rn.view(np.uint32))
