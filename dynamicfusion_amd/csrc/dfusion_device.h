@@ -118,6 +118,24 @@ __device__ __forceinline__ bool tsdf_sample(const DfIntegrateParams& P, f3 vc, f
     *tsdf_out = fminf(1.f, sdf * P.trunc_inv);            // :93
     return true;
 }
+// Branch-free form of tsdf_sample for the rigid sweep: every test is evaluated, the dists fetch uses a clamped
+// (always valid) address, and the verdict is the AND of the reference's conditions -- the same result for every
+// voxel (for a voxel that passes :82, (int)u is unchanged by the clamp), but four voxels per lane run as
+// independent straight-line chains instead of four nested divergent branches.
+__device__ __forceinline__ bool tsdf_sample_nb(const DfIntegrateParams& P, f3 vc, float* tsdf_out)
+{
+    const float u = fmaf(P.fx, vc.x / vc.z, P.cx);        // device.hpp:35
+    const float v = fmaf(P.fy, vc.y / vc.z, P.cy);        // device.hpp:36
+    bool ok = (vc.z > 0.f) & (u >= 0.f) & (v >= 0.f) & (u < (float)P.cols) & (v < (float)P.rows);   // :82, :86 (+NaN => skip)
+    const int ui = (int)fminf(fmaxf(u, 0.f), (float)(P.cols - 1));
+    const int vi = (int)fminf(fmaxf(v, 0.f), (float)(P.rows - 1));
+    const uint16_t* row = (const uint16_t*)((const char*)P.dists + (size_t)vi * P.pitch);
+    const float Dp = h2f_bits(row[ui]);                   // :85
+    const float sdf = Dp - sqrtf(dot3(vc, vc));           // :89
+    ok = ok & (Dp != 0.f) & (sdf >= -P.trunc);            // :86, :91
+    *tsdf_out = fminf(1.f, sdf * P.trunc_inv);            // :93
+    return ok;
+}
 // :97-103
 __device__ __forceinline__ uint32_t tsdf_fuse(uint32_t vox, float tsdf, int max_weight)
 {

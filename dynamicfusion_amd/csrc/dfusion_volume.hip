@@ -14,6 +14,7 @@
 //   * Voxels are read/written only when their update branch is taken (tsdf_volume.cu:91), exactly
 //     the traffic the algorithmic-bytes figure 8*N_upd counts.
 #include "dfusion_internal.h"
+#include <math.h>
 
 // ------------------------------------------------------------------------------------------ clear
 __global__ __launch_bounds__(256) void df_fill_zero_kernel(uint4* __restrict__ p, size_t n16)
@@ -94,8 +95,28 @@ struct DfRigidArgs {
     unsigned long long* n_upd;
 };
 
-template <int UNROLL>
-__global__ __launch_bounds__(256) void df_integrate_rigid_kernel(const DfRigidArgs a)
+// Signed test "certainly outside one image-frustum side plane or behind the camera by more than m metres".
+// The four side planes pass through the camera centre: u >= 0 <=> fx*x + cx*z >= 0, u < cols <=> -fx*x + (cols-cx)*z > 0,
+// same for v.  A voxel with z <= 0 is skipped by the exact test anyway, so the plane tests are safe for any z.
+struct DfFrustum { float nlx, nlz, nrx, nrz, nty, ntz, nby, nbz; };   // unit normals (pointing inside) of left/right/top/bottom
+__device__ __forceinline__ unsigned df_outside_mask(const DfFrustum& F, f3 p, float m)
+{
+    unsigned o = 0;
+    if (p.z < -m) o |= 1u;
+    if (F.nlx * p.x + F.nlz * p.z < -m) o |= 2u;
+    if (F.nrx * p.x + F.nrz * p.z < -m) o |= 4u;
+    if (F.nty * p.y + F.ntz * p.z < -m) o |= 8u;
+    if (F.nby * p.y + F.nbz * p.z < -m) o |= 16u;
+    return o;
+}
+
+// U = planes handled per batch.  Measured on MI355X (512^3): the sweep is bound by DEPENDENT LATENCY, not by VALU
+// throughput or HBM bandwidth -- each plane is a chain  divide -> dists fetch (L2) -> sqrt/compare -> voxel load (HBM)
+// -> fuse -> store,  and all 8192 waves of the launch are resident at once (8 per SIMD), so there is nothing else to
+// switch to.  Hence the straight-line, branch-free sample (4 columns x U planes = 4U independent chains per lane) and
+// the batched voxel loads: U dists-fetch groups and U 16-byte voxel loads are in flight per lane instead of one.
+template <int U>
+__global__ __launch_bounds__(256) void df_integrate_rigid_kernel(const DfRigidArgs a, const DfFrustum F)
 {
     const int xgroups = a.X >> 2;
     const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -113,30 +134,54 @@ __global__ __launch_bounds__(256) void df_integrate_rigid_kernel(const DfRigidAr
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             vc[i] = aff_mul(a.vol2cam, mk3((float)(x0 + i) * a.vsx, (float)y * a.vsy, 0.f));     // :71-72
-        for (int z = 0; z < zb; ++z) {                      // replay of `vc += zstep` (:75) for planes [0, zb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) vc[i] = add3(vc[i], zstep);
+        // Conservative, result-identical chunk rejection: the chunk's voxels of columns x0..x0+3 lie (up to the
+        // accumulated rounding of `vc += zstep`, < 1e-3 m over 1024 planes) in the convex hull of the four points
+        // {column 0, column 3} x {plane zb, plane ze-1}.  If all four are outside the SAME frustum plane by 5 mm,
+        // no voxel of the chunk can pass the exact test (:82,:86): skip it, including the replay.
+        bool culled;
+        {
+            const f3 a0 = add3(vc[0], scale3(zstep, (float)zb)), a3 = add3(vc[3], scale3(zstep, (float)zb));
+            const f3 span = scale3(zstep, (float)(ze - 1 - zb));
+            const float m = 5e-3f;
+            culled = (df_outside_mask(F, a0, m) & df_outside_mask(F, a3, m) & df_outside_mask(F, add3(a0, span), m) &
+                      df_outside_mask(F, add3(a3, span), m)) != 0u;
         }
-
-        const size_t plane = (size_t)a.X * a.Y;
-        uint32_t* p = a.vol + (size_t)(zb - a.z_store0) * plane + (size_t)y * a.X + x0;
-#pragma unroll UNROLL
-        for (int z = zb; z < ze; ++z, p += plane) {
-            float ts[4];
-            bool up[4];
-            bool any = false;
+        if (!culled) {
+            for (int z = 0; z < zb; ++z) {                  // replay of `vc += zstep` (:75) for planes [0, zb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { up[i] = tsdf_sample(a.P, vc[i], &ts[i]); any |= up[i]; }
-            if (any) {
-                uint4 v = *reinterpret_cast<const uint4*>(p);
-                if (up[0]) { v.x = tsdf_fuse(v.x, ts[0], a.P.max_weight); ++my_upd; }
-                if (up[1]) { v.y = tsdf_fuse(v.y, ts[1], a.P.max_weight); ++my_upd; }
-                if (up[2]) { v.z = tsdf_fuse(v.z, ts[2], a.P.max_weight); ++my_upd; }
-                if (up[3]) { v.w = tsdf_fuse(v.w, ts[3], a.P.max_weight); ++my_upd; }
-                *reinterpret_cast<uint4*>(p) = v;
+                for (int i = 0; i < 4; ++i) vc[i] = add3(vc[i], zstep);
             }
+            const size_t plane = (size_t)a.X * a.Y;
+            uint32_t* p = a.vol + (size_t)(zb - a.z_store0) * plane + (size_t)y * a.X + x0;
+            for (int z = zb; z < ze; z += U, p += U * plane) {
+                float ts[U][4];
+                bool up[U][4], any[U];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vc[i] = add3(vc[i], zstep);
+                for (int u = 0; u < U; ++u) {               // stage 1: 4U branch-free sample chains
+                    const bool inr = z + u < ze;
+                    any[u] = false;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        up[u][i] = tsdf_sample_nb(a.P, vc[i], &ts[u][i]) && inr;
+                        any[u] |= up[u][i];
+                        vc[i] = add3(vc[i], zstep);          // :75
+                    }
+                }
+                uint4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)                 // stage 2: all voxel loads of the batch in flight together
+                    if (any[u]) v[u] = *reinterpret_cast<const uint4*>(p + u * plane);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {               // stage 3: fuse (:97-103) and store
+                    if (any[u]) {
+                        if (up[u][0]) { v[u].x = tsdf_fuse(v[u].x, ts[u][0], a.P.max_weight); ++my_upd; }
+                        if (up[u][1]) { v[u].y = tsdf_fuse(v[u].y, ts[u][1], a.P.max_weight); ++my_upd; }
+                        if (up[u][2]) { v[u].z = tsdf_fuse(v[u].z, ts[u][2], a.P.max_weight); ++my_upd; }
+                        if (up[u][3]) { v[u].w = tsdf_fuse(v[u].w, ts[u][3], a.P.max_weight); ++my_upd; }
+                        *reinterpret_cast<uint4*>(p + u * plane) = v[u];
+                    }
+                }
+            }
         }
     }
     if (a.n_upd) {                                            // one atomic per wave
@@ -173,6 +218,17 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     a.P.max_weight = v.max_weight;
     a.n_upd = n_updated;
 
+    DfFrustum F;
+    {
+        const float fx = proj[0], fy = proj[1], cx = proj[2], cy = proj[3];
+        const float cr = (float)cols - cx, cb = (float)rows - cy;
+        const float nl = sqrtf(fx * fx + cx * cx), nr = sqrtf(fx * fx + cr * cr), nt = sqrtf(fy * fy + cy * cy), nb = sqrtf(fy * fy + cb * cb);
+        F.nlx = fx / nl; F.nlz = cx / nl; F.nrx = -fx / nr; F.nrz = cr / nr;
+        F.nty = fy / nt; F.ntz = cy / nt; F.nby = -fy / nb; F.nbz = cb / nb;
+        if (!(fx > 0.f && fy > 0.f && nl > 0.f && nr > 0.f && nt > 0.f && nb > 0.f)) {      // degenerate intrinsics: disable the pre-tests
+            F.nlx = F.nrx = F.nty = F.nby = 0.f; F.nlz = F.nrz = F.ntz = F.nbz = 0.f;
+        }
+    }
     const int groups = (a.X / 4) * a.Y;
     const int bx = (groups + 255) / 256;
     // Z chunking: enough chunks for >= ~8 waves per SIMD over 256 CUs, chunks of >= 16 planes.
@@ -186,13 +242,10 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     }
     a.zc = zc;
     dim3 grid(bx, (s.z_own_n + zc - 1) / zc);
-    const int unroll = df_env_int("DFUSION_RIGID_UNROLL", 2);
-    if (unroll >= 4)
-        hipLaunchKernelGGL(df_integrate_rigid_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else if (unroll >= 2)
-        hipLaunchKernelGGL(df_integrate_rigid_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(df_integrate_rigid_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    const int u = df_env_int("DFUSION_RIGID_BATCH", 2);
+    if (u >= 4) hipLaunchKernelGGL(df_integrate_rigid_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a, F);
+    else if (u >= 2) hipLaunchKernelGGL(df_integrate_rigid_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a, F);
+    else hipLaunchKernelGGL(df_integrate_rigid_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a, F);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }

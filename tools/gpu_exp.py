@@ -5,10 +5,9 @@ from tools.gpu_probe import timeit
 cfg = synth.CONFIGS["512"]; intr = Intr(*cfg.intr)
 depth = upload_u16(synth.depth_frame(cfg, 0)); dists = compute_dists(depth, intr); cam = synth.camera_pose(cfg, 1)
 vol = TsdfVolume(cfg.dims); vol.setSize([cfg.size]*3); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setPose(cfg.volume_pose)
-pos, sigma = synth.make_nodes(cfg); dq = synth.node_transforms(cfg, 1)
-wf = WarpField(k=cfg.k); wf.init(pos, sigma=sigma, transforms=dq)
-for nb in ("1", "2", "4"):
-    os.environ["DFUSION_ROWS_NB"] = nb
-    for rep in range(2):
-        ms = timeit(lambda: vol.integrate_warped(dists, cam, intr, wf, sync=False), iters=10, warm=2)
-        print("rows lds NB", nb, "%.3f ms" % ms)
+for zc in ("16", "32", "64", "128"):
+    os.environ["DFUSION_RIGID_ZCHUNK"] = zc
+    for u in ("1", "2", "4"):
+        os.environ["DFUSION_RIGID_BATCH"] = u
+        ms = timeit(lambda: vol.integrate(dists, cam, intr, sync=False), iters=20, warm=3)
+        print("rigid zchunk", zc, "batch", u, ": %.3f ms" % ms)
