@@ -1,12 +1,18 @@
 #!/bin/bash
-# PMC passes (separate runs, --pmc only with --kernel-trace) for the hot kernels at 512^3.
+# Round-1 measurement session: tests, bench, rocprofv3 kernel trace, PMC passes.  Everything lands in gpurun_out/.
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-rm -rf gpurun_out/pmc
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE GRBM_COUNT" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+echo "== pytest gpu"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tee gpurun_out/pytest_gpu.log | tail -3
+echo "== bench 512"; timeout 900 python bench.py --steps 40 --warmup 5 --rigid 2>&1 | tee gpurun_out/bench.log | tail -2
+echo "== bench 256"; timeout 300 python bench.py --steps 40 --warmup 5 --rigid --config 256 2>&1 | tee gpurun_out/bench_256.log | tail -2
+echo "== rocprof kernel trace"
+rm -rf gpurun_out/prof gpurun_out/pmc
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --rigid > $R/gpurun_out/rocprof.log 2>&1)
+tail -1 gpurun_out/rocprof.log
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   tag=$(echo $pass | cut -d' ' -f1)
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/pmc/$tag -o p -- python $R/tools/pmc_run.py 512 3 tables > $R/gpurun_out/pmc_$tag.log 2>&1)
   tail -1 gpurun_out/pmc_$tag.log
 done
-find gpurun_out/pmc -name "*counter_collection.csv" | head
+find gpurun_out/prof gpurun_out/pmc -name "*.csv" | head -20
