@@ -136,12 +136,15 @@ def main():
     t_index = time.time() - t0
 
     dists = torch.empty_like(depths[0])
-    pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev)
-    nrm = torch.empty_like(pts)
-    keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int32, device=dev) if world > 1 else None
+    keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device=dev) if world > 1 else None
     vertex = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev) if world > 1 else None
-    depth_in = torch.empty_like(depths[0])
-    dq_in = torch.empty_like(dqs[0])
+    out2 = torch.empty((2, cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev)
+    pts, nrm = out2[0], out2[1]
+    # frame inputs travel as ONE byte bundle (depth image + node transforms): one ncclBroadcast per frame
+    n_depth = cfg.rows * cfg.cols * 2
+    bundle = torch.empty(n_depth + cfg.nodes * 32, dtype=torch.uint8, device=dev)
+    depth_in = bundle[:n_depth].view(torch.int16).view(cfg.rows, cfg.cols)
+    dq_in = bundle[n_depth:].view(torch.float32).view(cfg.nodes, 8)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -151,7 +154,7 @@ def main():
         if world > 1:                                  # rank 0 owns the sensor frame and the solver output
             if rank == 0:
                 depth_in.copy_(depths[f]); dq_in.copy_(dqs[f])
-            sharded.broadcast_bytes(depth_in, 0); sharded.broadcast_bytes(dq_in, 0)
+            dist.broadcast(bundle, 0)
             d_in, q_in = depth_in, dq_in
         else:
             d_in, q_in = depths[f], dqs[f]
@@ -163,8 +166,9 @@ def main():
         if world > 1:
             sharded.exchange_halos(vol.data(), vol.z_store0, vol.z_own0, vol.z_own_n, Z, halo, rank, world)
         if world > 1:
-            out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, vertex),
-                                          lambda mk, vx: vol.raycast_shade(cam_poses[f], intr, vx.contiguous(), mk.contiguous(), pts, nrm),
+            out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, vertex, rank),
+                                          lambda mk, vx: vol.raycast_select(mk, vx, rank),
+                                          lambda mk, vx: (vol.raycast_shade(cam_poses[f], intr, vx, mk, pts, nrm), out2)[1],
                                           rank, world)
         else:
             vol.raycast(cam_poses[f], intr, pts, nrm)

@@ -30,7 +30,7 @@ DF_INDEX_WEIGHT_TABLE = 2
 # every symbol include/dfusion.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "dfusion_abi_version", "dfusion_error_string", "dfusion_clear", "dfusion_compute_dists", "dfusion_integrate",
-    "dfusion_raycast_points", "dfusion_raycast_depth", "dfusion_raycast_march", "dfusion_raycast_shade", "dfusion_warp_create", "dfusion_warp_destroy",
+    "dfusion_raycast_points", "dfusion_raycast_depth", "dfusion_raycast_march", "dfusion_raycast_select", "dfusion_raycast_shade", "dfusion_warp_create", "dfusion_warp_destroy",
     "dfusion_warp_set_nodes", "dfusion_warp_set_transforms", "dfusion_warp_build_index", "dfusion_knn",
     "dfusion_warp_points", "dfusion_integrate_warped", "dfusion_copy_bandwidth_probe",
 ]
@@ -72,7 +72,8 @@ def lib():
                                          C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]
     L.dfusion_raycast_depth.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, C.c_size_t, vp, C.c_size_t,
                                         C.c_int, C.c_int, C.c_float, C.c_float, vp]
-    L.dfusion_raycast_march.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, C.c_int, C.c_int, C.c_float, vp, vp, vp]
+    L.dfusion_raycast_march.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, C.c_int, C.c_int, C.c_float, C.c_uint, vp, vp, vp]
+    L.dfusion_raycast_select.argtypes = [vp, C.c_uint, vp, C.c_int, C.c_int, vp]
     L.dfusion_raycast_shade.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, vp, vp, C.c_size_t, vp, C.c_size_t,
                                         C.c_int, C.c_int, C.c_float, vp]
     L.dfusion_warp_create.argtypes = [C.POINTER(vp)]

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void df_raycast_kernel(const DfRayArgs a)
 }
 
 // ---- sharded cast, stage 1: first event on owned steps + located vertex (volume frame) of hits.
-__global__ __launch_bounds__(256) void df_raycast_march_kernel(const DfRayArgs a, float4* __restrict__ vertex)
+__global__ __launch_bounds__(256) void df_raycast_march_kernel(const DfRayArgs a, float4* __restrict__ vertex,
+                                                               unsigned long long* __restrict__ keys64, unsigned int rank_tag)
 {
     int x, y;
     if (!rc_pixel(a, &x, &y)) return;
@@ -197,18 +198,28 @@ __global__ __launch_bounds__(256) void df_raycast_march_kernel(const DfRayArgs a
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (h.hit) { const f3 p = rc_locate(a, h); v = make_float4(p.x, p.y, p.z, 0.f); }
     vertex[(size_t)y * a.cols + x] = v;
-    a.keys[(size_t)y * a.cols + x] = h.key;
+    // (event key << 8) | rank: a per-pixel MIN over ranks (ncclMin on int64) picks the first event and names its owner
+    keys64[(size_t)y * a.cols + x] = ((unsigned long long)h.key << 8) | rank_tag;
+}
+
+// ---- between the stages: keep the located vertex only where this rank won the MIN, zero bits elsewhere, so that an
+// integer SUM across ranks hands every rank the winner's vertex.
+__global__ __launch_bounds__(256) void df_raycast_select_kernel(const unsigned long long* __restrict__ merged, unsigned int rank_tag,
+                                                                uint4* __restrict__ vertex, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && (unsigned int)(merged[i] & 0xffull) != rank_tag) vertex[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // ---- sharded cast, stage 2: after the per-pixel MIN merge of keys and the broadcast of the winners' vertices,
 // the slab that owns the vertex' plane computes the normal.  Pixels this slab does not resolve get all-zero
 // bits (the host sums integer views across ranks); resolved misses get the reference's NaN fill.
 __global__ __launch_bounds__(256) void df_raycast_shade_kernel(const DfRayArgs a, const float4* __restrict__ vertex,
-                                                               const uint32_t* __restrict__ merged_keys)
+                                                               const unsigned long long* __restrict__ merged_keys)
 {
     int x, y;
     if (!rc_pixel(a, &x, &y)) return;
-    const uint32_t key = merged_keys[(size_t)y * a.cols + x];
+    const uint32_t key = (uint32_t)(merged_keys[(size_t)y * a.cols + x] >> 8);
     const float qn = qnanf_();
     float4 out_p = make_float4(0.f, 0.f, 0.f, 0.f), out_n = out_p;
     if (key != 0xffffffffu && (key & 1u)) {
@@ -281,21 +292,33 @@ extern "C" int dfusion_raycast_depth(DfVolume v, const DfSlab* slab, const float
 
 // ---- sharded (Z-slab) cast in two stages; no reference counterpart (the reference is single-GPU).
 extern "C" int dfusion_raycast_march(DfVolume v, const DfSlab* slab, const float cam2vol[12], const float reproj[4], int cols,
-                                     int rows, float step_factor, uint32_t* keys, float* vertex, dfStream stream)
+                                     int rows, float step_factor, unsigned int rank_tag, unsigned long long* keys, float* vertex,
+                                     dfStream stream)
 {
-    if (!keys || !vertex) return DF_E_INVALID;
+    if (!keys || !vertex || rank_tag > 255u) return DF_E_INVALID;
     DfRayArgs a;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     int rc = df_raycast_setup(a, v, slab, cam2vol, ident, reproj, cols, rows, step_factor, 0.5f);
     if (rc) return rc;
-    a.keys = keys;
-    hipLaunchKernelGGL(df_raycast_march_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, (float4*)vertex);
+    hipLaunchKernelGGL(df_raycast_march_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, (float4*)vertex, keys,
+                       rank_tag);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+extern "C" int dfusion_raycast_select(const unsigned long long* merged_keys, unsigned int rank_tag, float* vertex, int cols, int rows,
+                                      dfStream stream)
+{
+    if (!merged_keys || !vertex || cols <= 0 || rows <= 0) return DF_E_INVALID;
+    const int n = cols * rows;
+    hipLaunchKernelGGL(df_raycast_select_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, merged_keys, rank_tag,
+                       (uint4*)vertex, n);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }
 
 extern "C" int dfusion_raycast_shade(DfVolume v, const DfSlab* slab, const float cam2vol[12], const float Rinv[9],
-                                     const float reproj[4], const float* vertex, const uint32_t* merged_keys, float* points,
+                                     const float reproj[4], const float* vertex, const unsigned long long* merged_keys, float* points,
                                      size_t ppitch, float* normals, size_t npitch, int cols, int rows, float delta_factor,
                                      dfStream stream)
 {

@@ -71,29 +71,26 @@ def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, 
         r.wait()
 
 
-def raycast_sharded(march_fn, shade_fn, rank, world, dst=0, group=None):
-    """Two-stage sharded ray-cast (see include/dfusion.h, dfusion_raycast_march / _shade).
+def raycast_sharded(march_fn, select_fn, shade_fn, rank, world, dst=0, group=None):
+    """Two-stage sharded ray-cast (include/dfusion.h: dfusion_raycast_march / _select / _shade).
 
-    march_fn() -> (keys int32 [rows, cols] (uint32 bits), vertex float32 [rows, cols, 4]) of THIS rank's slab;
-    shade_fn(merged_keys int32, vertex float32) -> (points, normals) float32 [rows, cols, 4], all-zero bits for
-    pixels this slab does not resolve.  Returns the merged (points, normals) on rank `dst`, (None, None) elsewhere.
+    march_fn()              -> (keys64 int64 [rows, cols] = (event key << 8) | rank, vertex float32 [rows, cols, 4])
+    select_fn(keys64, vtx)  -> zeroes `vtx` in place wherever this rank did not win the MIN
+    shade_fn(keys64, vtx)   -> out float32 [2, rows, cols, 4] (points, normals); all-zero bits for pixels this slab does
+                               not resolve
+    Returns (points, normals) of the merged cast on rank `dst`, (None, None) elsewhere.
 
-    Collectives per frame: all_reduce(MIN) of int64 keys (2.4 MB at 640x480), all_reduce(SUM) of the winners'
-    vertex bits (4.9 MB), reduce(SUM) of the final point/normal bits (9.8 MB) -- every summand but one is integer
-    zero, so the result is bit-identical with the unsharded cast."""
-    keys, vertex = march_fn()
-    if world == 1:
-        return shade_fn(keys, vertex)
-    k64 = ((keys.to(torch.int64) & 0xFFFFFFFF) << 8) | rank
-    dist.all_reduce(k64, op=dist.ReduceOp.MIN, group=group)
-    mine = (k64 & 0xFF) == rank
-    vbits = vertex.view(torch.int32) * mine[:, :, None].to(torch.int32)
-    dist.all_reduce(vbits, op=dist.ReduceOp.SUM, group=group)
-    merged = (k64 >> 8).to(torch.int32)                       # uint32 bits (0xffffffff wraps to -1)
-    pts, nrm = shade_fn(merged, vbits.view(torch.float32))
-    buf = torch.stack([pts.view(torch.int32), nrm.view(torch.int32)])
-    dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    if rank != dst:
-        return None, None
-    out = buf.view(torch.float32)
+    Three collectives per frame: all_reduce(MIN) of the int64 keys (2.4 MB at 640x480), all_reduce(SUM) of the winners'
+    vertex bits (4.9 MB), reduce(SUM) of the final point/normal bits (9.8 MB).  Every summand but one is integer zero,
+    so the result is bit-identical with the unsharded cast."""
+    keys64, vertex = march_fn()
+    if world > 1:
+        dist.all_reduce(keys64, op=dist.ReduceOp.MIN, group=group)
+        select_fn(keys64, vertex)
+        dist.all_reduce(vertex.view(torch.int32), op=dist.ReduceOp.SUM, group=group)
+    out = shade_fn(keys64, vertex)
+    if world > 1:
+        dist.reduce(out.view(torch.int32), dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if rank != dst:
+            return None, None
     return out[0], out[1]

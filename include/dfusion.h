@@ -122,10 +122,17 @@ int dfusion_raycast_depth(DfVolume v, const DfSlab *slab, const float cam2vol[12
  * vertex' nearest plane compute the normal (needs a 2-plane halo) and write the final camera-frame
  * point/normal.  Pixels a slab does not resolve are written as all-zero BITS (the slab owning plane 0
  * writes the NaN fill of misses), so integer-summing the slabs' outputs equals the unsharded cast.      */
+/* stage 1: keys64_dev[pixel] = (event key << 8) | rank_tag (rank_tag <= 255), so a per-pixel MIN over ranks (ncclMin on
+ * int64) selects the first event and names its owner.                                                       */
 int dfusion_raycast_march(DfVolume v, const DfSlab *slab, const float cam2vol[12], const float reproj[4], int cols,
-                          int rows, float step_factor, uint32_t *keys_dev, float *vertex_dev, dfStream stream);
+                          int rows, float step_factor, unsigned int rank_tag, unsigned long long *keys64_dev,
+                          float *vertex_dev, dfStream stream);
+/* between the stages: zero this rank's vertex image wherever it did not win the MIN, so that an integer SUM over
+ * ranks (ncclSum on the int32 view) hands every rank the winners' vertices.                                   */
+int dfusion_raycast_select(const unsigned long long *merged_keys64_dev, unsigned int rank_tag, float *vertex_dev,
+                           int cols, int rows, dfStream stream);
 int dfusion_raycast_shade(DfVolume v, const DfSlab *slab, const float cam2vol[12], const float Rinv[9],
-                          const float reproj[4], const float *vertex_dev, const uint32_t *merged_keys_dev,
+                          const float reproj[4], const float *vertex_dev, const unsigned long long *merged_keys64_dev,
                           float *points_dev, size_t points_pitch, float *normals_dev, size_t normals_pitch, int cols,
                           int rows, float delta_factor, dfStream stream);
 

@@ -88,9 +88,7 @@ def test_full_size_properties_and_sampled_oracle(name):
     fn = torch.empty_like(fp)
     fk = torch.empty((cfg.rows, cfg.cols), dtype=torch.int32, device="cuda")
     a.raycast(sc.cam_poses[1], intr, fp, fn, keys=fk)
-    best = torch.full((cfg.rows, cfg.cols), 0xFFFFFFFF, dtype=torch.int64, device="cuda")
-    vtx = torch.zeros_like(fp)
-    slabs = []
+    slabs, k64s, vxs = [], [], []
     for r in range(world):
         zs, zn = sharded.slab_range(Z, r, world)
         v = setup(cfg, slab=(zs, zn, halo))
@@ -100,15 +98,17 @@ def test_full_size_properties_and_sampled_oracle(name):
         own = slice(v.z_own0 - v.z_store0, v.z_own0 - v.z_store0 + zn)
         assert torch.equal(v.data()[own], a.data()[zs:zs + zn])
         v.data().copy_(a.data()[v.z_store0:v.z_store0 + v.z_store_n])      # halos as the exchange would deliver them
-        k32, vx = torch.empty_like(fk), torch.empty_like(fp)
-        v.raycast_march(sc.cam_poses[1], intr, k32, vx)
-        k64 = k32.to(torch.int64) & 0xFFFFFFFF
-        better = k64 < best
-        best = torch.where(better, k64, best)
-        vtx[better] = vx[better]
-        slabs.append(v)
-    assert torch.equal(best, fk.to(torch.int64) & 0xFFFFFFFF)
-    merged = best.to(torch.int32)
+        k64 = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device="cuda")
+        vx = torch.empty_like(fp)
+        v.raycast_march(sc.cam_poses[1], intr, k64, vx, rank=r)
+        slabs.append(v); k64s.append(k64); vxs.append(vx)
+    merged = torch.stack(k64s).min(0).values.contiguous()
+    assert torch.equal(merged >> 8, fk.to(torch.int64) & 0xFFFFFFFF)
+    vsum = torch.zeros((cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
+    for r, v in enumerate(slabs):
+        v.raycast_select(merged, vxs[r], rank=r)
+        vsum += vxs[r].view(torch.int32)
+    vtx = vsum.view(torch.float32)
     acc = torch.zeros((2, cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
     for v in slabs:
         p, n = torch.empty_like(fp), torch.empty_like(fp)

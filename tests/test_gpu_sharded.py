@@ -36,17 +36,21 @@ def run_sharded(sc, world, frames, k=None):
             n_hi = a.data().shape[0] - a_hi
             a.data()[a_hi:a_hi + n_hi].copy_(b.data()[b_lo:b_lo + n_hi])             # b's bottom own planes -> a's upper halo
     f = frames - 1
-    best = torch.full((cfg.rows, cfg.cols), 0xFFFFFFFF, dtype=torch.int64, device="cuda")
-    vtx = torch.zeros((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
-    for v in vols:                                      # stage 1 + what all_reduce(MIN) / vertex broadcast compute
-        k32 = torch.empty((cfg.rows, cfg.cols), dtype=torch.int32, device="cuda")
+    # stage 1 per slab, then what all_reduce(MIN) computes
+    k64s, vxs = [], []
+    for r, v in enumerate(vols):
+        k64 = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device="cuda")
         vx = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
-        v.raycast_march(sc.cam_poses[f], intr, k32, vx)
-        k64 = k32.to(torch.int64) & 0xFFFFFFFF
-        better = k64 < best
-        best = torch.where(better, k64, best)
-        vtx[better] = vx[better]
-    merged = best.to(torch.int32)
+        v.raycast_march(sc.cam_poses[f], intr, k64, vx, rank=r)
+        k64s.append(k64); vxs.append(vx)
+    merged = torch.stack(k64s).min(0).values.contiguous()
+    # select per slab, then what all_reduce(SUM) of the int32 views computes
+    vsum = torch.zeros((cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
+    for r, v in enumerate(vols):
+        v.raycast_select(merged, vxs[r], rank=r)
+        vsum += vxs[r].view(torch.int32)
+    vtx = vsum.view(torch.float32)
+    best = merged >> 8
     acc = torch.zeros((2, cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
     for v in vols:                                      # stage 2 + what reduce(SUM) of the bit patterns computes
         p = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")

@@ -66,14 +66,18 @@ def _worker(rank, world, port):
             def march():
                 k, vx = O.raycast_march(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.reproj, CFG.cols, CFG.rows,
                                         CFG.raycast_step_factor, slab=slab)
-                return torch.from_numpy(k.view(np.int32)), torch.from_numpy(vx)
+                return (torch.from_numpy(k.astype(np.int64)) << 8) | rank, torch.from_numpy(vx)
 
-            def shade(merged, vx):
-                p, n = O.raycast_shade(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.rinv(f), vx.numpy(),
-                                       merged.numpy().view(np.uint32), CFG.cols, CFG.rows, CFG.gradient_delta_factor, slab=slab)
-                return torch.from_numpy(p), torch.from_numpy(n)
+            def select(k64, vx):
+                vx[(k64 & 0xFF) != rank] = 0
 
-            pts, nrm = sharded.raycast_sharded(march, shade, rank, world)
+            def shade(k64, vx):
+                merged = (k64 >> 8).numpy().astype(np.uint32)
+                p, n = O.raycast_shade(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.rinv(f), vx.numpy(), merged, CFG.cols, CFG.rows,
+                                       CFG.gradient_delta_factor, slab=slab)
+                return torch.from_numpy(np.stack([p, n]))
+
+            pts, nrm = sharded.raycast_sharded(march, select, shade, rank, world)
         # every rank checks its slab (own + halo planes) against the unsharded volume; rank 0 checks the merged cast
         full, fp, fn = _unsharded(sc)
         assert np.array_equal(vol, full[lo:hi]), "rank %d: slab (incl. exchanged halos) differs from the unsharded volume" % rank
@@ -95,6 +99,6 @@ def test_zslab_pipeline_over_gloo(world):
 
 def test_single_rank_is_a_no_op_path():
     p = torch.zeros((4, 4, 4))
-    out = sharded.raycast_sharded(lambda: (None, None), lambda k, v: (p, p), 0, 1)
+    out = sharded.raycast_sharded(lambda: (None, None), None, lambda k, v: (p, p), 0, 1)
     assert out[0] is p
     sharded.exchange_halos(None, 0, 0, 4, 4, 2, 0, 1)
