@@ -30,9 +30,10 @@ DF_INDEX_WEIGHT_TABLE = 2
 # every symbol include/dfusion.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "dfusion_abi_version", "dfusion_error_string", "dfusion_clear", "dfusion_compute_dists", "dfusion_integrate",
-    "dfusion_raycast_points", "dfusion_raycast_depth", "dfusion_raycast_march", "dfusion_raycast_select", "dfusion_raycast_shade", "dfusion_warp_create", "dfusion_warp_destroy",
+    "dfusion_raycast_points", "dfusion_raycast_depth", "dfusion_raycast_march", "dfusion_raycast_select", "dfusion_raycast_shade", "dfusion_extract_cloud",
+    "dfusion_extract_normals", "dfusion_warp_create", "dfusion_warp_destroy",
     "dfusion_warp_set_nodes", "dfusion_warp_set_transforms", "dfusion_warp_build_index", "dfusion_knn",
-    "dfusion_warp_points", "dfusion_integrate_warped", "dfusion_copy_bandwidth_probe",
+    "dfusion_warp_points", "dfusion_integrate_warped", "dfusion_copy_bandwidth_probe", "dfusion_read_bandwidth_probe",
 ]
 
 
@@ -76,6 +77,8 @@ def lib():
     L.dfusion_raycast_select.argtypes = [vp, C.c_uint, vp, C.c_int, C.c_int, vp]
     L.dfusion_raycast_shade.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, vp, vp, C.c_size_t, vp, C.c_size_t,
                                         C.c_int, C.c_int, C.c_float, vp]
+    L.dfusion_extract_cloud.argtypes = [DfVolume, C.POINTER(DfSlab), fp, vp, C.c_ulonglong, vp, vp]
+    L.dfusion_extract_normals.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, vp, C.c_ulonglong, C.c_float, vp, vp]
     L.dfusion_warp_create.argtypes = [C.POINTER(vp)]
     L.dfusion_warp_destroy.argtypes = [vp]
     L.dfusion_warp_set_nodes.argtypes = [vp, vp, vp, vp, C.c_int, vp]
@@ -86,6 +89,7 @@ def lib():
     L.dfusion_integrate_warped.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, DfVolume, C.POINTER(DfSlab), fp, fp, fp,
                                            vp, C.c_int, C.c_uint, vp, vp]
     L.dfusion_copy_bandwidth_probe.argtypes = [vp, vp, C.c_size_t, vp]
+    L.dfusion_read_bandwidth_probe.argtypes = [vp, C.c_size_t, vp, vp]
     for s in SYMBOLS:
         if s not in ("dfusion_error_string",):
             getattr(L, s).restype = C.c_int

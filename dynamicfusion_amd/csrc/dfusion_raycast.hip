@@ -332,3 +332,179 @@ extern "C" int dfusion_raycast_shade(DfVolume v, const DfSlab* slab, const float
     DF_LAUNCH_CHECK();
     return DF_OK;
 }
+
+// ====================================================================================== cloud / normal extraction
+// extract_kernel (FullScan6) + extract_normals_kernel, /root/reference/kfusion/src/cuda/tsdf_volume.cu:
+// 511-710, 714-795 -- called every frame by KinFu::dynamicfusion (kinfu.cpp:398-399) and once to seed the warp field.
+//
+// The scan is a pure HBM stream (4 B/voxel read, a few MB of points written).  A lane owns four x-adjacent voxels (one
+// global_load_dwordx4 per plane; 1 KiB contiguous per wave) and walks a Z chunk carrying plane z+1 in registers as the
+// next iteration's own plane; the +x neighbour of its 4th voxel comes from the next lane by DPP/shuffle, the +y row is a
+// second 16-byte load that hits L1/L2 (the row is some other wave's own).  Crossings are compacted per wave with
+// __ballot / popcount prefixes (12 slots: 4 voxels x 3 axes) and ONE atomicAdd per wave per plane -- no LDS staging, no
+// __device__ globals (the reference keeps global_count / output_count / blocks_done in globals, :506-508).
+struct DfExtractArgs {
+    const uint32_t* vol; int X, Y, Z;
+    int z_store0, z_own0, z_end;       // scans planes [z_own0, z_end), z_end <= Z-1
+    int zc;
+    float vsx, vsy, vsz;
+    DfAff aff;
+    float4* out; unsigned long long capacity; unsigned long long* count;
+};
+
+__device__ __forceinline__ bool ex_valid(uint32_t v) { return (v >> 16) != 0u && h2f_bits(v) != 1.f; }     // :548 W != 0 && F != 1.f
+__device__ __forceinline__ bool ex_cross(uint32_t a, uint32_t b)
+{
+    const float F = h2f_bits(a), Fn = h2f_bits(b);
+    return ex_valid(a) && ex_valid(b) && ((F > 0.f && Fn < 0.f) || (F < 0.f && Fn > 0.f));                 // :559
+}
+
+#define DF_EX_U 4      // planes whose loads are in flight per lane
+
+__global__ __launch_bounds__(256) void df_extract_kernel(const DfExtractArgs a)
+{
+    const int xgroups = a.X >> 2;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const bool active = gid < xgroups * a.Y;
+    const int y = active ? gid / xgroups : 0;
+    const int x0 = active ? (gid - y * xgroups) << 2 : 0;
+    const int zb = a.z_own0 + blockIdx.y * a.zc;
+    const int ze = min(zb + a.zc, a.z_end);
+    if (zb >= ze) return;                                   // block-uniform
+    const size_t plane = (size_t)a.X * a.Y;
+    const uint32_t* p = a.vol + (size_t)(zb - a.z_store0) * plane + (size_t)y * a.X + x0;
+    const bool has_xn = active && x0 + 4 < a.X, has_yn = active && y + 1 < a.Y;
+    const int lane = threadIdx.x & 63;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+
+    uint4 pl[DF_EX_U + 1];
+    pl[0] = active ? *reinterpret_cast<const uint4*>(p) : zero4;
+    for (int z = zb; z < ze; z += DF_EX_U, p += DF_EX_U * plane) {
+        // the next DF_EX_U planes of this lane's 4 columns: independent 16-byte loads, all in flight together
+        // (plane indices are clamped to ze, which exists: ze <= Z-1 and a slab stores it as its +z halo)
+#pragma unroll
+        for (int u = 1; u <= DF_EX_U; ++u)
+            pl[u] = active ? *reinterpret_cast<const uint4*>(p + (size_t)min(u, ze - z) * plane) : zero4;
+#pragma unroll
+        for (int u = 0; u < DF_EX_U; ++u) {
+            if (z + u < ze) {                               // block-uniform
+                const uint4 cur = pl[u], nz = pl[u + 1];
+                // a crossing needs a valid voxel (W != 0 && F != 1, :548) on THIS side: only the shell within the
+                // truncation band qualifies, so almost every wave skips the +y row load and the 12 crossing tests
+                const bool own = ex_valid(cur.x) | ex_valid(cur.y) | ex_valid(cur.z) | ex_valid(cur.w);
+                if (__any(own)) {
+                    const uint32_t* pz = p + (size_t)u * plane;
+                    const uint4 ny = has_yn ? *reinterpret_cast<const uint4*>(pz + a.X) : zero4;        // row y+1 (L1/L2 hit)
+                    uint32_t xn = __shfl_down(cur.x, 1, 64);                                           // lane+1 holds x0+4.. (same row iff has_xn)
+                    if (lane == 63 && has_xn) xn = pz[4];
+                    if (!has_xn) xn = 0u;
+                    const uint32_t c[4] = {cur.x, cur.y, cur.z, cur.w};
+                    const uint32_t nx[4] = {cur.y, cur.z, cur.w, xn};
+                    const uint32_t nyv[4] = {ny.x, ny.y, ny.z, ny.w};
+                    const uint32_t nzv[4] = {nz.x, nz.y, nz.z, nz.w};
+                    unsigned flags = 0;                                                                 // bit 3*i + axis
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (ex_cross(c[i], nx[i])) flags |= 1u << (3 * i);
+                        if (ex_cross(c[i], nyv[i])) flags |= 2u << (3 * i);
+                        if (ex_cross(c[i], nzv[i])) flags |= 4u << (3 * i);
+                    }
+                    if (__any(flags != 0u)) {
+                        unsigned long long bal[12];
+                        unsigned total = 0;
+#pragma unroll
+                        for (int s = 0; s < 12; ++s) { bal[s] = __ballot((flags >> s) & 1u); total += (unsigned)__popcll(bal[s]); }
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(a.count, (unsigned long long)total);
+                        base = __shfl(base, 0, 64);
+                        const unsigned long long lt = lane_mask_lt();
+#pragma unroll
+                        for (int s = 0; s < 12; ++s) {
+                            if ((flags >> s) & 1u) {
+                                const int i = s / 3, axis = s - 3 * i;
+                                const float F = fabsf(h2f_bits(c[i]));
+                                const float Fn = fabsf(h2f_bits(axis == 0 ? nx[i] : axis == 1 ? nyv[i] : nzv[i]));
+                                // voxel-CORNER convention of the extractor, :549-550,566
+                                f3 V = mk3(((float)(x0 + i) + 0.5f) * a.vsx, ((float)y + 0.5f) * a.vsy, ((float)(z + u) + 0.5f) * a.vsz);
+                                const float d_inv = 1.f / (F + Fn);                                     // :567
+                                if (axis == 0) { const float Vn = V.x + a.vsx; V.x = (V.x * Fn + Vn * F) * d_inv; }
+                                if (axis == 1) { const float Vn = V.y + a.vsy; V.y = (V.y * Fn + Vn * F) * d_inv; }
+                                if (axis == 2) { const float Vn = V.z + a.vsz; V.z = (V.z * Fn + Vn * F) * d_inv; }
+                                const f3 q = aff_mul(a.aff, V);                                         // :570
+                                const unsigned long long o = base + (unsigned long long)__popcll(bal[s] & lt);
+                                if (o < a.capacity) a.out[o] = make_float4(q.x, q.y, q.z, 0.f);
+                            }
+                            base += (unsigned long long)__popcll(bal[s]);
+                        }
+                    }
+                }
+            }
+        }
+        pl[0] = pl[DF_EX_U];
+    }
+}
+
+// extract_normals_kernel, :714-795 (the reference launches it with a (32,8) block but 1-D indexing: 8x redundant; fixed)
+__global__ __launch_bounds__(256) void df_extract_normals_kernel(const DfRayArgs a, const float4* __restrict__ points,
+                                                                 unsigned long long n, float4* __restrict__ out)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float qn = qnanf_();
+    f3 nrm = mk3(qn, qn, qn);
+    const float4 pp = points[i];
+    const f3 t = mk3(a.aff.t[0], a.aff.t[1], a.aff.t[2]);
+    const f3 point = mat3_mul(a.Rinv, sub3(mk3(pp.x, pp.y, pp.z), t));                          // :749
+    const int gx = (int)rintf(point.x * a.vsix), gy = (int)rintf(point.y * a.vsiy), gz = (int)rintf(point.z * a.vsiz);
+    if (gx > 1 && gy > 1 && gz > 1 && gx < a.X - 2 && gy < a.Y - 2 && gz < a.Z - 2) {            // :752
+        const f3 vsi = mk3(a.vsix, a.vsiy, a.vsiz);
+        f3 g;
+        g.x = (rc_interpolate(a, mul3(mk3(point.x + a.gdx, point.y, point.z), vsi)) -
+               rc_interpolate(a, mul3(mk3(point.x - a.gdx, point.y, point.z), vsi))) / a.gdx;
+        g.y = (rc_interpolate(a, mul3(mk3(point.x, point.y + a.gdy, point.z), vsi)) -
+               rc_interpolate(a, mul3(mk3(point.x, point.y - a.gdy, point.z), vsi))) / a.gdy;
+        g.z = (rc_interpolate(a, mul3(mk3(point.x, point.y, point.z + a.gdz), vsi)) -
+               rc_interpolate(a, mul3(mk3(point.x, point.y, point.z - a.gdz), vsi))) / a.gdz;
+        nrm = normalized3(mat3_mul(a.aff.R, g));                                                  // :789
+    }
+    out[i] = make_float4(nrm.x, nrm.y, nrm.z, 0.f);
+}
+
+extern "C" int dfusion_extract_cloud(DfVolume v, const DfSlab* slab, const float aff[12], float* points, unsigned long long capacity,
+                                     unsigned long long* count, dfStream stream)
+{
+    if (!aff || !points || !count || !df_volume_valid(v)) return DF_E_INVALID;
+    DfSlab s = df_slab_or_full(v, slab);
+    if (!df_slab_valid(v, s)) return DF_E_INVALID;
+    DfExtractArgs a;
+    a.vol = (const uint32_t*)v.data; a.X = v.dims[0]; a.Y = v.dims[1]; a.Z = v.dims[2];
+    a.z_store0 = s.z_store0; a.z_own0 = s.z_own0;
+    a.z_end = min(s.z_own0 + s.z_own_n, v.dims[2] - 1);                                          // :538 z < dims.z - 1
+    if (a.z_end > s.z_store0 + s.z_store_n - 1) return DF_E_INVALID;                              // needs plane z_end as a +z halo
+    if (a.z_end <= a.z_own0) return DF_OK;
+    a.vsx = v.voxel_size[0]; a.vsy = v.voxel_size[1]; a.vsz = v.voxel_size[2];
+    a.aff = df_aff(aff);
+    a.out = (float4*)points; a.capacity = capacity; a.count = count;
+    const int groups = (a.X / 4) * a.Y, bx = (groups + 255) / 256;
+    int chunks = (256 * 8 + bx - 1) / bx; if (chunks < 1) chunks = 1;
+    a.zc = (a.z_end - a.z_own0 + chunks - 1) / chunks; if (a.zc < 8) a.zc = 8;
+    dim3 grid(bx, (a.z_end - a.z_own0 + a.zc - 1) / a.zc);
+    hipLaunchKernelGGL(df_extract_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+extern "C" int dfusion_extract_normals(DfVolume v, const DfSlab* slab, const float aff[12], const float Rinv[9], const float* points,
+                                       unsigned long long n, float gradient_delta_factor, float* normals, dfStream stream)
+{
+    if (!points || !normals) return DF_E_INVALID;
+    if (n == 0) return DF_OK;
+    DfRayArgs a;
+    const float reproj[4] = {1.f, 1.f, 0.f, 0.f};
+    int rc = df_raycast_setup(a, v, slab, aff, Rinv, reproj, 1, 1, 0.75f, gradient_delta_factor);
+    if (rc) return rc;
+    hipLaunchKernelGGL(df_extract_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       (const float4*)points, n, (float4*)normals);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}

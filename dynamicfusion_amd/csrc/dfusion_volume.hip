@@ -55,6 +55,28 @@ extern "C" int dfusion_copy_bandwidth_probe(void* dst, const void* src, size_t b
     return DF_OK;
 }
 
+// read-only stream probe: the measured roofline denominator for scan kernels (extract)
+__global__ __launch_bounds__(256) void df_read_kernel(const uint4* __restrict__ s, size_t n16, unsigned int* __restrict__ sink)
+{
+    unsigned int acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = s[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;              // practically never true: keeps the loads alive without a store stream
+}
+
+extern "C" int dfusion_read_bandwidth_probe(const void* src, size_t bytes, void* sink4, dfStream stream)
+{
+    if (!src || !sink4 || (bytes % 16)) return DF_E_INVALID;
+    size_t n16 = bytes / 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(df_read_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, n16, (unsigned int*)sink4);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
 // ------------------------------------------------------------------------------------------ compute_dists
 // imgproc.cu:259-272.  The reference guard `x<cols || y<rows` is a bug (harmless when the grid
 // divides evenly); && here.

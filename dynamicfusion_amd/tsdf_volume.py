@@ -245,6 +245,32 @@ class TsdfVolume:
                                                     _stream()), "dfusion_raycast_shade")
         return points, normals
 
+    # ---- tsdf_volume.cpp:181-218 fetchCloud / fetchNormals (device tensors; count read back like the reference does)
+    def fetchCloud(self, cloud_buffer=None):
+        """cloud_buffer: float32 [capacity, 4] device tensor (default capacity 256^3, tsdf_volume.cpp:184, capped by the
+        voxel count).  Returns a view of the first min(found, capacity) points."""
+        if cloud_buffer is None:
+            cap = min(256 * 256 * 256, int(np.prod(self.dims_)))
+            cloud_buffer = torch.empty((cap, 4), dtype=torch.float32, device=self.device)
+        count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        capi.check(capi.lib().dfusion_extract_cloud(self.c_volume(), self.c_slab(), capi.floats(aff12(self.pose_)),
+                                                    _ptr(cloud_buffer), cloud_buffer.shape[0], _ptr(count), _stream()),
+                   "dfusion_extract_cloud")
+        n = int(count.item())                               # cudaMemcpyFromSymbol(output_count), tsdf_volume.cu:815
+        self.last_cloud_count_ = n
+        return cloud_buffer[:min(n, cloud_buffer.shape[0])]
+
+    def fetchNormals(self, cloud, normals=None):
+        n = int(cloud.shape[0])
+        if normals is None:
+            normals = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        Rinv = np.linalg.inv(self.pose_[:3, :3].astype(np.float64)).astype(F32)        # tsdf_volume.cpp:214
+        capi.check(capi.lib().dfusion_extract_normals(self.c_volume(), self.c_slab(), capi.floats(aff12(self.pose_)),
+                                                      capi.floats(Rinv.reshape(-1)), _ptr(cloud), n,
+                                                      self.gradient_delta_factor_, _ptr(normals), _stream()),
+                   "dfusion_extract_normals")
+        return normals
+
     # ---- convenience for tests
     def download(self):
         """uint32 numpy [z_store_n, Y, X] : lo16 = half tsdf bits, hi16 = weight."""

@@ -136,6 +136,18 @@ int dfusion_raycast_shade(DfVolume v, const DfSlab *slab, const float cam2vol[12
                           float *points_dev, size_t points_pitch, float *normals_dev, size_t normals_pitch, int cols,
                           int rows, float delta_factor, dfStream stream);
 
+/* ---- surface extraction -------------------------------------------------------
+ * device::extractCloud (internal.hpp:142; tsdf_volume.cu:511-710,798-817): zero crossings between every voxel and its
+ * +x/+y/+z neighbour, linearly interpolated, transformed by aff (= volume pose).  points_dev: float4 x capacity;
+ * *count_dev (device, zero it first) is INCREMENTED by the number of crossings found -- the number written is
+ * min(count, capacity); output order is unspecified (as in the reference).  A slab needs one halo plane above.  */
+int dfusion_extract_cloud(DfVolume v, const DfSlab *slab, const float aff[12], float *points_dev,
+                          unsigned long long capacity, unsigned long long *count_dev, dfStream stream);
+/* device::extractNormals (internal.hpp:143; tsdf_volume.cu:714-795,819-831): TSDF gradient at each extracted point. */
+int dfusion_extract_normals(DfVolume v, const DfSlab *slab, const float aff[12], const float Rinv[9],
+                            const float *points_dev, unsigned long long n, float gradient_delta_factor,
+                            float *normals_dev, dfStream stream);
+
 /* ---- warp field -----------------------------------------------------------------------------
  * WarpField::WarpField / ~WarpField (warp_field.cpp:17-34).                                    */
 int dfusion_warp_create(DfWarpField **out);
@@ -181,6 +193,8 @@ int dfusion_integrate_warped(const uint16_t *dists_dev, size_t dists_pitch, int 
 
 /* ---- measurement helper: plain device copy used as the MEASURED HBM roofline denominator ---- */
 int dfusion_copy_bandwidth_probe(void *dst_dev, const void *src_dev, size_t bytes, dfStream stream);
+/* read-only stream of `bytes` (sink4_dev: 4 writable device bytes): the measured denominator for scan kernels */
+int dfusion_read_bandwidth_probe(const void *src_dev, size_t bytes, void *sink4_dev, dfStream stream);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@
  *   clear                kfusion/src/cuda/tsdf_volume.cu:15-28
  *   integrate (rigid)    kfusion/src/cuda/tsdf_volume.cu:51-112, host :141-161
  *   raycast              kfusion/src/cuda/tsdf_volume.cu:202-474
+ *   extract cloud/normals kfusion/src/cuda/tsdf_volume.cu:511-710,714-795
  *   k-NN                 kfusion/src/warp_field.cpp:247-251 + knn_point_cloud.hpp:16-32
  *                        (nanoflann v1.2.3 exact L2, ascending; brute force here)
  *   weighting            kfusion/src/warp_field.cpp:238-241
@@ -665,6 +666,80 @@ ORC_API void orc_raycast_shade(OrcVolume v, const OrcSlab *slab, const float cam
                 prow[4 * x] = vtx.x; prow[4 * x + 1] = vtx.y; prow[4 * x + 2] = vtx.z; prow[4 * x + 3] = 0.f;
             }
         }
+    }
+}
+
+/* ================================================================ cloud / normal extraction
+ * tsdf_volume.cu:511-710 FullScan6: every voxel with W != 0 && F != 1 is compared with its +x, +y, +z neighbour;
+ * a sign change emits the linearly interpolated crossing, in voxel-CORNER convention ((i+0.5)*vs, :549-550,566 -- the
+ * reference is inconsistent with integrate's centre convention; reproduced), transformed by aff (= pose_).
+ * Output order in the reference depends on atomics; here z-major scan order -- compare as sets.  Returns the number of
+ * crossings found (may exceed capacity; only the first `capacity` are written).  A slab scans its own planes and
+ * needs plane z_own_end as a halo for the +z neighbour.                                                         */
+ORC_API uint64_t orc_extract_cloud(OrcVolume v, const OrcSlab *slab, const float aff[12], float *points /* float4 */,
+                                   uint64_t capacity)
+{
+    OrcSlab s; slab_or_full(&v, slab, &s);
+    const int X = v.dims[0], Y = v.dims[1], Z = v.dims[2];
+    const uint16_t *base = (const uint16_t *)v.data;
+    const float vsx = v.voxel_size[0], vsy = v.voxel_size[1], vsz = v.voxel_size[2];
+    uint64_t n = 0;
+    const int z_end = s.z_own0 + s.z_own_n < Z - 1 ? s.z_own0 + s.z_own_n : Z - 1;          /* :538 z < dims.z - 1 */
+    for (int z = s.z_own0; z < z_end; ++z)
+        for (int y = 0; y < Y; ++y)
+            for (int x = 0; x < X; ++x) {
+#define VOX(xx, yy, zz) (base + 2 * ((size_t)(xx) + (size_t)(yy) * X + (size_t)((zz) - s.z_store0) * X * Y))
+                const uint16_t *c = VOX(x, y, z);
+                int W = c[1]; float F = h2f(c[0]);
+                if (W == 0 || F == 1.f) continue;                                              /* :548 */
+                f3 V = mk3(((float)x + 0.5f) * vsx, ((float)y + 0.5f) * vsy, ((float)z + 0.5f) * vsz);
+                for (int axis = 0; axis < 3; ++axis) {
+                    if (axis == 0 && !(x + 1 < X)) continue;                                   /* :553 */
+                    if (axis == 1 && !(y + 1 < Y)) continue;                                   /* :574 */
+                    const uint16_t *nb = axis == 0 ? VOX(x + 1, y, z) : axis == 1 ? VOX(x, y + 1, z) : VOX(x, y, z + 1);
+                    int Wn = nb[1]; float Fn = h2f(nb[0]);
+                    if (Wn == 0 || Fn == 1.f) continue;
+                    if (!((F > 0 && Fn < 0) || (F < 0 && Fn > 0))) continue;                   /* :559 */
+                    float d_inv = 1.f / (fabsf(F) + fabsf(Fn));                                /* :567 */
+                    f3 p = V;
+                    if (axis == 0) { float Vn = V.x + vsx; p.x = (V.x * fabsf(Fn) + Vn * fabsf(F)) * d_inv; }
+                    if (axis == 1) { float Vn = V.y + vsy; p.y = (V.y * fabsf(Fn) + Vn * fabsf(F)) * d_inv; }
+                    if (axis == 2) { float Vn = V.z + vsz; p.z = (V.z * fabsf(Fn) + Vn * fabsf(F)) * d_inv; }
+                    f3 q = aff_mul(aff, p);                                                    /* :570 */
+                    if (n < capacity) { float *o = points + 4 * n; o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = 0.f; }
+                    ++n;
+                }
+#undef VOX
+            }
+    return n;
+}
+
+/* tsdf_volume.cu:714-795 ExtractNormals: gradient at each extracted point (Rinv*(p - aff.t) back to the volume frame),
+ * NaN unless the nearest voxel is at least 2 from every face; result normalized(aff.R * n), w = 0.                */
+ORC_API void orc_extract_normals(OrcVolume v, const OrcSlab *slab, const float aff[12], const float Rinv[9],
+                                 const float *points /* float4 */, uint64_t n, float gradient_delta_factor,
+                                 float *normals /* float4 */)
+{
+    rc_ctx c; rc_setup(&c, &v, slab, 0.75f, gradient_delta_factor);
+    const f3 t = mk3(aff[9], aff[10], aff[11]);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        const float *pp = points + 4 * i;
+        float qn = qnanf();
+        f3 nrm = mk3(qn, qn, qn);
+        f3 point = mat3_mul(Rinv, sub3(mk3(pp[0], pp[1], pp[2]), t));                         /* :749 */
+        int gx = (int)lrintf(point.x * c.vsi.x), gy = (int)lrintf(point.y * c.vsi.y), gz = (int)lrintf(point.z * c.vsi.z);
+        if (gx > 1 && gy > 1 && gz > 1 && gx < c.X - 2 && gy < c.Y - 2 && gz < c.Z - 2) {     /* :752 */
+            f3 g;
+            g.x = (interpolate(&c, mul3(mk3(point.x + c.gd.x, point.y, point.z), c.vsi)) -
+                   interpolate(&c, mul3(mk3(point.x - c.gd.x, point.y, point.z), c.vsi))) / c.gd.x;
+            g.y = (interpolate(&c, mul3(mk3(point.x, point.y + c.gd.y, point.z), c.vsi)) -
+                   interpolate(&c, mul3(mk3(point.x, point.y - c.gd.y, point.z), c.vsi))) / c.gd.y;
+            g.z = (interpolate(&c, mul3(mk3(point.x, point.y, point.z + c.gd.z), c.vsi)) -
+                   interpolate(&c, mul3(mk3(point.x, point.y, point.z - c.gd.z), c.vsi))) / c.gd.z;
+            nrm = normalized3(mat3_mul(aff, g));                                                /* :789 */
+        }
+        float *o = normals + 4 * i; o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = 0.f;
     }
 }
 

@@ -80,6 +80,10 @@ def lib():
         L.orc_raycast_shade.restype = None
         L.orc_raycast_shade.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, u32p, f32p, C.c_size_t, f32p, C.c_size_t,
                                         C.c_int, C.c_int, C.c_float]
+        L.orc_extract_cloud.restype = C.c_uint64
+        L.orc_extract_cloud.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, C.c_uint64]
+        L.orc_extract_normals.restype = None
+        L.orc_extract_normals.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, C.c_uint64, C.c_float, f32p]
         for name in ("orc_quat_mul",):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = [f32p, f32p, f32p]
@@ -215,6 +219,20 @@ def raycast_depth(volume, cam2vol, Rinv, reproj, cols, rows, step_factor, delta_
                             f32(reproj), dep, cols * 2, nrm.reshape(-1), cols * 16, cols, rows, step_factor,
                             delta_factor)
     return dep, nrm
+
+
+def extract_cloud(volume, aff, capacity, slab=None):
+    pts = np.zeros((capacity, 4), np.float32)
+    n = int(lib().orc_extract_cloud(volume, C.byref(slab) if slab else None, f32(aff).reshape(-1), pts.reshape(-1), capacity))
+    return pts[:min(n, capacity)], n
+
+
+def extract_normals(volume, aff, Rinv, points, gradient_delta_factor, slab=None):
+    points = np.ascontiguousarray(points, np.float32)
+    out = np.empty_like(points)
+    lib().orc_extract_normals(volume, C.byref(slab) if slab else None, f32(aff).reshape(-1), f32(Rinv).reshape(-1),
+                              points.reshape(-1), points.shape[0], gradient_delta_factor, out.reshape(-1))
+    return out
 
 
 def knn(pos, queries, k, use_ref=False):

@@ -17,12 +17,16 @@ def timeit(fn, iters=10, warm=2):
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "512"
     cfg = synth.CONFIGS[name]; intr = Intr(*cfg.intr)
+    st = torch.cuda.current_stream().cuda_stream
     print("config", cfg.name, torch.cuda.get_device_name(0))
     src = torch.zeros(1 << 30, dtype=torch.uint8, device="cuda"); dst = torch.empty_like(src)
     st = torch.cuda.current_stream().cuda_stream
     ms = timeit(lambda: capi.check(capi.lib().dfusion_copy_bandwidth_probe(dst.data_ptr(), src.data_ptr(), 1 << 30, st)))
     print("copy probe: %.1f GB/s (r+w)" % (2 * (1 << 30) / ms / 1e6))
     ms = timeit(lambda: dst.copy_(src)); print("torch copy: %.1f GB/s" % (2 * (1 << 30) / ms / 1e6))
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: capi.check(capi.lib().dfusion_read_bandwidth_probe(src.data_ptr(), 1 << 30, sink.data_ptr(), st)))
+    print("read probe: %.1f GB/s" % ((1 << 30) / ms / 1e6))
     del src, dst
     depth = upload_u16(synth.depth_frame(cfg, 0)); dists = compute_dists(depth, intr)
     cam = synth.camera_pose(cfg, 1)
@@ -48,6 +52,14 @@ def main():
             for cull in (True, False):
                 ms = timeit(lambda: vol.integrate_warped(dists, cam, intr, wf, cull=cull, use_table=tab, use_weights=wts, sync=False), iters=5, warm=1)
                 print("warped knn_table=%s w_table=%s cull=%s : %.3f ms  alg %.0f GB/s" % (tab, wts, cull, ms, 8 * nw / ms / 1e6))
+    buf = torch.empty((1 << 24, 4), dtype=torch.float32, device="cuda")
+    ms = timeit(lambda: vol.fetchCloud(buf)); npts = vol.last_cloud_count_
+    print("fetchCloud (incl. count readback): %.3f ms, %d points, scan %.0f GB/s" % (ms, npts, 4 * nvox / ms / 1e6))
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    from dynamicfusion_amd.synth import aff12
+    ms = timeit(lambda: capi.check(capi.lib().dfusion_extract_cloud(vol.c_volume(), None, capi.floats(aff12(vol.getPose())), buf.data_ptr(), buf.shape[0], cnt.data_ptr(), st)), iters=20)
+    print("extract kernel only: %.3f ms, scan %.0f GB/s" % (ms, 4 * nvox / ms / 1e6))
+    cl = vol.fetchCloud(buf); ms = timeit(lambda: vol.fetchNormals(cl)); print("fetchNormals: %.3f ms" % ms)
     pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
     ms = timeit(lambda: vol.raycast(cam, intr, pts, nrm)); print("raycast: %.3f ms, hits %.3f" % (ms, float(torch.isfinite(pts[..., 0]).float().mean())))
 
