@@ -4,7 +4,8 @@
 //   headless_frame <dims> <size_m> <cols> <rows> <frames> <nodes> <k> <in.bin> <out.bin>
 // in.bin : per frame { depth u16[rows*cols], camera pose f32[12] (R row-major, t) } , then nodes { pos f32[3M], dq f32[8M]
 //          per frame, sigma f32[M] } ; intrinsics fx fy cx cy f32[4] ; volume pose f32[12] first of all.
-// out.bin: volume u32[dims^3], points f32[rows*cols*4], normals f32[rows*cols*4] of the last frame.
+// out.bin: volume u32[dims^3], points f32[rows*cols*4], normals f32[rows*cols*4] of the last frame, then the extracted
+//          surface (kinfu.cpp:398-399 compute_points / compute_normals): count u64, cloud f32[count*4], normals f32[count*4].
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -93,6 +94,14 @@ int main(int argc, char** argv)
     normals.download(n.data(), (size_t)cols * 16);
     std::fwrite(p.data(), 4, p.size(), out);
     std::fwrite(n.data(), 4, n.size(), out);
+    volume.compute_points();                                                         // kinfu.cpp:398 (and :249 on frame 0)
+    volume.compute_normals();                                                        // kinfu.cpp:399
+    const unsigned long long cnt = volume.get_cloud_host().size();
+    std::fwrite(&cnt, 8, 1, out);
+    if (cnt) {
+        std::fwrite(volume.get_cloud_host().data(), 16, cnt, out);
+        std::fwrite(volume.get_normal_host().data(), 16, cnt, out);
+    }
     std::fclose(out);
     std::printf("headless_frame ok: %d frames, %d nodes\n", frames, M);
     return 0;

@@ -1,7 +1,7 @@
 // kfusion/cuda/tsdf_volume.hpp -- kfusion::cuda::TsdfVolume, source compatible with
 // /root/reference/kfusion/include/kfusion/cuda/tsdf_volume.hpp:11-100 for the hot path; every method forwards to the
-// C-ABI in include/dfusion.h.  Extraction (fetchCloud / fetchNormals / compute_points / compute_normals / get_*_host)
-// and psdf / surface_fusion's CPU loop are SURVEY.md 8(f) "next" rows and not declared here;
+// C-ABI in include/dfusion.h.  get_cloud_host()/get_normal_host() return std::vector<Point> (the reference returns
+// cv::Mat 1xN CV_32FC4 -- same bytes); psdf / surface_fusion's CPU loop is a SURVEY.md 8(f) "next" row and not declared;
 // getGridOrigin / setGridOrigin are declared but never defined in the reference (:49-50) and omitted.
 #pragma once
 #include <kfusion/types.hpp>
@@ -55,7 +55,18 @@ namespace kfusion
 
             void swap(CudaData& data);
 
+            DeviceArray<Point> fetchCloud(DeviceArray<Point>& cloud_buffer) const;                        // tsdf_volume.cpp:181-199
+            void fetchNormals(const DeviceArray<Point>& cloud, DeviceArray<Normal>& normals) const;       // :206-218
+            void compute_points();                                                                        // :313-318
+            void compute_normals();                                                                       // :320-325
+            const std::vector<Point>& get_cloud_host() const { return cloud_host_; }
+            const std::vector<Normal>& get_normal_host() const { return normal_host_; }
+
         private:
+            DeviceArray<Point> cloud_buffer_, cloud_;
+            DeviceArray<Normal> normal_buffer_;
+            std::vector<Point> cloud_host_;
+            std::vector<Normal> normal_host_;
             CudaData data_;
             float trunc_dist_;
             float max_weight_;                              // stored as float in the reference too (tsdf_volume.hpp:86)

@@ -190,6 +190,45 @@ void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Cloud& p
                                  nullptr));
 }
 
+// ------------------------------------------------------------------------------------------ extraction (tsdf_volume.cpp:181-218,313-325)
+DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>& cloud_buffer) const
+{
+    enum { DEFAULT_CLOUD_BUFFER_SIZE = 256 * 256 * 256 };                   // :184
+    if (cloud_buffer.empty()) cloud_buffer.create(DEFAULT_CLOUD_BUFFER_SIZE);
+    float aff[12]; affine_to_aff12(pose_, aff);
+    DeviceArray<unsigned long long> count(1);
+    KF_HIP(hipMemset(count.ptr(), 0, sizeof(unsigned long long)));
+    KF_DF(dfusion_extract_cloud(c_volume(*this), nullptr, aff, (float*)cloud_buffer.ptr(), cloud_buffer.size(), count.ptr(), nullptr));
+    unsigned long long n = 0;
+    count.download(&n);                                                     // cudaMemcpyFromSymbol(output_count), tsdf_volume.cu:815
+    if (n > cloud_buffer.size()) n = cloud_buffer.size();
+    return DeviceArray<Point>(cloud_buffer.ptr(), (size_t)n);               // non-owning view, like the reference (:198)
+}
+
+void TsdfVolume::fetchNormals(const DeviceArray<Point>& cloud, DeviceArray<Normal>& normals) const
+{
+    normals.create(cloud.size());
+    if (!cloud.size()) return;
+    float aff[12]; affine_to_aff12(pose_, aff);
+    const Mat3f ri = pose_.rotation().inv();                                // :214 inv(DECOMP_SVD)
+    KF_DF(dfusion_extract_normals(c_volume(*this), nullptr, aff, ri.val, (const float*)cloud.ptr(), cloud.size(), gradient_delta_factor_,
+                                  (float*)normals.ptr(), nullptr));
+}
+
+void TsdfVolume::compute_points()
+{
+    cloud_ = fetchCloud(cloud_buffer_);
+    cloud_host_.resize(cloud_.size());
+    if (cloud_.size()) cloud_.download(cloud_host_.data());
+}
+
+void TsdfVolume::compute_normals()
+{
+    fetchNormals(cloud_, normal_buffer_);
+    normal_host_.resize(cloud_.size());
+    if (cloud_.size()) normal_buffer_.download(normal_host_.data());
+}
+
 // ------------------------------------------------------------------------------------------ WarpField
 WarpField::WarpField(int k) : k_(k), handle_(nullptr), out_dist_sqr_(k), ret_index_(k), index_ok_(false), index_volume_(nullptr)
 {

@@ -61,8 +61,13 @@ def run_harness(tmp_path, cfg, sc, frames, with_nodes):
     raw = np.fromfile(fout, np.uint8)
     nv = int(np.prod(cfg.dims))
     vol = raw[:4 * nv].view(np.uint32).reshape(cfg.dims[2], cfg.dims[1], cfg.dims[0])
-    img = raw[4 * nv:].view(np.float32).reshape(2, cfg.rows, cfg.cols, 4)
-    return vol, img[0], img[1]
+    n_img = 2 * cfg.rows * cfg.cols * 16
+    img = raw[4 * nv:4 * nv + n_img].view(np.float32).reshape(2, cfg.rows, cfg.cols, 4)
+    tail = raw[4 * nv + n_img:]
+    cnt = int(tail[:8].view(np.uint64)[0])
+    cloud = tail[8:8 + 16 * cnt].view(np.float32).reshape(cnt, 4)
+    cnormals = tail[8 + 16 * cnt:8 + 32 * cnt].view(np.float32).reshape(cnt, 4)
+    return vol, img[0], img[1], cloud, cnormals
 
 
 @pytest.mark.parametrize("with_nodes", [False, True], ids=["rigid", "warped"])
@@ -70,7 +75,7 @@ def test_cxx_api_matches_oracle(tmp_path, with_nodes):
     cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=100, k=8)
     frames = 2
     sc = Scene(cfg, n_frames=frames)
-    vol, pts, nrm = run_harness(tmp_path, cfg, sc, frames, with_nodes)
+    vol, pts, nrm, cloud, cnormals = run_harness(tmp_path, cfg, sc, frames, with_nodes)
     ref = sc.new_volume()
     for f in range(frames):
         cam_inv = cxx_inv(sc.cam_poses[f])
@@ -88,3 +93,11 @@ def test_cxx_api_matches_oracle(tmp_path, with_nodes):
                                         cfg.raycast_step_factor, cfg.gradient_delta_factor)
     assert stats[1] > 1000
     assert np.array_equal(pts.view(np.uint32), rp.view(np.uint32)) and np.array_equal(nrm.view(np.uint32), rn.view(np.uint32))
+    # compute_points / compute_normals (kinfu.cpp:398-399) through the C++ class: same SET of points as the oracle
+    rc, n = O.extract_cloud(sc.ovol(ref), synth.aff12(sc.pose), 1 << 22)
+    assert n == cloud.shape[0] > 1000
+    order = lambda a: a[np.lexsort(np.ascontiguousarray(a).view(np.uint32).T[::-1])]
+    assert np.array_equal(order(cloud).view(np.uint32), order(rc).view(np.uint32))
+    pinv = cxx_inv(sc.pose)[:3, :3]
+    rnrm = O.extract_normals(sc.ovol(ref), synth.aff12(sc.pose), pinv, cloud, cfg.gradient_delta_factor)
+    assert np.array_equal(cnormals.view(np.uint32), rnrm.view(np.uint32))
