@@ -234,10 +234,44 @@ def main():
         extra["rigid_integrate"] = {"ms": ms_r, "achieved_GBps": b_r / (ms_r * 1e-3) / 1e9, "frac_of_peak": b_r / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                     "n_updated": float(nr.item()) / F}
         del vol2
+        # surface extraction (kinfu.cpp:398-399) on the fused volume: a pure HBM scan, 4 B/voxel
+        st = torch.cuda.current_stream().cuda_stream
+        buf = torch.empty((1 << 22, 4), dtype=torch.float32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        aff = capi.floats(synth.aff12(vol.getPose()))
+        ex = lambda: capi.check(capi.lib().dfusion_extract_cloud(vol.c_volume(), None, aff, buf.data_ptr(), buf.shape[0], cnt.data_ptr(), st))
+        for _ in range(3):
+            ex()
+        cnt.zero_()
+        e0.record()
+        for _ in range(20):
+            ex()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_e = e0.elapsed_time(e1) / 20
+        n_pts = float(cnt.item()) / 20
+        b_e = 4.0 * X * Y * Z + 16.0 * n_pts
+        sink = torch.zeros(4, dtype=torch.int32, device=dev)
+        src = torch.zeros(1 << 30, dtype=torch.uint8, device=dev)
+        rd = lambda: capi.check(capi.lib().dfusion_read_bandwidth_probe(src.data_ptr(), 1 << 30, sink.data_ptr(), st))
+        rd(); e0.record()
+        for _ in range(10):
+            rd()
+        e1.record(); torch.cuda.synchronize()
+        read_gbps = (1 << 30) / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9
+        extra["extract_cloud"] = {"kernel": "df_extract_kernel<4>", "ms": ms_e, "points": n_pts, "bound": "hbm",
+                                  "achieved_GBps": b_e / (ms_e * 1e-3) / 1e9, "frac_of_peak": b_e / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                  "measured_read_GBps": read_gbps}
+        del buf, src
 
     # kernel that ran + its per-voxel cache footprint; PMC traffic comes from the committed rocprofv3 --pmc passes
     lds_ok = cfg.nodes * 32 <= 128 * 1024
-    kernel_name = "df_warp_rows_lds_kernel<%d, true, 2>" % cfg.k if lds_ok else "df_warp_rows_kernel<%d, true, 4>" % cfg.k
+    if lds_ok and cfg.k in (4, 8):
+        kernel_name = "df_warp_rows_pipe_kernel<%d>" % cfg.k
+    elif lds_ok:
+        kernel_name = "df_warp_rows_lds_kernel<%d, true, 2>" % cfg.k
+    else:
+        kernel_name = "df_warp_rows_kernel<%d, true, 4>" % cfg.k
     table_bytes = int(X) * Y * vol.z_own_n * cfg.k * 6
     traffic, traffic_src = None, None
     pmc_file = os.path.join(REPO, "profiles", "pmc_latest.json")

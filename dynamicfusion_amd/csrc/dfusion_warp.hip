@@ -487,12 +487,25 @@ struct DfWarpedArgs {
     float kf;                      // (float)k
     float tile_r;                  // half diagonal of a work tile's voxel-centre lattice (world metres), inflated
     float cam_scale;               // >= operator norm of world2cam.R (1 for a rigid pose), inflated
-    // per-voxel tables over planes [tab_z0, tab_z0 + tab_zn), x fastest (voxel = ((z-tab_z0)*Y + y)*X + x):
+    // per-voxel tables over planes [tab_z0, tab_z0 + tab_zn), TILE-MAJOR (private layout, see df_tab_index): the
+    // 32x16x8 voxels a sweep workgroup owns are contiguous, so it streams 8 KiB (k-NN) + 2 x 8 KiB (weights) runs per plane:
     //   knn_tab  K uint16 node indices per voxel, ascending distance (16 B/voxel at K = 8: one dwordx4 per lane)
     //   w_tab    K float weights per voxel, stored as K/4 float4 PLANES of tab_nvox entries each, so that a wave of
     //            x-adjacent lanes reads 1 KiB contiguous per instruction
-    uint16_t* knn_tab; float* w_tab; int tab_z0; size_t tab_nvox;
+    uint16_t* knn_tab; float* w_tab; int tab_z0; size_t tab_nvox; int tab_ntx, tab_nty;
 };
+
+// table entry of voxel (x, y, z): tiles of 32(x) x 16(y) x 8(z) voxels, tile-major; inside a tile z, then y, then x --
+// a wave of the sweep (32 x-lanes x 2 y rows) reads 64 consecutive entries, a workgroup plane 512.
+#define DF_TAB_TX 32
+#define DF_TAB_TY 16
+#define DF_TAB_TZ 8
+__device__ __forceinline__ size_t df_tab_index(const DfWarpedArgs& a, int x, int y, int z)
+{
+    const int zl = z - a.tab_z0;
+    const size_t tile = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty + (y / DF_TAB_TY)) * a.tab_ntx + (x / DF_TAB_TX);
+    return tile * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ) + ((zl % DF_TAB_TZ) * DF_TAB_TY + (y % DF_TAB_TY)) * DF_TAB_TX + (x % DF_TAB_TX);
+}
 
 #define DF_CAND_CHUNK 256
 
@@ -671,7 +684,7 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
     const size_t plane = (size_t)a.X * a.Y;
     float wt0[K], wt1[K];
     if constexpr (BUILD) {
-        const size_t tv0 = (size_t)(z0 - a.tab_z0) * plane + (size_t)y * a.X + x, tv1 = tv0 + 4 * plane;
+        const size_t tv0 = df_tab_index(a, x, y, z0), tv1 = df_tab_index(a, x, y, z1);
         if (act0) { knn_tab_store<K>(a.knn_tab, tv0, bi0); if (a.w_tab) { dqb_weights<K>(W, bd0, bi0, wt0); w_tab_store<K>(a.w_tab, a.tab_nvox, tv0, wt0); } }
         if (act1) { knn_tab_store<K>(a.knn_tab, tv1, bi1); if (a.w_tab) { dqb_weights<K>(W, bd1, bi1, wt1); w_tab_store<K>(a.w_tab, a.tab_nvox, tv1, wt1); } }
     } else {
@@ -718,7 +731,7 @@ __global__ __launch_bounds__(256, UNROLL) void df_warp_rows_kernel(const DfWarpe
     unsigned int my_upd = 0;
     if (in_xy) {
         for (int z = zb; z < ze; ++z) {
-            const size_t tv = (size_t)(z - a.tab_z0) * plane + (size_t)y * a.X + x;
+            const size_t tv = df_tab_index(a, x, y, z);
             const f3 q = aff_mul(a.vol2world, mk3(fxv, fyv, (float)z * a.vsz));     // canonical position
             int bi[K]; float wt[K];
             knn_tab_load<K>(a.knn_tab, tv, bi);
@@ -777,7 +790,7 @@ __global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArg
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int z = min(z0 + u, ze - 1);                        // clamp: tail lanes re-read a valid entry
-                const size_t tv = (size_t)(z - a.tab_z0) * plane + (size_t)y * a.X + x;
+                const size_t tv = df_tab_index(a, x, y, z);
                 knn_tab_load<K>(a.knn_tab, tv, bi[u]);
                 if constexpr (HAS_W) w_tab_load<K>(a.w_tab, a.tab_nvox, tv, wt[u]);
             }
@@ -801,6 +814,159 @@ __global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArg
                     }
                 }
             }
+        }
+    }
+    df_count_updates(a, my_upd);
+}
+
+// ---- software-pipelined form of the kernel above (the default).  PMC on the batched kernel: waves spend ~45 % of their
+// cycles parked on the table loads and raising occupancy is not possible (LDS node table: 2 workgroups per CU; ~100 VGPRs),
+// so the loads of batch b+1 are issued in the middle of batch b.  Vector-memory results return IN ORDER (vmcnt), hence the
+// order inside a batch matters:  volume words + dists gathers of batch b (needed now)  ->  table loads of batch b+1 (needed
+// next iteration)  ->  wait only for the former (vmcnt leaves the 6 prefetches in flight)  ->  sqrt / fuse / store, then the
+// whole blend of batch b+1 runs while nothing is waited for.  The sample is the branch-free form (clamped, always-valid
+// dists address; same verdict as tsdf_sample for every voxel) so the gathers can be issued before the verdict is known; the
+// voxel word is read unconditionally (it is the read half of the RMW for 1 voxel in 4, +4 B for the others).
+// raw (still packed) table record of one voxel: kept packed while in flight, so that nothing consumes a prefetched
+// register before the next iteration (an unpack right after the load would make the compiler wait for it at once)
+template <int K> struct DfTabRaw;
+template <> struct DfTabRaw<8> { uint4 idx; float4 w0, w1; };
+template <> struct DfTabRaw<4> { uint2 idx; float4 w0; };
+__device__ __forceinline__ void tab_raw_load(const DfWarpedArgs& a, size_t tv, DfTabRaw<8>& r)
+{
+    r.idx = reinterpret_cast<const uint4*>(a.knn_tab)[tv];
+    r.w0 = reinterpret_cast<const float4*>(a.w_tab)[tv];
+    r.w1 = reinterpret_cast<const float4*>(a.w_tab)[a.tab_nvox + tv];
+}
+__device__ __forceinline__ void tab_raw_load(const DfWarpedArgs& a, size_t tv, DfTabRaw<4>& r)
+{
+    r.idx = reinterpret_cast<const uint2*>(a.knn_tab)[tv];
+    r.w0 = reinterpret_cast<const float4*>(a.w_tab)[tv];
+}
+__device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<8>& r, int (&bi)[8], float (&wt)[8])
+{
+    bi[0] = r.idx.x & 0xffff; bi[1] = r.idx.x >> 16; bi[2] = r.idx.y & 0xffff; bi[3] = r.idx.y >> 16;
+    bi[4] = r.idx.z & 0xffff; bi[5] = r.idx.z >> 16; bi[6] = r.idx.w & 0xffff; bi[7] = r.idx.w >> 16;
+    wt[0] = r.w0.x; wt[1] = r.w0.y; wt[2] = r.w0.z; wt[3] = r.w0.w; wt[4] = r.w1.x; wt[5] = r.w1.y; wt[6] = r.w1.z; wt[7] = r.w1.w;
+}
+__device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<4>& r, int (&bi)[4], float (&wt)[4])
+{
+    bi[0] = r.idx.x & 0xffff; bi[1] = r.idx.x >> 16; bi[2] = r.idx.y & 0xffff; bi[3] = r.idx.y >> 16;
+    wt[0] = r.w0.x; wt[1] = r.w0.y; wt[2] = r.w0.z; wt[3] = r.w0.w;
+}
+
+template <int K>
+__global__ __launch_bounds__(512) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [M] rot, then [M] node_t
+    float4* s_rot = s_nodes;
+    float4* s_nt = s_nodes + W.M;
+    for (int j = threadIdx.x; j < W.M; j += 512) { s_rot[j] = W.rot[j]; s_nt[j] = W.node_t[j]; }
+    __syncthreads();
+
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * DF_ROW_TX + (threadIdx.x & (DF_ROW_TX - 1));
+    const int y = ty * DF_LDS_TY + (threadIdx.x >> 5);
+    const bool in_xy = x < a.X && y < a.Y;
+    const int xc = min(x, a.X - 1), yc = min(y, a.Y - 1);                 // clamped: out-of-volume lanes read valid entries, write nothing
+    const size_t plane = (size_t)a.X * a.Y;
+    const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
+    const int lt0 = a.bz0 + blockIdx.y * DF_LDS_ZT;                        // first tile layer of this workgroup
+    const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
+    auto layer_zb = [&](int l) { return max((lt0 + l) * DF_ROW_TZ, a.z_own0); };
+    auto layer_ze = [&](int l) { return min((lt0 + l + 1) * DF_ROW_TZ, own1); };
+
+    unsigned alive = 0;                                                    // block-uniform: layers that are in range and not culled
+    for (int l = 0; l < DF_LDS_ZT; ++l) {
+        if (layer_zb(l) >= layer_ze(l)) continue;
+        bool culled = false;
+        if (a.cull) {
+            const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX) + 0.5f * (DF_ROW_TX - 1)) * a.vsx,
+                                                  ((float)(ty * DF_LDS_TY) + 0.5f * (DF_LDS_TY - 1)) * a.vsy,
+                                                  ((float)((lt0 + l) * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
+            culled = df_tile_culled(a, c);
+        }
+        if (!culled) alive |= 1u << l;
+    }
+    unsigned int my_upd = 0;
+    if (alive) {
+        // batch sequence: 2 planes per batch inside a layer, then the first batch of the next alive layer; l < 0 = none
+        auto advance = [&](int l, int z0, int* nl, int* nz0) {
+            *nl = l; *nz0 = z0 + 2;
+            if (*nz0 >= layer_ze(l)) {
+                const unsigned rem = alive >> (l + 1);
+                *nl = rem ? l + 1 + (__ffs(rem) - 1) : -1;
+                *nz0 = *nl >= 0 ? layer_zb(*nl) : 0;
+            }
+        };
+        // prefetch distance is TWO batches (two packed register sets, used alternately): the tables of batch b+2 are
+        // requested in the middle of batch b and consumed at the start of batch b+2, a whole blend later.
+        auto load_batch = [&](DfTabRaw<K> (&S)[2], int l, int z0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) tab_raw_load(a, df_tab_index(a, xc, yc, min(z0 + u, layer_ze(l) - 1)), S[u]);
+        };
+        int l = __ffs(alive) - 1, z0 = layer_zb(l);
+        int l1, z1; advance(l, z0, &l1, &z1);
+        DfTabRaw<K> S0[2], S1[2];
+        load_batch(S0, l, z0);
+        load_batch(S1, l1 >= 0 ? l1 : l, l1 >= 0 ? z1 : z0);               // dummy re-read when there is no second batch
+
+        // one batch: consumes S (tables of batch (l, z0)), then refills S with the tables of batch (l2, z2)
+        auto step = [&](DfTabRaw<K> (&S)[2], int l, int z0, int l2, int z2) {
+            const int ze = layer_ze(l);
+            int bi[2][K]; float wt[2][K];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) tab_raw_unpack(S[u], bi[u], wt[u]);
+            // (1) voxel words of this batch (unconditional; clamped plane for the tail)
+            uint32_t* vp[2]; uint32_t vox[2]; bool inz[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                inz[u] = in_xy && z0 + u < ze;
+                vp[u] = a.vol + (size_t)(min(z0 + u, ze - 1) - a.z_store0) * plane + (size_t)yc * a.X + xc;
+                vox[u] = *vp[u];
+            }
+            // (2) blend -> transform -> project, then the dists gathers (clamped address, always valid)
+            f3 vc[2]; bool ok[2]; uint16_t dpb[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f3 q = aff_mul(a.vol2world, mk3(fxv, fyv, (float)(z0 + u) * a.vsz));   // canonical position
+                quat rot, dual;
+                dqb_blend_lds<K>(s_rot, s_nt, wt[u], bi[u], &rot, &dual);
+                vc[u] = aff_mul(a.world2cam, dq_transform(rot, dual, q));
+                const float pu = fmaf(a.P.fx, vc[u].x / vc[u].z, a.P.cx);                     // device.hpp:35
+                const float pv = fmaf(a.P.fy, vc[u].y / vc[u].z, a.P.cy);                     // device.hpp:36
+                ok[u] = inz[u] & (vc[u].z > 0.f) & (pu >= 0.f) & (pv >= 0.f) & (pu < (float)a.P.cols) & (pv < (float)a.P.rows);   // :82,:86
+                const int ui = (int)fminf(fmaxf(pu, 0.f), (float)(a.P.cols - 1));
+                const int vi = (int)fminf(fmaxf(pv, 0.f), (float)(a.P.rows - 1));
+                dpb[u] = *(const uint16_t*)((const char*)a.P.dists + (size_t)vi * a.P.pitch + 2 * (size_t)ui);   // :85
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (3) tables of batch b+2 into the set just consumed.  Unconditional (a dummy re-read at the end): a branch here
+            // would make the compiler assume the loads may not have been issued and wait for most of the prefetch.
+            load_batch(S, l2 >= 0 ? l2 : l, l2 >= 0 ? z2 : z0);
+            __builtin_amdgcn_sched_barrier(0);
+            // (4) finish the sample (:85-93), fuse (:97-103), store
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float Dp = h2f_bits(dpb[u]);
+                const float sdf = Dp - sqrtf(dot3(vc[u], vc[u]));                             // :89
+                const bool upd = ok[u] & (Dp != 0.f) & (sdf >= -a.P.trunc);                   // :86, :91
+                if (upd) {
+                    *vp[u] = tsdf_fuse(vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight);   // :93
+                    ++my_upd;
+                }
+            }
+        };
+        for (;;) {
+            int l2, z2;
+            if (l1 >= 0) advance(l1, z1, &l2, &z2); else { l2 = -1; z2 = 0; }
+            step(S0, l, z0, l2, z2);
+            if (l1 < 0) break;
+            int l3, z3;
+            if (l2 >= 0) advance(l2, z2, &l3, &z3); else { l3 = -1; z3 = 0; }
+            step(S1, l1, z1, l3, z3);
+            if (l2 < 0) break;
+            l = l2; z0 = z2; l1 = l3; z1 = z3;
         }
     }
     df_count_updates(a, my_upd);
@@ -865,7 +1031,11 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     const bool use_tab = wf->tab_valid && wf->tab_k == k && !(flags & DF_WARP_NO_TABLE) && s.z_own0 >= wf->tab_z0 &&
                          s.z_own0 + s.z_own_n <= wf->tab_z0 + wf->tab_zn;
     const bool use_w = use_tab && wf->w_tab_valid && !(flags & DF_WARP_NO_WEIGHT_TABLE);
-    if (use_tab) { a.knn_tab = wf->knn_tab; a.tab_z0 = wf->tab_z0; a.tab_nvox = (size_t)a.X * a.Y * wf->tab_zn; }
+    if (use_tab) {
+        a.knn_tab = wf->knn_tab; a.tab_z0 = wf->tab_z0;
+        a.tab_ntx = (a.X + DF_TAB_TX - 1) / DF_TAB_TX; a.tab_nty = (a.Y + DF_TAB_TY - 1) / DF_TAB_TY;
+        a.tab_nvox = (size_t)a.tab_ntx * DF_TAB_TX * a.tab_nty * DF_TAB_TY * wf->tab_zn;
+    }
     if (use_w) a.w_tab = wf->w_tab;
 
     if (!(flags & DF_WARP_NO_CULL) && proj[0] > 0.f && proj[1] > 0.f) {
@@ -897,7 +1067,13 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
 #define DF_LAUNCH_LDS(HW, NBV)                                                                                                          \
         DF_DISPATCH_K(k, { DF_HIP(hipFuncSetAttribute((const void*)df_warp_rows_lds_kernel<K, HW, NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                            df_warp_rows_lds_kernel<K, HW, NBV><<<grid, dim3(512), lds, st>>>(a, W, tiles_x); })
-        if (use_w) {
+        const char* evp = getenv("DFUSION_ROWS_PIPE");
+        if (use_w && (k == 8 || k == 4) && !(evp && atoi(evp) == 0)) {
+            if (k == 8) { DF_HIP(hipFuncSetAttribute((const void*)df_warp_rows_pipe_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                          df_warp_rows_pipe_kernel<8><<<grid, dim3(512), lds, st>>>(a, W, tiles_x); }
+            else { DF_HIP(hipFuncSetAttribute((const void*)df_warp_rows_pipe_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                   df_warp_rows_pipe_kernel<4><<<grid, dim3(512), lds, st>>>(a, W, tiles_x); }
+        } else if (use_w) {
             if (nb == 1) { DF_LAUNCH_LDS(true, 1); } else if (nb == 4) { DF_LAUNCH_LDS(true, 4); } else { DF_LAUNCH_LDS(true, 2); }
         } else { DF_LAUNCH_LDS(false, 1); }
 #undef DF_LAUNCH_LDS
@@ -931,7 +1107,8 @@ static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab
     // table planes are brick-aligned so that both voxels of a build thread (z, z+4) index inside it
     const int bz_lo = s.z_own0 / DF_BRICK, bz_hi = (s.z_own0 + s.z_own_n - 1) / DF_BRICK;
     const int tz0 = bz_lo * DF_BRICK, tzn = (bz_hi - bz_lo + 1) * DF_BRICK;
-    const size_t nvox = (size_t)v.dims[0] * v.dims[1] * tzn;
+    const int ntx = (v.dims[0] + DF_TAB_TX - 1) / DF_TAB_TX, nty = (v.dims[1] + DF_TAB_TY - 1) / DF_TAB_TY;
+    const size_t nvox = (size_t)ntx * DF_TAB_TX * nty * DF_TAB_TY * tzn;          // padded to whole tiles
     const size_t need = nvox * k;
     if (need > wf->knn_tab_cap) {
         (void)hipFree(wf->knn_tab); wf->knn_tab = nullptr; wf->knn_tab_cap = 0;
@@ -950,7 +1127,7 @@ static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab
     a.z_store0 = tz0; a.z_own0 = tz0; a.z_own_n = tzn;        // every voxel of the covered bricks gets an entry
     a.vsx = v.voxel_size[0]; a.vsy = v.voxel_size[1]; a.vsz = v.voxel_size[2];
     a.vol2world = df_aff(vol2world);
-    a.knn_tab = wf->knn_tab; a.tab_z0 = tz0; a.tab_nvox = nvox; a.bz0 = bz_lo;
+    a.knn_tab = wf->knn_tab; a.tab_z0 = tz0; a.tab_nvox = nvox; a.tab_ntx = ntx; a.tab_nty = nty; a.bz0 = bz_lo;
     DfWarpView W = df_view(wf);
     dim3 grid((unsigned)(W.bx * W.by), (unsigned)(bz_hi - bz_lo + 1));
     DF_DISPATCH_K(k, df_warp_brick_kernel<K, true><<<grid, dim3(256), 0, st>>>(a, W));
