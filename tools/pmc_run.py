@@ -19,5 +19,7 @@ for _ in range(n):
     vol.raycast(cam, intr, pts, nrm)
 for _ in range(n):
     vol.integrate(dists, cam, intr, sync=False)
+for _ in range(n):
+    vol.fetchCloud()
 torch.cuda.synchronize()
 print("done", cfg.name, mode)
