@@ -29,7 +29,7 @@ DF_INDEX_WEIGHT_TABLE = 2
 
 # every symbol include/dfusion.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "dfusion_abi_version", "dfusion_error_string", "dfusion_clear", "dfusion_compute_dists", "dfusion_integrate",
+    "dfusion_abi_version", "dfusion_error_string", "dfusion_clear", "dfusion_compute_dists", "dfusion_project_and_remove", "dfusion_integrate",
     "dfusion_raycast_points", "dfusion_raycast_depth", "dfusion_raycast_march", "dfusion_raycast_select", "dfusion_raycast_shade", "dfusion_extract_cloud",
     "dfusion_extract_normals", "dfusion_warp_create", "dfusion_warp_destroy",
     "dfusion_warp_set_nodes", "dfusion_warp_set_transforms", "dfusion_warp_build_index", "dfusion_knn",
@@ -68,6 +68,7 @@ def lib():
     L.dfusion_error_string.argtypes = [C.c_int]
     L.dfusion_clear.argtypes = [DfVolume, C.POINTER(DfSlab), vp]
     L.dfusion_compute_dists.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, fp, vp]
+    L.dfusion_project_and_remove.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, vp, C.c_ulonglong, fp, vp, vp, vp]
     L.dfusion_integrate.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, DfVolume, C.POINTER(DfSlab), fp, fp, vp, vp]
     L.dfusion_raycast_points.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, C.c_size_t, vp, C.c_size_t,
                                          C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]

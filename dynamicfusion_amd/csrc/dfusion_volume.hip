@@ -105,6 +105,61 @@ extern "C" int dfusion_compute_dists(const uint16_t* depth, size_t depth_pitch, 
     return DF_OK;
 }
 
+// ------------------------------------------------------------------------------------------ project_and_remove / psdf
+// project_kernel, tsdf_volume.cu:113-139, plus the per-point arithmetic of TsdfVolume::psdf (tsdf_volume.cpp:284-290):
+// ro = (K^-1 * (coo.x*Dp, coo.y*Dp, Dp))[2] - point.z = b22*Dp - point.z with b22 from the closed-form 3x3 inverse.
+// Reads the immutable dists_in, zeroes dists_out (the reference does both on one image: racy, see include/dfusion.h).
+__global__ __launch_bounds__(256) void df_project_kernel(const uint16_t* __restrict__ din, size_t ipitch,
+                                                         uint16_t* __restrict__ dout, size_t opitch, int cols, int rows,
+                                                         float4* __restrict__ points, unsigned long long n, float fx, float fy,
+                                                         float cx, float cy, float b22, float* __restrict__ ro,
+                                                         unsigned long long* __restrict__ n_inside)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    bool inside = false;
+    if (i < n) {
+        const float4 p = points[i];
+        const float qnan = __uint_as_float(0x7fffffffu);
+        if (isnan(p.x) || isnan(p.y) || isnan(p.z)) {                       // :121
+            if (ro) ro[i] = qnan;
+        } else {
+            const float u = fmaf(fx, p.x / p.z, cx);                        // device.hpp:35
+            const float v = fmaf(fy, p.y / p.z, cy);                        // device.hpp:36
+            if (!(u >= 0.f && v >= 0.f && v < (float)rows && u < (float)cols)) {   // :125 (+NaN => outside)
+                points[i] = make_float4(qnan, qnan, qnan, 0.f);
+                if (ro) ro[i] = qnan;
+            } else {
+                const float Dp = h2f_bits(*(const uint16_t*)((const char*)din + (size_t)(int)v * ipitch + 2 * (size_t)(int)u));
+                if (dout) *(uint16_t*)((char*)dout + (size_t)(int)v * opitch + 2 * (size_t)(int)u) = 0;   // :132
+                points[i] = make_float4(u * Dp, v * Dp, Dp, 0.f);           // :133
+                if (ro) ro[i] = (0.f + b22 * Dp) - p.z;
+                inside = true;
+            }
+        }
+    }
+    if (n_inside) {
+        const unsigned long long m = __ballot(inside);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_inside, (unsigned long long)__popcll(m));
+    }
+}
+
+extern "C" int dfusion_project_and_remove(const uint16_t* dists_in, size_t in_pitch, uint16_t* dists_out, size_t out_pitch,
+                                          int cols, int rows, float* points, unsigned long long n, const float proj[4],
+                                          float* ro, unsigned long long* n_inside, dfStream stream)
+{
+    if (!dists_in || !points || !proj || cols <= 0 || rows <= 0) return DF_E_INVALID;
+    if (dists_out == dists_in) return DF_E_INVALID;
+    if (n == 0) return DF_OK;
+    const float P = proj[0] * proj[1];
+    const float dinv = 1.f / P;
+    const float b22 = P * dinv;                                             // Matx33f::inv(), third row (0, 0, b22)
+    hipLaunchKernelGGL(df_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dists_in,
+                       in_pitch, dists_out, out_pitch, cols, rows, (float4*)points, n, proj[0], proj[1], proj[2], proj[3], b22,
+                       ro, n_inside);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
 // ------------------------------------------------------------------------------------------ integrate (rigid)
 struct DfRigidArgs {
     uint32_t* vol;            // first stored plane

@@ -1,11 +1,14 @@
 // headless_frame.cpp -- the hot-path call sequence of KinFu::operator() / KinFu::dynamicfusion
 // (/root/reference/kfusion/src/kinfu.cpp:226,248,297,351,385,391) through the source-compatible C++ API, without the GUI,
 // ICP or solver.  Inputs and outputs are raw binary files so that tests can drive it and diff against the oracle:
-//   headless_frame <dims> <size_m> <cols> <rows> <frames> <nodes> <k> <in.bin> <out.bin>
+//   headless_frame <dims> <size_m> <cols> <rows> <frames> <nodes> <k> <in.bin> <out.bin> [surface_fusion]
 // in.bin : per frame { depth u16[rows*cols], camera pose f32[12] (R row-major, t) } , then nodes { pos f32[3M], dq f32[8M]
 //          per frame, sigma f32[M] } ; intrinsics fx fy cx cy f32[4] ; volume pose f32[12] first of all.
 // out.bin: volume u32[dims^3], points f32[rows*cols*4], normals f32[rows*cols*4] of the last frame, then the extracted
 //          surface (kinfu.cpp:398-399 compute_points / compute_normals): count u64, cloud f32[count*4], normals f32[count*4].
+//          With the trailing `surface_fusion` argument the body of KinFu::dynamicfusion (kinfu.cpp:344-391, minus the solver)
+//          then runs on the last frame: ray-cast points -> canonical -> WarpField::warp -> TsdfVolume::surface_fusion, and
+//          out.bin continues with: warped f32[rows*cols*3], depth after removal u16[rows*cols], volume u32[dims^3].
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -27,7 +30,7 @@ static Affine3f read_affine(FILE* f)
 
 int main(int argc, char** argv)
 {
-    if (argc != 10) { std::fprintf(stderr, "usage: %s dims size cols rows frames nodes k in.bin out.bin\n", argv[0]); return 2; }
+    if (argc != 10 && argc != 11) { std::fprintf(stderr, "usage: %s dims size cols rows frames nodes k in.bin out.bin\n", argv[0]); return 2; }
     const int dims = std::atoi(argv[1]); const float size = (float)std::atof(argv[2]);
     const int cols = std::atoi(argv[3]), rows = std::atoi(argv[4]), frames = std::atoi(argv[5]), M = std::atoi(argv[6]), k = std::atoi(argv[7]);
     FILE* in = std::fopen(argv[8], "rb");
@@ -101,6 +104,24 @@ int main(int argc, char** argv)
     if (cnt) {
         std::fwrite(volume.get_cloud_host().data(), 16, cnt, out);
         std::fwrite(volume.get_normal_host().data(), 16, cnt, out);
+    }
+    if (argc == 11 && M > 0) {
+        const Affine3f camera_pose = cam[frames - 1];
+        const Affine3f inverse_pose = camera_pose.inv();                             // kinfu.cpp:357
+        std::vector<Vec3f> canonical((size_t)rows * cols), canonical_normals((size_t)rows * cols);
+        for (size_t i = 0; i < canonical.size(); ++i) {
+            canonical[i] = inverse_pose * Vec3f(p[4 * i], p[4 * i + 1], p[4 * i + 2]);   // :358-363
+            canonical_normals[i] = Vec3f(n[4 * i], n[4 * i + 1], n[4 * i + 2]);          // :378-383
+        }
+        std::vector<Vec3f> canonical_visible(canonical);                             // :385
+        warp.warp(canonical, canonical_normals);                                     // :387 (the solver, :389, is out of scope)
+        volume.surface_fusion(warp, canonical, canonical_visible, depth_device, camera_pose, intr);   // :393
+        std::vector<unsigned short> depth_after((size_t)rows * cols);
+        depth_device.download(depth_after.data(), (size_t)cols * 2);                 // :395-396 "Depth diff"
+        std::fwrite(canonical[0].val, 12, canonical.size(), out);
+        std::fwrite(depth_after.data(), 2, depth_after.size(), out);
+        volume.data().download(vol.data());
+        std::fwrite(vol.data(), 4, vol.size(), out);
     }
     std::fclose(out);
     std::printf("headless_frame ok: %d frames, %d nodes\n", frames, M);

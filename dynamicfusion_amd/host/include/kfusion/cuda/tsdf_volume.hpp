@@ -1,7 +1,7 @@
 // kfusion/cuda/tsdf_volume.hpp -- kfusion::cuda::TsdfVolume, source compatible with
 // /root/reference/kfusion/include/kfusion/cuda/tsdf_volume.hpp:11-100 for the hot path; every method forwards to the
 // C-ABI in include/dfusion.h.  get_cloud_host()/get_normal_host() return std::vector<Point> (the reference returns
-// cv::Mat 1xN CV_32FC4 -- same bytes); psdf / surface_fusion's CPU loop is a SURVEY.md 8(f) "next" row and not declared;
+// cv::Mat 1xN CV_32FC4 -- same bytes); psdf / surface_fusion run on the GPU (dfusion_project_and_remove);
 // getGridOrigin / setGridOrigin are declared but never defined in the reference (:49-50) and omitted.
 #pragma once
 #include <kfusion/types.hpp>
@@ -54,6 +54,18 @@ namespace kfusion
             virtual void integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr, const WarpField& warp);
 
             void swap(CudaData& data);
+
+            /// tsdf_volume.cpp:228-255.  Observable behaviour of the reference: depth pixels explained by a warped model
+            /// point are zeroed, the leftover depth is fused RIGIDLY; the per-point weights loop (:241-254) has no effect
+            /// there (update lines commented out) and is not run.  psdf is handed dists computed from `depth` (the
+            /// reference binds the mm image as half, :235/:281 -- fixed).
+            void surface_fusion(const WarpField& warp_field, std::vector<Vec3f> warped, std::vector<Vec3f> canonical,
+                                cuda::Depth& depth, const Affine3f& camera_pose, const Intr& intr);
+            /// tsdf_volume.cpp:266-292: ro[i] = dists at the projection of warped[i] - warped[i].z (NaN when the point is
+            /// NaN or projects outside); pixels of `dists` hit by a point are zeroed.
+            std::vector<float> psdf(const std::vector<Vec3f>& warped, Dists& dists, const Intr& intr);
+            /// tsdf_volume.cpp:300-306
+            float weighting(const std::vector<float>& dist_sqr, int k) const;
 
             DeviceArray<Point> fetchCloud(DeviceArray<Point>& cloud_buffer) const;                        // tsdf_volume.cpp:181-199
             void fetchNormals(const DeviceArray<Point>& cloud, DeviceArray<Normal>& normals) const;       // :206-218

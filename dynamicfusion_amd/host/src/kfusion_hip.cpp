@@ -1,6 +1,7 @@
 // kfusion_hip.cpp -- host side of the drop-in boundary: kfusion::cuda::{DeviceMemory, TsdfVolume, computeDists} and
 // kfusion::WarpField implemented over the C-ABI (include/dfusion.h) and the HIP runtime.  The call sequences mirror
 // /root/reference/kfusion/src/tsdf_volume.cpp, device_memory.cpp, imgproc.cpp and warp_field.cpp (cited per function).
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <hip/hip_runtime_api.h>
@@ -227,6 +228,51 @@ void TsdfVolume::compute_normals()
     fetchNormals(cloud_, normal_buffer_);
     normal_host_.resize(cloud_.size());
     if (cloud_.size()) normal_buffer_.download(normal_host_.data());
+}
+
+// ------------------------------------------------------------------------------------------ psdf / surface_fusion (tsdf_volume.cpp:228-306)
+// project_and_remove + the K^-1 arithmetic run in one kernel; `removed` receives the zeros (dists itself when null).
+static std::vector<float> psdf_impl(const std::vector<Vec3f>& warped, const Dists& dists, DeviceArray2D<unsigned short>* removed,
+                                    const Intr& intr)
+{
+    std::vector<float> distances(warped.size());
+    if (warped.empty()) return distances;
+    std::vector<Point> pts(warped.size());
+    for (size_t i = 0; i < warped.size(); ++i) { pts[i].x = warped[i][0]; pts[i].y = warped[i][1]; pts[i].z = warped[i][2]; pts[i].data[3] = 0.f; }   // :272-278
+    DeviceArray<Point> d_pts; d_pts.upload(pts);
+    DeviceArray<float> d_ro(warped.size());
+    const float proj[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
+    KF_DF(dfusion_project_and_remove(dists.ptr(), dists.step(), removed->ptr(), removed->step(), dists.cols(), dists.rows(),
+                                     (float*)d_pts.ptr(), warped.size(), proj, d_ro.ptr(), nullptr, nullptr));
+    d_ro.download(distances.data());
+    return distances;
+}
+
+std::vector<float> TsdfVolume::psdf(const std::vector<Vec3f>& warped, Dists& dists, const Intr& intr)
+{
+    Dists snapshot;                                                         // samples come from an immutable copy (include/dfusion.h)
+    snapshot.create(dists.rows(), dists.cols());
+    KF_HIP(hipMemcpy2D(snapshot.ptr(), snapshot.step(), dists.ptr(), dists.step(), dists.cols() * sizeof(unsigned short), dists.rows(),
+                       hipMemcpyDeviceToDevice));
+    return psdf_impl(warped, snapshot, &dists, intr);
+}
+
+float TsdfVolume::weighting(const std::vector<float>& dist_sqr, int k) const
+{
+    float distances = 0;
+    for (float d : dist_sqr) distances += std::sqrt(d);
+    return distances / k;
+}
+
+void TsdfVolume::surface_fusion(const WarpField& /*warp_field*/, std::vector<Vec3f> warped, std::vector<Vec3f> /*canonical*/,
+                                cuda::Depth& depth, const Affine3f& camera_pose, const Intr& intr)
+{
+    cuda::Dists dists;
+    cuda::computeDists(depth, dists, intr);                                 // metres for psdf (the reference samples the mm image as half)
+    std::vector<float> ro = psdf_impl(warped, dists, &depth, intr);         // :235  zeroes the explained pixels of `depth`
+    (void)ro;
+    cuda::computeDists(depth, dists, intr);                                 // :237-238
+    integrate(dists, camera_pose, intr);                                    // :239
 }
 
 // ------------------------------------------------------------------------------------------ WarpField

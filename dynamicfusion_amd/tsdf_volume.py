@@ -271,6 +271,22 @@ class TsdfVolume:
                    "dfusion_extract_normals")
         return normals
 
+    # ---- tsdf_volume.cpp:266-292 psdf (device::project_and_remove + the per-point K^-1 arithmetic, fused on the GPU)
+    def psdf(self, warped, dists, intr, return_points=False):
+        """warped: float32 [n, 3] or [n, 4] device tensor of camera-frame points; dists: u16 [rows, cols] device tensor,
+        pixels hit by a warped point are zeroed IN PLACE (sampled from a snapshot taken first, see include/dfusion.h).
+        Returns ro [n] (device), optionally also the projected points [n, 4]."""
+        n = int(warped.shape[0])
+        pts = torch.zeros((n, 4), dtype=torch.float32, device=self.device)
+        pts[:, :3] = warped[:, :3]
+        ro = torch.empty(n, dtype=torch.float32, device=self.device)
+        snapshot = dists.clone()
+        rows, cols = dists.shape
+        capi.check(capi.lib().dfusion_project_and_remove(_ptr(snapshot), cols * 2, _ptr(dists), cols * 2, cols, rows,
+                                                         _ptr(pts), n, intr.as_proj(), _ptr(ro), None, _stream()),
+                   "dfusion_project_and_remove")
+        return (ro, pts) if return_points else ro
+
     # ---- convenience for tests
     def download(self):
         """uint32 numpy [z_store_n, Y, X] : lo16 = half tsdf bits, hi16 = weight."""

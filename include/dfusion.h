@@ -92,6 +92,19 @@ int dfusion_clear(DfVolume v, const DfSlab *slab, dfStream stream);
 int dfusion_compute_dists(const uint16_t *depth_dev, size_t depth_pitch, uint16_t *dists_dev, size_t dists_pitch,
                           int cols, int rows, const float intr[4], dfStream stream);
 
+/* device::project_and_remove / device::project (internal.hpp:107-109; project_kernel tsdf_volume.cu:113-139, launched
+ * by :163-192) fused with the per-point arithmetic of TsdfVolume::psdf (tsdf_volume.cpp:266-292).
+ * points_dev: n float4 (camera frame), updated in place: NaN points untouched; points projecting outside the image ->
+ * (qnan, qnan, qnan, 0); otherwise (coo.x*Dp, coo.y*Dp, Dp, 0) with Dp = dists(coo) and the dists pixel "removed" (<- 0).
+ * The reference samples and zeroes ONE image concurrently (a second point on the same pixel may see 0 or the old
+ * value); here samples come from dists_in and the zeros go to dists_out (nullable; must not alias dists_in; the caller
+ * seeds it with a copy of dists_in).  ro_dev (nullable): n floats, psdf's return value
+ * (K^-1 * new_point)[2] - old_point.z, NaN for NaN / outside points.  n_inside_dev (nullable) is INCREMENTED by the
+ * number of points that landed inside the image.                                                                  */
+int dfusion_project_and_remove(const uint16_t *dists_in_dev, size_t in_pitch, uint16_t *dists_out_dev, size_t out_pitch,
+                               int cols, int rows, float *points_dev, unsigned long long n, const float proj[4],
+                               float *ro_dev, unsigned long long *n_inside_dev, dfStream stream);
+
 /* device::integrate (internal.hpp:106; tsdf_volume.cu:51-112,141-161): rigid projective TSDF
  * update.  proj = {fx, fy, cx, cy} (device::Projector).  n_updated_dev (nullable) is
  * INCREMENTED by the number of voxels whose update branch (tsdf_volume.cu:91) was taken.       */

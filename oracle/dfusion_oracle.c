@@ -743,6 +743,51 @@ ORC_API void orc_extract_normals(OrcVolume v, const OrcSlab *slab, const float a
     }
 }
 
+/* ---------------------------------------------------------------- project_and_remove / psdf
+ * project_kernel, tsdf_volume.cu:113-139 (device::project_and_remove :163-176, device::project :179-192 -- the two
+ * launch the same kernel) and the host arithmetic of TsdfVolume::psdf, tsdf_volume.cpp:266-292.
+ * For every non-NaN point: coo = proj(point) (device.hpp:35-36); outside the image -> (qnan,qnan,qnan,0); otherwise
+ * Dp = dists(coo) (point filter), the dists pixel is zeroed ("removed") and the point becomes (coo.x*Dp, coo.y*Dp, Dp, 0).
+ * ro[i] (nullable) = (K^-1 * new_point)[2] - old_point.z, psdf :284-290.  K^-1 is cv::Matx33f::inv(DECOMP_LU) == OpenCV's
+ * closed-form 3x3 inverse (third-party, not in the reference tree: opencv2/core/operations.hpp Matx_FastInvOp<_Tp,3>):
+ * d = 1/fl(fx*fy); third row = (0, 0, fl(fl(fx*fy)*d)); the product accumulates 0*X + 0*Y + b22*Z in f32.
+ * Deviations (header): the guard `x<cols || y<rows` (:119) is dropped -- points are a flat list here; NaN image
+ * coordinates count as outside; the reference reads dists through a texture while other threads zero the same image
+ * (racy: a second point landing on an already-removed pixel may read 0 or the old value) -- here reads come from the
+ * immutable `dists_in` and the zeros go to `dists_out` (nullable; must not alias dists_in).
+ * Returns the number of points that landed inside the image.                                                     */
+ORC_API uint64_t orc_project_and_remove(const uint16_t *dists_in, size_t in_pitch, uint16_t *dists_out, size_t out_pitch,
+                                        int cols, int rows, float *points /* float4 */, uint64_t n, const float proj[4],
+                                        float *ro /* nullable */)
+{
+    const float P = proj[0] * proj[1];
+    const float dinv = 1.f / P;
+    const float b22 = P * dinv;
+    uint64_t inside = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        float *p = points + 4 * i;
+        const float px = p[0], py = p[1], pz = p[2];
+        if (isnan(px) || isnan(py) || isnan(pz)) {                 /* :121 */
+            if (ro) ro[i] = qnanf();                               /* (K^-1 * NaN)[2] - z */
+            continue;
+        }
+        const float u = fmaf(proj[0], px / pz, proj[2]);
+        const float w = fmaf(proj[1], py / pz, proj[3]);
+        if (!(u >= 0 && w >= 0 && w < (float)rows && u < (float)cols)) {   /* :125 */
+            p[0] = p[1] = p[2] = qnanf(); p[3] = 0.f;
+            if (ro) ro[i] = qnanf();
+            continue;
+        }
+        const uint16_t *row = (const uint16_t *)((const char *)dists_in + (size_t)(int)w * in_pitch);
+        const float Dp = h2f(row[(int)u]);                         /* :131 */
+        if (dists_out) ((uint16_t *)((char *)dists_out + (size_t)(int)w * out_pitch))[(int)u] = 0;   /* :132 */
+        p[0] = u * Dp; p[1] = w * Dp; p[2] = Dp; p[3] = 0.f;        /* :133 */
+        if (ro) { float s = 0.f; s = s + 0.f * p[0]; s = s + 0.f * p[1]; s = s + b22 * p[2]; ro[i] = s - pz; }
+        ++inside;
+    }
+    return inside;
+}
+
 ORC_API int orc_num_threads(void)
 {
 #ifdef _OPENMP

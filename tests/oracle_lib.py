@@ -82,6 +82,8 @@ def lib():
                                         C.c_int, C.c_int, C.c_float]
         L.orc_extract_cloud.restype = C.c_uint64
         L.orc_extract_cloud.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, C.c_uint64]
+        L.orc_project_and_remove.restype = C.c_uint64
+        L.orc_project_and_remove.argtypes = [u16p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, f32p, C.c_uint64, f32p, C.c_void_p]
         L.orc_extract_normals.restype = None
         L.orc_extract_normals.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, C.c_uint64, C.c_float, f32p]
         for name in ("orc_quat_mul",):
@@ -233,6 +235,18 @@ def extract_normals(volume, aff, Rinv, points, gradient_delta_factor, slab=None)
     lib().orc_extract_normals(volume, C.byref(slab) if slab else None, f32(aff).reshape(-1), f32(Rinv).reshape(-1),
                               points.reshape(-1), points.shape[0], gradient_delta_factor, out.reshape(-1))
     return out
+
+
+def project_and_remove(dists, points, proj, remove=True, want_ro=True):
+    """Returns (new_points [n,4], dists_after (copy with removed pixels zeroed, or None), ro [n] or None, n_inside)."""
+    rows, cols = dists.shape
+    dists = np.ascontiguousarray(dists)
+    pts = np.array(points, np.float32, copy=True).reshape(-1, 4)
+    out = dists.copy() if remove else None
+    ro = np.empty(pts.shape[0], np.float32) if want_ro else None
+    n = lib().orc_project_and_remove(dists, cols * 2, out.ctypes.data if remove else None, cols * 2, cols, rows,
+                                     pts.reshape(-1), pts.shape[0], f32(proj), ro.ctypes.data if want_ro else None)
+    return pts, out, ro, int(n)
 
 
 def knn(pos, queries, k, use_ref=False):

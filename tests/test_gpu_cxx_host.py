@@ -40,7 +40,7 @@ def cxx_mul(a, b):
     return out
 
 
-def run_harness(tmp_path, cfg, sc, frames, with_nodes):
+def run_harness(tmp_path, cfg, sc, frames, with_nodes, surface_fusion=False):
     _, app = build.build_host()
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     M = cfg.nodes if with_nodes else 0
@@ -55,7 +55,7 @@ def run_harness(tmp_path, cfg, sc, frames, with_nodes):
             for i in range(frames):
                 f.write(sc.dqs[i].astype(F32).tobytes())
             f.write(sc.sigma.astype(F32).tobytes())
-    r = subprocess.run([app, str(cfg.dims[0]), str(cfg.size), str(cfg.cols), str(cfg.rows), str(frames), str(M), str(cfg.k), fin, fout],
+    r = subprocess.run([app, str(cfg.dims[0]), str(cfg.size), str(cfg.cols), str(cfg.rows), str(frames), str(M), str(cfg.k), fin, fout] + (["surface_fusion"] if surface_fusion else []),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     raw = np.fromfile(fout, np.uint8)
@@ -67,6 +67,13 @@ def run_harness(tmp_path, cfg, sc, frames, with_nodes):
     cnt = int(tail[:8].view(np.uint64)[0])
     cloud = tail[8:8 + 16 * cnt].view(np.float32).reshape(cnt, 4)
     cnormals = tail[8 + 16 * cnt:8 + 32 * cnt].view(np.float32).reshape(cnt, 4)
+    if surface_fusion:
+        rest = tail[8 + 32 * cnt:]
+        npx = cfg.rows * cfg.cols
+        warped = rest[:12 * npx].view(np.float32).reshape(npx, 3)
+        depth_after = rest[12 * npx:14 * npx].view(np.uint16).reshape(cfg.rows, cfg.cols)
+        vol_after = rest[14 * npx:14 * npx + 4 * nv].view(np.uint32).reshape(cfg.dims[2], cfg.dims[1], cfg.dims[0])
+        return vol, img[0], img[1], cloud, cnormals, warped, depth_after, vol_after
     return vol, img[0], img[1], cloud, cnormals
 
 
@@ -101,3 +108,38 @@ def test_cxx_api_matches_oracle(tmp_path, with_nodes):
     pinv = cxx_inv(sc.pose)[:3, :3]
     rnrm = O.extract_normals(sc.ovol(ref), synth.aff12(sc.pose), pinv, cloud, cfg.gradient_delta_factor)
     assert np.array_equal(cnormals.view(np.uint32), rnrm.view(np.uint32))
+
+
+def test_cxx_surface_fusion_matches_oracle(tmp_path):
+    """KinFu::dynamicfusion's tail (kinfu.cpp:344-393): canonical points -> WarpField::warp -> TsdfVolume::surface_fusion
+    (psdf on the GPU, explained depth pixels removed, leftover depth fused rigidly)."""
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=100, k=8)
+    frames = 2
+    sc = Scene(cfg, n_frames=frames)
+    vol, pts, nrm, _, _, warped, depth_after, vol_after = run_harness(tmp_path, cfg, sc, frames, True, surface_fusion=True)
+    f = frames - 1
+    # the warp the harness applied == the oracle's warp of the same canonical points (kinfu.cpp:357-387)
+    inv = cxx_inv(sc.cam_poses[f])
+    P = pts.reshape(-1, 4)[:, :3]
+    canonical = np.empty_like(P)
+    for i in range(3):
+        canonical[:, i] = ((inv[i, 0] * P[:, 0] + inv[i, 1] * P[:, 1]) + inv[i, 2] * P[:, 2]) + inv[i, 3]
+    wp, _ = O.warp_points(sc.pos, sc.dqs[f], sc.sigma, canonical, nrm.reshape(-1, 4)[:, :3], cfg.k)
+    nan_a, nan_b = np.isnan(wp), np.isnan(warped)
+    assert np.array_equal(nan_a, nan_b) and 1000 < (~nan_a[:, 0]).sum() < wp.shape[0]
+    assert np.array_equal(wp.view(np.uint32)[~nan_a], warped.view(np.uint32)[~nan_a])
+    # psdf + removal + rigid integrate of the leftover depth
+    dists0 = O.compute_dists(sc.depths[f], sc.intr)
+    w4 = np.zeros((warped.shape[0], 4), F32); w4[:, :3] = warped
+    _, removed_mask_img, ro, n_in = O.project_and_remove(dists0, w4, sc.intr)
+    assert n_in > 1000
+    expect_depth = sc.depths[f].copy()
+    expect_depth[(removed_mask_img == 0) & (dists0 != 0)] = 0
+    assert np.array_equal(depth_after, expect_depth)
+    assert (depth_after == 0).sum() > (sc.depths[f] == 0).sum()
+    ref = vol.copy()
+    cam_inv = cxx_inv(sc.cam_poses[f])
+    O.integrate(O.compute_dists(expect_depth, sc.intr), ref, sc.ovol(ref), synth.aff12(cxx_mul(cam_inv, sc.pose)), sc.intr)
+    s = compare_volumes(vol_after, ref)
+    assert s["bits_mismatch"] == 0, s
+    assert not np.array_equal(vol_after, vol)

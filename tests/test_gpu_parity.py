@@ -306,3 +306,40 @@ def test_errors_are_reported_not_swallowed():
         capi.floats(synth.aff12(sc.pose)), capi.floats(synth.aff12(sc.world2cam(0))), Intr(*SMALL.intr).as_proj(),
         wf2.handle, 4, 0, None, None)
     assert rc == 100002                                  # DF_E_NO_INDEX: index not built yet
+
+
+def test_project_and_remove_and_psdf_match_oracle():
+    """device::project_and_remove (tsdf_volume.cu:113-139,163-176) + TsdfVolume::psdf's arithmetic (tsdf_volume.cpp:266-292):
+    projected points, removed dists pixels, ro and the inside count are bit-identical with the oracle."""
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=100, k=8)
+    sc = Scene(cfg, n_frames=1)
+    dists = O.compute_dists(sc.depths[0], sc.intr)
+    rng = np.random.default_rng(5)
+    n = 40000
+    pts = np.zeros((n, 4), F32)
+    pts[:, 0] = rng.uniform(-0.9, 0.9, n); pts[:, 1] = rng.uniform(-0.7, 0.7, n); pts[:, 2] = rng.uniform(0.3, 1.6, n)
+    pts[::97, 2] = 0.0                       # x/0 -> +-inf / NaN image coordinates => outside
+    pts[::101, 1] = np.nan                   # NaN points stay untouched
+    pts[::103, 2] = -0.5                     # behind the camera: projects somewhere, reference does not test z
+    exp_pts, exp_dists, exp_ro, exp_n = O.project_and_remove(dists, pts, sc.intr)
+    d_in = upload_u16(dists); d_out = d_in.clone()
+    d_pts = torch.from_numpy(pts).cuda(); d_ro = torch.empty(n, dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    capi.check(capi.lib().dfusion_project_and_remove(d_in.data_ptr(), cfg.cols * 2, d_out.data_ptr(), cfg.cols * 2, cfg.cols, cfg.rows,
+                                                     d_pts.data_ptr(), n, capi.floats(sc.intr), d_ro.data_ptr(), cnt.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == exp_n and 1000 < exp_n < n
+    assert np.array_equal(d_pts.cpu().numpy().view(np.uint32), exp_pts.view(np.uint32))
+    assert np.array_equal(d_ro.cpu().numpy().view(np.uint32), exp_ro.view(np.uint32))
+    got_d = d_out.cpu().numpy().view(np.uint16)
+    assert np.array_equal(got_d, exp_dists) and (got_d != dists).sum() > 500
+    # the Python mirror of TsdfVolume::psdf (in-place removal from a snapshot)
+    from dynamicfusion_amd import Intr, TsdfVolume
+    tv = TsdfVolume(cfg.dims)
+    d2 = upload_u16(dists)
+    ro2 = tv.psdf(torch.from_numpy(pts[:, :3].copy()).cuda(), d2, Intr(*cfg.intr))
+    assert np.array_equal(ro2.cpu().numpy().view(np.uint32), exp_ro.view(np.uint32))
+    assert np.array_equal(d2.cpu().numpy().view(np.uint16), exp_dists)
+    # aliasing the sampled and the zeroed image is refused (racy in the reference)
+    assert capi.lib().dfusion_project_and_remove(d_in.data_ptr(), cfg.cols * 2, d_in.data_ptr(), cfg.cols * 2, cfg.cols, cfg.rows,
+                                                 d_pts.data_ptr(), n, capi.floats(sc.intr), None, None, None) == 100001

@@ -169,3 +169,35 @@ def test_raycast_two_stage_slab_cast_equals_full():
         best, acc_p, acc_n = _two_stage_cast(sc, vol, 1, world, halo, cfg)
         assert np.array_equal(best, fk)
         assert np.array_equal(acc_p, fp.view(np.uint32)) and np.array_equal(acc_n, fn.view(np.uint32))
+
+
+def test_project_and_remove_roundtrip():
+    """project_kernel (tsdf_volume.cu:113-139) + psdf (tsdf_volume.cpp:266-292): back-projected pixel centres land on
+    their own pixel, read its dists value, remove exactly those pixels; NaN / outside points follow the documented rules."""
+    sc = Scene(CFG, n_frames=1, with_nodes=False)
+    dists = O.compute_dists(sc.depths[0], sc.intr)
+    fx, fy, cx, cy = [float(v) for v in sc.intr]
+    ys, xs = np.mgrid[0:CFG.rows:3, 0:CFG.cols:3]
+    z = (sc.depths[0][ys, xs].astype(F32) * F32(0.001)).ravel()
+    keep = z > 0
+    xs, ys, z = xs.ravel()[keep], ys.ravel()[keep], z[keep]
+    pts = np.zeros((z.size, 4), F32)
+    pts[:, 0] = (xs + 0.5 - cx) / fx * z; pts[:, 1] = (ys + 0.5 - cy) / fy * z; pts[:, 2] = z
+    out, after, ro, n_in = O.project_and_remove(dists, pts, sc.intr)
+    assert n_in == z.size
+    Dp = dists[ys, xs].view(np.float16).astype(F32)
+    assert np.array_equal(out[:, 2], Dp)
+    assert np.allclose(out[:, 0], (xs + 0.5) * Dp, rtol=1e-5) and np.allclose(out[:, 1], (ys + 0.5) * Dp, rtol=1e-5)
+    assert np.allclose(ro, Dp - z, atol=1e-6)                      # b22 == 1 up to one ulp
+    removed = np.zeros_like(dists, bool); removed[ys, xs] = True
+    assert np.array_equal(after[removed], np.zeros(removed.sum(), np.uint16)) and np.array_equal(after[~removed], dists[~removed])
+    # NaN points untouched, outside points -> (qnan, qnan, qnan, 0), ro NaN for both; nothing removed
+    odd = np.array([[np.nan, 0, 1, 7], [0, 0, -1e-3, 0], [10, 0, 1, 0], [0, -10, 1, 0], [1, 1, 0, 0]], F32)
+    odd[1, :2] = [5, 5]                                           # behind the camera, far off-image
+    out2, after2, ro2, n2 = O.project_and_remove(dists, odd, sc.intr)
+    assert n2 == 0 and np.array_equal(after2, dists) and np.isnan(ro2).all()
+    assert np.array_equal(out2[0].view(np.uint32), odd[0].view(np.uint32))
+    assert (out2[1:, :3].view(np.uint32) == 0x7fffffff).all() and (out2[1:, 3] == 0).all()
+    # empty input
+    _, after3, ro3, n3 = O.project_and_remove(dists, np.zeros((0, 4), F32), sc.intr)
+    assert n3 == 0 and ro3.size == 0 and np.array_equal(after3, dists)
