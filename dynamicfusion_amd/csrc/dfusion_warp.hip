@@ -179,25 +179,29 @@ __device__ __forceinline__ void dqb_blend_w(const DfWarpView& W, const float (&w
     *rot_out = rsum;
     *dual_out = q_mul(half, rsum);                    // dual_quaternion.hpp:59-63
 }
-// Same blend with the node transforms staged in LDS (s_rot / s_nt indexed by GLOBAL node id).
+// Same blend with the node transforms staged in LDS: s_node[2j] = rot_j, s_node[2j+1] = node_t_j (GLOBAL node id j), so
+// the two ds_read_b128 of a node share one address (the second uses the instruction's immediate offset).  The sums are
+// kept as two float2 halves in MEMORY order ((w,x),(y,z)): the backend maps them 1:1 onto v_pk_mul_f32 / v_pk_add_f32
+// without register shuffles (left to itself it paired (w,z),(x,y) and spent ~65 v_mov per voxel re-pairing the LDS
+// words).  Element-wise IEEE mul then add, exactly the scalar sequence of :211-212.
+typedef float df_v2f __attribute__((ext_vector_type(2)));
 template <int K>
-__device__ __forceinline__ void dqb_blend_lds(const float4* s_rot, const float4* s_nt, const float (&wt)[K], const int (&bi)[K],
-                                              quat* rot_out, quat* dual_out)
+__device__ __forceinline__ void dqb_blend_lds(const float4* s_node, const float (&wt)[K], const int (&bi)[K], quat* rot_out,
+                                              quat* dual_out)
 {
-    quat tsum, rsum;
-    tsum.w = tsum.x = tsum.y = tsum.z = 0.f;
-    rsum.w = rsum.x = rsum.y = rsum.z = 0.f;
+    df_v2f t01 = {0.f, 0.f}, t23 = {0.f, 0.f}, r01 = {0.f, 0.f}, r23 = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        const int j = bi[i];
-        const float w = wt[i];
-        const float4 t4 = s_nt[j], r4 = s_rot[j];
-        quat t, r;
-        t.w = t4.x; t.x = t4.y; t.y = t4.z; t.z = t4.w;
-        r.w = r4.x; r.x = r4.y; r.y = r4.z; r.z = r4.w;
-        tsum = q_add(tsum, q_scale(w, t));            // :211
-        rsum = q_add(rsum, q_scale(w, r));            // :212
+        const float4* nd = s_node + 2 * bi[i];
+        const float4 r4 = nd[0], t4 = nd[1];
+        const df_v2f ww = {wt[i], wt[i]};
+        const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
+        t01 = t01 + ww * ta; t23 = t23 + ww * tb;     // :211
+        r01 = r01 + ww * ra; r23 = r23 + ww * rb;     // :212
     }
+    quat tsum, rsum;
+    tsum.w = t01.x; tsum.x = t01.y; tsum.y = t23.x; tsum.z = t23.y;
+    rsum.w = r01.x; rsum.x = r01.y; rsum.y = r23.x; rsum.z = r23.y;
     rsum = q_normalize(rsum);                         // :214
     quat half;
     half.w = 0.5f * tsum.w; half.x = 0.5f * tsum.x; half.y = 0.5f * tsum.y; half.z = 0.5f * tsum.z;
@@ -759,10 +763,8 @@ __global__ __launch_bounds__(256, UNROLL) void df_warp_rows_kernel(const DfWarpe
 template <int K, bool HAS_W, int NB>
 __global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [M] rot, then [M] node_t
-    float4* s_rot = s_nodes;
-    float4* s_nt = s_nodes + W.M;
-    for (int j = threadIdx.x; j < W.M; j += 512) { s_rot[j] = W.rot[j]; s_nt[j] = W.node_t[j]; }
+    extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
+    for (int j = threadIdx.x; j < W.M; j += 512) { s_nodes[2 * j] = W.rot[j]; s_nodes[2 * j + 1] = W.node_t[j]; }
     __syncthreads();
 
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArg
                         for (int i = 0; i < K; ++i) { const float4 p = W.pos_sigma[bi[u][i]]; wt[u][i] = dqb_weight(knn_dist2(q, p.x, p.y, p.z), p.w); }
                     }
                     quat rot, dual;
-                    dqb_blend_lds<K>(s_rot, s_nt, wt[u], bi[u], &rot, &dual);
+                    dqb_blend_lds<K>(s_nodes, wt[u], bi[u], &rot, &dual);
                     const f3 vc = aff_mul(a.world2cam, dq_transform(rot, dual, q));
                     float ts;
                     if (tsdf_sample(a.P, vc, &ts)) {
@@ -856,12 +858,10 @@ __device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<4>& r, int (&bi)[4
 }
 
 template <int K>
-__global__ __launch_bounds__(512) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
+__global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [M] rot, then [M] node_t
-    float4* s_rot = s_nodes;
-    float4* s_nt = s_nodes + W.M;
-    for (int j = threadIdx.x; j < W.M; j += 512) { s_rot[j] = W.rot[j]; s_nt[j] = W.node_t[j]; }
+    extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
+    for (int j = threadIdx.x; j < W.M; j += 512) { s_nodes[2 * j] = W.rot[j]; s_nodes[2 * j + 1] = W.node_t[j]; }
     __syncthreads();
 
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(512) void df_warp_rows_pipe_kernel(const DfWarpedAr
             for (int u = 0; u < 2; ++u) {
                 const f3 q = aff_mul(a.vol2world, mk3(fxv, fyv, (float)(z0 + u) * a.vsz));   // canonical position
                 quat rot, dual;
-                dqb_blend_lds<K>(s_rot, s_nt, wt[u], bi[u], &rot, &dual);
+                dqb_blend_lds<K>(s_nodes, wt[u], bi[u], &rot, &dual);
                 vc[u] = aff_mul(a.world2cam, dq_transform(rot, dual, q));
                 const float pu = fmaf(a.P.fx, vc[u].x / vc[u].z, a.P.cx);                     // device.hpp:35
                 const float pv = fmaf(a.P.fy, vc[u].y / vc[u].z, a.P.cy);                     // device.hpp:36
