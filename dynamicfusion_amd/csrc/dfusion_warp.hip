@@ -1054,7 +1054,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
 
     DfWarpView W = df_view(wf);
     const char* evl = getenv("DFUSION_ROWS_LDS");
-    const bool lds_ok = (size_t)wf->M * 32 <= 128 * 1024 && !(evl && atoi(evl) == 0);
+    const bool lds_ok = (size_t)wf->M * 32 <= 160 * 1024 && !(evl && atoi(evl) == 0);
     if (use_tab && lds_ok) {
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_LDS_TY - 1) / DF_LDS_TY;
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;

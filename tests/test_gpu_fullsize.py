@@ -1,4 +1,4 @@
-"""BASELINE.json full sizes (256^3 / 500 nodes / k=4 and the 512^3 / 2000 nodes / k=8 headline): the oracle
+"""BASELINE.json full sizes (256^3 / 500 nodes / k=4, the 512^3 / 2000 nodes / k=8 headline, 1024^3 / 5000 nodes): the oracle
 cannot sweep these in seconds, so parity rests on (i) oracle checks on a bounded sample of planes / rays and
 (ii) size-independent properties: cull on == cull off, slab-sharded == unsharded, update counts consistent with
 weights, reference-header golden vectors reproduced by the HIP k-NN / warp kernels."""
@@ -47,7 +47,7 @@ def test_knn_and_warp_reproduce_reference_header_goldens():
             assert np.array_equal(bits(n.cpu().numpy()), bits(w["warp_n_%s_k%d" % (tag, k)]))
 
 
-@pytest.mark.parametrize("name", ["256", "512"])
+@pytest.mark.parametrize("name", ["256", "512", "1024"])
 def test_full_size_properties_and_sampled_oracle(name):
     cfg = synth.CONFIGS[name]
     intr = Intr(*cfg.intr)
