@@ -24,6 +24,8 @@ class DfSlab(C.Structure):
 DF_WARP_NO_CULL = 1
 DF_WARP_NO_TABLE = 2
 DF_WARP_NO_WEIGHT_TABLE = 4
+DF_WARP_NO_LDS = 8
+DF_WARP_NO_PIPELINE = 16
 DF_INDEX_VOXEL_TABLE = 1
 DF_INDEX_WEIGHT_TABLE = 2
 

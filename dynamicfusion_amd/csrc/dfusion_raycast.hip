@@ -543,8 +543,7 @@ extern "C" int dfusion_extract_cloud(DfVolume v, const DfSlab* slab, const float
     const size_t n4 = (size_t)a.X * a.Y * (size_t)(a.z_end - a.z_own0) / 4;
     const size_t n_items = (n4 + 63) / 64;
     size_t blocks = (n4 + 255) / 256;
-    { size_t per_cu = 32; const char* e = getenv("DFUSION_EX_BLOCKS_PER_CU"); if (e && atoi(e) > 0) per_cu = (size_t)atoi(e);
-      if (blocks > 256 * per_cu) blocks = 256 * per_cu; }
+    if (blocks > 256 * 32) blocks = 256 * 32;                 // 32 workgroups per CU (measured best of 8..64)
     const int U = 4;
     // wave-items a scan workgroup can see: 4 waves x U items per trip x trips
     const size_t trips = (n4 + blocks * 256 * U - 1) / (blocks * 256 * U);

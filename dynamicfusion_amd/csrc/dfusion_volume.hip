@@ -269,11 +269,6 @@ __global__ __launch_bounds__(256) void df_integrate_rigid_kernel(const DfRigidAr
     }
 }
 
-static int df_env_int(const char* name, int dflt)
-{
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
 
 extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
                                  const float vol2cam[12], const float proj[4], unsigned long long* n_updated,
@@ -309,20 +304,14 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     const int groups = (a.X / 4) * a.Y;
     const int bx = (groups + 255) / 256;
     // Z chunking: enough chunks for >= ~8 waves per SIMD over 256 CUs, chunks of >= 16 planes.
-    int zc = df_env_int("DFUSION_RIGID_ZCHUNK", 0);
-    if (zc <= 0) {
-        const long long want_blocks = 256LL * 8;            // 8 blocks of 4 waves per CU
-        int chunks = (int)((want_blocks + bx - 1) / bx);
-        if (chunks < 1) chunks = 1;
-        zc = (s.z_own_n + chunks - 1) / chunks;
-        if (zc < 16) zc = 16;
-    }
+    const long long want_blocks = 256LL * 8;                // 8 blocks of 4 waves per CU
+    int chunks = (int)((want_blocks + bx - 1) / bx);
+    if (chunks < 1) chunks = 1;
+    int zc = (s.z_own_n + chunks - 1) / chunks;
+    if (zc < 16) zc = 16;
     a.zc = zc;
     dim3 grid(bx, (s.z_own_n + zc - 1) / zc);
-    const int u = df_env_int("DFUSION_RIGID_BATCH", 2);
-    if (u >= 4) hipLaunchKernelGGL(df_integrate_rigid_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a, F);
-    else if (u >= 2) hipLaunchKernelGGL(df_integrate_rigid_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a, F);
-    else hipLaunchKernelGGL(df_integrate_rigid_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a, F);
+    hipLaunchKernelGGL(df_integrate_rigid_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a, F);   // 2 planes per load batch (measured best of 1/2/4)
     DF_LAUNCH_CHECK();
     return DF_OK;
 }

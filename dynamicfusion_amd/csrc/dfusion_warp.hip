@@ -1053,41 +1053,29 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     }
 
     DfWarpView W = df_view(wf);
-    const char* evl = getenv("DFUSION_ROWS_LDS");
-    const bool lds_ok = (size_t)wf->M * 32 <= 160 * 1024 && !(evl && atoi(evl) == 0);
+    // LDS node table: 32 B per node, up to the whole 160 KiB of a CU (then one 512-thread workgroup per CU)
+    const bool lds_ok = (size_t)wf->M * 32 <= 160 * 1024 && !(flags & DF_WARP_NO_LDS);
     if (use_tab && lds_ok) {
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_LDS_TY - 1) / DF_LDS_TY;
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
         a.bz0 = zt_lo;
-        if (!(flags & DF_WARP_NO_CULL) && a.cull) a.tile_r = (float)(df_tile_radius(vol2world, DF_ROW_TX, DF_LDS_TY, DF_ROW_TZ, v) * 1.001 + 1e-6);
+        if (a.cull) a.tile_r = (float)(df_tile_radius(vol2world, DF_ROW_TX, DF_LDS_TY, DF_ROW_TZ, v) * 1.001 + 1e-6);
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + DF_LDS_ZT - 1) / DF_LDS_ZT));
         const size_t lds = (size_t)wf->M * 32;
-        const char* evb = getenv("DFUSION_ROWS_NB");
-        const int nb = evb ? atoi(evb) : 2;
-#define DF_LAUNCH_LDS(HW, NBV)                                                                                                          \
-        DF_DISPATCH_K(k, { DF_HIP(hipFuncSetAttribute((const void*)df_warp_rows_lds_kernel<K, HW, NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                           df_warp_rows_lds_kernel<K, HW, NBV><<<grid, dim3(512), lds, st>>>(a, W, tiles_x); })
-        const char* evp = getenv("DFUSION_ROWS_PIPE");
-        if (use_w && (k == 8 || k == 4) && !(evp && atoi(evp) == 0)) {
-            if (k == 8) { DF_HIP(hipFuncSetAttribute((const void*)df_warp_rows_pipe_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                          df_warp_rows_pipe_kernel<8><<<grid, dim3(512), lds, st>>>(a, W, tiles_x); }
-            else { DF_HIP(hipFuncSetAttribute((const void*)df_warp_rows_pipe_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                   df_warp_rows_pipe_kernel<4><<<grid, dim3(512), lds, st>>>(a, W, tiles_x); }
-        } else if (use_w) {
-            if (nb == 1) { DF_LAUNCH_LDS(true, 1); } else if (nb == 4) { DF_LAUNCH_LDS(true, 4); } else { DF_LAUNCH_LDS(true, 2); }
-        } else { DF_LAUNCH_LDS(false, 1); }
-#undef DF_LAUNCH_LDS
+        typedef void (*lds_kernel_t)(const DfWarpedArgs, const DfWarpView, int);
+        lds_kernel_t kern = nullptr;
+        if (use_w && k == 8 && !(flags & DF_WARP_NO_PIPELINE)) kern = df_warp_rows_pipe_kernel<8>;
+        else if (use_w && k == 4 && !(flags & DF_WARP_NO_PIPELINE)) kern = df_warp_rows_pipe_kernel<4>;
+        else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
+        else { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, false, 1>)); }
+        DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<grid, dim3(512), lds, st>>>(a, W, tiles_x);
     } else if (use_tab) {
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_ROW_TY - 1) / DF_ROW_TY;
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
         a.bz0 = zt_lo;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(zt_hi - zt_lo + 1));
-        const char* ev = getenv("DFUSION_ROWS_UNROLL");
-        const int unroll = ev ? atoi(ev) : 2;
-        if (use_w && unroll == 5) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true, 5><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
-        else if (use_w && unroll == 6) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true, 6><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
-        else if (use_w && unroll == 8) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true, 8><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
-        else if (use_w) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true, 4><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
+        if (use_w) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true, 4><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
         else { DF_DISPATCH_K(k, df_warp_rows_kernel<K, false, 4><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
     } else {
         const int bz_lo = s.z_own0 / DF_BRICK, bz_hi = (s.z_own0 + s.z_own_n - 1) / DF_BRICK;

@@ -72,6 +72,9 @@ enum {
 #define DF_WARP_NO_CULL 1u   /* disable the (result-identical) conservative brick culling     */
 #define DF_WARP_NO_TABLE 2u  /* ignore the per-voxel k-NN table even if built (re-rank per frame) */
 #define DF_WARP_NO_WEIGHT_TABLE 4u /* ignore the per-voxel weight table (recompute exp per frame)   */
+#define DF_WARP_NO_LDS 8u    /* gather node transforms from global memory (the path taken when the
+                                node table exceeds the 160 KiB LDS, M > 5120); validation switch  */
+#define DF_WARP_NO_PIPELINE 16u /* batched instead of software-pipelined table loads; validation switch */
 /* flags for dfusion_warp_build_index */
 #define DF_INDEX_VOXEL_TABLE 1u /* also cache the exact k-NN of EVERY voxel of the slab in HBM:
                                    k * 2 bytes per voxel (2 GiB at 512^3, k = 8) -- the per-frame

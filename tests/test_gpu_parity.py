@@ -201,6 +201,10 @@ def test_voxel_knn_table_equals_on_the_fly_search(cfg):
     wf_fly = WarpField(k=cfg.k, voxel_table=False)
     wf_fly.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
     a, b, c, e = make_gpu_volume(sc), make_gpu_volume(sc), make_gpu_volume(sc), make_gpu_volume(sc)
+    # every sweep kernel the dispatcher can pick (include/dfusion.h DF_WARP_* validation switches): pipelined (default),
+    # batched LDS, global-gather with / without the weight table
+    variants = [dict(pipelined=False), dict(use_lds=False), dict(use_lds=False, use_weights=False)]
+    others = [make_gpu_volume(sc) for _ in variants]
     for f in range(2):
         d = upload_u16(sc.dists[f])
         for wf in (wf_tab, wf_fly):
@@ -209,7 +213,11 @@ def test_voxel_knn_table_equals_on_the_fly_search(cfg):
         b.integrate_warped(d, sc.cam_poses[f], intr, wf_fly)
         c.integrate_warped(d, sc.cam_poses[f], intr, wf_tab, use_table=False)
         e.integrate_warped(d, sc.cam_poses[f], intr, wf_tab, use_weights=False)
+        for v, kw in zip(others, variants):
+            v.integrate_warped(d, sc.cam_poses[f], intr, wf_tab, **kw)
     assert torch.equal(a.data(), b.data()) and torch.equal(a.data(), c.data()) and torch.equal(a.data(), e.data())
+    for v in others:
+        assert torch.equal(a.data(), v.data())
 
 
 def test_integrate_warped_identity_nodes_close_to_rigid():

@@ -36,12 +36,8 @@ def main():
     ms = timeit(lambda: vol.clear()); print("clear: %.3f ms  %.1f GB/s" % (ms, 4 * nvox / ms / 1e6))
     n = torch.zeros(1, dtype=torch.int64, device="cuda")
     vol.integrate(dists, cam, intr, n_updated=n); nupd = int(n.item()); print("rigid n_upd", nupd, nupd / nvox)
-    for unroll in (1, 2, 4):
-        for zc in (0, 16, 32, 64, 128, 512):
-            os.environ["DFUSION_RIGID_UNROLL"] = str(unroll); os.environ["DFUSION_RIGID_ZCHUNK"] = str(zc)
-            ms = timeit(lambda: vol.integrate(dists, cam, intr, sync=False))
-            print("rigid unroll=%d zchunk=%-3d : %.3f ms  alg %.0f GB/s  sweep %.0f GB/s" % (unroll, zc, ms, 8 * nupd / ms / 1e6, 8 * nvox / ms / 1e6))
-    os.environ.pop("DFUSION_RIGID_UNROLL"); os.environ.pop("DFUSION_RIGID_ZCHUNK")
+    ms = timeit(lambda: vol.integrate(dists, cam, intr, sync=False))
+    print("rigid : %.3f ms  alg %.0f GB/s  sweep %.0f GB/s" % (ms, 8 * nupd / ms / 1e6, 8 * nvox / ms / 1e6))
     if cfg.nodes:
         pos, sigma = synth.make_nodes(cfg); dq = synth.node_transforms(cfg, 1)
         wf = WarpField(k=cfg.k); wf.init(pos, sigma=sigma, transforms=dq)
@@ -52,6 +48,9 @@ def main():
             for cull in (True, False):
                 ms = timeit(lambda: vol.integrate_warped(dists, cam, intr, wf, cull=cull, use_table=tab, use_weights=wts, sync=False), iters=5, warm=1)
                 print("warped knn_table=%s w_table=%s cull=%s : %.3f ms  alg %.0f GB/s" % (tab, wts, cull, ms, 8 * nw / ms / 1e6))
+        for kw in (dict(pipelined=False), dict(use_lds=False)):
+            ms = timeit(lambda: vol.integrate_warped(dists, cam, intr, wf, sync=False, **kw), iters=5, warm=1)
+            print("warped tables %s : %.3f ms" % (kw, ms))
     buf = torch.empty((1 << 24, 4), dtype=torch.float32, device="cuda")
     ms = timeit(lambda: vol.fetchCloud(buf)); npts = vol.last_cloud_count_
     print("fetchCloud (incl. count readback): %.3f ms, %d points, scan %.0f GB/s" % (ms, npts, 4 * nvox / ms / 1e6))
