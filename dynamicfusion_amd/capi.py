@@ -36,6 +36,9 @@ SYMBOLS = [
     "dfusion_extract_normals", "dfusion_warp_create", "dfusion_warp_destroy",
     "dfusion_warp_set_nodes", "dfusion_warp_set_transforms", "dfusion_warp_build_index", "dfusion_knn",
     "dfusion_warp_points", "dfusion_integrate_warped", "dfusion_copy_bandwidth_probe", "dfusion_read_bandwidth_probe",
+    "dfusion_bilateral_filter", "dfusion_truncate_depth", "dfusion_depth_pyramid", "dfusion_compute_normals_mask_depth",
+    "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
+    "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth",
 ]
 
 
@@ -91,6 +94,17 @@ def lib():
     L.dfusion_warp_points.argtypes = [vp, C.c_int, vp, vp, C.c_int, fp, vp]
     L.dfusion_integrate_warped.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, DfVolume, C.POINTER(DfSlab), fp, fp, fp,
                                            vp, C.c_int, C.c_uint, vp, vp]
+    sz = C.c_size_t
+    L.dfusion_bilateral_filter.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]
+    L.dfusion_truncate_depth.argtypes = [vp, sz, C.c_int, C.c_int, C.c_float, vp]
+    L.dfusion_depth_pyramid.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, C.c_float, vp]
+    L.dfusion_compute_normals_mask_depth.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, fp, vp]
+    L.dfusion_compute_point_normals.argtypes = [vp, sz, vp, sz, vp, sz, C.c_int, C.c_int, fp, vp]
+    L.dfusion_resize_depth_normals.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, vp, sz, vp, sz, vp]
+    L.dfusion_resize_points_normals.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, vp, sz, vp, sz, vp]
+    L.dfusion_icp_workspace_floats.argtypes = [C.c_int, C.c_int]
+    L.dfusion_icp_sums_points.argtypes = [vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, vp, vp, vp, vp]
+    L.dfusion_icp_sums_depth.argtypes = [vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, vp, vp, vp, vp]
     L.dfusion_copy_bandwidth_probe.argtypes = [vp, vp, C.c_size_t, vp]
     L.dfusion_read_bandwidth_probe.argtypes = [vp, C.c_size_t, vp, vp]
     for s in SYMBOLS:

@@ -1,0 +1,440 @@
+// dfusion_frontend.hip -- depth front-end and projective-ICP reduction (gfx950), SURVEY.md 8(f) "next" #3.
+//
+// Replaces kfusion/src/cuda/imgproc.cu:11-252,309-414 (bilateral, truncation, pyramid, normals, resize) and
+// kfusion/src/cuda/proj_icp.cu:30-397 (correspondence search + 27-sum reduction).  Small 2-D kernels: one wave64 covers a
+// 64-pixel run of one image row (the reference's warp a 32-pixel run), blocks are 64 x 4.
+// Arithmetic follows oracle/dfusion_frontend_oracle.c (see its header for the two hardware-defined operations of the
+// reference, __expf and rsqrt, and what stands in for them).
+#include "dfusion_internal.h"
+
+#pragma clang fp contract(off)
+
+#define FE_BX 64
+#define FE_BY 4
+#define FE_GRID(cols, rows) dim3(((cols) + FE_BX - 1) / FE_BX, ((rows) + FE_BY - 1) / FE_BY)
+#define FE_XY const int x = blockIdx.x * FE_BX + (threadIdx.x & 63); const int y = blockIdx.y * FE_BY + (threadIdx.x >> 6)
+
+__device__ __forceinline__ uint16_t ld16(const uint16_t* b, size_t pitch, int y, int x) { return *(const uint16_t*)((const char*)b + (size_t)y * pitch + 2 * (size_t)x); }
+__device__ __forceinline__ void st16(uint16_t* b, size_t pitch, int y, int x, uint16_t v) { *(uint16_t*)((char*)b + (size_t)y * pitch + 2 * (size_t)x) = v; }
+__device__ __forceinline__ float4 ld4(const float* b, size_t pitch, int y, int x) { return *(const float4*)((const char*)b + (size_t)y * pitch + 16 * (size_t)x); }
+__device__ __forceinline__ void st4(float* b, size_t pitch, int y, int x, float4 v) { *(float4*)((char*)b + (size_t)y * pitch + 16 * (size_t)x) = v; }
+
+// Reprojector::operator() device.hpp:42-47 / ComputeIcpHelper::reproj proj_icp.cu:39-44
+struct FeIntr { float fx, fy, cx, cy, finvx, finvy; };
+__device__ __forceinline__ f3 fe_reproj(const FeIntr& I, float u, float v, float z) { return mk3(z * (u - I.cx) * I.finvx, z * (v - I.cy) * I.finvy, z); }
+static FeIntr fe_intr(const float intr[4])
+{
+    FeIntr I; I.fx = intr[0]; I.fy = intr[1]; I.cx = intr[2]; I.cy = intr[3]; I.finvx = 1.f / intr[0]; I.finvy = 1.f / intr[1];   // precomp.cpp:55
+    return I;
+}
+
+// ------------------------------------------------------------------------------------------ bilateral (imgproc.cu:11-59)
+__global__ __launch_bounds__(256) void df_bilateral_kernel(const uint16_t* __restrict__ src, size_t spitch, uint16_t* __restrict__ dst,
+                                                           size_t dpitch, int cols, int rows, int ksz, float ss, float sd)
+{
+    FE_XY;
+    if (x >= cols || y >= rows) return;
+    const int value = ld16(src, spitch, y, x);
+    const int tx = min(x - ksz / 2 + ksz, cols - 1);
+    const int ty = min(y - ksz / 2 + ksz, rows - 1);
+    float sum1 = 0.f, sum2 = 0.f;
+    for (int cy = max(y - ksz / 2, 0); cy < ty; ++cy)
+        for (int cx = max(x - ksz / 2, 0); cx < tx; ++cx) {
+            const int depth = ld16(src, spitch, cy, cx);
+            const float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
+            const float color2 = (float)(int)((unsigned)(value - depth) * (unsigned)(value - depth));
+            const float weight = (float)exp((double)(-(space2 * ss + color2 * sd)));     // __expf stand-in (oracle header)
+            sum1 += (float)depth * weight;
+            sum2 += weight;
+        }
+    st16(dst, dpitch, y, x, (uint16_t)(int)rintf(sum1 / sum2));                          // __float2int_rn
+}
+
+extern "C" int dfusion_bilateral_filter(const uint16_t* src, size_t src_pitch, uint16_t* dst, size_t dst_pitch, int cols, int rows,
+                                        int kernel_size, float sigma_spatial, float sigma_depth, dfStream stream)
+{
+    if (!src || !dst || src == dst || cols <= 0 || rows <= 0 || kernel_size <= 0 || !(sigma_spatial > 0.f) || !(sigma_depth > 0.f)) return DF_E_INVALID;
+    sigma_depth *= 1000;                                                                 // :50 metres -> mm
+    hipLaunchKernelGGL(df_bilateral_kernel, FE_GRID(cols, rows), dim3(256), 0, (hipStream_t)stream, src, src_pitch, dst, dst_pitch, cols,
+                       rows, kernel_size, 0.5f / (sigma_spatial * sigma_spatial), 0.5f / (sigma_depth * sigma_depth));   // :56
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ truncation (imgproc.cu:66-85)
+__global__ __launch_bounds__(256) void df_truncate_kernel(uint16_t* depth, size_t pitch, int cols, int rows, uint16_t max_mm)
+{
+    FE_XY;
+    if (x < cols && y < rows && ld16(depth, pitch, y, x) > max_mm) st16(depth, pitch, y, x, 0);
+}
+
+extern "C" int dfusion_truncate_depth(uint16_t* depth, size_t pitch, int cols, int rows, float max_dist, dfStream stream)
+{
+    if (!depth || cols <= 0 || rows <= 0 || !(max_dist >= 0.f) || !(max_dist * 1000.f < 65536.f)) return DF_E_INVALID;
+    hipLaunchKernelGGL(df_truncate_kernel, FE_GRID(cols, rows), dim3(256), 0, (hipStream_t)stream, depth, pitch, cols, rows,
+                       (uint16_t)(max_dist * 1000.f));                                   // :83
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ pyramid (imgproc.cu:94-137)
+__global__ __launch_bounds__(256) void df_pyramid_kernel(const uint16_t* __restrict__ src, size_t spitch, int scols, int srows,
+                                                         uint16_t* __restrict__ dst, size_t dpitch, int dcols, int drows, float thr)
+{
+    FE_XY;
+    if (x >= dcols || y >= drows) return;
+    const int D = 5;
+    const int center = ld16(src, spitch, 2 * y, 2 * x);
+    const int tx = min(2 * x - D / 2 + D, scols - 1);
+    const int ty = min(2 * y - D / 2 + D, srows - 1);
+    int sum = 0, count = 0;
+    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+            const int val = ld16(src, spitch, cy, cx);
+            if ((float)abs(val - center) < thr) { sum += val; ++count; }
+        }
+    st16(dst, dpitch, y, x, (uint16_t)(count == 0 ? 0 : sum / count));
+}
+
+extern "C" int dfusion_depth_pyramid(const uint16_t* src, size_t src_pitch, int src_cols, int src_rows, uint16_t* dst, size_t dst_pitch,
+                                     float sigma_depth, dfStream stream)
+{
+    if (!src || !dst || src_cols < 2 || src_rows < 2) return DF_E_INVALID;
+    sigma_depth *= 1000;                                                                 // :130
+    const int dc = src_cols / 2, dr = src_rows / 2;                                      // imgproc.cpp:36
+    hipLaunchKernelGGL(df_pyramid_kernel, FE_GRID(dc, dr), dim3(256), 0, (hipStream_t)stream, src, src_pitch, src_cols, src_rows, dst,
+                       dst_pitch, dc, dr, sigma_depth * 3);                              // :135
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ normals (imgproc.cu:145-252)
+__device__ __forceinline__ bool fe_normal_at(const uint16_t* depth, size_t pitch, int cols, int rows, int x, int y, const FeIntr& I, f3* n,
+                                             f3* v00)
+{
+    if (!(x < cols - 1 && y < rows - 1)) return false;
+    const float z00 = (float)ld16(depth, pitch, y, x) * 0.001f;
+    const float z01 = (float)ld16(depth, pitch, y, x + 1) * 0.001f;
+    const float z10 = (float)ld16(depth, pitch, y + 1, x) * 0.001f;
+    if (!(z00 * z01 * z10 != 0.f)) return false;
+    *v00 = fe_reproj(I, (float)x, (float)y, z00);
+    const f3 v01 = fe_reproj(I, (float)(x + 1), (float)y, z01);
+    const f3 v10 = fe_reproj(I, (float)x, (float)(y + 1), z10);
+    const f3 c = normalized3(cross3(sub3(v01, *v00), sub3(v10, *v00)));
+    *n = mk3(-c.x, -c.y, -c.z);
+    return true;
+}
+
+// MASK: also zero the depth pixel whose normal is NaN (mask_depth_kernel :177-188).  A pixel's normal reads the depth of its
+// +x / +y neighbours, which another thread may be zeroing: so the mask is a second launch, like the reference.
+__global__ __launch_bounds__(256) void df_normals_kernel(const uint16_t* __restrict__ depth, size_t dpitch, float* __restrict__ normals,
+                                                         size_t npitch, int cols, int rows, FeIntr I)
+{
+    FE_XY;
+    if (x >= cols || y >= rows) return;
+    const float q = qnanf_();
+    f3 n, v;
+    if (fe_normal_at(depth, dpitch, cols, rows, x, y, I, &n, &v)) st4(normals, npitch, y, x, make_float4(n.x, n.y, n.z, 0.f));
+    else st4(normals, npitch, y, x, make_float4(q, q, q, 0.f));
+}
+__global__ __launch_bounds__(256) void df_mask_depth_kernel(const float* __restrict__ normals, size_t npitch, uint16_t* depth, size_t dpitch,
+                                                            int cols, int rows)
+{
+    FE_XY;
+    if (x < cols && y < rows && isnan(ld4(normals, npitch, y, x).x)) st16(depth, dpitch, y, x, 0);
+}
+
+extern "C" int dfusion_compute_normals_mask_depth(uint16_t* depth, size_t depth_pitch, float* normals, size_t normals_pitch, int cols,
+                                                  int rows, const float intr[4], dfStream stream)
+{
+    if (!depth || !normals || !intr || cols <= 0 || rows <= 0) return DF_E_INVALID;
+    hipLaunchKernelGGL(df_normals_kernel, FE_GRID(cols, rows), dim3(256), 0, (hipStream_t)stream, depth, depth_pitch, normals, normals_pitch,
+                       cols, rows, fe_intr(intr));
+    DF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(df_mask_depth_kernel, FE_GRID(cols, rows), dim3(256), 0, (hipStream_t)stream, normals, normals_pitch, depth,
+                       depth_pitch, cols, rows);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+__global__ __launch_bounds__(256) void df_point_normals_kernel(const uint16_t* __restrict__ depth, size_t dpitch, float* __restrict__ points,
+                                                               size_t ppitch, float* __restrict__ normals, size_t npitch, int cols, int rows,
+                                                               FeIntr I)
+{
+    FE_XY;
+    if (x >= cols || y >= rows) return;
+    const float q = qnanf_();
+    f3 n, v;
+    if (fe_normal_at(depth, dpitch, cols, rows, x, y, I, &n, &v)) {
+        st4(normals, npitch, y, x, make_float4(n.x, n.y, n.z, 0.f));
+        st4(points, ppitch, y, x, make_float4(v.x, v.y, v.z, 0.f));
+    } else {
+        st4(normals, npitch, y, x, make_float4(q, q, q, q));                             // :220
+        st4(points, ppitch, y, x, make_float4(q, q, q, q));
+    }
+}
+
+extern "C" int dfusion_compute_point_normals(const uint16_t* depth, size_t depth_pitch, float* points, size_t points_pitch, float* normals,
+                                             size_t normals_pitch, int cols, int rows, const float intr[4], dfStream stream)
+{
+    if (!depth || !points || !normals || !intr || cols <= 0 || rows <= 0) return DF_E_INVALID;
+    hipLaunchKernelGGL(df_point_normals_kernel, FE_GRID(cols, rows), dim3(256), 0, (hipStream_t)stream, depth, depth_pitch, points,
+                       points_pitch, normals, normals_pitch, cols, rows, fe_intr(intr));
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ resize (imgproc.cu:309-414)
+__global__ __launch_bounds__(256) void df_resize_depth_normals_kernel(const uint16_t* __restrict__ dsrc, size_t dspitch,
+                                                                      const float* __restrict__ nsrc, size_t nspitch,
+                                                                      uint16_t* __restrict__ ddst, size_t ddpitch, float* __restrict__ ndst,
+                                                                      size_t ndpitch, int dcols, int drows)
+{
+    FE_XY;
+    if (x >= dcols || y >= drows) return;
+    const float q = qnanf_();
+    const int xs = 2 * x, ys = 2 * y;
+    const int d00 = ld16(dsrc, dspitch, ys, xs), d01 = ld16(dsrc, dspitch, ys, xs + 1);
+    const int d10 = ld16(dsrc, dspitch, ys + 1, xs), d11 = ld16(dsrc, dspitch, ys + 1, xs + 1);
+    uint16_t d = 0;
+    float4 n = make_float4(q, q, q, q);
+    if ((int)((unsigned)d00 * (unsigned)d01) != 0 && (int)((unsigned)d10 * (unsigned)d11) != 0) {
+        d = (uint16_t)((d00 + d01 + d10 + d11) / 4);
+        const float4 a = ld4(nsrc, nspitch, ys, xs), b = ld4(nsrc, nspitch, ys, xs + 1);
+        const float4 c = ld4(nsrc, nspitch, ys + 1, xs), e = ld4(nsrc, nspitch, ys + 1, xs + 1);
+        n.x = (((a.x + b.x) + c.x) + e.x) * 0.25f;                                       // :343-345 (x0.25 is exact in either precision)
+        n.y = (((a.y + b.y) + c.y) + e.y) * 0.25f;
+        n.z = (((a.z + b.z) + c.z) + e.z) * 0.25f;
+    }
+    st16(ddst, ddpitch, y, x, d);
+    st4(ndst, ndpitch, y, x, n);
+}
+
+extern "C" int dfusion_resize_depth_normals(const uint16_t* depth, size_t depth_pitch, const float* normals, size_t normals_pitch,
+                                            int src_cols, int src_rows, uint16_t* depth_out, size_t depth_out_pitch, float* normals_out,
+                                            size_t normals_out_pitch, dfStream stream)
+{
+    if (!depth || !normals || !depth_out || !normals_out || src_cols < 2 || src_rows < 2) return DF_E_INVALID;
+    const int dc = src_cols / 2, dr = src_rows / 2;
+    hipLaunchKernelGGL(df_resize_depth_normals_kernel, FE_GRID(dc, dr), dim3(256), 0, (hipStream_t)stream, depth, depth_pitch, normals,
+                       normals_pitch, depth_out, depth_out_pitch, normals_out, normals_out_pitch, dc, dr);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+__global__ __launch_bounds__(256) void df_resize_points_normals_kernel(const float* __restrict__ vsrc, size_t vspitch,
+                                                                       const float* __restrict__ nsrc, size_t nspitch,
+                                                                       float* __restrict__ vdst, size_t vdpitch, float* __restrict__ ndst,
+                                                                       size_t ndpitch, int dcols, int drows)
+{
+    FE_XY;
+    if (x >= dcols || y >= drows) return;
+    const float q = qnanf_();
+    const int xs = 2 * x, ys = 2 * y;
+    float4 vo = make_float4(q, q, q, 0.f), no = make_float4(q, q, q, 0.f);
+    const float4 a = ld4(vsrc, vspitch, ys, xs), b = ld4(vsrc, vspitch, ys, xs + 1);
+    const float4 c = ld4(vsrc, vspitch, ys + 1, xs), e = ld4(vsrc, vspitch, ys + 1, xs + 1);
+    if (!isnan(a.x * b.x * c.x * e.x)) {
+        vo.x = (((a.x + b.x) + c.x) + e.x) * 0.25f; vo.y = (((a.y + b.y) + c.y) + e.y) * 0.25f; vo.z = (((a.z + b.z) + c.z) + e.z) * 0.25f;
+        const float4 na = ld4(nsrc, nspitch, ys, xs), nb = ld4(nsrc, nspitch, ys, xs + 1);
+        const float4 nc = ld4(nsrc, nspitch, ys + 1, xs), ne = ld4(nsrc, nspitch, ys + 1, xs + 1);
+        no.x = (((na.x + nb.x) + nc.x) + ne.x) * 0.25f; no.y = (((na.y + nb.y) + nc.y) + ne.y) * 0.25f; no.z = (((na.z + nb.z) + nc.z) + ne.z) * 0.25f;
+    }
+    st4(vdst, vdpitch, y, x, vo);
+    st4(ndst, ndpitch, y, x, no);
+}
+
+extern "C" int dfusion_resize_points_normals(const float* points, size_t points_pitch, const float* normals, size_t normals_pitch,
+                                             int src_cols, int src_rows, float* points_out, size_t points_out_pitch, float* normals_out,
+                                             size_t normals_out_pitch, dfStream stream)
+{
+    if (!points || !normals || !points_out || !normals_out || src_cols < 2 || src_rows < 2) return DF_E_INVALID;
+    const int dc = src_cols / 2, dr = src_rows / 2;
+    hipLaunchKernelGGL(df_resize_points_normals_kernel, FE_GRID(dc, dr), dim3(256), 0, (hipStream_t)stream, points, points_pitch, normals,
+                       normals_pitch, points_out, points_out_pitch, normals_out, normals_out_pitch, dc, dr);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ projective ICP (proj_icp.cu:30-397)
+struct DfIcpArgs {
+    int cols, rows;
+    DfAff aff;
+    FeIntr I;
+    float min_cosine, dist2_thres;
+    const float* vcurr; size_t vcpitch; const float* ncurr; size_t ncpitch;
+    const float* vprev; size_t vppitch; const float* nprev; size_t nppitch;
+    const uint16_t* dcurr; size_t dcpitch; const uint16_t* dprev; size_t dppitch;
+    float* partial; int partials;      // [27][partials]
+    int* accepted;                     // nullable
+};
+
+// find_coresp, :47-110.  DEPTH selects the USE_DEPTH build's variant.
+template <bool DEPTH>
+__device__ __forceinline__ int fe_find_coresp(const DfIcpArgs& A, int x, int y, f3* nd, f3* d, f3* s)
+{
+    if constexpr (DEPTH) {
+        const int src_z = ld16(A.dcurr, A.dcpitch, y, x);
+        if (src_z == 0) return 40;
+        *s = aff_mul(A.aff, fe_reproj(A.I, (float)x, (float)y, (float)src_z * 0.001f));
+    } else {
+        const float4 p = ld4(A.vcurr, A.vcpitch, y, x);
+        if (isnan(p.x)) return 40;
+        *s = aff_mul(A.aff, mk3(p.x, p.y, p.z));
+    }
+    const float u = fmaf(A.I.fx, s->x / s->z, A.I.cx);                                   // :33-34
+    const float v = fmaf(A.I.fy, s->y / s->z, A.I.cy);
+    if (s->z <= 0.f || !(u >= 0.f && v >= 0.f && u < (float)A.cols && v < (float)A.rows)) return 80;   // (+NaN => outside)
+    const int ui = (int)u, vi = (int)v;
+    if constexpr (DEPTH) {
+        const int dst_z = ld16(A.dprev, A.dppitch, vi, ui);
+        if (dst_z == 0) return 120;
+        *d = fe_reproj(A.I, u, v, (float)dst_z * 0.001f);
+    } else {
+        const float4 q = ld4(A.vprev, A.vppitch, vi, ui);
+        if (isnan(q.x)) return 120;
+        *d = mk3(q.x, q.y, q.z);
+    }
+    const f3 diff = sub3(*s, *d);
+    if (dot3(diff, diff) > A.dist2_thres) return 160;
+    const float4 nc = ld4(A.ncurr, A.ncpitch, y, x);
+    const f3 ns = mat3_mul(A.aff.R, mk3(nc.x, nc.y, nc.z));
+    const float4 np = ld4(A.nprev, A.nppitch, vi, ui);
+    *nd = mk3(np.x, np.y, np.z);
+    if (fabsf(dot3(ns, *nd)) < A.min_cosine) return 200;
+    return 0;
+}
+
+// Block::reduce<256> (temp_utils.hpp:503-523) for NV values per thread at once.  Only thread 0's result is defined, and it is
+// the reference's tree: pairs (t, t+s) for s = 128, 64 (through LDS: wave w+2 -> w, wave 1 -> 0, same lane), then s = 32..1
+// inside wave 0 (lane t+s -> lane t).  Float addition is commutative, so op(val, other) order is immaterial.
+template <int NV>
+__device__ __forceinline__ void fe_tree256(float (&v)[NV], float* lds /* [NV][128] */)
+{
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    if (w >= 2) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) lds[k * 128 + (t - 128)] = v[k];
+    }
+    __syncthreads();
+    if (w < 2) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = v[k] + lds[k * 128 + t];
+    }
+    __syncthreads();
+    if (w == 1) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) lds[k * 128 + l] = v[k];
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            float a = v[k] + lds[k * 128 + l];
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) a = a + __shfl_down(a, s, 64);
+            v[k] = a;
+        }
+    }
+}
+
+// icp_helper_kernel (:350-371) + partial_reduce (:112-348): the block is the reference's 32 x 8 pixel tile (the partial sums,
+// hence the final float sums, depend on which pixels share a block), tid = ty * 32 + tx.
+template <bool DEPTH>
+__global__ __launch_bounds__(256) void df_icp_partial_kernel(const DfIcpArgs A)
+{
+    __shared__ float lds[27 * 128];
+    const int t = threadIdx.x;
+    const int x = (t & 31) + blockIdx.x * 32, y = (t >> 5) + blockIdx.y * 8;
+    f3 n, d, s;
+    float row[7];
+    const int filtered = (x < A.cols && y < A.rows) ? fe_find_coresp<DEPTH>(A, x, y, &n, &d, &s) : 1;
+    if (!filtered) {
+        const f3 c = cross3(s, n);
+        row[0] = c.x; row[1] = c.y; row[2] = c.z; row[3] = n.x; row[4] = n.y; row[5] = n.z;
+        row[6] = dot3(n, sub3(d, s));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) row[i] = 0.f;
+    }
+    float v[27];
+    {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 7; ++j) v[k++] = row[i] * row[j];
+    }
+    fe_tree256<27>(v, lds);
+    if (t == 0) {
+        const int pos = blockIdx.x + gridDim.x * blockIdx.y;                             // :117
+#pragma unroll
+        for (int k = 0; k < 27; ++k) A.partial[(size_t)k * A.partials + pos] = v[k];
+    }
+    if (A.accepted) {
+        const unsigned long long m = __ballot(!filtered);
+        if ((t & 63) == 0 && m) atomicAdd(A.accepted, __popcll(m));
+    }
+}
+
+// icp_final_reduce_kernel (:373-397): block k sums row k of the partials -- strided serial sums, then the same tree.
+__global__ __launch_bounds__(256) void df_icp_final_kernel(const float* __restrict__ partial, int partials, float* __restrict__ out)
+{
+    __shared__ float lds[128];
+    const float* beg = partial + (size_t)blockIdx.x * partials;
+    float v[1];
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < partials; i += 256) sum += beg[i];
+    v[0] = sum;
+    fe_tree256<1>(v, lds);
+    if (threadIdx.x == 0) out[blockIdx.x] = v[0];
+}
+
+extern "C" int dfusion_icp_workspace_floats(int cols, int rows)
+{
+    if (cols <= 0 || rows <= 0) return 0;
+    return 27 * (((cols + 31) / 32) * ((rows + 7) / 8));
+}
+
+static int df_icp_launch(DfIcpArgs& A, bool depth, const float aff[12], const float intr[4], float dist2_thres, float min_cosine,
+                         float* workspace, float* sums, int* accepted, hipStream_t st)
+{
+    if (!aff || !intr || !workspace || !sums || A.cols <= 0 || A.rows <= 0) return DF_E_INVALID;
+    A.aff = df_aff(aff); A.I = fe_intr(intr); A.min_cosine = min_cosine; A.dist2_thres = dist2_thres;
+    const dim3 grid((A.cols + 31) / 32, (A.rows + 7) / 8);                              // :406-407
+    A.partial = workspace; A.partials = (int)(grid.x * grid.y); A.accepted = accepted;
+    if (depth) hipLaunchKernelGGL(df_icp_partial_kernel<true>, grid, dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(df_icp_partial_kernel<false>, grid, dim3(256), 0, st, A);
+    DF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(df_icp_final_kernel, dim3(27), dim3(256), 0, st, workspace, A.partials, sums);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+extern "C" int dfusion_icp_sums_points(const float* vcurr, size_t vcurr_pitch, const float* ncurr, size_t ncurr_pitch, const float* vprev,
+                                       size_t vprev_pitch, const float* nprev, size_t nprev_pitch, int cols, int rows, const float aff[12],
+                                       const float intr[4], float dist2_thres, float min_cosine, float* workspace, float* sums,
+                                       int* accepted, dfStream stream)
+{
+    if (!vcurr || !ncurr || !vprev || !nprev) return DF_E_INVALID;
+    DfIcpArgs A;
+    memset(&A, 0, sizeof(A));
+    A.cols = cols; A.rows = rows;
+    A.vcurr = vcurr; A.vcpitch = vcurr_pitch; A.ncurr = ncurr; A.ncpitch = ncurr_pitch;
+    A.vprev = vprev; A.vppitch = vprev_pitch; A.nprev = nprev; A.nppitch = nprev_pitch;
+    return df_icp_launch(A, false, aff, intr, dist2_thres, min_cosine, workspace, sums, accepted, (hipStream_t)stream);
+}
+
+extern "C" int dfusion_icp_sums_depth(const uint16_t* dcurr, size_t dcurr_pitch, const float* ncurr, size_t ncurr_pitch,
+                                      const uint16_t* dprev, size_t dprev_pitch, const float* nprev, size_t nprev_pitch, int cols, int rows,
+                                      const float aff[12], const float intr[4], float dist2_thres, float min_cosine, float* workspace,
+                                      float* sums, int* accepted, dfStream stream)
+{
+    if (!dcurr || !ncurr || !dprev || !nprev) return DF_E_INVALID;
+    DfIcpArgs A;
+    memset(&A, 0, sizeof(A));
+    A.cols = cols; A.rows = rows;
+    A.dcurr = dcurr; A.dcpitch = dcurr_pitch; A.ncurr = ncurr; A.ncpitch = ncurr_pitch;
+    A.dprev = dprev; A.dppitch = dprev_pitch; A.nprev = nprev; A.nppitch = nprev_pitch;
+    return df_icp_launch(A, true, aff, intr, dist2_thres, min_cosine, workspace, sums, accepted, (hipStream_t)stream);
+}

@@ -207,6 +207,53 @@ int dfusion_integrate_warped(const uint16_t *dists_dev, size_t dists_pitch, int 
                              const float proj[4], DfWarpField *wf, int k, unsigned flags,
                              unsigned long long *n_updated_dev, dfStream stream);
 
+/* ---- depth front-end + projective ICP -----------------------------------------------------
+ * All images are pitched device memory: depth u16 mm, points / normals float4.  `intr` = {fx, fy, cx, cy} of the
+ * pyramid LEVEL the images belong to (Intr::operator()(level) / setLevelIntr divide by 2^level).
+ * The reference's __expf (bilateral weight) and rsqrt (normalisation) are hardware approximations; this library uses
+ * (float)exp((double)x) and 1/sqrtf -- see oracle/dfusion_frontend_oracle.c.                                          */
+
+/* device::bilateralFilter (internal.hpp:128; kfusion/src/cuda/imgproc.cu:11-59).  sigma_depth in metres. src != dst. */
+int dfusion_bilateral_filter(const uint16_t *src_dev, size_t src_pitch, uint16_t *dst_dev, size_t dst_pitch, int cols, int rows,
+                             int kernel_size, float sigma_spatial, float sigma_depth, dfStream stream);
+/* device::truncateDepth (internal.hpp:127; imgproc.cu:66-85): depth > max_dist (metres) <- 0, in place.            */
+int dfusion_truncate_depth(uint16_t *depth_dev, size_t pitch, int cols, int rows, float max_dist, dfStream stream);
+/* device::depthPyr (internal.hpp:129; imgproc.cu:94-137): dst is (src_rows/2) x (src_cols/2).                       */
+int dfusion_depth_pyramid(const uint16_t *src_dev, size_t src_pitch, int src_cols, int src_rows, uint16_t *dst_dev, size_t dst_pitch,
+                          float sigma_depth, dfStream stream);
+/* device::computeNormalsAndMaskDepth (internal.hpp:134; imgproc.cu:145-201): normals (x,y,z,0) or (qnan,qnan,qnan,0);
+ * depth pixels without a normal are zeroed in place.                                                                 */
+int dfusion_compute_normals_mask_depth(uint16_t *depth_dev, size_t depth_pitch, float *normals_dev, size_t normals_pitch, int cols,
+                                       int rows, const float intr[4], dfStream stream);
+/* device::computePointNormals (internal.hpp:135; imgproc.cu:210-252): invalid pixels are all-NaN in both outputs.    */
+int dfusion_compute_point_normals(const uint16_t *depth_dev, size_t depth_pitch, float *points_dev, size_t points_pitch,
+                                  float *normals_dev, size_t normals_pitch, int cols, int rows, const float intr[4], dfStream stream);
+/* device::resizeDepthNormals / resizePointsNormals (internal.hpp:131-132; imgproc.cu:309-414): outputs are half size. */
+int dfusion_resize_depth_normals(const uint16_t *depth_dev, size_t depth_pitch, const float *normals_dev, size_t normals_pitch,
+                                 int src_cols, int src_rows, uint16_t *depth_out_dev, size_t depth_out_pitch, float *normals_out_dev,
+                                 size_t normals_out_pitch, dfStream stream);
+int dfusion_resize_points_normals(const float *points_dev, size_t points_pitch, const float *normals_dev, size_t normals_pitch,
+                                  int src_cols, int src_rows, float *points_out_dev, size_t points_out_pitch, float *normals_out_dev,
+                                  size_t normals_out_pitch, dfStream stream);
+
+/* device::ComputeIcpHelper::operator() (internal.hpp:91-92; kfusion/src/cuda/proj_icp.cu:30-441): one Gauss-Newton
+ * accumulation of point-to-plane ICP.  aff = current estimate curr -> prev; dist2_thres = dist_thres^2 and
+ * min_cosine = cos(angle_thres) (projective_icp.cpp:11-15).  sums_dev[27] = the upper triangle of A (6x6) interleaved
+ * with b exactly as StreamHelper::get unpacks it (projective_icp.cpp:43-61): for i in 0..5, for j in i..6.
+ * The float sums are taken over the reference's reduction tree (32x8-pixel blocks, strides 128..1, then 256 strided
+ * partial sums), so they are reproducible bit for bit.  workspace_dev: dfusion_icp_workspace_floats(cols, rows) floats
+ * (ComputeIcpHelper::allocate_buffer, proj_icp.cu:446-464).  accepted_dev (nullable) is INCREMENTED by the number of
+ * accepted correspondences.  The 6x6 solve stays on the host (cv::solve in the reference).                           */
+int dfusion_icp_workspace_floats(int cols, int rows);
+int dfusion_icp_sums_points(const float *vcurr_dev, size_t vcurr_pitch, const float *ncurr_dev, size_t ncurr_pitch,
+                            const float *vprev_dev, size_t vprev_pitch, const float *nprev_dev, size_t nprev_pitch, int cols, int rows,
+                            const float aff[12], const float intr[4], float dist2_thres, float min_cosine, float *workspace_dev,
+                            float *sums_dev, int *accepted_dev, dfStream stream);
+int dfusion_icp_sums_depth(const uint16_t *dcurr_dev, size_t dcurr_pitch, const float *ncurr_dev, size_t ncurr_pitch,
+                           const uint16_t *dprev_dev, size_t dprev_pitch, const float *nprev_dev, size_t nprev_pitch, int cols, int rows,
+                           const float aff[12], const float intr[4], float dist2_thres, float min_cosine, float *workspace_dev,
+                           float *sums_dev, int *accepted_dev, dfStream stream);
+
 /* ---- measurement helper: plain device copy used as the MEASURED HBM roofline denominator ---- */
 int dfusion_copy_bandwidth_probe(void *dst_dev, const void *src_dev, size_t bytes, dfStream stream);
 /* read-only stream of `bytes` (sink4_dev: 4 writable device bytes): the measured denominator for scan kernels */

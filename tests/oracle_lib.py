@@ -84,6 +84,27 @@ def lib():
         L.orc_extract_cloud.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, C.c_uint64]
         L.orc_project_and_remove.restype = C.c_uint64
         L.orc_project_and_remove.argtypes = [u16p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, f32p, C.c_uint64, f32p, C.c_void_p]
+        sz = C.c_size_t
+        L.orc_bilateral.restype = None
+        L.orc_bilateral.argtypes = [u16p, sz, u16p, sz, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.orc_truncate_depth.restype = None
+        L.orc_truncate_depth.argtypes = [u16p, sz, C.c_int, C.c_int, C.c_float]
+        L.orc_depth_pyramid.restype = None
+        L.orc_depth_pyramid.argtypes = [u16p, sz, C.c_int, C.c_int, u16p, sz, C.c_float]
+        L.orc_compute_normals_mask_depth.restype = None
+        L.orc_compute_normals_mask_depth.argtypes = [u16p, sz, f32p, sz, C.c_int, C.c_int, f32p]
+        L.orc_compute_point_normals.restype = None
+        L.orc_compute_point_normals.argtypes = [u16p, sz, f32p, sz, f32p, sz, C.c_int, C.c_int, f32p]
+        L.orc_resize_depth_normals.restype = None
+        L.orc_resize_depth_normals.argtypes = [u16p, sz, f32p, sz, C.c_int, C.c_int, u16p, sz, f32p, sz]
+        L.orc_resize_points_normals.restype = None
+        L.orc_resize_points_normals.argtypes = [f32p, sz, f32p, sz, C.c_int, C.c_int, f32p, sz, f32p, sz]
+        L.orc_icp_sums_points.restype = None
+        L.orc_icp_sums_points.argtypes = [f32p, sz, f32p, sz, f32p, sz, f32p, sz, C.c_int, C.c_int, f32p, f32p, C.c_float, C.c_float,
+                                          f32p, C.POINTER(C.c_int)]
+        L.orc_icp_sums_depth.restype = None
+        L.orc_icp_sums_depth.argtypes = [u16p, sz, f32p, sz, u16p, sz, f32p, sz, C.c_int, C.c_int, f32p, f32p, C.c_float, C.c_float,
+                                         f32p, C.POINTER(C.c_int)]
         L.orc_extract_normals.restype = None
         L.orc_extract_normals.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, C.c_uint64, C.c_float, f32p]
         for name in ("orc_quat_mul",):
@@ -280,3 +301,73 @@ def warp_points(pos, dq, sigma, points, normals, k, warp_to_live=None, use_ref=F
         lib().orc_warp_points(pos.reshape(-1), dq.reshape(-1), sigma, pos.shape[0], k, pts.reshape(-1), nptr,
                               pts.shape[0], f32(warp_to_live).reshape(-1))
     return pts, nrm
+
+
+# ---- depth front-end + ICP (oracle/dfusion_frontend_oracle.c) -------------------------------------------------------
+def _u16(a):
+    return np.ascontiguousarray(a, np.uint16)
+
+
+def bilateral(depth, ksz, sigma_spatial, sigma_depth):
+    depth = _u16(depth); rows, cols = depth.shape
+    out = np.zeros_like(depth)
+    lib().orc_bilateral(depth, cols * 2, out, cols * 2, cols, rows, ksz, sigma_spatial, sigma_depth)
+    return out
+
+
+def truncate_depth(depth, max_dist):
+    out = _u16(depth).copy(); rows, cols = out.shape
+    lib().orc_truncate_depth(out, cols * 2, cols, rows, max_dist)
+    return out
+
+
+def depth_pyramid(depth, sigma_depth):
+    depth = _u16(depth); rows, cols = depth.shape
+    out = np.zeros((rows // 2, cols // 2), np.uint16)
+    lib().orc_depth_pyramid(depth, cols * 2, cols, rows, out, (cols // 2) * 2, sigma_depth)
+    return out
+
+
+def compute_normals_mask_depth(depth, intr):
+    d = _u16(depth).copy(); rows, cols = d.shape
+    n = np.zeros((rows, cols, 4), np.float32)
+    lib().orc_compute_normals_mask_depth(d, cols * 2, n.reshape(-1), cols * 16, cols, rows, f32(intr))
+    return d, n
+
+
+def compute_point_normals(depth, intr):
+    d = _u16(depth); rows, cols = d.shape
+    p = np.zeros((rows, cols, 4), np.float32); n = np.zeros_like(p)
+    lib().orc_compute_point_normals(d, cols * 2, p.reshape(-1), cols * 16, n.reshape(-1), cols * 16, cols, rows, f32(intr))
+    return p, n
+
+
+def resize_depth_normals(depth, normals):
+    d = _u16(depth); rows, cols = d.shape
+    nrm = f32(normals)
+    do = np.zeros((rows // 2, cols // 2), np.uint16); no = np.zeros((rows // 2, cols // 2, 4), np.float32)
+    lib().orc_resize_depth_normals(d, cols * 2, nrm.reshape(-1), cols * 16, cols, rows, do, (cols // 2) * 2, no.reshape(-1), (cols // 2) * 16)
+    return do, no
+
+
+def resize_points_normals(points, normals):
+    p, nrm = f32(points), f32(normals); rows, cols = p.shape[:2]
+    po = np.zeros((rows // 2, cols // 2, 4), np.float32); no = np.zeros_like(po)
+    lib().orc_resize_points_normals(p.reshape(-1), cols * 16, nrm.reshape(-1), cols * 16, cols, rows, po.reshape(-1), (cols // 2) * 16,
+                                    no.reshape(-1), (cols // 2) * 16)
+    return po, no
+
+
+def icp_sums(curr, ncurr, prev, nprev, aff, intr, dist2_thres, min_cosine, depth_variant=False):
+    """Returns (sums[27] f32, accepted)."""
+    ncurr, nprev = f32(ncurr), f32(nprev)
+    rows, cols = nprev.shape[:2]
+    out = np.zeros(27, np.float32); acc = C.c_int(0)
+    if depth_variant:
+        lib().orc_icp_sums_depth(_u16(curr), cols * 2, ncurr.reshape(-1), cols * 16, _u16(prev), cols * 2, nprev.reshape(-1), cols * 16,
+                                 cols, rows, f32(aff).reshape(-1), f32(intr), dist2_thres, min_cosine, out, C.byref(acc))
+    else:
+        lib().orc_icp_sums_points(f32(curr).reshape(-1), cols * 16, ncurr.reshape(-1), cols * 16, f32(prev).reshape(-1), cols * 16,
+                                  nprev.reshape(-1), cols * 16, cols, rows, f32(aff).reshape(-1), f32(intr), dist2_thres, min_cosine, out,
+                                  C.byref(acc))
+    return out, acc.value
