@@ -52,6 +52,7 @@ def build_library(force=False, verbose=False):
 HOST_DIR = os.path.join(PKG_DIR, "host")
 HOST_LIB = os.path.join(HOST_DIR, "libkfusion_hip.so")
 HOST_APP = os.path.join(HOST_DIR, "headless_frame")
+HOST_KINFU_APP = os.path.join(HOST_DIR, "kinfu_headless")
 
 
 def build_host(force=False, verbose=False):
@@ -59,16 +60,18 @@ def build_host(force=False, verbose=False):
     build_library(force=False)
     src = os.path.join(HOST_DIR, "src", "kfusion_hip.cpp")
     app = os.path.join(HOST_DIR, "apps", "headless_frame.cpp")
-    deps = [src, app, LIB_PATH] + [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(HOST_DIR, "include")) for f in fs]
-    if not force and os.path.exists(HOST_LIB) and os.path.exists(HOST_APP) and \
-            min(os.path.getmtime(HOST_LIB), os.path.getmtime(HOST_APP)) >= max(os.path.getmtime(d) for d in deps):
+    app2 = os.path.join(HOST_DIR, "apps", "kinfu_headless.cpp")
+    deps = [src, app, app2, LIB_PATH] + [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(HOST_DIR, "include")) for f in fs]
+    if not force and all(os.path.exists(f) for f in (HOST_LIB, HOST_APP, HOST_KINFU_APP)) and \
+            min(os.path.getmtime(f) for f in (HOST_LIB, HOST_APP, HOST_KINFU_APP)) >= max(os.path.getmtime(d) for d in deps):
         return HOST_LIB, HOST_APP
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     common = ["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HOST_DIR, "include"),
               "-I", os.path.join(REPO_DIR, "include"), "-I", os.path.join(rocm, "include")]
     link = ["-L", PKG_DIR, "-ldfusion_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64"]
     cmds = [common + ["-fPIC", "-shared", src, "-o", HOST_LIB] + link + ["-Wl,-rpath,$ORIGIN/.."],
-            common + [app, "-o", HOST_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
+            common + [app, "-o", HOST_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
+            common + [app2, "-o", HOST_KINFU_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
     for c in cmds:
         if verbose:
             print(" ".join(c))

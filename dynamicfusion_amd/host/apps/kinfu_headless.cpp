@@ -1,0 +1,57 @@
+// kinfu_headless.cpp -- apps/demo.cpp (/root/reference/apps/demo.cpp:60-110) without OpenNI capture and the viz window: feeds depth
+// frames from a file to kfusion::KinFu::operator() and records what the demo would display -- the camera pose per frame.
+//   kinfu_headless <cols> <rows> <frames> <dims> <size_m> <in.bin> <out.bin> [warped]
+// in.bin : intrinsics fx fy cx cy f32[4], then per frame depth u16[rows*cols] (mm).
+// out.bin: per frame { tracked i32 (operator()'s return value), pose f32[12] (R row-major, t) }, then the extracted surface
+//          count u64 and the volume u32[dims^3].
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <kfusion/kinfu.hpp>
+#include <kfusion/cuda/imgproc.hpp>
+
+using namespace kfusion;
+
+int main(int argc, char** argv)
+{
+    if (argc != 8 && argc != 9) { std::fprintf(stderr, "usage: %s cols rows frames dims size in.bin out.bin [warped]\n", argv[0]); return 2; }
+    const int cols = std::atoi(argv[1]), rows = std::atoi(argv[2]), frames = std::atoi(argv[3]), dims = std::atoi(argv[4]);
+    const float size = (float)std::atof(argv[5]);
+    FILE* in = std::fopen(argv[6], "rb");
+    if (!in) { std::perror("in"); return 2; }
+    float iv[4];
+    if (std::fread(iv, 4, 4, in) != 4) return 2;
+
+    KinFuParams p = KinFuParams::default_params_dynamicfusion();        // demo.cpp:120
+    p.cols = cols; p.rows = rows;
+    p.intr = Intr(iv[0], iv[1], iv[2], iv[3]);
+    p.volume_dims = Vec3i::all(dims);
+    p.volume_size = Vec3f::all(size);
+    p.volume_pose = Affine3f().translate(Vec3f(-size / 2, -size / 2, 0.5f));
+    p.warped_fusion = (argc == 9);
+    KinFu kinfu(p);
+
+    FILE* out = std::fopen(argv[7], "wb");
+    if (!out) { std::perror("out"); return 2; }
+    std::vector<unsigned short> depth((size_t)rows * cols);
+    cuda::Depth depth_device;
+    for (int f = 0; f < frames; ++f) {
+        if (std::fread(depth.data(), 2, depth.size(), in) != depth.size()) return 2;
+        depth_device.upload(depth.data(), (size_t)cols * 2, rows, cols);    // demo.cpp:89
+        const int tracked = kinfu(depth_device) ? 1 : 0;                    // demo.cpp:93
+        float pose[12]; affine_to_aff12(kinfu.getCameraPose(), pose);
+        std::fwrite(&tracked, 4, 1, out);
+        std::fwrite(pose, 4, 12, out);
+    }
+    std::fclose(in);
+    kinfu.tsdf().compute_points();
+    const unsigned long long cnt = kinfu.tsdf().get_cloud_host().size();
+    std::fwrite(&cnt, 8, 1, out);
+    std::vector<unsigned int> vol((size_t)dims * dims * dims);
+    kinfu.tsdf().data().download(vol.data());
+    std::fwrite(vol.data(), 4, vol.size(), out);
+    std::fclose(out);
+    std::printf("kinfu_headless ok: %d frames, %zu warp nodes, %llu surface points\n", frames, kinfu.getWarp().getNodes()->size(), cnt);
+    return 0;
+}

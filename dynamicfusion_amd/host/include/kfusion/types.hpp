@@ -61,6 +61,20 @@ namespace kfusion
         Mat3f R; Vec3f t;
         Affine3f() {}
         Affine3f(const Mat3f& R_, const Vec3f& t_) : R(R_), t(t_) {}
+        /// cv::Affine3f(rvec, t): Rodrigues rotation (opencv2/core/affine.hpp Affine3<T>::rotation(const Vec3&)), in double
+        Affine3f(const Vec3f& rvec, const Vec3f& t_) : t(t_)
+        {
+            const double rx = rvec[0], ry = rvec[1], rz = rvec[2];
+            const double theta = std::sqrt(rx * rx + ry * ry + rz * rz);
+            if (theta >= 2.220446049250313e-16) {
+                const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, it = 1. / theta;
+                const double k[3] = {rx * it, ry * it, rz * it};
+                const double K[9] = {0, -k[2], k[1], k[2], 0, -k[0], -k[1], k[0], 0};
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j)
+                        R(i, j) = (float)(c * (i == j ? 1. : 0.) + c1 * k[i] * k[j] + s * K[3 * i + j]);
+            }
+        }
         static Affine3f Identity() { return Affine3f(); }
         Mat3f rotation() const { return R; }
         Vec3f translation() const { return t; }
@@ -111,7 +125,17 @@ namespace kfusion
         typedef DeviceArray2D<unsigned short> Dists;
         typedef DeviceArray2D<Normal> Normals;
         typedef DeviceArray2D<Point> Cloud;
+        struct RGB { unsigned char b, g, r, a; };          // types.hpp:42-50 (rendering itself is out of scope)
+        typedef DeviceArray2D<RGB> Image;
+        struct Frame                                     // types.hpp:65-72
+        {
+            bool use_points;
+            std::vector<Depth> depth_pyr;
+            std::vector<Cloud> points_pyr;
+            std::vector<Normals> normals_pyr;
+        };
     }
+    inline float deg2rad(float alpha) { return alpha * 0.017453293f; }   // types.hpp:75
 
     // row-major R[9] then t[3]: device::Aff3f as the C-ABI wants it (precomp.hpp:19-28 device_cast)
     inline void affine_to_aff12(const Affine3f& a, float out[12])

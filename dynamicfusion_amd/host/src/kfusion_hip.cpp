@@ -8,6 +8,9 @@
 #include <kfusion/cuda/tsdf_volume.hpp>
 #include <kfusion/cuda/imgproc.hpp>
 #include <kfusion/warp_field.hpp>
+#include <kfusion/cuda/projective_icp.hpp>
+#include <kfusion/kinfu.hpp>
+#include <algorithm>
 #include "dfusion.h"
 
 using namespace kfusion;
@@ -341,4 +344,323 @@ void WarpField::warp(std::vector<Vec3f>& points, std::vector<Vec3f>& normals) co
     KF_DF(dfusion_warp_points(handle_, k_, p.ptr(), normals.empty() ? nullptr : n.ptr(), (int)points.size(), live, nullptr));
     p.download(points[0].val);
     if (!normals.empty()) n.download(normals[0].val);
+}
+
+// ------------------------------------------------------------------------------------------ depth front-end (imgproc.cpp:10-141)
+void kfusion::cuda::depthBilateralFilter(const Depth& in, Depth& out, int ksz, float sigma_spatial, float sigma_depth)
+{
+    out.create(in.rows(), in.cols());
+    KF_DF(dfusion_bilateral_filter(in.ptr(), in.step(), out.ptr(), out.step(), in.cols(), in.rows(), ksz, sigma_spatial, sigma_depth, nullptr));
+}
+void kfusion::cuda::depthTruncation(Depth& depth, float threshold)
+{
+    KF_DF(dfusion_truncate_depth(depth.ptr(), depth.step(), depth.cols(), depth.rows(), threshold, nullptr));
+}
+void kfusion::cuda::depthBuildPyramid(const Depth& depth, Depth& pyramid, float sigma_depth)
+{
+    pyramid.create(depth.rows() / 2, depth.cols() / 2);
+    KF_DF(dfusion_depth_pyramid(depth.ptr(), depth.step(), depth.cols(), depth.rows(), pyramid.ptr(), pyramid.step(), sigma_depth, nullptr));
+}
+void kfusion::cuda::computeNormalsAndMaskDepth(const Intr& intr, Depth& depth, Normals& normals)
+{
+    normals.create(depth.rows(), depth.cols());
+    const float in[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
+    KF_DF(dfusion_compute_normals_mask_depth(depth.ptr(), depth.step(), (float*)normals.ptr(), normals.step(), depth.cols(), depth.rows(), in, nullptr));
+}
+void kfusion::cuda::computePointNormals(const Intr& intr, const Depth& depth, Cloud& points, Normals& normals)
+{
+    points.create(depth.rows(), depth.cols());
+    normals.create(depth.rows(), depth.cols());
+    const float in[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
+    KF_DF(dfusion_compute_point_normals(depth.ptr(), depth.step(), (float*)points.ptr(), points.step(), (float*)normals.ptr(), normals.step(),
+                                        depth.cols(), depth.rows(), in, nullptr));
+}
+void kfusion::cuda::resizeDepthNormals(const Depth& depth, const Normals& normals, Depth& depth_out, Normals& normals_out)
+{
+    depth_out.create(depth.rows() / 2, depth.cols() / 2);
+    normals_out.create(normals.rows() / 2, normals.cols() / 2);
+    KF_DF(dfusion_resize_depth_normals(depth.ptr(), depth.step(), (const float*)normals.ptr(), normals.step(), depth.cols(), depth.rows(),
+                                       depth_out.ptr(), depth_out.step(), (float*)normals_out.ptr(), normals_out.step(), nullptr));
+}
+void kfusion::cuda::resizePointsNormals(const Cloud& points, const Normals& normals, Cloud& points_out, Normals& normals_out)
+{
+    points_out.create(points.rows() / 2, points.cols() / 2);
+    normals_out.create(normals.rows() / 2, normals.cols() / 2);
+    KF_DF(dfusion_resize_points_normals((const float*)points.ptr(), points.step(), (const float*)normals.ptr(), normals.step(), points.cols(),
+                                        points.rows(), (float*)points_out.ptr(), points_out.step(), (float*)normals_out.ptr(),
+                                        normals_out.step(), nullptr));
+}
+
+// ------------------------------------------------------------------------------------------ ProjectiveICP (projective_icp.cpp:64-213)
+ProjectiveICP::ProjectiveICP() : angle_thres_(deg2rad(20.f)), dist_thres_(0.1f)
+{
+    const int iters[] = {10, 5, 4, 0};
+    setIterationsNum(std::vector<int>(iters, iters + 4));
+}
+ProjectiveICP::~ProjectiveICP() {}
+float ProjectiveICP::getDistThreshold() const { return dist_thres_; }
+void ProjectiveICP::setDistThreshold(float distance) { dist_thres_ = distance; }
+float ProjectiveICP::getAngleThreshold() const { return angle_thres_; }
+void ProjectiveICP::setAngleThreshold(float angle) { angle_thres_ = angle; }
+void ProjectiveICP::setIterationsNum(const std::vector<int>& iters)
+{
+    if (iters.size() >= MAX_PYRAMID_LEVELS) iters_.assign(iters.begin(), iters.begin() + MAX_PYRAMID_LEVELS);
+    else { iters_ = std::vector<int>(MAX_PYRAMID_LEVELS, 0); std::copy(iters.begin(), iters.end(), iters_.begin()); }
+}
+int ProjectiveICP::getUsedLevelsNum() const
+{
+    int i = MAX_PYRAMID_LEVELS - 1;
+    for (; i >= 0 && !iters_[i]; --i);
+    return i + 1;
+}
+
+// A r = b for the symmetric 6x6 normal equations, and det(A): LU with partial pivoting in double.  (The reference calls
+// cv::determinant and cv::solve(DECOMP_SVD) on float matrices, projective_icp.cpp:150,159 -- OpenCV is not part of the
+// reference tree; any backward-stable solver agrees with it to ~1e-6 relative on these well-scaled systems.)
+static bool solve6(const float A[36], const float b[6], double& det, float r[6])
+{
+    double M[6][7];
+    for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) M[i][j] = A[6 * i + j]; M[i][6] = b[i]; }
+    det = 1.0;
+    bool singular = false;
+    for (int c = 0; c < 6; ++c) {
+        int p = c;
+        for (int i = c + 1; i < 6; ++i) if (std::fabs(M[i][c]) > std::fabs(M[p][c])) p = i;
+        if (M[p][c] == 0.0 || std::isnan(M[p][c])) { det = std::isnan(M[p][c]) ? M[p][c] : 0.0; singular = true; break; }
+        if (p != c) { for (int j = 0; j < 7; ++j) std::swap(M[p][j], M[c][j]); det = -det; }
+        det *= M[c][c];
+        for (int i = c + 1; i < 6; ++i) {
+            const double f = M[i][c] / M[c][c];
+            for (int j = c; j < 7; ++j) M[i][j] -= f * M[c][j];
+        }
+    }
+    if (singular) return false;
+    for (int i = 5; i >= 0; --i) {
+        double s = M[i][6];
+        for (int j = i + 1; j < 6; ++j) s -= M[i][j] * (double)r[j];
+        r[i] = (float)(s / M[i][i]);
+    }
+    return true;
+}
+
+bool ProjectiveICP::iterate(Affine3f& affine, const Intr& intr, const void* const* curr, const NormalsPyr& ncurr, const void* const* prev,
+                            const NormalsPyr& nprev, const size_t* curr_step, const size_t* prev_step, bool depth_variant)
+{
+    const int LEVELS = getUsedLevelsNum();
+    const float dist2_thres = dist_thres_ * dist_thres_;               // ComputeIcpHelper ctor, projective_icp.cpp:11-15
+    const float min_cosine = std::cos(angle_thres_);
+    affine = Affine3f::Identity();
+    for (int level_index = LEVELS - 1; level_index >= 0; --level_index) {
+        const Normals& n = nprev[level_index];
+        const int rows = n.rows(), cols = n.cols();
+        const int div = 1 << level_index;                              // setLevelIntr, :17-23
+        const float li[4] = {intr.fx / div, intr.fy / div, intr.cx / div, intr.cy / div};
+        const size_t need = (size_t)dfusion_icp_workspace_floats(cols, rows) + 27;
+        if (buffer_.size() < need) buffer_.create(need);
+        float* sums_dev = buffer_.ptr() + (need - 27);
+        for (int iter = 0; iter < iters_[level_index]; ++iter) {
+            float aff[12]; affine_to_aff12(affine, aff);
+            if (depth_variant)
+                KF_DF(dfusion_icp_sums_depth((const unsigned short*)curr[level_index], curr_step[level_index], (const float*)ncurr[level_index].ptr(),
+                                             ncurr[level_index].step(), (const unsigned short*)prev[level_index], prev_step[level_index],
+                                             (const float*)n.ptr(), n.step(), cols, rows, aff, li, dist2_thres, min_cosine, buffer_.ptr(), sums_dev,
+                                             nullptr, nullptr));
+            else
+                KF_DF(dfusion_icp_sums_points((const float*)curr[level_index], curr_step[level_index], (const float*)ncurr[level_index].ptr(),
+                                              ncurr[level_index].step(), (const float*)prev[level_index], prev_step[level_index],
+                                              (const float*)n.ptr(), n.step(), cols, rows, aff, li, dist2_thres, min_cosine, buffer_.ptr(), sums_dev,
+                                              nullptr, nullptr));
+            float s[27];
+            KF_HIP(hipMemcpy(s, sums_dev, sizeof(s), hipMemcpyDeviceToHost));   // cudaMemcpyAsync + cudaStreamSynchronize (:45)
+            float A[36], b[6];
+            int shift = 0;                                                  // StreamHelper::get, :43-61
+            for (int i = 0; i < 6; ++i)
+                for (int j = i; j < 7; ++j) {
+                    const float value = s[shift++];
+                    if (j == 6) b[i] = value; else A[j * 6 + i] = A[i * 6 + j] = value;
+                }
+            double det; float r[6];
+            const bool solved = solve6(A, b, det, r);
+            if (std::fabs(det) < 1e-15 || std::isnan(det) || !solved) {     // :152-156
+                if (std::isnan(det)) std::printf("qnan\n");
+                return false;
+            }
+            const Affine3f Tinc(Vec3f(r[0], r[1], r[2]), Vec3f(r[3], r[4], r[5]));   // :162
+            affine = Tinc * affine;
+        }
+    }
+    return true;
+}
+
+bool ProjectiveICP::estimateTransform(Affine3f& affine, const Intr& intr, const DepthPyr& dcurr, const NormalsPyr ncurr, const DepthPyr dprev,
+                                      const NormalsPyr nprev)
+{
+    const void* c[MAX_PYRAMID_LEVELS] = {}; const void* p[MAX_PYRAMID_LEVELS] = {}; size_t cs[MAX_PYRAMID_LEVELS] = {}, ps[MAX_PYRAMID_LEVELS] = {};
+    for (int i = 0; i < getUsedLevelsNum(); ++i) { c[i] = dcurr[i].ptr(); cs[i] = dcurr[i].step(); p[i] = dprev[i].ptr(); ps[i] = dprev[i].step(); }
+    return iterate(affine, intr, c, ncurr, p, nprev, cs, ps, true);
+}
+bool ProjectiveICP::estimateTransform(Affine3f& affine, const Intr& intr, const PointsPyr& vcurr, const NormalsPyr ncurr, const PointsPyr vprev,
+                                      const NormalsPyr nprev)
+{
+    const void* c[MAX_PYRAMID_LEVELS] = {}; const void* p[MAX_PYRAMID_LEVELS] = {}; size_t cs[MAX_PYRAMID_LEVELS] = {}, ps[MAX_PYRAMID_LEVELS] = {};
+    for (int i = 0; i < getUsedLevelsNum(); ++i) { c[i] = vcurr[i].ptr(); cs[i] = vcurr[i].step(); p[i] = vprev[i].ptr(); ps[i] = vprev[i].step(); }
+    return iterate(affine, intr, c, ncurr, p, nprev, cs, ps, false);
+}
+
+// ------------------------------------------------------------------------------------------ KinFu (kinfu.cpp)
+KinFuParams KinFuParams::default_params_dynamicfusion()                // kinfu.cpp:15-50
+{
+    const int iters[] = {10, 5, 4, 0};
+    KinFuParams p;
+    p.cols = 640; p.rows = 480;
+    p.intr = Intr(570.342f, 570.342f, 320.f, 240.f);
+    p.volume_dims = Vec3i::all(256);
+    p.volume_size = Vec3f::all(1.f);
+    p.volume_pose = Affine3f().translate(Vec3f(-p.volume_size[0] / 2, -p.volume_size[1] / 2, 0.5f));
+    p.bilateral_sigma_depth = 0.04f; p.bilateral_sigma_spatial = 4.5; p.bilateral_kernel_size = 7;
+    p.icp_truncate_depth_dist = 0.f; p.icp_dist_thres = 0.1f; p.icp_angle_thres = deg2rad(30.f);
+    p.icp_iter_num.assign(iters, iters + 4);
+    p.tsdf_min_camera_movement = 0.f; p.tsdf_trunc_dist = 0.04f; p.tsdf_max_weight = 64;
+    p.raycast_step_factor = 0.75f; p.gradient_delta_factor = 0.5f;
+    p.light_pose = Vec3f::all(0.f);
+    return p;
+}
+KinFuParams KinFuParams::default_params()                              // kinfu.cpp:55-89
+{
+    KinFuParams p = default_params_dynamicfusion();
+    p.intr = Intr(525.f, 525.f, p.cols / 2 - 0.5f, p.rows / 2 - 0.5f);
+    p.volume_dims = Vec3i::all(512);
+    p.volume_size = Vec3f::all(3.f);
+    p.volume_pose = Affine3f().translate(Vec3f(-p.volume_size[0] / 2, -p.volume_size[1] / 2, 0.5f));
+    return p;
+}
+
+KinFu::KinFu(const KinFuParams& params) : frame_counter_(0), params_(params)     // kinfu.cpp:95-125
+{
+    if (params.volume_dims[0] % 32 != 0) kfusion::cuda::error("volume_dims[0] % 32 == 0", __FILE__, __LINE__, "KinFu");
+    volume_.reset(new cuda::TsdfVolume(params_.volume_dims));
+    warp_.reset(new WarpField());
+    volume_->setTruncDist(params_.tsdf_trunc_dist);                     // NB the reference's order: trunc before size (clamp quirk kept)
+    volume_->setMaxWeight(params_.tsdf_max_weight);
+    volume_->setSize(params_.volume_size);
+    volume_->setPose(params_.volume_pose);
+    volume_->setRaycastStepFactor(params_.raycast_step_factor);
+    volume_->setGradientDeltaFactor(params_.gradient_delta_factor);
+    icp_.reset(new cuda::ProjectiveICP());
+    icp_->setDistThreshold(params_.icp_dist_thres);
+    icp_->setAngleThreshold(params_.icp_angle_thres);
+    icp_->setIterationsNum(params_.icp_iter_num);
+    allocate_buffers();
+    reset();
+}
+
+void KinFu::allocate_buffers()                                         // kinfu.cpp:150-190
+{
+    const int LEVELS = cuda::ProjectiveICP::MAX_PYRAMID_LEVELS;
+    int cols = params_.cols, rows = params_.rows;
+    dists_.create(rows, cols);
+    for (cuda::Frame* f : {&curr_, &prev_, &first_}) { f->depth_pyr.resize(LEVELS); f->normals_pyr.resize(LEVELS); f->points_pyr.resize(LEVELS); }
+    for (int i = 0; i < LEVELS; ++i) {
+        for (cuda::Frame* f : {&curr_, &prev_, &first_}) { f->depth_pyr[i].create(rows, cols); f->normals_pyr[i].create(rows, cols); f->points_pyr[i].create(rows, cols); }
+        cols /= 2; rows /= 2;
+    }
+}
+
+void KinFu::reset()                                                    // kinfu.cpp:195-206
+{
+    if (frame_counter_) std::printf("Reset\n");
+    frame_counter_ = 0;
+    poses_.clear();
+    poses_.reserve(30000);
+    poses_.push_back(Affine3f::Identity());
+    volume_->clear();
+}
+
+Affine3f KinFu::getCameraPose(int time) const                          // kinfu.cpp:213-218
+{
+    if (time > (int)poses_.size() || time < 0) time = (int)poses_.size() - 1;
+    return poses_[time];
+}
+
+bool KinFu::operator()(const cuda::Depth& depth, const cuda::Image& /*image*/)    // kinfu.cpp:220-304 (default build: points pyramids)
+{
+    const KinFuParams& p = params_;
+    const int LEVELS = icp_->getUsedLevelsNum();
+    cuda::computeDists(depth, dists_, p.intr);
+    cuda::depthBilateralFilter(depth, curr_.depth_pyr[0], p.bilateral_kernel_size, p.bilateral_sigma_spatial, p.bilateral_sigma_depth);
+    if (p.icp_truncate_depth_dist > 0) cuda::depthTruncation(curr_.depth_pyr[0], p.icp_truncate_depth_dist);
+    for (int i = 1; i < LEVELS; ++i) cuda::depthBuildPyramid(curr_.depth_pyr[i - 1], curr_.depth_pyr[i], p.bilateral_sigma_depth);
+    for (int i = 0; i < LEVELS; ++i) cuda::computePointNormals(p.intr(i), curr_.depth_pyr[i], curr_.points_pyr[i], curr_.normals_pyr[i]);
+    cuda::waitAllDefaultStream();
+
+    if (frame_counter_ == 0) {                                          // :246-265
+        volume_->integrate(dists_, poses_.back(), p.intr);
+        volume_->compute_points();
+        volume_->compute_normals();
+        // warp_->init(cloud): the reference's cv::Mat overload keeps every 50th point (warp_field.cpp:49-60) and leaves the rest of
+        // the node array zero-initialised; here only the kept points become nodes, with a larger stride if they would not fit
+        const std::vector<Point>& cloud = volume_->get_cloud_host();
+        size_t step = 50;
+        const size_t max_nodes = (size_t)std::max(1, std::min(params_.max_warp_nodes, 65535));
+        while (cloud.size() / step > max_nodes) ++step;
+        std::vector<Vec3f> seeds;
+        for (size_t i = 0; i < cloud.size(); i += step) seeds.push_back(Vec3f(cloud[i].x, cloud[i].y, cloud[i].z));
+        if (seeds.size() >= (size_t)warp_->k()) warp_->init(seeds);
+        curr_.points_pyr.swap(prev_.points_pyr);
+        curr_.points_pyr.swap(first_.points_pyr);
+        curr_.normals_pyr.swap(prev_.normals_pyr);
+        curr_.normals_pyr.swap(first_.normals_pyr);
+        return ++frame_counter_, false;
+    }
+
+    Affine3f affine;                                                    // curr -> prev
+    if (!icp_->estimateTransform(affine, p.intr, curr_.points_pyr, curr_.normals_pyr, prev_.points_pyr, prev_.normals_pyr))
+        return reset(), false;
+    poses_.push_back(poses_.back() * affine);                           // curr -> global
+    cuda::Depth d = curr_.depth_pyr[0];
+    dynamicfusion(d, curr_.points_pyr[0], curr_.normals_pyr[0]);
+
+    volume_->raycast(poses_.back(), p.intr, prev_.points_pyr[0], prev_.normals_pyr[0]);    // :296-299
+    for (int i = 1; i < LEVELS; ++i)
+        cuda::resizePointsNormals(prev_.points_pyr[i - 1], prev_.normals_pyr[i - 1], prev_.points_pyr[i], prev_.normals_pyr[i]);
+    cuda::waitAllDefaultStream();
+    return ++frame_counter_, true;
+}
+
+void KinFu::dynamicfusion(cuda::Depth& depth, cuda::Cloud live_frame, cuda::Normals /*current_normals*/)   // kinfu.cpp:344-400
+{
+    const Affine3f camera_pose = poses_.back();
+    if (warp_->getNodes()->size() < (size_t)warp_->k()) {               // no usable warp field (empty first frame): plain KinFu fusion
+        cuda::Dists dists; cuda::computeDists(depth, dists, params_.intr);
+        volume_->integrate(dists, camera_pose, params_.intr);
+        return;
+    }
+    cuda::Cloud cloud; cuda::Normals normals;
+    cloud.create(depth.rows(), depth.cols());
+    normals.create(depth.rows(), depth.cols());
+    volume_->raycast(camera_pose, params_.intr, cloud, normals);
+    const size_t n = (size_t)depth.rows() * depth.cols();
+    std::vector<Point> cloud_host(n), normal_host(n), live_host(n);
+    cloud.download(cloud_host.data(), (size_t)depth.cols() * sizeof(Point));
+    normals.download(normal_host.data(), (size_t)depth.cols() * sizeof(Point));
+    live_frame.download(live_host.data(), (size_t)depth.cols() * sizeof(Point));
+    const Affine3f inverse_pose = camera_pose.inv();
+    std::vector<Vec3f> canonical(n), canonical_normals(n), live(n);
+    for (size_t i = 0; i < n; ++i) {
+        canonical[i] = inverse_pose * Vec3f(cloud_host[i].x, cloud_host[i].y, cloud_host[i].z);
+        canonical_normals[i] = Vec3f(normal_host[i].x, normal_host[i].y, normal_host[i].z);
+        live[i] = Vec3f(live_host[i].x, live_host[i].y, live_host[i].z);
+    }
+    std::vector<Vec3f> canonical_visible(canonical);
+    warp_->warp(canonical, canonical_normals);                          // :387
+    optimiseWarp(canonical, canonical_normals, live);                   // :389 (solver out of scope: no-op unless overridden)
+    warp_->warp(canonical, canonical_normals);                          // :391
+    if (params_.warped_fusion) {
+        cuda::Dists dists; cuda::computeDists(depth, dists, params_.intr);
+        volume_->integrate(dists, camera_pose, params_.intr, *warp_);
+    } else {
+        volume_->surface_fusion(*warp_, canonical, canonical_visible, depth, camera_pose, params_.intr);   // :393
+    }
+    volume_->compute_points();                                          // :398-399
+    volume_->compute_normals();
 }
