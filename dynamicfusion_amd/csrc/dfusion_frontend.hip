@@ -256,6 +256,42 @@ extern "C" int dfusion_resize_points_normals(const float* points, size_t points_
     return DF_OK;
 }
 
+// ------------------------------------------------------------------------------------------ point-set glue (kinfu.cpp:353-383)
+// The host loops of KinFu::dynamicfusion that turn the ray-cast image into `canonical` (inverse_pose * point) and strip the
+// float4 padding, kept on the device.  Arithmetic of cv::Affine3f * Vec3f as the host mirror evaluates it
+// (host/include/kfusion/types.hpp): R(i,0)*x + R(i,1)*y + R(i,2)*z + t(i), plain float products summed left to right.
+__global__ __launch_bounds__(256) void df_transform_points_kernel(const float* __restrict__ in, size_t in_pitch, int in_stride,
+                                                                 float* __restrict__ out, size_t out_pitch, int out_stride, int cols, int rows,
+                                                                 DfAff A, int use_aff)
+{
+    FE_XY;
+    if (x >= cols || y >= rows) return;
+    const float* p = (const float*)((const char*)in + (size_t)y * in_pitch) + (size_t)x * in_stride;
+    float* o = (float*)((char*)out + (size_t)y * out_pitch) + (size_t)x * out_stride;
+    const float px = p[0], py = p[1], pz = p[2];
+    float rx = px, ry = py, rz = pz;
+    if (use_aff) {
+        rx = A.R[0] * px + A.R[1] * py + A.R[2] * pz + A.t[0];
+        ry = A.R[3] * px + A.R[4] * py + A.R[5] * pz + A.t[1];
+        rz = A.R[6] * px + A.R[7] * py + A.R[8] * pz + A.t[2];
+    }
+    o[0] = rx; o[1] = ry; o[2] = rz;
+    if (out_stride > 3) o[3] = 0.f;
+}
+
+extern "C" int dfusion_transform_points(const float* in, size_t in_pitch, int in_stride, float* out, size_t out_pitch, int out_stride,
+                                        int cols, int rows, const float aff[12], dfStream stream)
+{
+    if (!in || !out || in == out || cols <= 0 || rows <= 0 || in_stride < 3 || out_stride < 3 || out_stride > 4) return DF_E_INVALID;
+    DfAff A;
+    memset(&A, 0, sizeof(A));
+    if (aff) A = df_aff(aff);
+    hipLaunchKernelGGL(df_transform_points_kernel, FE_GRID(cols, rows), dim3(256), 0, (hipStream_t)stream, in, in_pitch, in_stride, out,
+                       out_pitch, out_stride, cols, rows, A, aff ? 1 : 0);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
 // ------------------------------------------------------------------------------------------ projective ICP (proj_icp.cu:30-397)
 struct DfIcpArgs {
     int cols, rows;

@@ -1,12 +1,15 @@
 // kinfu_headless.cpp -- apps/demo.cpp (/root/reference/apps/demo.cpp:60-110) without OpenNI capture and the viz window: feeds depth
 // frames from a file to kfusion::KinFu::operator() and records what the demo would display -- the camera pose per frame.
-//   kinfu_headless <cols> <rows> <frames> <dims> <size_m> <in.bin> <out.bin> [warped]
+//   kinfu_headless <cols> <rows> <frames> <dims> <size_m> <in.bin> <out.bin> [warped|host|warped-host]
+//   (warped: per-voxel warped integrate instead of surface_fusion; host: the reference's host-staged data flow)
 // in.bin : intrinsics fx fy cx cy f32[4], then per frame depth u16[rows*cols] (mm).
 // out.bin: per frame { tracked i32 (operator()'s return value), pose f32[12] (R row-major, t) }, then the extracted surface
 //          count u64 and the volume u32[dims^3].
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <string>
 #include <vector>
 #include <kfusion/kinfu.hpp>
 #include <kfusion/cuda/imgproc.hpp>
@@ -15,7 +18,7 @@ using namespace kfusion;
 
 int main(int argc, char** argv)
 {
-    if (argc != 8 && argc != 9) { std::fprintf(stderr, "usage: %s cols rows frames dims size in.bin out.bin [warped]\n", argv[0]); return 2; }
+    if (argc != 8 && argc != 9) { std::fprintf(stderr, "usage: %s cols rows frames dims size in.bin out.bin [warped|host|warped-host]\n", argv[0]); return 2; }
     const int cols = std::atoi(argv[1]), rows = std::atoi(argv[2]), frames = std::atoi(argv[3]), dims = std::atoi(argv[4]);
     const float size = (float)std::atof(argv[5]);
     FILE* in = std::fopen(argv[6], "rb");
@@ -29,17 +32,24 @@ int main(int argc, char** argv)
     p.volume_dims = Vec3i::all(dims);
     p.volume_size = Vec3f::all(size);
     p.volume_pose = Affine3f().translate(Vec3f(-size / 2, -size / 2, 0.5f));
-    p.warped_fusion = (argc == 9);
+    const std::string mode = argc == 9 ? argv[8] : "";
+    p.warped_fusion = mode.find("warped") != std::string::npos;
+    p.device_resident = mode.find("host") == std::string::npos;
     KinFu kinfu(p);
 
     FILE* out = std::fopen(argv[7], "wb");
     if (!out) { std::perror("out"); return 2; }
     std::vector<unsigned short> depth((size_t)rows * cols);
     cuda::Depth depth_device;
+    double total_ms = 0.0; int timed = 0;
     for (int f = 0; f < frames; ++f) {
         if (std::fread(depth.data(), 2, depth.size(), in) != depth.size()) return 2;
         depth_device.upload(depth.data(), (size_t)cols * 2, rows, cols);    // demo.cpp:89
+        const auto t0 = std::chrono::steady_clock::now();
         const int tracked = kinfu(depth_device) ? 1 : 0;                    // demo.cpp:93
+        cuda::waitAllDefaultStream();
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (f >= 2) { total_ms += ms; ++timed; }
         float pose[12]; affine_to_aff12(kinfu.getCameraPose(), pose);
         std::fwrite(&tracked, 4, 1, out);
         std::fwrite(pose, 4, 12, out);
@@ -52,6 +62,7 @@ int main(int argc, char** argv)
     kinfu.tsdf().data().download(vol.data());
     std::fwrite(vol.data(), 4, vol.size(), out);
     std::fclose(out);
-    std::printf("kinfu_headless ok: %d frames, %zu warp nodes, %llu surface points\n", frames, kinfu.getWarp().getNodes()->size(), cnt);
+    std::printf("kinfu_headless ok: %d frames, %zu warp nodes, %llu surface points, %.3f ms/frame (KinFu::operator(), frames 2.., wall clock)\n",
+                frames, kinfu.getWarp().getNodes()->size(), cnt, timed ? total_ms / timed : 0.0);
     return 0;
 }

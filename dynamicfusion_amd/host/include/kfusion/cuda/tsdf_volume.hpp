@@ -71,14 +71,24 @@ namespace kfusion
             void fetchNormals(const DeviceArray<Point>& cloud, DeviceArray<Normal>& normals) const;       // :206-218
             void compute_points();                                                                        // :313-318
             void compute_normals();                                                                       // :320-325
-            const std::vector<Point>& get_cloud_host() const { return cloud_host_; }
-            const std::vector<Normal>& get_normal_host() const { return normal_host_; }
+            /// host copies are fetched lazily: compute_points / compute_normals only run the device kernels, the download
+            /// happens on the first get_*_host() after them (the reference downloads eagerly, tsdf_volume.cpp:316,323)
+            const std::vector<Point>& get_cloud_host() const;
+            const std::vector<Normal>& get_normal_host() const;
+            const DeviceArray<Point>& get_cloud_device() const { return cloud_; }
+
+            /// surface_fusion with the warped model points already on the device (float4, camera... world frame as the host overload):
+            /// same result, no host staging
+            void surface_fusion(const WarpField& warp_field, DeviceArray<Point>& warped, cuda::Depth& depth, const Affine3f& camera_pose,
+                                const Intr& intr);
 
         private:
             DeviceArray<Point> cloud_buffer_, cloud_;
             DeviceArray<Normal> normal_buffer_;
-            std::vector<Point> cloud_host_;
-            std::vector<Normal> normal_host_;
+            mutable std::vector<Point> cloud_host_;
+            mutable std::vector<Normal> normal_host_;
+            mutable bool cloud_host_stale_ = false, normal_host_stale_ = false;
+            Dists fusion_dists_;                            // scratch of surface_fusion
             CudaData data_;
             float trunc_dist_;
             float max_weight_;                              // stored as float in the reference too (tsdf_volume.hpp:86)

@@ -1,8 +1,9 @@
 // kfusion/kinfu.hpp -- kfusion::KinFuParams / kfusion::KinFu with the reference's interface
 // (/root/reference/kfusion/include/kfusion/kinfu.hpp:15-112) minus viz (renderImage) and the Opt/Ceres solver.
-// Extensions, all defaulting to the reference's behaviour: max_warp_nodes (the reference seeds ONE node per extracted
-// surface point, kinfu.cpp:252; node ids are 16-bit here, so the seed cloud is decimated by a regular stride) and
-// warped_fusion (call the per-voxel warped integrate instead of surface_fusion).
+// Extensions: max_warp_nodes (node ids are 16-bit here; the seed cloud's stride-50 sampling, warp_field.cpp:49-60, widens if needed),
+// warped_fusion (call the per-voxel warped integrate instead of surface_fusion; default off = the reference's behaviour) and
+// device_resident (default on: same results as the reference's host staging, bit for bit, without the ~50 MB/frame of PCIe traffic;
+// switch off when optimiseWarp is overridden, which needs the host vectors).
 #pragma once
 #include <memory>
 #include <vector>
@@ -32,8 +33,9 @@ namespace kfusion
         float raycast_step_factor, gradient_delta_factor;
         Vec3f light_pose;
         // extensions
-        int max_warp_nodes = 4096;
+        int max_warp_nodes = 65535;
         bool warped_fusion = false;
+        bool device_resident = true;   // keep dynamicfusion()'s point sets on the GPU (no host staging); false = the reference's data flow
     };
 
     class KinFu
@@ -71,5 +73,9 @@ namespace kfusion
         std::unique_ptr<cuda::TsdfVolume> volume_;
         std::unique_ptr<cuda::ProjectiveICP> icp_;
         std::unique_ptr<WarpField> warp_;
+        // scratch of the device-resident dynamicfusion()
+        cuda::Cloud df_cloud_; cuda::Normals df_normals_;
+        cuda::DeviceArray<float> df_points3_, df_normals3_;
+        cuda::DeviceArray<Point> df_warped4_;
     };
 }

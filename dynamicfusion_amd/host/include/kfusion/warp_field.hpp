@@ -39,6 +39,8 @@ namespace kfusion
 
         /// warp_field.cpp:180-195, on the GPU; vectors are modified in place
         void warp(std::vector<Vec3f>& points, std::vector<Vec3f>& normals) const;
+        /// the same on device-resident packed float3 arrays (n points; normals may be empty)
+        void warp(cuda::DeviceArray<float>& points, cuda::DeviceArray<float>& normals, int n) const;
         /// warp_field.cpp:247-251; results via getRetIndex / getDistSquared like the reference's globals
         void KNN(Vec3f point) const;
         std::vector<float>* getDistSquared() const { return &out_dist_sqr_; }

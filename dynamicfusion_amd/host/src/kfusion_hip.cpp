@@ -222,15 +222,33 @@ void TsdfVolume::fetchNormals(const DeviceArray<Point>& cloud, DeviceArray<Norma
 void TsdfVolume::compute_points()
 {
     cloud_ = fetchCloud(cloud_buffer_);
-    cloud_host_.resize(cloud_.size());
-    if (cloud_.size()) cloud_.download(cloud_host_.data());
+    cloud_host_stale_ = true;
 }
 
 void TsdfVolume::compute_normals()
 {
     fetchNormals(cloud_, normal_buffer_);
-    normal_host_.resize(cloud_.size());
-    if (cloud_.size()) normal_buffer_.download(normal_host_.data());
+    normal_host_stale_ = true;
+}
+
+const std::vector<Point>& TsdfVolume::get_cloud_host() const
+{
+    if (cloud_host_stale_) {
+        cloud_host_.resize(cloud_.size());
+        if (cloud_.size()) cloud_.download(cloud_host_.data());
+        cloud_host_stale_ = false;
+    }
+    return cloud_host_;
+}
+
+const std::vector<Normal>& TsdfVolume::get_normal_host() const
+{
+    if (normal_host_stale_) {
+        normal_host_.resize(cloud_.size());
+        if (cloud_.size()) normal_buffer_.download(normal_host_.data());
+        normal_host_stale_ = false;
+    }
+    return normal_host_;
 }
 
 // ------------------------------------------------------------------------------------------ psdf / surface_fusion (tsdf_volume.cpp:228-306)
@@ -265,6 +283,18 @@ float TsdfVolume::weighting(const std::vector<float>& dist_sqr, int k) const
     float distances = 0;
     for (float d : dist_sqr) distances += std::sqrt(d);
     return distances / k;
+}
+
+void TsdfVolume::surface_fusion(const WarpField& /*warp_field*/, DeviceArray<Point>& warped, cuda::Depth& depth, const Affine3f& camera_pose,
+                                const Intr& intr)
+{
+    cuda::computeDists(depth, fusion_dists_, intr);
+    const float proj[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
+    if (warped.size())
+        KF_DF(dfusion_project_and_remove(fusion_dists_.ptr(), fusion_dists_.step(), depth.ptr(), depth.step(), depth.cols(), depth.rows(),
+                                         (float*)warped.ptr(), warped.size(), proj, nullptr, nullptr, nullptr));
+    cuda::computeDists(depth, fusion_dists_, intr);
+    integrate(fusion_dists_, camera_pose, intr);
 }
 
 void TsdfVolume::surface_fusion(const WarpField& /*warp_field*/, std::vector<Vec3f> warped, std::vector<Vec3f> /*canonical*/,
@@ -332,6 +362,12 @@ void WarpField::KNN(Vec3f point) const
     KF_DF(dfusion_knn(handle_, k_, q.ptr(), 1, idx.ptr(), d2.ptr(), nullptr));
     std::vector<int> hi; idx.download(hi); d2.download(out_dist_sqr_);
     for (int i = 0; i < k_; ++i) ret_index_[i] = (size_t)hi[i];
+}
+
+void WarpField::warp(cuda::DeviceArray<float>& points, cuda::DeviceArray<float>& normals, int n) const
+{
+    float live[12]; affine_to_aff12(warp_to_live_, live);
+    KF_DF(dfusion_warp_points(handle_, k_, points.ptr(), normals.empty() ? nullptr : normals.ptr(), n, live, nullptr));
 }
 
 void WarpField::warp(std::vector<Vec3f>& points, std::vector<Vec3f>& normals) const
@@ -635,11 +671,38 @@ void KinFu::dynamicfusion(cuda::Depth& depth, cuda::Cloud live_frame, cuda::Norm
         volume_->integrate(dists, camera_pose, params_.intr);
         return;
     }
+    const size_t n = (size_t)depth.rows() * depth.cols();
+    if (params_.device_resident) {
+        // kinfu.cpp:346-393 with every point set kept on the GPU: raycast -> canonical = inverse_pose * point (and the float4 ->
+        // float3 repack) -> warp twice (as the reference does, :387 and :391) -> psdf / removal -> fusion
+        df_cloud_.create(depth.rows(), depth.cols());
+        df_normals_.create(depth.rows(), depth.cols());
+        volume_->raycast(camera_pose, params_.intr, df_cloud_, df_normals_);
+        if (df_points3_.size() < 3 * n) { df_points3_.create(3 * n); df_normals3_.create(3 * n); df_warped4_.create(n); }
+        float inv12[12]; affine_to_aff12(camera_pose.inv(), inv12);
+        KF_DF(dfusion_transform_points((const float*)df_cloud_.ptr(), df_cloud_.step(), 4, df_points3_.ptr(), (size_t)depth.cols() * 12, 3,
+                                       depth.cols(), depth.rows(), inv12, nullptr));
+        KF_DF(dfusion_transform_points((const float*)df_normals_.ptr(), df_normals_.step(), 4, df_normals3_.ptr(), (size_t)depth.cols() * 12, 3,
+                                       depth.cols(), depth.rows(), nullptr, nullptr));
+        warp_->warp(df_points3_, df_normals3_, (int)n);
+        warp_->warp(df_points3_, df_normals3_, (int)n);
+        if (params_.warped_fusion) {
+            cuda::Dists dists; cuda::computeDists(depth, dists, params_.intr);
+            volume_->integrate(dists, camera_pose, params_.intr, *warp_);
+        } else {
+            KF_DF(dfusion_transform_points(df_points3_.ptr(), 3 * n * sizeof(float), 3, (float*)df_warped4_.ptr(), n * sizeof(Point), 4, (int)n, 1,
+                                           nullptr, nullptr));
+            cuda::DeviceArray<Point> warped(df_warped4_.ptr(), n);
+            volume_->surface_fusion(*warp_, warped, depth, camera_pose, params_.intr);
+        }
+        volume_->compute_points();
+        volume_->compute_normals();
+        return;
+    }
     cuda::Cloud cloud; cuda::Normals normals;
     cloud.create(depth.rows(), depth.cols());
     normals.create(depth.rows(), depth.cols());
     volume_->raycast(camera_pose, params_.intr, cloud, normals);
-    const size_t n = (size_t)depth.rows() * depth.cols();
     std::vector<Point> cloud_host(n), normal_host(n), live_host(n);
     cloud.download(cloud_host.data(), (size_t)depth.cols() * sizeof(Point));
     normals.download(normal_host.data(), (size_t)depth.cols() * sizeof(Point));

@@ -236,6 +236,13 @@ int dfusion_resize_points_normals(const float *points_dev, size_t points_pitch, 
                                   int src_cols, int src_rows, float *points_out_dev, size_t points_out_pitch, float *normals_out_dev,
                                   size_t normals_out_pitch, dfStream stream);
 
+/* The host loops of KinFu::dynamicfusion (kinfu.cpp:353-383) on the device: out(y,x) = aff * in(y,x) for a rows x cols grid of
+ * 3-vectors (aff nullable = plain re-striding), with cv::Affine3f * Vec3f float arithmetic (products summed left to right,
+ * then + t).  Element strides in floats (input >= 3, output 3 or 4; a 4th output component is set to 0), row pitches in
+ * bytes; a flat list of n points is rows = 1, cols = n.  NaN components propagate.  in != out.                        */
+int dfusion_transform_points(const float *in_dev, size_t in_pitch, int in_stride, float *out_dev, size_t out_pitch, int out_stride,
+                             int cols, int rows, const float aff[12], dfStream stream);
+
 /* device::ComputeIcpHelper::operator() (internal.hpp:91-92; kfusion/src/cuda/proj_icp.cu:30-441): one Gauss-Newton
  * accumulation of point-to-plane ICP.  aff = current estimate curr -> prev; dist2_thres = dist_thres^2 and
  * min_cosine = cos(angle_thres) (projective_icp.cpp:11-15).  sums_dev[27] = the upper triangle of A (6x6) interleaved

@@ -161,11 +161,13 @@ def test_cxx_kinfu_tracks_the_camera(tmp_path):
         f.write(np.asarray(cfg.intr, F32).tobytes())
         for d in depths:
             f.write(d.tobytes())
-    for extra in ([], ["warped"]):
-        r = subprocess.run([build.HOST_KINFU_APP, str(cfg.cols), str(cfg.rows), str(frames), str(cfg.dims[0]), str(cfg.size), fin, fout] + extra,
-                           capture_output=True, text=True, timeout=300)
+    outputs = {}
+    for mode in ("", "host", "warped", "warped-host"):
+        r = subprocess.run([build.HOST_KINFU_APP, str(cfg.cols), str(cfg.rows), str(frames), str(cfg.dims[0]), str(cfg.size), fin, fout] +
+                           ([mode] if mode else []), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         raw = np.fromfile(fout, np.uint8)
+        outputs[mode] = raw
         rec = raw[:frames * 52].reshape(frames, 52)
         tracked = rec[:, :4].copy().view(np.int32).ravel()
         poses = rec[:, 4:].copy().view(np.float32).reshape(frames, 12)
@@ -192,6 +194,10 @@ def test_cxx_kinfu_tracks_the_camera(tmp_path):
             got = poses[f]
             assert np.abs(got[9:12] - true[:3, 3]).max() < 1e-2, (f, got[9:12], true[:3, 3])
             assert np.abs(got[[2, 5, 8]] - true[:3, 2]).max() < 1e-2
+    # the device-resident data flow of dynamicfusion() (default) and the reference's host-staged one give the same bytes:
+    # poses, surface count and the whole volume
+    assert np.array_equal(outputs[""], outputs["host"]) and np.array_equal(outputs["warped"], outputs["warped-host"])
+    assert not np.array_equal(outputs[""], outputs["warped"])
     # frame 0 only: the volume is the oracle's rigid integrate of frame 0 at the identity pose, bit for bit
     r = subprocess.run([build.HOST_KINFU_APP, str(cfg.cols), str(cfg.rows), "1", str(cfg.dims[0]), str(cfg.size), fin, fout],
                        capture_output=True, text=True, timeout=300)
