@@ -36,7 +36,9 @@ def parse():
     ap.add_argument("--config", default="512", choices=sorted(synth.CONFIGS))
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--rigid", action="store_true", help="also time the rigid integrate kernel (extra JSON fields)")
+    ap.add_argument("--rigid", action="store_true", help="(kept for old command lines; the extra kernels are timed by default)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (rigid_integrate, extract_cloud, kinfu_frame)")
+    ap.add_argument("--no-kinfu", action="store_true", help="skip the kinfu_frame extra (it runs a child process; use under profilers)")
     return ap.parse_args()
 
 
@@ -87,6 +89,29 @@ def cpu_baseline(cfg, sc_inputs, vol_u32, budget_planes=4):
     return {"value": 1.0 / (t_int + t_ray), "unit": "frames/s", "cores": int(O.lib().orc_num_threads()), "kind": "port",
             "sample": "oracle (OpenMP, brute-force k-NN) integrate_warped on %d of %d Z planes scaled x%d (est %.1f s/frame) "
                       "+ full %dx%d raycast (%.2f s)" % (budget_planes, Z, Z // budget_planes, t_int, cfg.cols, cfg.rows, t_ray)}
+
+
+def kinfu_frame_ms(cfg, frames=12):
+    """Wall clock of kfusion::KinFu::operator() in dynamicfusion_amd/host/kinfu_headless on the synthetic sequence."""
+    import re
+    import subprocess
+    import tempfile
+    from dynamicfusion_amd import build
+    build.build_host()
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.asarray(cfg.intr, np.float32).tobytes())
+            for i in range(frames):
+                f.write(synth.depth_frame(cfg, i).tobytes())
+        r = subprocess.run([build.HOST_KINFU_APP, str(cfg.cols), str(cfg.rows), str(frames), str(cfg.dims[0]), str(cfg.size), fin, fout],
+                           capture_output=True, text=True, timeout=300)
+    m = re.search(r"(\d+) warp nodes, (\d+) surface points, ([0-9.]+) ms/frame", r.stdout)
+    if r.returncode != 0 or not m:
+        raise RuntimeError((r.stdout + r.stderr)[-200:])
+    return {"ms": float(m.group(3)), "warp_nodes": int(m.group(1)), "surface_points": int(m.group(2)), "frames": frames,
+            "what": "C++ kfusion::KinFu::operator() per frame, wall clock: bilateral, pyramid, normals, 19 ICP iterations, ray-cast, "
+                    "2x WarpField::warp, psdf, fusion, extract, ray-cast, resize (device-resident data flow)"}
 
 
 def main():
@@ -214,7 +239,7 @@ def main():
     achieved = alg_bytes / (ms_int * 1e-3) / 1e9
 
     extra = {}
-    if args.rigid and world == 1:
+    if not args.no_extras and world == 1:
         vol2 = TsdfVolume(cfg.dims, device=dev)
         vol2.setSize([cfg.size] * 3); vol2.setTruncDist(cfg.trunc_dist); vol2.setMaxWeight(cfg.max_weight); vol2.setPose(cfg.volume_pose)
         nr = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -263,6 +288,12 @@ def main():
                                   "achieved_GBps": b_e / (ms_e * 1e-3) / 1e9, "frac_of_peak": b_e / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                   "measured_read_GBps": read_gbps}
         del buf, src
+        # one whole KinFu::operator() frame (front-end, ICP, dynamicfusion, ray-cast) through the C++ mirror, for context
+        if not args.no_kinfu:
+            try:
+                extra["kinfu_frame"] = kinfu_frame_ms(cfg)
+            except Exception as e:      # the extras never fail the bench line
+                extra["kinfu_frame"] = {"error": str(e)[:200]}
 
     # kernel that ran + its per-voxel cache footprint; PMC traffic comes from the committed rocprofv3 --pmc passes
     lds_ok = cfg.nodes * 32 <= 160 * 1024

@@ -4,11 +4,11 @@ set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 echo "== pytest gpu"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tee gpurun_out/pytest_gpu.log | tail -3
-echo "== bench 512"; timeout 900 python bench.py --steps 40 --warmup 5 --rigid 2>&1 | tee gpurun_out/bench.log | tail -2
-echo "== bench 256"; timeout 300 python bench.py --steps 40 --warmup 5 --rigid --config 256 2>&1 | tee gpurun_out/bench_256.log | tail -2
+echo "== bench 512"; timeout 900 python bench.py --steps 40 --warmup 5 2>&1 | tee gpurun_out/bench.log | tail -2
+echo "== bench 256"; timeout 300 python bench.py --steps 40 --warmup 5 --config 256 2>&1 | tee gpurun_out/bench_256.log | tail -2
 echo "== rocprof kernel trace"
 rm -rf gpurun_out/prof gpurun_out/pmc
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --rigid > $R/gpurun_out/rocprof.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kinfu > $R/gpurun_out/rocprof.log 2>&1)
 tail -1 gpurun_out/rocprof.log
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   tag=$(echo $pass | cut -d' ' -f1)
