@@ -57,4 +57,6 @@ struct DfWarpField {
     float* w_tab; size_t w_tab_cap; bool w_tab_valid;   // per-voxel blend weights (optional, DF_INDEX_WEIGHT_TABLE)
     // device scalars for the conservative brick cull: [0] max |t_i|, [1] max sin(theta_i/2), [2] max dists
     float* bounds_dev;
+    // scratch of dfusion_warp_solve_data_term (grown on demand)
+    void* solver_ws; size_t solver_ws_cap;
 };

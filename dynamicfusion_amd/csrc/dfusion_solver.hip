@@ -1,0 +1,274 @@
+// dfusion_solver.hip -- the warp-field data term on the GPU (gfx950), SURVEY.md 8(f) "next" #4.
+//
+// Replaces WarpFieldOptimiser::optimiseWarpData -> CombinedSolver (Opt, kfusion/solvers/dynamicfusion.t:26-52) and
+// WarpField::energy_data (Ceres, kfusion/src/warp_field.cpp:117-163 with the functor of
+// kfusion/include/kfusion/optimisation.hpp:36-71).  Both hand the SAME energy to a third-party non-linear solver:
+//     E(T) = sum_v | (live_v - canonical_v) - sum_{i<k} w_vi * T_{n_vi} |^2
+// with n_vi / w_vi the k nearest nodes of canonical_v and their weights exp(-d^2 / 2 sigma^2) (getWeightsAndUpdateKNN); only
+// the node TRANSLATIONS T are unknowns (RotationDeform is declared but unused in dynamicfusion.t; the Ceres functor reads only
+// the translation slots), and there is no regularisation term in the reference (optimisation.hpp:125-157 is never added).
+// E is linear least squares, so Gauss-Newton is one linear solve: here `iters` steps of conjugate gradients on the normal
+// equations (W^T W + lambda I) delta = W^T e0, e0 the residual at the current translations, matrix-free:
+//   W   (N x M, k non-zeros per row)  : one lane per point, gathers its k node entries in slot order;
+//   W^T (M x N)                       : a node-major copy of the entries (stable radix sort by node id, so every node's list
+//                                       is in ascending point order), one wave64 per node, lane-strided partial sums then a
+//                                       butterfly -- no float atomics, so the result is reproducible (and bit-comparable
+//                                       with the restatement in oracle/dfusion_frontend_oracle.c);
+//   dot products / vector updates     : one 1024-thread workgroup (M <= 65535), fixed tree.
+// Nothing returns to the host between iterations.
+#include <hipcub/hipcub.hpp>
+#include "dfusion_internal.h"
+
+#pragma clang fp contract(off)
+
+#define SV_BLOCK 1024
+
+// ---- per point: validity, weights, node ids (sort keys), residual at the current translations
+__global__ __launch_bounds__(256) void df_sv_setup_kernel(const float* __restrict__ canonical, const float* __restrict__ live, int N, int k,
+                                                          const int* __restrict__ idx, const float* __restrict__ d2,
+                                                          const float4* __restrict__ pos_sigma, const float4* __restrict__ node_t, int M,
+                                                          float* __restrict__ w, unsigned int* __restrict__ keys,
+                                                          unsigned int* __restrict__ vals, float* __restrict__ e0)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= N) return;
+    const float cx = canonical[3 * v], cy = canonical[3 * v + 1], cz = canonical[3 * v + 2];
+    const float lx = live[3 * v], ly = live[3 * v + 1], lz = live[3 * v + 2];
+    const bool valid = !(isnan(cx) || isnan(cy) || isnan(cz) || isnan(lx) || isnan(ly) || isnan(lz));   // warp_field.cpp:130-136
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int e = v * k + j;
+        const int n = valid ? idx[e] : M;                               // invalid points sort behind every node
+        float wj = 0.f;
+        if (valid) {
+            wj = dqb_weight(d2[e], pos_sigma[n].w);                     // warp_field.cpp:238-241
+            const float4 t = node_t[n];                                 // (w, x, y, z): translation in .y .z .w
+            sx = sx + wj * t.y; sy = sy + wj * t.z; sz = sz + wj * t.w; // optimisation.hpp:58-60
+        }
+        w[e] = wj;
+        keys[e] = (unsigned int)n;
+        vals[e] = (unsigned int)e;
+    }
+    e0[3 * v] = valid ? (lx - cx) - sx : 0.f;                           // optimisation.hpp:64-66
+    e0[3 * v + 1] = valid ? (ly - cy) - sy : 0.f;
+    e0[3 * v + 2] = valid ? (lz - cz) - sz : 0.f;
+}
+
+// ---- node offsets into the sorted entry list: off[n] = first position whose key >= n (off[M] = number of valid entries)
+__global__ __launch_bounds__(256) void df_sv_offsets_kernel(const unsigned int* __restrict__ sorted_keys, int E, int M, unsigned int* __restrict__ off)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i > E) return;
+    const unsigned int cur = i < E ? min(sorted_keys[i], (unsigned int)M) : (unsigned int)M;
+    const unsigned int prev = i > 0 ? min(sorted_keys[i - 1], (unsigned int)M) : 0u;
+    const unsigned int lo = i > 0 ? prev + 1 : 0u;
+    for (unsigned int n = lo; n <= cur; ++n) off[n] = (unsigned int)i;
+}
+
+// ---- u = W p : per point, slot order
+__global__ __launch_bounds__(256) void df_sv_w_apply_kernel(const float* __restrict__ w, const unsigned int* __restrict__ keys, int N, int k,
+                                                            int M, const float* __restrict__ p, float* __restrict__ u)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= N) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int e = v * k + j;
+        const unsigned int n = keys[e];
+        if (n < (unsigned int)M) {
+            const float wj = w[e];
+            sx = sx + wj * p[3 * n]; sy = sy + wj * p[3 * n + 1]; sz = sz + wj * p[3 * n + 2];
+        }
+    }
+    u[3 * v] = sx; u[3 * v + 1] = sy; u[3 * v + 2] = sz;
+}
+
+// ---- out = W^T u (+ lambda * p) : one wave per node over its (ascending-point-order) entry list
+__global__ __launch_bounds__(256) void df_sv_wt_apply_kernel(const unsigned int* __restrict__ off, const unsigned int* __restrict__ sorted_vals,
+                                                             const float* __restrict__ w, int k, int M, const float* __restrict__ u,
+                                                             float lambda, const float* __restrict__ p, float* __restrict__ out)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (n >= M) return;
+    const unsigned int b = off[n], e_end = off[n + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (unsigned int i = b + l; i < e_end; i += 64) {
+        const unsigned int e = sorted_vals[i];
+        const unsigned int v = e / (unsigned int)k;
+        const float we = w[e];
+        sx = sx + we * u[3 * v]; sy = sy + we * u[3 * v + 1]; sz = sz + we * u[3 * v + 2];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { sx = sx + __shfl_xor(sx, o, 64); sy = sy + __shfl_xor(sy, o, 64); sz = sz + __shfl_xor(sz, o, 64); }
+    if (l == 0) {
+        if (p) { sx = sx + lambda * p[3 * n]; sy = sy + lambda * p[3 * n + 1]; sz = sz + lambda * p[3 * n + 2]; }
+        out[3 * n] = sx; out[3 * n + 1] = sy; out[3 * n + 2] = sz;
+    }
+}
+
+// ---- single-workgroup vector algebra: three independent CG recurrences (x, y, z components share the matrix)
+// block-wide sums of three values: thread t owns elements t, t + 1024, ... ; then the tree 512 .. 1 in LDS
+__device__ __forceinline__ void sv_block_sum3(float (&s)[3], float* lds /* [3][1024] */)
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lds[c * SV_BLOCK + t] = s[c];
+    __syncthreads();
+    for (int st = SV_BLOCK / 2; st >= 1; st >>= 1) {
+        if (t < st) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lds[c * SV_BLOCK + t] = lds[c * SV_BLOCK + t] + lds[c * SV_BLOCK + t + st];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s[c] = lds[c * SV_BLOCK];
+    __syncthreads();
+}
+
+// scal: [0..2] rr, [3] stop flag (as float 0/1), [4] initial energy, [5] final energy
+__global__ __launch_bounds__(SV_BLOCK) void df_sv_init_kernel(const float* __restrict__ r, int M, float* __restrict__ x, float* __restrict__ p,
+                                                              float* __restrict__ scal)
+{
+    __shared__ float lds[3 * SV_BLOCK];
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int n = threadIdx.x; n < M; n += SV_BLOCK)
+        for (int c = 0; c < 3; ++c) { const float rv = r[3 * n + c]; x[3 * n + c] = 0.f; p[3 * n + c] = rv; s[c] = s[c] + rv * rv; }
+    sv_block_sum3(s, lds);
+    if (threadIdx.x == 0) { scal[0] = s[0]; scal[1] = s[1]; scal[2] = s[2]; scal[3] = 0.f; }
+}
+
+__global__ __launch_bounds__(SV_BLOCK) void df_sv_step_kernel(const float* __restrict__ q, int M, float* __restrict__ x, float* __restrict__ r,
+                                                              float* __restrict__ p, float* __restrict__ scal)
+{
+    __shared__ float lds[3 * SV_BLOCK];
+    float pq[3] = {0.f, 0.f, 0.f};
+    for (int n = threadIdx.x; n < M; n += SV_BLOCK)
+        for (int c = 0; c < 3; ++c) pq[c] = pq[c] + p[3 * n + c] * q[3 * n + c];
+    sv_block_sum3(pq, lds);
+    float alpha[3], rr_old[3];
+    for (int c = 0; c < 3; ++c) {
+        rr_old[c] = scal[c];
+        alpha[c] = (pq[c] > 0.f && rr_old[c] > 0.f) ? rr_old[c] / pq[c] : 0.f;        // converged / degenerate component: frozen
+    }
+    float rr[3] = {0.f, 0.f, 0.f};
+    for (int n = threadIdx.x; n < M; n += SV_BLOCK)
+        for (int c = 0; c < 3; ++c) {
+            x[3 * n + c] = x[3 * n + c] + alpha[c] * p[3 * n + c];
+            const float rv = r[3 * n + c] - alpha[c] * q[3 * n + c];
+            r[3 * n + c] = rv;
+            rr[c] = rr[c] + rv * rv;
+        }
+    sv_block_sum3(rr, lds);
+    float beta[3];
+    for (int c = 0; c < 3; ++c) beta[c] = (alpha[c] != 0.f && rr_old[c] > 0.f) ? rr[c] / rr_old[c] : 0.f;
+    for (int n = threadIdx.x; n < M; n += SV_BLOCK)
+        for (int c = 0; c < 3; ++c) p[3 * n + c] = r[3 * n + c] + beta[c] * p[3 * n + c];
+    __syncthreads();
+    if (threadIdx.x == 0) for (int c = 0; c < 3; ++c) scal[c] = alpha[c] != 0.f ? rr[c] : 0.f;
+}
+
+// ---- energy = sum_v |e_v|^2 (single workgroup, same tree)
+__global__ __launch_bounds__(SV_BLOCK) void df_sv_energy_kernel(const float* __restrict__ e, int N, float* __restrict__ out)
+{
+    __shared__ float lds[3 * SV_BLOCK];
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int v = threadIdx.x; v < N; v += SV_BLOCK)
+        for (int c = 0; c < 3; ++c) s[c] = s[c] + e[3 * v + c] * e[3 * v + c];
+    sv_block_sum3(s, lds);
+    if (threadIdx.x == 0) *out = (s[0] + s[1]) + s[2];
+}
+
+// e1 = e0 - W x  (final residual, for the reported energy)
+__global__ __launch_bounds__(256) void df_sv_residual_kernel(const float* __restrict__ e0, const float* wx, int n3, float* e1)   // e1 may alias wx
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n3) e1[i] = e0[i] - wx[i];
+}
+
+// ---- write back: T = T0 + x ; translation_ = 0.5 * (0, T) * rotation_ (encodeTranslation, dual_quaternion.hpp:82-85)
+__global__ __launch_bounds__(256) void df_sv_writeback_kernel(const float4* __restrict__ rot, const float4* __restrict__ node_t,
+                                                              const float* __restrict__ x, int M, float* __restrict__ dq_out)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= M) return;
+    const float4 r4 = rot[n], t4 = node_t[n];
+    quat r; r.w = r4.x; r.x = r4.y; r.y = r4.z; r.z = r4.w;
+    quat T; T.w = 0.f; T.x = t4.y + x[3 * n]; T.y = t4.z + x[3 * n + 1]; T.z = t4.w + x[3 * n + 2];
+    const quat d = q_mul(q_scale(0.5f, T), r);
+    float* o = dq_out + 8 * (size_t)n;
+    o[0] = r.w; o[1] = r.x; o[2] = r.y; o[3] = r.z; o[4] = d.w; o[5] = d.x; o[6] = d.y; o[7] = d.z;
+}
+
+static int sv_reserve(DfWarpField* wf, size_t bytes)
+{
+    if (bytes <= wf->solver_ws_cap) return DF_OK;
+    (void)hipFree(wf->solver_ws); wf->solver_ws = nullptr; wf->solver_ws_cap = 0;
+    DF_HIP(hipMalloc(&wf->solver_ws, bytes));
+    wf->solver_ws_cap = bytes;
+    return DF_OK;
+}
+
+extern "C" int dfusion_warp_solve_data_term(DfWarpField* wf, int k, const float* canonical, const float* live, int N, int iters, float lambda,
+                                            float* dq_out, float* energy, dfStream stream)
+{
+    if (!wf || !canonical || !live || N <= 0 || iters < 0 || !(lambda >= 0.f) || wf->M <= 0 || k < 1 || k > 8 || wf->M < k) return DF_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int M = wf->M;
+    const size_t E = (size_t)N * k;
+    if (E > 0x7fffffffu) return DF_E_INVALID;
+    // workspace carve-up (256-byte aligned pieces)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_idx = take(E * 4), o_d2 = take(E * 4), o_w = take(E * 4), o_keys = take(E * 4), o_vals = take(E * 4), o_skeys = take(E * 4),
+                 o_svals = take(E * 4), o_e0 = take((size_t)N * 12), o_u = take((size_t)N * 12), o_off = take(((size_t)M + 2) * 4),
+                 o_x = take((size_t)M * 12), o_r = take((size_t)M * 12), o_p = take((size_t)M * 12), o_q = take((size_t)M * 12),
+                 o_scal = take(64), o_dq = take((size_t)M * 32);
+    size_t sort_bytes = 0;
+    DF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const unsigned int*)nullptr, (unsigned int*)nullptr, (const unsigned int*)nullptr,
+                                              (unsigned int*)nullptr, (int)E, 0, 17, st));
+    const size_t o_sort = take(sort_bytes);
+    int rc = sv_reserve(wf, off);
+    if (rc) return rc;
+    char* ws = (char*)wf->solver_ws;
+    int* idx = (int*)(ws + o_idx); float* d2 = (float*)(ws + o_d2); float* w = (float*)(ws + o_w);
+    unsigned int* keys = (unsigned int*)(ws + o_keys); unsigned int* vals = (unsigned int*)(ws + o_vals);
+    unsigned int* skeys = (unsigned int*)(ws + o_skeys); unsigned int* svals = (unsigned int*)(ws + o_svals);
+    float* e0 = (float*)(ws + o_e0); float* u = (float*)(ws + o_u); unsigned int* offs = (unsigned int*)(ws + o_off);
+    float* x = (float*)(ws + o_x); float* r = (float*)(ws + o_r); float* p = (float*)(ws + o_p); float* q = (float*)(ws + o_q);
+    float* scal = (float*)(ws + o_scal); float* dq = (float*)(ws + o_dq);
+
+    rc = dfusion_knn(wf, k, canonical, N, idx, d2, stream);           // getWeightsAndUpdateKNN's k-NN (NaN queries are masked below)
+    if (rc) return rc;
+    const dim3 gN((N + 255) / 256), gM((M + 255) / 256);
+    hipLaunchKernelGGL(df_sv_setup_kernel, gN, dim3(256), 0, st, canonical, live, N, k, idx, d2, wf->pos_sigma, wf->node_t, M, w, keys, vals, e0);
+    DF_LAUNCH_CHECK();
+    DF_HIP(hipcub::DeviceRadixSort::SortPairs(ws + o_sort, sort_bytes, keys, skeys, vals, svals, (int)E, 0, 17, st));   // stable
+    hipLaunchKernelGGL(df_sv_offsets_kernel, dim3((unsigned)((E + 1 + 255) / 256)), dim3(256), 0, st, skeys, (int)E, M, offs);
+    DF_LAUNCH_CHECK();
+    if (energy) { hipLaunchKernelGGL(df_sv_energy_kernel, dim3(1), dim3(SV_BLOCK), 0, st, e0, N, scal + 4); DF_LAUNCH_CHECK(); }
+    // r0 = W^T e0 ; p0 = r0 ; x0 = 0
+    const dim3 gW((M + 3) / 4);
+    hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, svals, w, k, M, e0, 0.f, (const float*)nullptr, r);
+    DF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(df_sv_init_kernel, dim3(1), dim3(SV_BLOCK), 0, st, r, M, x, p, scal);
+    DF_LAUNCH_CHECK();
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL(df_sv_w_apply_kernel, gN, dim3(256), 0, st, w, keys, N, k, M, p, u);
+        hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, svals, w, k, M, u, lambda, p, q);
+        hipLaunchKernelGGL(df_sv_step_kernel, dim3(1), dim3(SV_BLOCK), 0, st, q, M, x, r, p, scal);
+        DF_LAUNCH_CHECK();
+    }
+    if (energy) {
+        hipLaunchKernelGGL(df_sv_w_apply_kernel, gN, dim3(256), 0, st, w, keys, N, k, M, x, u);
+        hipLaunchKernelGGL(df_sv_residual_kernel, dim3((unsigned)((3 * (size_t)N + 255) / 256)), dim3(256), 0, st, e0, u, 3 * N, u);
+        hipLaunchKernelGGL(df_sv_energy_kernel, dim3(1), dim3(SV_BLOCK), 0, st, u, N, scal + 5);
+        DF_LAUNCH_CHECK();
+        DF_HIP(hipMemcpyAsync(energy, scal + 4, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    hipLaunchKernelGGL(df_sv_writeback_kernel, gM, dim3(256), 0, st, wf->rot, wf->node_t, x, M, dq);
+    DF_LAUNCH_CHECK();
+    if (dq_out) DF_HIP(hipMemcpyAsync(dq_out, dq, (size_t)M * 32, hipMemcpyDeviceToDevice, st));
+    return dfusion_warp_set_transforms(wf, dq, stream);
+}

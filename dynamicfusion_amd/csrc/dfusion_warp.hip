@@ -80,7 +80,7 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     if (!wf) return DF_OK;
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev);
-    (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab);
+    (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws);
     free(wf);
     return DF_OK;
 }

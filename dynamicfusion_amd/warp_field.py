@@ -2,7 +2,7 @@
 
 Mirrors /root/reference/kfusion/include/kfusion/warp_field.hpp:41-88 for the hot-path methods:
 init / getNodes / KNN / warp / setWarpToLive / buildKDTree (here: the GPU brick index).
-Solver-side methods (energy*, Ceres) are out of scope.
+energy_data (the Opt / Ceres data term of the reference) is a conjugate-gradient solve on the GPU (dfusion_warp_solve_data_term).
 """
 import ctypes as C
 
@@ -95,3 +95,15 @@ class WarpField:
                                                   _ptr(normals_dev) if normals_dev is not None else None, n,
                                                   capi.floats(aff12(self.warp_to_live_)), _stream()),
                    "dfusion_warp_points")
+
+    # ---- WarpField::energy_data (warp_field.cpp:117-163) / WarpFieldOptimiser::optimiseWarpData: the data term, on the GPU
+    def energy_data(self, canonical_dev, live_dev, iters=100, lam=0.0, k=None):
+        """Least-squares update of the node translations so that canonical + sum_i w_i T_i meets live (device [N,3] tensors).
+        Returns (dq [M,8] device tensor of the updated transforms, energy [before, after] device tensor)."""
+        k = self.k if k is None else k
+        n = int(canonical_dev.shape[0])
+        dq = torch.empty((self.M, 8), dtype=torch.float32, device=self.device)
+        en = torch.zeros(2, dtype=torch.float32, device=self.device)
+        capi.check(capi.lib().dfusion_warp_solve_data_term(self.handle, k, _ptr(canonical_dev), _ptr(live_dev), n, int(iters), float(lam),
+                                                           _ptr(dq), _ptr(en), _stream()), "dfusion_warp_solve_data_term")
+        return dq, en

@@ -199,6 +199,21 @@ int dfusion_knn(DfWarpField *wf, int k, const float *queries_dev, int N, int *id
 int dfusion_warp_points(DfWarpField *wf, int k, float *points_dev, float *normals_dev, int N,
                         const float warp_to_live[12], dfStream stream);
 
+/* WarpFieldOptimiser::optimiseWarpData (CombinedSolver / Opt energy kfusion/solvers/dynamicfusion.t:26-52) and
+ * WarpField::energy_data (Ceres, warp_field.cpp:117-163, functor optimisation.hpp:36-71): the DATA term
+ *     E(T) = sum_v | (live_v - canonical_v) - sum_{i<k} w_vi * T_{n_vi} |^2
+ * over the node translations T (n_vi, w_vi: the k nearest nodes of canonical_v and their weights; rotations are not
+ * unknowns and there is no regularisation term in the reference either).  Linear least squares: `iters` conjugate-
+ * gradient steps on (W^T W + lambda I) delta = W^T e(T_now), all on the device, then T <- T_now + delta and every node's
+ * translation_ <- 0.5 * (0, T) * rotation_ (encodeTranslation, dual_quaternion.hpp:82-85) -- the node transforms of `wf`
+ * are updated in place (the k-NN index stays valid: positions are untouched).
+ *   canonical_dev, live_dev  [N*3] packed; a NaN component in either skips the point (warp_field.cpp:130-136)
+ *   dq_out_dev (nullable)    [M*8] the updated transforms, layout of dfusion_warp_set_nodes
+ *   energy_dev (nullable)    2 floats: E before, E after
+ * Float sums use fixed trees (no atomics): the result is reproducible run to run.                                      */
+int dfusion_warp_solve_data_term(DfWarpField *wf, int k, const float *canonical_dev, const float *live_dev, int N, int iters,
+                                 float lambda, float *dq_out_dev, float *energy_dev, dfStream stream);
+
 /* The north-star kernel: per-voxel DQB (WarpField::DQB, warp_field.cpp:203-217) composed with
  * TsdfIntegrator (tsdf_volume.cu:77-104): x_c = vol2world*voxel, x_w = DQB(x_c).transform(x_c),
  * vc = world2cam*x_w, then the projective update.  Requires dfusion_warp_build_index.         */

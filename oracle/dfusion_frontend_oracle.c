@@ -349,3 +349,149 @@ ORC_API void orc_icp_sums_depth(const uint16_t *dcurr, size_t dcpitch, const flo
     A.dprev = dprev; A.dppitch = dppitch; A.nprev = nprev; A.nppitch = nppitch;
     icp_sums(&A, out, accepted);
 }
+
+/* ---------------------------------------------------------------- warp-field data term
+ * The energy the reference hands to Opt (kfusion/solvers/dynamicfusion.t:26-52) and to Ceres (warp_field.cpp:117-163,
+ * optimisation.hpp:36-71):  E(T) = sum_v | (live_v - canonical_v) - sum_i w_vi T_{n_vi} |^2  over the node translations.
+ * Opt (pinned by the reference's CMake to the niessner/Opt checkout) and Ceres are third-party and absent from the reference
+ * tree; E is linear least squares, so what they converge to is the least-squares solution reached from the current translations.
+ * This restates the conjugate-gradient solve of dynamicfusion_amd/csrc/dfusion_solver.hip operation for operation (lane-strided
+ * partial sums, butterfly / tree orders), so that the two are comparable bit for bit; the reference's own solver tests
+ * (tests/ceres_warp_test.cpp: after energy_data + warp the source vertices sit on the targets within 1e-3) pin the behaviour. */
+void orc_knn(const float *pos, int M, const float *queries, int N, int k, int *idx_out, float *d2_out);
+void orc_node_translation(const float dq[8], float out[4]);
+
+static void sv_wt_apply(const unsigned *off, const unsigned *svals, const float *w, int k, int M, const float *u, float lambda,
+                        const float *p, float *out)
+{
+    for (int n = 0; n < M; ++n) {
+        float s[3][64];
+        for (int l = 0; l < 64; ++l) {
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (unsigned i = off[n] + (unsigned)l; i < off[n + 1]; i += 64) {
+                const unsigned e = svals[i], v = e / (unsigned)k;
+                const float we = w[e];
+                sx = sx + we * u[3 * v]; sy = sy + we * u[3 * v + 1]; sz = sz + we * u[3 * v + 2];
+            }
+            s[0][l] = sx; s[1][l] = sy; s[2][l] = sz;
+        }
+        for (int o = 32; o >= 1; o >>= 1)
+            for (int c = 0; c < 3; ++c) {
+                float t[64];
+                for (int l = 0; l < 64; ++l) t[l] = s[c][l] + s[c][l ^ o];
+                memcpy(s[c], t, sizeof(t));
+            }
+        for (int c = 0; c < 3; ++c) {
+            float r = s[c][0];
+            if (p) r = r + lambda * p[3 * n + c];
+            out[3 * n + c] = r;
+        }
+    }
+}
+
+static void sv_w_apply(const float *w, const unsigned *keys, int N, int k, int M, const float *p, float *u)
+{
+    for (int v = 0; v < N; ++v) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int e = v * k + j;
+            const unsigned n = keys[e];
+            if (n < (unsigned)M) { const float wj = w[e]; sx = sx + wj * p[3 * n]; sy = sy + wj * p[3 * n + 1]; sz = sz + wj * p[3 * n + 2]; }
+        }
+        u[3 * v] = sx; u[3 * v + 1] = sy; u[3 * v + 2] = sz;
+    }
+}
+
+/* 1024-thread block sum: thread t owns elements t, t + 1024, ... (partials given), then the tree 512 .. 1 */
+static float sv_tree1024(float *part) { for (int st = 512; st >= 1; st >>= 1) for (int t = 0; t < st; ++t) part[t] = part[t] + part[t + st]; return part[0]; }
+
+static float sv_energy(const float *e, int N)
+{
+    float part[3][1024];
+    memset(part, 0, sizeof(part));
+    for (int t = 0; t < 1024; ++t)
+        for (int v = t; v < N; v += 1024)
+            for (int c = 0; c < 3; ++c) part[c][t] = part[c][t] + e[3 * v + c] * e[3 * v + c];
+    const float s0 = sv_tree1024(part[0]), s1 = sv_tree1024(part[1]), s2 = sv_tree1024(part[2]);
+    return (s0 + s1) + s2;
+}
+
+ORC_API void orc_solve_data_term(const float *pos, const float *dq, const float *sigma, int M, int k, const float *canonical,
+                                 const float *live, int N, int iters, float lambda, float *dq_out, float energy[2])
+{
+    const size_t E = (size_t)N * k;
+    int *idx = (int *)malloc(E * sizeof(int)); float *d2 = (float *)malloc(E * sizeof(float));
+    float *w = (float *)calloc(E, sizeof(float)); unsigned *keys = (unsigned *)malloc(E * sizeof(unsigned));
+    unsigned *svals = (unsigned *)malloc(E * sizeof(unsigned)); unsigned *off = (unsigned *)calloc((size_t)M + 2, sizeof(unsigned));
+    float *e0 = (float *)calloc((size_t)N * 3, sizeof(float)), *u = (float *)calloc((size_t)N * 3, sizeof(float));
+    float *node_t = (float *)malloc((size_t)M * 16);
+    float *x = (float *)calloc((size_t)M * 3, 4), *r = (float *)calloc((size_t)M * 3, 4), *p = (float *)calloc((size_t)M * 3, 4), *q = (float *)calloc((size_t)M * 3, 4);
+    for (int n = 0; n < M; ++n) orc_node_translation(dq + 8 * n, node_t + 4 * n);
+    orc_knn(pos, M, canonical, N, k, idx, d2);
+    for (int v = 0; v < N; ++v) {
+        const float *c = canonical + 3 * v, *l = live + 3 * v;
+        const int valid = !(isnan(c[0]) || isnan(c[1]) || isnan(c[2]) || isnan(l[0]) || isnan(l[1]) || isnan(l[2]));
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const size_t e = (size_t)v * k + j;
+            const int n = valid ? idx[e] : M;
+            float wj = 0.f;
+            if (valid) {
+                const float sg = sigma[n];
+                wj = (float)exp((double)(-d2[e] / (2 * sg * sg)));
+                const float *t = node_t + 4 * n;
+                sx = sx + wj * t[1]; sy = sy + wj * t[2]; sz = sz + wj * t[3];
+            }
+            w[e] = wj; keys[e] = (unsigned)n;
+        }
+        e0[3 * v] = valid ? (l[0] - c[0]) - sx : 0.f; e0[3 * v + 1] = valid ? (l[1] - c[1]) - sy : 0.f; e0[3 * v + 2] = valid ? (l[2] - c[2]) - sz : 0.f;
+    }
+    /* node-major entry list, ascending entry index inside a node (what a stable sort by node id produces) */
+    for (size_t e = 0; e < E; ++e) if (keys[e] < (unsigned)M) ++off[keys[e] + 1];
+    for (int n = 0; n < M; ++n) off[n + 1] += off[n];
+    { unsigned *cur = (unsigned *)malloc((size_t)M * sizeof(unsigned)); memcpy(cur, off, (size_t)M * sizeof(unsigned));
+      for (size_t e = 0; e < E; ++e) if (keys[e] < (unsigned)M) svals[cur[keys[e]]++] = (unsigned)e;
+      free(cur); }
+    if (energy) energy[0] = sv_energy(e0, N);
+    sv_wt_apply(off, svals, w, k, M, e0, 0.f, NULL, r);
+    float rr[3];
+    {   /* df_sv_init_kernel */
+        float part[3][1024]; memset(part, 0, sizeof(part));
+        for (int t = 0; t < 1024; ++t) for (int n = t; n < M; n += 1024) for (int c = 0; c < 3; ++c) { const float rv = r[3 * n + c]; p[3 * n + c] = rv; part[c][t] = part[c][t] + rv * rv; }
+        for (int c = 0; c < 3; ++c) rr[c] = sv_tree1024(part[c]);
+    }
+    for (int it = 0; it < iters; ++it) {
+        sv_w_apply(w, keys, N, k, M, p, u);
+        sv_wt_apply(off, svals, w, k, M, u, lambda, p, q);
+        float part[3][1024], pq[3], alpha[3], rn[3], beta[3];
+        memset(part, 0, sizeof(part));
+        for (int t = 0; t < 1024; ++t) for (int n = t; n < M; n += 1024) for (int c = 0; c < 3; ++c) part[c][t] = part[c][t] + p[3 * n + c] * q[3 * n + c];
+        for (int c = 0; c < 3; ++c) { pq[c] = sv_tree1024(part[c]); alpha[c] = (pq[c] > 0.f && rr[c] > 0.f) ? rr[c] / pq[c] : 0.f; }
+        memset(part, 0, sizeof(part));
+        for (int t = 0; t < 1024; ++t) for (int n = t; n < M; n += 1024) for (int c = 0; c < 3; ++c) {
+            x[3 * n + c] = x[3 * n + c] + alpha[c] * p[3 * n + c];
+            const float rv = r[3 * n + c] - alpha[c] * q[3 * n + c];
+            r[3 * n + c] = rv; part[c][t] = part[c][t] + rv * rv;
+        }
+        for (int c = 0; c < 3; ++c) { rn[c] = sv_tree1024(part[c]); beta[c] = (alpha[c] != 0.f && rr[c] > 0.f) ? rn[c] / rr[c] : 0.f; }
+        for (int n = 0; n < M; ++n) for (int c = 0; c < 3; ++c) p[3 * n + c] = r[3 * n + c] + beta[c] * p[3 * n + c];
+        for (int c = 0; c < 3; ++c) rr[c] = alpha[c] != 0.f ? rn[c] : 0.f;
+    }
+    if (energy) {
+        sv_w_apply(w, keys, N, k, M, x, u);
+        for (size_t i = 0; i < (size_t)N * 3; ++i) u[i] = e0[i] - u[i];
+        energy[1] = sv_energy(u, N);
+    }
+    for (int n = 0; n < M; ++n) {       /* encodeTranslation (dual_quaternion.hpp:82-85): 0.5 * (0, T) * rotation_ ; product quaternion.hpp:186-194 */
+        const float *ro = dq + 8 * n, *t = node_t + 4 * n;
+        const float aw = 0.5f * 0.f, ax = 0.5f * (t[1] + x[3 * n]), ay = 0.5f * (t[2] + x[3 * n + 1]), az = 0.5f * (t[3] + x[3 * n + 2]);
+        const float bw = ro[0], bx = ro[1], by = ro[2], bz = ro[3];
+        float *o = dq_out + 8 * n;
+        o[0] = bw; o[1] = bx; o[2] = by; o[3] = bz;
+        o[4] = ((aw * bw) - (ax * bx) - (ay * by) - (az * bz));
+        o[5] = ((aw * bx) + (ax * bw) + (ay * bz) - (az * by));
+        o[6] = ((aw * by) - (ax * bz) + (ay * bw) + (az * bx));
+        o[7] = ((aw * bz) + (ax * by) - (ay * bx) + (az * bw));
+    }
+    free(idx); free(d2); free(w); free(keys); free(svals); free(off); free(e0); free(u); free(node_t); free(x); free(r); free(p); free(q);
+}

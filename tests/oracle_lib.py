@@ -105,6 +105,8 @@ def lib():
         L.orc_icp_sums_depth.restype = None
         L.orc_icp_sums_depth.argtypes = [u16p, sz, f32p, sz, u16p, sz, f32p, sz, C.c_int, C.c_int, f32p, f32p, C.c_float, C.c_float,
                                          f32p, C.POINTER(C.c_int)]
+        L.orc_solve_data_term.restype = None
+        L.orc_solve_data_term.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_float, f32p, f32p]
         L.orc_extract_normals.restype = None
         L.orc_extract_normals.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, C.c_uint64, C.c_float, f32p]
         for name in ("orc_quat_mul",):
@@ -371,3 +373,13 @@ def icp_sums(curr, ncurr, prev, nprev, aff, intr, dist2_thres, min_cosine, depth
                                   nprev.reshape(-1), cols * 16, cols, rows, f32(aff).reshape(-1), f32(intr), dist2_thres, min_cosine, out,
                                   C.byref(acc))
     return out, acc.value
+
+
+def solve_data_term(pos, dq, sigma, canonical, live, k, iters, lam=0.0):
+    """Returns (dq_out [M, 8], energy [before, after])."""
+    pos, dq, sigma = f32(pos), f32(dq), f32(sigma)
+    canonical, live = f32(canonical), f32(live)
+    out = np.zeros_like(dq); en = np.zeros(2, np.float32)
+    lib().orc_solve_data_term(pos.reshape(-1), dq.reshape(-1), sigma, pos.shape[0], k, canonical.reshape(-1), live.reshape(-1),
+                              canonical.shape[0], iters, lam, out.reshape(-1), en)
+    return out, en
