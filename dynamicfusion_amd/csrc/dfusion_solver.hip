@@ -127,7 +127,9 @@ __device__ __forceinline__ void sv_block_sum3(float (&s)[3], float* lds /* [3][1
     __syncthreads();
 }
 
-// scal: [0..2] rr, [3] stop flag (as float 0/1), [4] initial energy, [5] final energy
+// scal: [0..2] rr (0 = component converged / frozen), [3] number of components still iterating, [4] initial energy,
+// [5] final energy, [6..8] rr of the first residual (the convergence test is relative to it)
+#define SV_REL_TOL2 1.0e-12f        // stop a component once |r|^2 <= 1e-12 |r0|^2
 __global__ __launch_bounds__(SV_BLOCK) void df_sv_init_kernel(const float* __restrict__ r, int M, float* __restrict__ x, float* __restrict__ p,
                                                               float* __restrict__ scal)
 {
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(SV_BLOCK) void df_sv_init_kernel(const float* __res
     for (int n = threadIdx.x; n < M; n += SV_BLOCK)
         for (int c = 0; c < 3; ++c) { const float rv = r[3 * n + c]; x[3 * n + c] = 0.f; p[3 * n + c] = rv; s[c] = s[c] + rv * rv; }
     sv_block_sum3(s, lds);
-    if (threadIdx.x == 0) { scal[0] = s[0]; scal[1] = s[1]; scal[2] = s[2]; scal[3] = 0.f; }
+    if (threadIdx.x == 0) { scal[0] = s[0]; scal[1] = s[1]; scal[2] = s[2]; scal[6] = s[0]; scal[7] = s[1]; scal[8] = s[2];
+                            scal[3] = (float)((s[0] > 0.f) + (s[1] > 0.f) + (s[2] > 0.f)); }
 }
 
 __global__ __launch_bounds__(SV_BLOCK) void df_sv_step_kernel(const float* __restrict__ q, int M, float* __restrict__ x, float* __restrict__ r,
@@ -166,7 +169,15 @@ __global__ __launch_bounds__(SV_BLOCK) void df_sv_step_kernel(const float* __res
     for (int n = threadIdx.x; n < M; n += SV_BLOCK)
         for (int c = 0; c < 3; ++c) p[3 * n + c] = r[3 * n + c] + beta[c] * p[3 * n + c];
     __syncthreads();
-    if (threadIdx.x == 0) for (int c = 0; c < 3; ++c) scal[c] = alpha[c] != 0.f ? rr[c] : 0.f;
+    if (threadIdx.x == 0) {
+        float active = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float keep = (alpha[c] != 0.f && rr[c] > SV_REL_TOL2 * scal[6 + c]) ? rr[c] : 0.f;
+            scal[c] = keep;
+            active += keep > 0.f ? 1.f : 0.f;
+        }
+        scal[3] = active;
+    }
 }
 
 // ---- energy = sum_v |e_v|^2 (single workgroup, same tree)
@@ -259,6 +270,12 @@ extern "C" int dfusion_warp_solve_data_term(DfWarpField* wf, int k, const float*
         hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, svals, w, k, M, u, lambda, p, q);
         hipLaunchKernelGGL(df_sv_step_kernel, dim3(1), dim3(SV_BLOCK), 0, st, q, M, x, r, p, scal);
         DF_LAUNCH_CHECK();
+        if ((it & 15) == 15 && it + 1 < iters) {            // converged components are frozen (further steps are exact no-ops): stop launching
+            float active = 1.f;
+            DF_HIP(hipMemcpyAsync(&active, scal + 3, sizeof(float), hipMemcpyDeviceToHost, st));
+            DF_HIP(hipStreamSynchronize(st));
+            if (active == 0.f) break;
+        }
     }
     if (energy) {
         hipLaunchKernelGGL(df_sv_w_apply_kernel, gN, dim3(256), 0, st, w, keys, N, k, M, x, u);

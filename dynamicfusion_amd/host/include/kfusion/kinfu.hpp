@@ -36,6 +36,7 @@ namespace kfusion
         int max_warp_nodes = 65535;
         bool warped_fusion = false;
         bool device_resident = true;   // keep dynamicfusion()'s point sets on the GPU (no host staging); false = the reference's data flow
+        int warp_solver_iterations = 100; // conjugate-gradient steps of the warp data term per frame (Opt's linearIter, kinfu.cpp:118); 0 = off
     };
 
     class KinFu
@@ -60,9 +61,9 @@ namespace kfusion
         Affine3f getCameraPose(int time = -1) const;
 
     protected:
-        /// stand-in for optimiser_->optimiseWarpData (kinfu.cpp:389; Opt/Ceres solver): override to move nodes
-        virtual void optimiseWarp(std::vector<Vec3f>& /*canonical*/, std::vector<Vec3f>& /*canonical_normals*/,
-                                  const std::vector<Vec3f>& /*live*/) {}
+        /// optimiser_->optimiseWarpData(canonical, canonical_normals, live, canonical_normals) (kinfu.cpp:389) on the host-staged data
+        /// flow (device_resident = false); the default runs WarpField::energy_data, the GPU data-term solve
+        virtual void optimiseWarp(std::vector<Vec3f>& canonical, std::vector<Vec3f>& canonical_normals, const std::vector<Vec3f>& live);
     private:
         void allocate_buffers();
         int frame_counter_;
@@ -75,7 +76,7 @@ namespace kfusion
         std::unique_ptr<WarpField> warp_;
         // scratch of the device-resident dynamicfusion()
         cuda::Cloud df_cloud_; cuda::Normals df_normals_;
-        cuda::DeviceArray<float> df_points3_, df_normals3_;
+        cuda::DeviceArray<float> df_points3_, df_normals3_, df_live3_;
         cuda::DeviceArray<Point> df_warped4_;
     };
 }

@@ -1,6 +1,7 @@
 // kfusion/warp_field.hpp -- WarpField with the reference's hot-path interface
 // (/root/reference/kfusion/include/kfusion/warp_field.hpp:41-88): host node store + GPU k-NN / DQB / warp through the
-// C-ABI.  Solver-side members (energy*, Ceres, getNodesAsMat) are out of scope.
+// C-ABI.  energy_data is the GPU data-term solve; energy_reg / getNodesAsMat are out of scope (no regularisation term is ever
+// added to the reference's problem either).
 #pragma once
 #include <vector>
 #include <kfusion/types.hpp>
@@ -41,6 +42,19 @@ namespace kfusion
         void warp(std::vector<Vec3f>& points, std::vector<Vec3f>& normals) const;
         /// the same on device-resident packed float3 arrays (n points; normals may be empty)
         void warp(cuda::DeviceArray<float>& points, cuda::DeviceArray<float>& normals, int n) const;
+        /// warp_field.cpp:117-163 (Ceres) == WarpFieldOptimiser::optimiseWarpData (Opt): least-squares update of the node
+        /// translations from the data term, solved on the GPU (dfusion_warp_solve_data_term); the nodes are updated like
+        /// WarpProblem::updateWarp / copyResultToCPUFromFloat3 do.  The normals are unused, as in the reference's energy.
+        void energy_data(const std::vector<Vec3f>& canonical_vertices, const std::vector<Vec3f>& canonical_normals,
+                         const std::vector<Vec3f>& live_vertices, const std::vector<Vec3f>& live_normals);
+        void energy_data(const cuda::DeviceArray<float>& canonical_vertices, const cuda::DeviceArray<float>& live_vertices, int n);
+        /// conjugate-gradient steps of energy_data (Opt's linearIter = 100, kinfu.cpp:118) and its damping
+        void setSolverIterations(int iters) { solver_iters_ = iters; }
+        int getSolverIterations() const { return solver_iters_; }
+        void setSolverDamping(float lambda) { solver_lambda_ = lambda; }
+        /// E before / after the last energy_data
+        float lastEnergyBefore() const { return last_energy_[0]; }
+        float lastEnergyAfter() const { return last_energy_[1]; }
         /// warp_field.cpp:247-251; results via getRetIndex / getDistSquared like the reference's globals
         void KNN(Vec3f point) const;
         std::vector<float>* getDistSquared() const { return &out_dist_sqr_; }
@@ -62,5 +76,8 @@ namespace kfusion
         mutable std::vector<size_t> ret_index_;
         mutable bool index_ok_;
         mutable const void* index_volume_;
+        int solver_iters_ = 100;
+        float solver_lambda_ = 0.f;
+        float last_energy_[2] = {0.f, 0.f};
     };
 }

@@ -347,6 +347,30 @@ void WarpField::commit(bool positions_changed)
     KF_HIP(hipDeviceSynchronize());                       // the temporaries above are freed on return
 }
 
+void WarpField::energy_data(const cuda::DeviceArray<float>& canonical_vertices, const cuda::DeviceArray<float>& live_vertices, int n)
+{
+    const size_t M = nodes_.size();
+    if (!M || n <= 0) return;
+    DeviceArray<float> d_dq(M * 8), d_energy(2);
+    KF_DF(dfusion_warp_solve_data_term(handle_, k_, canonical_vertices.ptr(), live_vertices.ptr(), n, solver_iters_, solver_lambda_, d_dq.ptr(),
+                                       d_energy.ptr(), nullptr));
+    std::vector<float> dq(M * 8);
+    d_dq.download(dq.data());                              // the host node store follows (updateWarp, optimisation.hpp:211-218)
+    d_energy.download(last_energy_);
+    for (size_t i = 0; i < M; ++i) std::memcpy((void*)nodes_[i].transform.raw(), &dq[8 * i], 32);
+}
+
+void WarpField::energy_data(const std::vector<Vec3f>& canonical_vertices, const std::vector<Vec3f>& /*canonical_normals*/,
+                            const std::vector<Vec3f>& live_vertices, const std::vector<Vec3f>& /*live_normals*/)
+{
+    const size_t n = std::min(canonical_vertices.size(), live_vertices.size());
+    if (!n) return;
+    DeviceArray<float> c, l;
+    c.upload(canonical_vertices[0].val, n * 3);
+    l.upload(live_vertices[0].val, n * 3);
+    energy_data(c, l, (int)n);
+}
+
 void WarpField::ensureIndex(const cuda::TsdfVolume& volume) const
 {
     if (index_ok_ && index_volume_ == &volume) return;
@@ -612,6 +636,13 @@ void KinFu::reset()                                                    // kinfu.
     volume_->clear();
 }
 
+void KinFu::optimiseWarp(std::vector<Vec3f>& canonical, std::vector<Vec3f>& canonical_normals, const std::vector<Vec3f>& live)
+{
+    if (params_.warp_solver_iterations <= 0) return;
+    warp_->setSolverIterations(params_.warp_solver_iterations);
+    warp_->energy_data(canonical, canonical_normals, live, canonical_normals);
+}
+
 Affine3f KinFu::getCameraPose(int time) const                          // kinfu.cpp:213-218
 {
     if (time > (int)poses_.size() || time < 0) time = (int)poses_.size() - 1;
@@ -635,7 +666,11 @@ bool KinFu::operator()(const cuda::Depth& depth, const cuda::Image& /*image*/)  
         volume_->compute_normals();
         // warp_->init(cloud): the reference's cv::Mat overload keeps every 50th point (warp_field.cpp:49-60) and leaves the rest of
         // the node array zero-initialised; here only the kept points become nodes, with a larger stride if they would not fit
-        const std::vector<Point>& cloud = volume_->get_cloud_host();
+        // The extraction order depends on atomics (here and in the reference); the seed set must not, or every run would deform
+        // differently: the cloud is put in (z, y, x) order before sampling.
+        std::vector<Point> cloud = volume_->get_cloud_host();
+        std::sort(cloud.begin(), cloud.end(), [](const Point& a, const Point& b) {
+            return a.z != b.z ? a.z < b.z : (a.y != b.y ? a.y < b.y : a.x < b.x); });
         size_t step = 50;
         const size_t max_nodes = (size_t)std::max(1, std::min(params_.max_warp_nodes, 65535));
         while (cloud.size() / step > max_nodes) ++step;
@@ -684,8 +719,15 @@ void KinFu::dynamicfusion(cuda::Depth& depth, cuda::Cloud live_frame, cuda::Norm
                                        depth.cols(), depth.rows(), inv12, nullptr));
         KF_DF(dfusion_transform_points((const float*)df_normals_.ptr(), df_normals_.step(), 4, df_normals3_.ptr(), (size_t)depth.cols() * 12, 3,
                                        depth.cols(), depth.rows(), nullptr, nullptr));
-        warp_->warp(df_points3_, df_normals3_, (int)n);
-        warp_->warp(df_points3_, df_normals3_, (int)n);
+        warp_->warp(df_points3_, df_normals3_, (int)n);                      // :387
+        if (params_.warp_solver_iterations > 0) {                           // :389 optimiser_->optimiseWarpData(canonical, normals, live, normals)
+            if (df_live3_.size() < 3 * n) df_live3_.create(3 * n);
+            KF_DF(dfusion_transform_points((const float*)live_frame.ptr(), live_frame.step(), 4, df_live3_.ptr(), (size_t)depth.cols() * 12, 3,
+                                           depth.cols(), depth.rows(), nullptr, nullptr));
+            warp_->setSolverIterations(params_.warp_solver_iterations);
+            warp_->energy_data(df_points3_, df_live3_, (int)n);
+        }
+        warp_->warp(df_points3_, df_normals3_, (int)n);                      // :391
         if (params_.warped_fusion) {
             cuda::Dists dists; cuda::computeDists(depth, dists, params_.intr);
             volume_->integrate(dists, camera_pose, params_.intr, *warp_);
@@ -716,7 +758,7 @@ void KinFu::dynamicfusion(cuda::Depth& depth, cuda::Cloud live_frame, cuda::Norm
     }
     std::vector<Vec3f> canonical_visible(canonical);
     warp_->warp(canonical, canonical_normals);                          // :387
-    optimiseWarp(canonical, canonical_normals, live);                   // :389 (solver out of scope: no-op unless overridden)
+    optimiseWarp(canonical, canonical_normals, live);                   // :389
     warp_->warp(canonical, canonical_normals);                          // :391
     if (params_.warped_fusion) {
         cuda::Dists dists; cuda::computeDists(depth, dists, params_.intr);

@@ -454,11 +454,11 @@ ORC_API void orc_solve_data_term(const float *pos, const float *dq, const float 
       free(cur); }
     if (energy) energy[0] = sv_energy(e0, N);
     sv_wt_apply(off, svals, w, k, M, e0, 0.f, NULL, r);
-    float rr[3];
+    float rr[3], rr0[3];
     {   /* df_sv_init_kernel */
         float part[3][1024]; memset(part, 0, sizeof(part));
         for (int t = 0; t < 1024; ++t) for (int n = t; n < M; n += 1024) for (int c = 0; c < 3; ++c) { const float rv = r[3 * n + c]; p[3 * n + c] = rv; part[c][t] = part[c][t] + rv * rv; }
-        for (int c = 0; c < 3; ++c) rr[c] = sv_tree1024(part[c]);
+        for (int c = 0; c < 3; ++c) rr0[c] = rr[c] = sv_tree1024(part[c]);
     }
     for (int it = 0; it < iters; ++it) {
         sv_w_apply(w, keys, N, k, M, p, u);
@@ -475,7 +475,7 @@ ORC_API void orc_solve_data_term(const float *pos, const float *dq, const float 
         }
         for (int c = 0; c < 3; ++c) { rn[c] = sv_tree1024(part[c]); beta[c] = (alpha[c] != 0.f && rr[c] > 0.f) ? rn[c] / rr[c] : 0.f; }
         for (int n = 0; n < M; ++n) for (int c = 0; c < 3; ++c) p[3 * n + c] = r[3 * n + c] + beta[c] * p[3 * n + c];
-        for (int c = 0; c < 3; ++c) rr[c] = alpha[c] != 0.f ? rn[c] : 0.f;
+        for (int c = 0; c < 3; ++c) rr[c] = (alpha[c] != 0.f && rn[c] > 1.0e-12f * rr0[c]) ? rn[c] : 0.f;   /* converged: frozen */
     }
     if (energy) {
         sv_w_apply(w, keys, N, k, M, x, u);

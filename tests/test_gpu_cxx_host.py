@@ -162,7 +162,7 @@ def test_cxx_kinfu_tracks_the_camera(tmp_path):
         for d in depths:
             f.write(d.tobytes())
     outputs = {}
-    for mode in ("", "host", "warped", "warped-host"):
+    for mode in ("nosolver", "", "host", "warped", "warped-host"):
         r = subprocess.run([build.HOST_KINFU_APP, str(cfg.cols), str(cfg.rows), str(frames), str(cfg.dims[0]), str(cfg.size), fin, fout] +
                            ([mode] if mode else []), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -192,12 +192,14 @@ def test_cxx_kinfu_tracks_the_camera(tmp_path):
         for f in range(1, frames):
             true = synth.affine_mul(synth.affine_inv(synth.camera_pose(cfg, 0)), synth.camera_pose(cfg, 2 * f))
             got = poses[f]
-            assert np.abs(got[9:12] - true[:3, 3]).max() < 1e-2, (f, got[9:12], true[:3, 3])
-            assert np.abs(got[[2, 5, 8]] - true[:3, 2]).max() < 1e-2
+            # with the warp solver on, the (unregularised, as in the reference) deformation absorbs part of the camera motion
+            tol = 1e-2 if mode == "nosolver" else 5e-2
+            assert np.abs(got[9:12] - true[:3, 3]).max() < tol, (mode, f, got[9:12], true[:3, 3])
+            assert np.abs(got[[2, 5, 8]] - true[:3, 2]).max() < tol
     # the device-resident data flow of dynamicfusion() (default) and the reference's host-staged one give the same bytes:
     # poses, surface count and the whole volume
     assert np.array_equal(outputs[""], outputs["host"]) and np.array_equal(outputs["warped"], outputs["warped-host"])
-    assert not np.array_equal(outputs[""], outputs["warped"])
+    assert not np.array_equal(outputs[""], outputs["warped"]) and not np.array_equal(outputs[""], outputs["nosolver"])
     # frame 0 only: the volume is the oracle's rigid integrate of frame 0 at the identity pose, bit for bit
     r = subprocess.run([build.HOST_KINFU_APP, str(cfg.cols), str(cfg.rows), "1", str(cfg.dims[0]), str(cfg.size), fin, fout],
                        capture_output=True, text=True, timeout=300)
