@@ -36,7 +36,8 @@ namespace kfusion
         int max_warp_nodes = 65535;
         bool warped_fusion = false;
         bool device_resident = true;   // keep dynamicfusion()'s point sets on the GPU (no host staging); false = the reference's data flow
-        int warp_solver_iterations = 100; // conjugate-gradient steps of the warp data term per frame (Opt's linearIter, kinfu.cpp:118); 0 = off
+        int warp_solver_iterations = 40;  // conjugate-gradient steps of the warp data term per frame, 0 = off (Opt is capped at linearIter = 100,
+                                          // kinfu.cpp:118; on the synthetic sequence the energy has converged to 4 digits by 40)
     };
 
     class KinFu

@@ -52,7 +52,8 @@ namespace kfusion
         void setSolverIterations(int iters) { solver_iters_ = iters; }
         int getSolverIterations() const { return solver_iters_; }
         void setSolverDamping(float lambda) { solver_lambda_ = lambda; }
-        /// E before / after the last energy_data
+        /// E before / after the last energy_data (evaluated only when asked for: two extra passes over the points)
+        void setTrackEnergy(bool on) { track_energy_ = on; }
         float lastEnergyBefore() const { return last_energy_[0]; }
         float lastEnergyAfter() const { return last_energy_[1]; }
         /// warp_field.cpp:247-251; results via getRetIndex / getDistSquared like the reference's globals
@@ -79,5 +80,6 @@ namespace kfusion
         int solver_iters_ = 100;
         float solver_lambda_ = 0.f;
         float last_energy_[2] = {0.f, 0.f};
+        bool track_energy_ = false;
     };
 }

@@ -353,10 +353,10 @@ void WarpField::energy_data(const cuda::DeviceArray<float>& canonical_vertices, 
     if (!M || n <= 0) return;
     DeviceArray<float> d_dq(M * 8), d_energy(2);
     KF_DF(dfusion_warp_solve_data_term(handle_, k_, canonical_vertices.ptr(), live_vertices.ptr(), n, solver_iters_, solver_lambda_, d_dq.ptr(),
-                                       d_energy.ptr(), nullptr));
+                                       track_energy_ ? d_energy.ptr() : nullptr, nullptr));
     std::vector<float> dq(M * 8);
     d_dq.download(dq.data());                              // the host node store follows (updateWarp, optimisation.hpp:211-218)
-    d_energy.download(last_energy_);
+    if (track_energy_) d_energy.download(last_energy_);
     for (size_t i = 0; i < M; ++i) std::memcpy((void*)nodes_[i].transform.raw(), &dq[8 * i], 32);
 }
 

@@ -355,8 +355,8 @@ ORC_API void orc_icp_sums_depth(const uint16_t *dcurr, size_t dcpitch, const flo
  * optimisation.hpp:36-71):  E(T) = sum_v | (live_v - canonical_v) - sum_i w_vi T_{n_vi} |^2  over the node translations.
  * Opt (pinned by the reference's CMake to the niessner/Opt checkout) and Ceres are third-party and absent from the reference
  * tree; E is linear least squares, so what they converge to is the least-squares solution reached from the current translations.
- * This restates the conjugate-gradient solve of dynamicfusion_amd/csrc/dfusion_solver.hip operation for operation (lane-strided
- * partial sums, butterfly / tree orders), so that the two are comparable bit for bit; the reference's own solver tests
+ * This restates the conjugate-gradient solve of dynamicfusion_amd/csrc/dfusion_solver.hip operation for operation (thread-strided
+ * partial sums, tree orders), so that the two are comparable bit for bit; the reference's own solver tests
  * (tests/ceres_warp_test.cpp: after energy_data + warp the source vertices sit on the targets within 1e-3) pin the behaviour. */
 void orc_knn(const float *pos, int M, const float *queries, int N, int k, int *idx_out, float *d2_out);
 void orc_node_translation(const float dq[8], float out[4]);
@@ -365,24 +365,18 @@ static void sv_wt_apply(const unsigned *off, const unsigned *svals, const float 
                         const float *p, float *out)
 {
     for (int n = 0; n < M; ++n) {
-        float s[3][64];
-        for (int l = 0; l < 64; ++l) {
+        float part[3][256];
+        for (int t = 0; t < 256; ++t) {                      /* thread t of the node's workgroup: entries t, t + 256, ... */
             float sx = 0.f, sy = 0.f, sz = 0.f;
-            for (unsigned i = off[n] + (unsigned)l; i < off[n + 1]; i += 64) {
+            for (unsigned i = off[n] + (unsigned)t; i < off[n + 1]; i += 256) {
                 const unsigned e = svals[i], v = e / (unsigned)k;
                 const float we = w[e];
                 sx = sx + we * u[3 * v]; sy = sy + we * u[3 * v + 1]; sz = sz + we * u[3 * v + 2];
             }
-            s[0][l] = sx; s[1][l] = sy; s[2][l] = sz;
+            part[0][t] = sx; part[1][t] = sy; part[2][t] = sz;
         }
-        for (int o = 32; o >= 1; o >>= 1)
-            for (int c = 0; c < 3; ++c) {
-                float t[64];
-                for (int l = 0; l < 64; ++l) t[l] = s[c][l] + s[c][l ^ o];
-                memcpy(s[c], t, sizeof(t));
-            }
         for (int c = 0; c < 3; ++c) {
-            float r = s[c][0];
+            float r = tree256(part[c]);                      /* pairs (t, t + s), s = 128 .. 1 */
             if (p) r = r + lambda * p[3 * n + c];
             out[3 * n + c] = r;
         }
@@ -475,7 +469,7 @@ ORC_API void orc_solve_data_term(const float *pos, const float *dq, const float 
         }
         for (int c = 0; c < 3; ++c) { rn[c] = sv_tree1024(part[c]); beta[c] = (alpha[c] != 0.f && rr[c] > 0.f) ? rn[c] / rr[c] : 0.f; }
         for (int n = 0; n < M; ++n) for (int c = 0; c < 3; ++c) p[3 * n + c] = r[3 * n + c] + beta[c] * p[3 * n + c];
-        for (int c = 0; c < 3; ++c) rr[c] = (alpha[c] != 0.f && rn[c] > 1.0e-12f * rr0[c]) ? rn[c] : 0.f;   /* converged: frozen */
+        for (int c = 0; c < 3; ++c) rr[c] = (alpha[c] != 0.f && rn[c] > 1.0e-10f * rr0[c]) ? rn[c] : 0.f;   /* converged: frozen */
     }
     if (energy) {
         sv_w_apply(w, keys, N, k, M, x, u);
