@@ -38,6 +38,7 @@ struct DfWarpView {
     // brick index
     const uint32_t* brick_off; // [nb+1]
     const uint16_t* brick_list;
+    const float* brick_thr;    // [nb] list radius: nodes outside brick b's list are farther than this from its centre
     int bx, by, bz;            // brick grid over the GLOBAL volume
 };
 
@@ -46,10 +47,11 @@ struct DfWarpField {
     int M, cap;
     float4 *pos_sigma, *rot, *dual, *node_t;
     // index
-    uint32_t* brick_off; uint32_t* brick_cnt; uint16_t* brick_list;
+    uint32_t* brick_off; uint32_t* brick_cnt; uint16_t* brick_list; float* brick_thr;
     size_t off_cap, list_cap;
     int bx, by, bz, k_built;
     int geom_dims[3]; float geom_vs[3]; float geom_aff[12];
+    float geom_inv[12]; bool geom_inv_ok;      // world -> volume (locates the brick of a query point)
     bool index_valid;
     // per-voxel k-NN table (optional, DF_INDEX_VOXEL_TABLE)
     uint16_t* knn_tab; size_t knn_tab_cap;      // elements (uint16)
@@ -59,4 +61,6 @@ struct DfWarpField {
     float* bounds_dev;
     // scratch of dfusion_warp_solve_data_term (grown on demand)
     void* solver_ws; size_t solver_ws_cap;
+    // points an indexed k-NN / warp pass left to the scan kernel: [0] count, [1..] ids
+    int* pt_ids; size_t pt_ids_cap;
 };

@@ -79,8 +79,8 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
 {
     if (!wf) return DF_OK;
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
-    (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev);
-    (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws);
+    (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
+    (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids);
     free(wf);
     return DF_OK;
 }
@@ -228,6 +228,38 @@ __device__ __forceinline__ void dqb_blend(const DfWarpView& W, const float (&bd)
 // One lane per query point; all M node positions stream through LDS in chunks (broadcast reads).
 #define DF_PT_CHUNK 1024
 
+// what a point kernel does with the k nearest nodes of point i: MODE 0 writes them out (WarpField::KNN), MODE 1 warps the point
+// (and its normal) in place (WarpField::warp, warp_field.cpp:185-192; the index drift on NaN is fixed)
+template <int K, int MODE>
+__device__ __forceinline__ void df_point_finish(const DfWarpView& W, int i, f3 q, const float (&bd)[K], const int (&bi)[K],
+                                                int* __restrict__ idx_out, float* __restrict__ d2_out, float* __restrict__ points,
+                                                float* __restrict__ normals, const DfAff& to_live)
+{
+    if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) { idx_out[(size_t)i * K + j] = bi[j]; d2_out[(size_t)i * K + j] = bd[j]; }
+    } else {
+        bool skip = q.x != q.x;
+        f3 nq = mk3(0.f, 0.f, 0.f);
+        if (normals) { nq = mk3(normals[3 * (size_t)i], normals[3 * (size_t)i + 1], normals[3 * (size_t)i + 2]); skip = skip || (nq.x != nq.x); }
+        if (skip) return;
+        quat rot, dual;
+        dqb_blend<K>(W, bd, bi, &rot, &dual);
+        f3 p = dq_transform(rot, dual, q);
+        // cv::Affine3f * Vec3f : left-associated, no fma (opencv affine.hpp)
+        const float* A = to_live.R; const float* T = to_live.t;
+        points[3 * (size_t)i]     = A[0] * p.x + A[1] * p.y + A[2] * p.z + T[0];
+        points[3 * (size_t)i + 1] = A[3] * p.x + A[4] * p.y + A[5] * p.z + T[1];
+        points[3 * (size_t)i + 2] = A[6] * p.x + A[7] * p.y + A[8] * p.z + T[2];
+        if (normals) {
+            f3 nn = dq_transform(rot, dual, nq);      // reference translates normals too (warp_field.cpp:191)
+            normals[3 * (size_t)i]     = A[0] * nn.x + A[1] * nn.y + A[2] * nn.z + T[0];
+            normals[3 * (size_t)i + 1] = A[3] * nn.x + A[4] * nn.y + A[5] * nn.z + T[1];
+            normals[3 * (size_t)i + 2] = A[6] * nn.x + A[7] * nn.y + A[8] * nn.z + T[2];
+        }
+    }
+}
+
 template <int K, int MODE /* 0 = knn out, 1 = warp points */>
 __global__ __launch_bounds__(256) void df_points_kernel(DfWarpView W, const float* __restrict__ queries, int N,
                                                         int* __restrict__ idx_out, float* __restrict__ d2_out,
@@ -253,29 +285,128 @@ __global__ __launch_bounds__(256) void df_points_kernel(DfWarpView W, const floa
         }
     }
     if (!active) return;
-    if (MODE == 0) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) { idx_out[(size_t)i * K + j] = bi[j]; d2_out[(size_t)i * K + j] = bd[j]; }
-    } else {
-        // warp_field.cpp:185-192 (index drift fixed: SURVEY.md 9.6)
-        bool skip = q.x != q.x;
-        f3 nq = mk3(0.f, 0.f, 0.f);
-        if (normals) { nq = mk3(normals[3 * (size_t)i], normals[3 * (size_t)i + 1], normals[3 * (size_t)i + 2]); skip = skip || (nq.x != nq.x); }
-        if (skip) return;
-        quat rot, dual;
-        dqb_blend<K>(W, bd, bi, &rot, &dual);
-        f3 p = dq_transform(rot, dual, q);
-        // cv::Affine3f * Vec3f : left-associated, no fma (opencv affine.hpp)
-        const float* A = to_live.R; const float* T = to_live.t;
-        points[3 * (size_t)i]     = A[0] * p.x + A[1] * p.y + A[2] * p.z + T[0];
-        points[3 * (size_t)i + 1] = A[3] * p.x + A[4] * p.y + A[5] * p.z + T[1];
-        points[3 * (size_t)i + 2] = A[6] * p.x + A[7] * p.y + A[8] * p.z + T[2];
-        if (normals) {
-            f3 nn = dq_transform(rot, dual, nq);      // reference translates normals too (warp_field.cpp:191)
-            normals[3 * (size_t)i]     = A[0] * nn.x + A[1] * nn.y + A[2] * nn.z + T[0];
-            normals[3 * (size_t)i + 1] = A[3] * nn.x + A[4] * nn.y + A[5] * nn.z + T[1];
-            normals[3 * (size_t)i + 2] = A[6] * nn.x + A[7] * nn.y + A[8] * nn.z + T[2];
+    df_point_finish<K, MODE>(W, i, q, bd, bi, idx_out, d2_out, points, normals, to_live);
+}
+
+// Exact k-NN of arbitrary points through the brick candidate lists: a point that rounds to a voxel of brick B lies inside B's
+// cell, whose half-diagonal the lists were built for, so top-k over B's list (node-index order, like the brute-force scan) is the
+// brute-force answer; points outside the grid search the nearest boundary brick.  Every result is verified by a distance bound
+// (see the end of the kernel) and the rare points that fail it are handled by the scan kernel in a second launch; NaN points
+// find nothing, as in the scan.
+// ~50-150 candidates per point instead of all M.
+struct DfPointIndex { DfAff world2vol, vol2world; int X, Y, Z; float ivx, ivy, ivz, vsx, vsy, vsz; };
+template <int K, int MODE>
+__global__ __launch_bounds__(64) void df_points_index_kernel(DfWarpView W, DfPointIndex G, const float* __restrict__ queries, int N,
+                                                             int* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                             float* __restrict__ points, float* __restrict__ normals, DfAff to_live,
+                                                             int* __restrict__ out_ids, int* __restrict__ out_count)
+{
+    // One wave64 per workgroup (so __syncthreads is a wave-level barrier and every loop below is wave-uniform).  Neighbouring
+    // query points (pixels) mostly share a brick: the wave visits its DISTINCT bricks one after the other, stages each brick's
+    // candidate positions through LDS with coalesced loads (a per-lane walk of the list is a chain of dependent global loads --
+    // measured no faster than scanning all nodes), and the lanes of that brick rank them from LDS.
+    __shared__ float4 s_pos[64];
+    __shared__ int s_id[64];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
+    const bool active = i < N;
+    f3 q = mk3(0.f, 0.f, 0.f);
+    const float* src = MODE == 0 ? queries : points;
+    if (active) q = mk3(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2]);
+    float bd[K]; int bi[K];
+    topk_init<K>(bd, bi);
+    const bool is_nan = (q.x != q.x) || (q.y != q.y) || (q.z != q.z);
+    int brick = -1;                                        // -1: nothing to search (inactive / NaN)
+    float dq = 0.f;                                        // distance to the centre of the brick that is searched
+    if (active && !is_nan) {
+        const f3 v = aff_mul(G.world2vol, q);
+        // nearest brick (clamped to the grid: a point outside is tested against the closest boundary brick)
+        const float fx = fminf(fmaxf(floorf(v.x * G.ivx + 0.5f), 0.f), (float)(G.X - 1));
+        const float fy = fminf(fmaxf(floorf(v.y * G.ivy + 0.5f), 0.f), (float)(G.Y - 1));
+        const float fz = fminf(fmaxf(floorf(v.z * G.ivz + 0.5f), 0.f), (float)(G.Z - 1));
+        const int bxx = (int)fx / DF_BRICK, byy = (int)fy / DF_BRICK, bzz = (int)fz / DF_BRICK;
+        if (fx == fx && fy == fy && fz == fz) {
+            brick = (bzz * W.by + byy) * W.bx + bxx;
+            const f3 c = aff_mul(G.vol2world, mk3(((float)(bxx * DF_BRICK) + 3.5f) * G.vsx, ((float)(byy * DF_BRICK) + 3.5f) * G.vsy,
+                                                  ((float)(bzz * DF_BRICK) + 3.5f) * G.vsz));          // as df_brick_index_kernel
+            const f3 dc = sub3(q, c);
+            dq = sqrtf(dot3(dc, dc));
         }
+    }
+    unsigned long long todo = __ballot(brick != -1);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b = __shfl(brick, leader, 64);
+        const bool mine = brick == b;
+        todo &= ~__ballot(mine);
+        const uint32_t beg = W.brick_off[b], end = W.brick_off[b + 1];
+        for (uint32_t c0 = beg; c0 < end; c0 += 64) {
+            const int n = (int)min(64u, end - c0);
+            __syncthreads();
+            if (lane < n) {
+                const int j = (int)W.brick_list[c0 + lane];
+                s_id[lane] = j;
+                s_pos[lane] = W.pos_sigma[j];
+            }
+            __syncthreads();
+            if (mine)
+                for (int c = 0; c < n; ++c) {
+                    const float4 p = s_pos[c];
+                    topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), s_id[c]);
+                }
+        }
+    }
+    // Exactness check: a node outside the brick's list is farther than thr from the brick centre, hence farther than thr - dq from
+    // the query; if the k-th distance found is within that, nothing outside the list can belong to the k nearest.  (Always true for
+    // a point inside the brick's cell; for a point outside the grid it decides whether the boundary brick's list suffices.)  The rare
+    // failures -- and inf coordinates -- are listed for the scan kernel (second launch).
+    bool outside = false;
+    if (active && !is_nan) {
+        const float slack = brick >= 0 ? (W.brick_thr[brick] - dq) * 0.9999f - 1e-6f : -1.f;
+        outside = !(slack > 0.f && bd[K - 1] <= slack * slack);
+        if (outside) out_ids[atomicAdd(out_count, 1)] = i;
+    }
+    if (!active || outside) return;
+    df_point_finish<K, MODE>(W, i, q, bd, bi, idx_out, d2_out, points, normals, to_live);
+}
+
+// Second pass of the indexed query: ONE WAVE per listed point.  The lanes split the nodes (lane, lane + 64, ...), each keeps its own
+// top-K, and the wave merges them with K pops of the lexicographic minimum (distance, node index) -- the order of a serial scan in
+// node-index order with strict '<' insertion, ties to the lower index.  A serial scan by one lane takes ~0.5 ms whatever the number
+// of points (it is the depth of df_points_kernel); this takes M / 64 steps.
+template <int K, int MODE>
+__global__ __launch_bounds__(256) void df_points_wave_kernel(DfWarpView W, const float* __restrict__ queries, int* __restrict__ idx_out,
+                                                             float* __restrict__ d2_out, float* __restrict__ points,
+                                                             float* __restrict__ normals, DfAff to_live, const int* __restrict__ ids,
+                                                             const int* __restrict__ id_count)
+{
+    const int lane = threadIdx.x & 63;
+    const int n_ids = *id_count;
+    for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < n_ids; slot += gridDim.x * 4) {      // wave-uniform
+        const int i = ids[slot];
+        const float* src = MODE == 0 ? queries : points;
+        const f3 q = mk3(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2]);
+        float bd[K]; int bi[K];
+        topk_init<K>(bd, bi);
+        for (int j = lane; j < W.M; j += 64) {
+            const float4 p = W.pos_sigma[j];
+            topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), j);
+        }
+        float rd[K]; int ri[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const float m = wave_min_f32(bd[0]);
+            int cand = (bd[0] == m) ? bi[0] : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+            rd[r] = m; ri[r] = cand;
+            if (bd[0] == m && bi[0] == cand) {              // the owner pops its head
+#pragma unroll
+                for (int t = 0; t < K - 1; ++t) { bd[t] = bd[t + 1]; bi[t] = bi[t + 1]; }
+                bd[K - 1] = __uint_as_float(0x7f800000u); bi[K - 1] = -1;
+            }
+        }
+        if (lane == 0) df_point_finish<K, MODE>(W, i, q, rd, ri, idx_out, d2_out, points, normals, to_live);
     }
 }
 
@@ -283,7 +414,7 @@ static DfWarpView df_view(const DfWarpField* wf)
 {
     DfWarpView W;
     W.pos_sigma = wf->pos_sigma; W.rot = wf->rot; W.dual = wf->dual; W.node_t = wf->node_t; W.M = wf->M;
-    W.brick_off = wf->brick_off; W.brick_list = wf->brick_list; W.bx = wf->bx; W.by = wf->by; W.bz = wf->bz;
+    W.brick_off = wf->brick_off; W.brick_list = wf->brick_list; W.brick_thr = wf->brick_thr; W.bx = wf->bx; W.by = wf->by; W.bz = wf->bz;
     return W;
 }
 
@@ -300,12 +431,56 @@ static DfWarpView df_view(const DfWarpField* wf)
         default: return DF_E_INVALID;                     \
     }
 
+extern "C" int dfusion_warp_index_info(const DfWarpField* wf, unsigned long long* total_entries, unsigned int* n_bricks, int* k_built)
+{
+    if (!wf || !wf->index_valid) return DF_E_NO_INDEX;
+    const size_t nb = (size_t)wf->bx * wf->by * wf->bz;
+    uint32_t total = 0;
+    DF_HIP(hipMemcpy(&total, wf->brick_off + nb, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (total_entries) *total_entries = total;
+    if (n_bricks) *n_bricks = (unsigned int)nb;
+    if (k_built) *k_built = wf->k_built;
+    return DF_OK;
+}
+
+// the brick lists serve point queries when an index for >= k neighbours exists (a list built for k_built >= k contains the k nearest)
+// [0] = count, [1..] = ids of the points the indexed pass left to the scan; zeroed per call
+static int df_point_fallback_reserve(DfWarpField* wf, int N, hipStream_t st)
+{
+    if ((size_t)N + 1 > wf->pt_ids_cap) {
+        (void)hipFree(wf->pt_ids); wf->pt_ids = nullptr; wf->pt_ids_cap = 0;
+        DF_HIP(hipMalloc((void**)&wf->pt_ids, ((size_t)N + 1) * sizeof(int)));
+        wf->pt_ids_cap = (size_t)N + 1;
+    }
+    DF_HIP(hipMemsetAsync(wf->pt_ids, 0, sizeof(int), st));
+    return DF_OK;
+}
+
+static bool df_point_index(const DfWarpField* wf, int k, DfPointIndex* G)
+{
+    if (!wf->index_valid || wf->k_built < k || !wf->geom_inv_ok) return false;
+    G->world2vol = df_aff(wf->geom_inv);
+    G->X = wf->geom_dims[0]; G->Y = wf->geom_dims[1]; G->Z = wf->geom_dims[2];
+    G->ivx = 1.f / wf->geom_vs[0]; G->ivy = 1.f / wf->geom_vs[1]; G->ivz = 1.f / wf->geom_vs[2];
+    G->vol2world = df_aff(wf->geom_aff); G->vsx = wf->geom_vs[0]; G->vsy = wf->geom_vs[1]; G->vsz = wf->geom_vs[2];
+    return wf->brick_thr != nullptr;
+}
+
 extern "C" int dfusion_knn(DfWarpField* wf, int k, const float* queries, int N, int* idx, float* d2, dfStream stream)
 {
     if (!wf || !queries || !idx || !d2 || N < 0 || wf->M < k || k < 1) return DF_E_INVALID;
     if (N == 0) return DF_OK;
     DfWarpView W = df_view(wf);
     DfAff ident; memset(&ident, 0, sizeof(ident));
+    DfPointIndex G;
+    if (df_point_index(wf, k, &G)) {
+        int rc = df_point_fallback_reserve(wf, N, (hipStream_t)stream);
+        if (rc) return rc;
+        DF_DISPATCH_K(k, df_points_index_kernel<K, 0><<<dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
+                             W, G, queries, N, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_ids + 1, wf->pt_ids));
+        DF_DISPATCH_K(k, df_points_wave_kernel<K, 0><<<dim3(2048), dim3(256), 0, (hipStream_t)stream>>>(
+                             W, queries, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_ids + 1, wf->pt_ids));
+    } else
     DF_DISPATCH_K(k, df_points_kernel<K, 0><<<dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
                          W, queries, N, idx, d2, (float*)nullptr, (float*)nullptr, ident));
     DF_LAUNCH_CHECK();
@@ -319,6 +494,15 @@ extern "C" int dfusion_warp_points(DfWarpField* wf, int k, float* points, float*
     if (N == 0) return DF_OK;
     DfWarpView W = df_view(wf);
     DfAff live = df_aff(warp_to_live);
+    DfPointIndex G;
+    if (df_point_index(wf, k, &G)) {
+        int rc = df_point_fallback_reserve(wf, N, (hipStream_t)stream);
+        if (rc) return rc;
+        DF_DISPATCH_K(k, df_points_index_kernel<K, 1><<<dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
+                             W, G, (const float*)nullptr, N, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_ids + 1, wf->pt_ids));
+        DF_DISPATCH_K(k, df_points_wave_kernel<K, 1><<<dim3(2048), dim3(256), 0, (hipStream_t)stream>>>(
+                             W, (const float*)nullptr, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_ids + 1, wf->pt_ids));
+    } else
     DF_DISPATCH_K(k, df_points_kernel<K, 1><<<dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
                          W, (const float*)nullptr, N, (int*)nullptr, (float*)nullptr, points, normals, live));
     DF_LAUNCH_CHECK();
@@ -330,14 +514,14 @@ struct DfIndexGeom {
     int X, Y, Z; int bx, by, bz;
     float vsx, vsy, vsz;
     DfAff vol2world;
-    float r2x;            // 2 * half-diagonal of the voxel-centre lattice of a brick (metres), inflated
+    float r2x;            // 2 * half-diagonal of a brick's cell (metres), inflated
 };
 
 // One wave per brick.  FILL = false: cnt[b] = |candidates| ; FILL = true: write list at off[b].
 template <int K, bool FILL>
 __global__ __launch_bounds__(256) void df_brick_index_kernel(const float4* __restrict__ pos_sigma, int M, DfIndexGeom g,
                                                              uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
-                                                             uint16_t* __restrict__ list)
+                                                             uint16_t* __restrict__ list, float* __restrict__ brick_thr)
 {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -385,6 +569,7 @@ __global__ __launch_bounds__(256) void df_brick_index_kernel(const float4* __res
         total += (uint32_t)__popcll(m);
     }
     if (!FILL && lane == 0) cnt[b] = total;
+    if (FILL && lane == 0 && brick_thr) brick_thr[b] = thr;   // every node NOT in the list is farther than this from the brick centre
 }
 
 // Exclusive scan of n counts into off[0..n] with ONE 1024-thread block (n <= a few million).
@@ -425,10 +610,11 @@ extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const DfSla
     g.bx = (g.X + DF_BRICK - 1) / DF_BRICK; g.by = (g.Y + DF_BRICK - 1) / DF_BRICK; g.bz = (g.Z + DF_BRICK - 1) / DF_BRICK;
     g.vsx = v.voxel_size[0]; g.vsy = v.voxel_size[1]; g.vsz = v.voxel_size[2];
     g.vol2world = df_aff(vol2world);
-    {   // half diagonal of the 8x8x8 lattice of voxel CENTRES under vol2world (allowing a non-orthonormal R)
+    {   // half diagonal of a brick's CELL (8 voxels wide: every point that rounds to one of its voxels, not only the 8x8x8 voxel
+        // centres, so that dfusion_knn / dfusion_warp_points can use the lists for arbitrary points) under vol2world
         double r = 0.0;
         for (int sx = -1; sx <= 1; sx += 2) for (int sy = -1; sy <= 1; sy += 2) for (int sz = -1; sz <= 1; sz += 2) {
-            double ex = sx * 3.5 * g.vsx, ey = sy * 3.5 * g.vsy, ez = sz * 3.5 * g.vsz;
+            double ex = sx * 4.0 * g.vsx, ey = sy * 4.0 * g.vsy, ez = sz * 4.0 * g.vsz;
             double wx = vol2world[0] * ex + vol2world[1] * ey + vol2world[2] * ez;
             double wy = vol2world[3] * ex + vol2world[4] * ey + vol2world[5] * ez;
             double wz = vol2world[6] * ex + vol2world[7] * ey + vol2world[8] * ez;
@@ -442,11 +628,13 @@ extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const DfSla
         (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); wf->brick_off = wf->brick_cnt = nullptr; wf->off_cap = 0;
         DF_HIP(hipMalloc((void**)&wf->brick_off, (nb + 1) * sizeof(uint32_t)));
         DF_HIP(hipMalloc((void**)&wf->brick_cnt, (nb + 1) * sizeof(uint32_t)));
+        (void)hipFree(wf->brick_thr); wf->brick_thr = nullptr;
+        DF_HIP(hipMalloc((void**)&wf->brick_thr, (nb + 1) * sizeof(float)));
         wf->off_cap = nb + 1;
     }
     const dim3 grid((unsigned)((nb + 3) / 4));
     DF_DISPATCH_K(k, df_brick_index_kernel<K, false><<<grid, dim3(256), 0, st>>>(wf->pos_sigma, wf->M, g, wf->brick_cnt,
-                                                                                 (const uint32_t*)nullptr, (uint16_t*)nullptr));
+                                                                                 (const uint32_t*)nullptr, (uint16_t*)nullptr, (float*)nullptr));
     DF_LAUNCH_CHECK();
     hipLaunchKernelGGL(df_scan_kernel, dim3(1), dim3(1024), 0, st, wf->brick_cnt, wf->brick_off, (int)nb);
     DF_LAUNCH_CHECK();
@@ -460,13 +648,24 @@ extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const DfSla
         wf->list_cap = cap;
     }
     DF_DISPATCH_K(k, df_brick_index_kernel<K, true><<<grid, dim3(256), 0, st>>>(wf->pos_sigma, wf->M, g, (uint32_t*)nullptr,
-                                                                                (const uint32_t*)wf->brick_off, wf->brick_list));
+                                                                                (const uint32_t*)wf->brick_off, wf->brick_list, wf->brick_thr));
     DF_LAUNCH_CHECK();
     DF_HIP(hipStreamSynchronize(st));
     wf->bx = g.bx; wf->by = g.by; wf->bz = g.bz; wf->k_built = k;
     memcpy(wf->geom_dims, v.dims, sizeof(wf->geom_dims));
     memcpy(wf->geom_vs, v.voxel_size, sizeof(wf->geom_vs));
     memcpy(wf->geom_aff, vol2world, sizeof(wf->geom_aff));
+    {   // world -> volume, for locating the brick of a query point (double adjugate; only used to pick a cell, never in results)
+        const float* m = vol2world; double d[9];
+        d[0] = (double)m[4] * m[8] - (double)m[5] * m[7]; d[1] = (double)m[2] * m[7] - (double)m[1] * m[8]; d[2] = (double)m[1] * m[5] - (double)m[2] * m[4];
+        d[3] = (double)m[5] * m[6] - (double)m[3] * m[8]; d[4] = (double)m[0] * m[8] - (double)m[2] * m[6]; d[5] = (double)m[2] * m[3] - (double)m[0] * m[5];
+        d[6] = (double)m[3] * m[7] - (double)m[4] * m[6]; d[7] = (double)m[1] * m[6] - (double)m[0] * m[7]; d[8] = (double)m[0] * m[4] - (double)m[1] * m[3];
+        const double det = m[0] * d[0] + m[1] * d[3] + m[2] * d[6];
+        wf->geom_inv_ok = fabs(det) > 1e-30;
+        for (int i = 0; i < 9; ++i) wf->geom_inv[i] = (float)(d[i] / det);
+        for (int i = 0; i < 3; ++i)
+            wf->geom_inv[9 + i] = (float)-((d[3 * i] * m[9] + d[3 * i + 1] * m[10] + d[3 * i + 2] * m[11]) / det);
+    }
     wf->index_valid = true;
     wf->tab_valid = false;
     wf->w_tab_valid = false;

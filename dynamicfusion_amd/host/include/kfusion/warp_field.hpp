@@ -67,7 +67,9 @@ namespace kfusion
         int k() const { return k_; }
         DfWarpField* handle() const { return handle_; }
         /// exact k-NN index (+ per-voxel tables) for one volume; rebuilt only when positions / geometry change
-        void ensureIndex(const cuda::TsdfVolume& volume) const;
+        /// `tables` = also the per-voxel k-NN + weight caches the warped integrate streams (6 GiB at 512^3); without them only the
+        /// brick candidate lists are built, which is all point queries (KNN, warp, energy_data) need
+        void ensureIndex(const cuda::TsdfVolume& volume, bool tables = true) const;
     private:
         std::vector<deformation_node> nodes_;
         Affine3f warp_to_live_;
@@ -77,6 +79,7 @@ namespace kfusion
         mutable std::vector<size_t> ret_index_;
         mutable bool index_ok_;
         mutable const void* index_volume_;
+        mutable bool index_tables_ = false;
         int solver_iters_ = 100;
         float solver_lambda_ = 0.f;
         float last_energy_[2] = {0.f, 0.f};

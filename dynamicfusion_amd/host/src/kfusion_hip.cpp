@@ -371,12 +371,12 @@ void WarpField::energy_data(const std::vector<Vec3f>& canonical_vertices, const 
     energy_data(c, l, (int)n);
 }
 
-void WarpField::ensureIndex(const cuda::TsdfVolume& volume) const
+void WarpField::ensureIndex(const cuda::TsdfVolume& volume, bool tables) const
 {
-    if (index_ok_ && index_volume_ == &volume) return;
+    if (index_ok_ && index_volume_ == &volume && (index_tables_ || !tables)) return;
     float v2w[12]; affine_to_aff12(volume.getPose(), v2w);
-    KF_DF(dfusion_warp_build_index(handle_, c_volume(volume), nullptr, v2w, k_, DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE, nullptr));
-    index_ok_ = true; index_volume_ = &volume;
+    KF_DF(dfusion_warp_build_index(handle_, c_volume(volume), nullptr, v2w, k_, tables ? (DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE) : 0u, nullptr));
+    index_ok_ = true; index_volume_ = &volume; index_tables_ = tables;
 }
 
 void WarpField::KNN(Vec3f point) const
@@ -707,6 +707,7 @@ void KinFu::dynamicfusion(cuda::Depth& depth, cuda::Cloud live_frame, cuda::Norm
         return;
     }
     const size_t n = (size_t)depth.rows() * depth.cols();
+    warp_->ensureIndex(*volume_, params_.warped_fusion);                // brick lists: exact k-NN of the points below without scanning all nodes
     if (params_.device_resident) {
         // kinfu.cpp:346-393 with every point set kept on the GPU: raycast -> canonical = inverse_pose * point (and the float4 ->
         // float3 repack) -> warp twice (as the reference does, :387 and :391) -> psdf / removal -> fusion

@@ -190,6 +190,9 @@ int dfusion_warp_set_transforms(DfWarpField *wf, const float *dq_dev, dfStream s
 int dfusion_warp_build_index(DfWarpField *wf, DfVolume geometry, const DfSlab *slab, const float vol2world[12], int k,
                              unsigned flags, dfStream stream);
 
+/* Introspection of the k-NN index (blocking): total candidate-list entries, number of 8^3 bricks, k it was built for. */
+int dfusion_warp_index_info(const DfWarpField *wf, unsigned long long *total_entries, unsigned int *n_bricks, int *k_built);
+
 /* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k],
  * ascending distance, ties -> lower node index.                                               */
 int dfusion_knn(DfWarpField *wf, int k, const float *queries_dev, int N, int *idx_dev, float *d2_dev, dfStream stream);

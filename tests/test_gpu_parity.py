@@ -351,3 +351,34 @@ def test_project_and_remove_and_psdf_match_oracle():
     # aliasing the sampled and the zeroed image is refused (racy in the reference)
     assert capi.lib().dfusion_project_and_remove(d_in.data_ptr(), cfg.cols * 2, d_in.data_ptr(), cfg.cols * 2, cfg.cols, cfg.rows,
                                                  d_pts.data_ptr(), n, capi.floats(sc.intr), None, None, None) == 100001
+
+
+@pytest.mark.parametrize("cfg", [SMALL, MID], ids=["64-k4", "128-k8"])
+def test_point_queries_through_the_brick_index_equal_brute_force(cfg):
+    """dfusion_knn / dfusion_warp_points use the brick candidate lists once an index exists (a point inside the grid is inside its
+    brick's cell, which the lists cover); points outside the grid fall back to the scan in the same launch; NaN points find nothing.
+    Same indices, distances and warped coordinates, bit for bit, as before the index was built."""
+    sc = Scene(cfg, n_frames=1)
+    rng = np.random.default_rng(9)
+    n = 50000
+    lo = sc.pose[:3, 3].astype(np.float64)
+    q = (lo + rng.uniform(-0.2, cfg.size + 0.2, (n, 3))).astype(F32)          # ~30 % outside the volume
+    q[::53] = np.nan
+    q[7::211, 1] = np.nan
+    nrm = rng.normal(size=(n, 3)).astype(F32)
+    wf = make_gpu_warp(sc)
+    dq = torch.from_numpy(q).cuda()
+    i0, d0 = wf.KNN(dq)
+    p0, n0 = dq.clone(), torch.from_numpy(nrm).cuda()
+    wf.warp(p0, n0)
+    vol = make_gpu_volume(sc)
+    wf.ensure_index(vol, cfg.k)
+    i1, d1 = wf.KNN(dq)
+    p1, n1 = dq.clone(), torch.from_numpy(nrm).cuda()
+    wf.warp(p1, n1)
+    torch.cuda.synchronize()
+    assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
+    assert torch.equal(p0.view(torch.int32), p1.view(torch.int32)) and torch.equal(n0.view(torch.int32), n1.view(torch.int32))
+    ri, rd = O.knn(sc.pos, np.nan_to_num(q[:3000], nan=0.3), cfg.k)
+    i2, d2 = wf.KNN(torch.from_numpy(np.nan_to_num(q[:3000], nan=0.3)).cuda())
+    assert np.array_equal(i2.cpu().numpy(), ri) and np.array_equal(d2.cpu().numpy().view(np.uint32), rd.view(np.uint32))

@@ -16,4 +16,4 @@ for name in ("256", "512"):
         for extra in ([], ["nosolver"], ["host"], ["warped"], ["warped-host"]):
             r = subprocess.run([build.HOST_KINFU_APP, str(cfg.cols), str(cfg.rows), str(frames), str(cfg.dims[0]), str(cfg.size), fin, fout] + extra,
                                capture_output=True, text=True, timeout=600)
-            print(name, extra[0] if extra else "default", r.stdout.strip(), r.stderr.strip()[-200:])
+            print(name, extra[0] if extra else "default", r.stdout.strip(), r.stderr.strip()[-400:])
