@@ -17,6 +17,12 @@ class DfVolume(C.Structure):
                 ("trunc_dist", C.c_float), ("max_weight", C.c_int)]
 
 
+class DfIcpLevel(C.Structure):
+    _fields_ = [("curr", C.c_void_p), ("curr_pitch", C.c_size_t), ("ncurr", C.c_void_p), ("ncurr_pitch", C.c_size_t),
+                ("prev", C.c_void_p), ("prev_pitch", C.c_size_t), ("nprev", C.c_void_p), ("nprev_pitch", C.c_size_t),
+                ("cols", C.c_int), ("rows", C.c_int), ("iters", C.c_int)]
+
+
 class DfSlab(C.Structure):
     _fields_ = [("z_store0", C.c_int), ("z_store_n", C.c_int), ("z_own0", C.c_int), ("z_own_n", C.c_int)]
 
@@ -38,7 +44,7 @@ SYMBOLS = [
     "dfusion_warp_points", "dfusion_integrate_warped", "dfusion_copy_bandwidth_probe", "dfusion_read_bandwidth_probe",
     "dfusion_bilateral_filter", "dfusion_truncate_depth", "dfusion_depth_pyramid", "dfusion_compute_normals_mask_depth",
     "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
-    "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info",
+    "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate",
 ]
 
 
@@ -105,6 +111,7 @@ def lib():
     L.dfusion_transform_points.argtypes = [vp, sz, C.c_int, vp, sz, C.c_int, C.c_int, C.c_int, fp, vp]
     L.dfusion_warp_solve_data_term.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]
     L.dfusion_warp_index_info.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+    L.dfusion_icp_estimate.argtypes = [C.POINTER(DfIcpLevel), C.c_int, C.c_int, fp, C.c_float, C.c_float, vp, vp, vp]
     L.dfusion_icp_workspace_floats.argtypes = [C.c_int, C.c_int]
     L.dfusion_icp_sums_points.argtypes = [vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, vp, vp, vp, vp]
     L.dfusion_icp_sums_depth.argtypes = [vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, vp, vp, vp, vp]

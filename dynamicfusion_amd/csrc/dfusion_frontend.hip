@@ -303,6 +303,7 @@ struct DfIcpArgs {
     const uint16_t* dcurr; size_t dcpitch; const uint16_t* dprev; size_t dppitch;
     float* partial; int partials;      // [27][partials]
     int* accepted;                     // nullable
+    const float* state;                // nullable: device-resident estimate {affine[12], ok} (dfusion_icp_estimate); overrides `aff`
 };
 
 // find_coresp, :47-110.  DEPTH selects the USE_DEPTH build's variant.
@@ -384,7 +385,14 @@ __global__ __launch_bounds__(256) void df_icp_partial_kernel(const DfIcpArgs A)
     const int x = (t & 31) + blockIdx.x * 32, y = (t >> 5) + blockIdx.y * 8;
     f3 n, d, s;
     float row[7];
-    const int filtered = (x < A.cols && y < A.rows) ? fe_find_coresp<DEPTH>(A, x, y, &n, &d, &s) : 1;
+    DfIcpArgs B = A;
+    if (A.state) {                                                                       // estimate kept on the device between iterations
+#pragma unroll
+        for (int i = 0; i < 9; ++i) B.aff.R[i] = A.state[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) B.aff.t[i] = A.state[9 + i];
+    }
+    const int filtered = (x < A.cols && y < A.rows) ? fe_find_coresp<DEPTH>(B, x, y, &n, &d, &s) : 1;
     if (!filtered) {
         const f3 c = cross3(s, n);
         row[0] = c.x; row[1] = c.y; row[2] = c.z; row[3] = n.x; row[4] = n.y; row[5] = n.z;
@@ -473,4 +481,111 @@ extern "C" int dfusion_icp_sums_depth(const uint16_t* dcurr, size_t dcurr_pitch,
     A.dcurr = dcurr; A.dcpitch = dcurr_pitch; A.ncurr = ncurr; A.ncpitch = ncurr_pitch;
     A.dprev = dprev; A.dppitch = dprev_pitch; A.nprev = nprev; A.nppitch = nprev_pitch;
     return df_icp_launch(A, true, aff, intr, dist2_thres, min_cosine, workspace, sums, accepted, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------ the whole ICP loop on the device
+// projective_icp.cpp:129-213 without the per-iteration round trip (cudaMemcpyAsync + cudaStreamSynchronize + cv::solve on the host,
+// :45,:150-163): after the two reduction kernels a one-thread kernel unpacks the 27 sums (StreamHelper::get), solves the 6x6 system
+// (LU with partial pivoting in double -- the arithmetic of the host mirror's solve6), applies the determinant test, builds Tinc by
+// Rodrigues and composes it into the estimate that lives in device memory; the next iteration's kernels read it from there.
+// state = {affine R[9], t[3], ok (1 / 0)}.  Once ok == 0 (|det| < 1e-15 or NaN, :152-156) the estimate is frozen.
+__global__ void df_icp_solve_kernel(const float* __restrict__ sums, float* __restrict__ state)
+{
+    // the augmented matrix lives in LDS: the pivot search indexes it dynamically, which in registers would spill to scratch
+    __shared__ double M[6][7];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (state[12] == 0.f) return;
+    {
+        int shift = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 7; ++j) {
+                const double value = (double)sums[shift++];
+                if (j == 6) M[i][6] = value; else { M[i][j] = value; M[j][i] = value; }
+            }
+    }
+    double det = 1.0;
+    bool singular = false;
+    for (int c = 0; c < 6 && !singular; ++c) {
+        int p = c;
+        for (int i = c + 1; i < 6; ++i) if (fabs(M[i][c]) > fabs(M[p][c])) p = i;
+        if (M[p][c] == 0.0 || M[p][c] != M[p][c]) { det = (M[p][c] != M[p][c]) ? M[p][c] : 0.0; singular = true; break; }
+        if (p != c) { for (int j = 0; j < 7; ++j) { const double tmp = M[p][j]; M[p][j] = M[c][j]; M[c][j] = tmp; } det = -det; }
+        det *= M[c][c];
+        for (int i = c + 1; i < 6; ++i) {
+            const double f = M[i][c] / M[c][c];
+            for (int j = c; j < 7; ++j) M[i][j] -= f * M[c][j];
+        }
+    }
+    if (singular || fabs(det) < 1e-15 || det != det) { state[12] = 0.f; return; }
+    float r[6];
+    for (int i = 5; i >= 0; --i) {
+        double sacc = M[i][6];
+        for (int j = i + 1; j < 6; ++j) sacc -= M[i][j] * (double)r[j];
+        r[i] = (float)(sacc / M[i][i]);
+    }
+    // Tinc = Affine3f(rvec = r[0..2], t = r[3..5]) (Rodrigues, host/include/kfusion/types.hpp), affine <- Tinc * affine
+    float TR[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+    {
+        const double rx = r[0], ry = r[1], rz = r[2];
+        const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+        if (theta >= 2.220446049250313e-16) {
+            const double c = cos(theta), sn = sin(theta), c1 = 1. - c, it = 1. / theta;
+            const double k[3] = {rx * it, ry * it, rz * it};
+            const double Kx[9] = {0, -k[2], k[1], k[2], 0, -k[0], -k[1], k[0], 0};
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    TR[3 * i + j] = (float)(c * (i == j ? 1. : 0.) + c1 * k[i] * k[j] + sn * Kx[3 * i + j]);
+        }
+    }
+    float R[9], tt[3];
+    for (int i = 0; i < 9; ++i) R[i] = state[i];
+    for (int i = 0; i < 3; ++i) tt[i] = state[9 + i];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            state[3 * i + j] = (float)((double)TR[3 * i] * R[j] + (double)TR[3 * i + 1] * R[3 + j] + (double)TR[3 * i + 2] * R[6 + j]);
+        state[9 + i] = (float)((double)TR[3 * i] * tt[0] + (double)TR[3 * i + 1] * tt[1] + (double)TR[3 * i + 2] * tt[2] + (double)r[3 + i]);
+    }
+}
+
+__global__ void df_icp_state_init_kernel(float* state)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < 12; ++i) state[i] = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+        state[12] = 1.f;
+    }
+}
+
+extern "C" int dfusion_icp_estimate(const DfIcpLevel* levels, int n_levels, int depth_variant, const float intr[4], float dist2_thres,
+                                    float min_cosine, float* workspace, float* state, dfStream stream)
+{
+    if (!levels || n_levels <= 0 || n_levels > 8 || !intr || !workspace || !state) return DF_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(df_icp_state_init_kernel, dim3(1), dim3(64), 0, st, state);
+    DF_LAUNCH_CHECK();
+    for (int level = n_levels - 1; level >= 0; --level) {                                // coarse to fine, :135
+        const DfIcpLevel& L = levels[level];
+        if (L.iters <= 0) continue;
+        if (!L.curr || !L.ncurr || !L.prev || !L.nprev || L.cols <= 0 || L.rows <= 0) return DF_E_INVALID;
+        const int div = 1 << level;                                                      // setLevelIntr, :17-23
+        const float li[4] = {intr[0] / div, intr[1] / div, intr[2] / div, intr[3] / div};
+        DfIcpArgs A;
+        memset(&A, 0, sizeof(A));
+        A.cols = L.cols; A.rows = L.rows;
+        if (depth_variant) { A.dcurr = (const uint16_t*)L.curr; A.dcpitch = L.curr_pitch; A.dprev = (const uint16_t*)L.prev; A.dppitch = L.prev_pitch; }
+        else { A.vcurr = (const float*)L.curr; A.vcpitch = L.curr_pitch; A.vprev = (const float*)L.prev; A.vppitch = L.prev_pitch; }
+        A.ncurr = L.ncurr; A.ncpitch = L.ncurr_pitch; A.nprev = L.nprev; A.nppitch = L.nprev_pitch;
+        A.I = fe_intr(li); A.min_cosine = min_cosine; A.dist2_thres = dist2_thres;
+        const dim3 grid((A.cols + 31) / 32, (A.rows + 7) / 8);
+        A.partials = (int)(grid.x * grid.y);
+        A.partial = workspace; A.state = state;
+        float* sums = workspace + (size_t)27 * A.partials;
+        for (int it = 0; it < L.iters; ++it) {
+            if (depth_variant) hipLaunchKernelGGL(df_icp_partial_kernel<true>, grid, dim3(256), 0, st, A);
+            else hipLaunchKernelGGL(df_icp_partial_kernel<false>, grid, dim3(256), 0, st, A);
+            hipLaunchKernelGGL(df_icp_final_kernel, dim3(27), dim3(256), 0, st, workspace, A.partials, sums);
+            hipLaunchKernelGGL(df_icp_solve_kernel, dim3(1), dim3(64), 0, st, sums, state);
+            DF_LAUNCH_CHECK();
+        }
+    }
+    return DF_OK;
 }

@@ -164,7 +164,8 @@ class ProjectiveICP:
         rows, cols = nprev.shape[:2]
         need = capi.lib().dfusion_icp_workspace_floats(cols, rows)
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(max(need, 27 * 1200), dtype=torch.float32, device=nprev.device)
+            self._ws = torch.empty(max(need, 27 * 1200 + 27), dtype=torch.float32, device=nprev.device)
+        if self._sums is None:
             self._sums = torch.empty(27, dtype=torch.float32, device=nprev.device)
         acc = torch.zeros(1, dtype=torch.int32, device=nprev.device)
         d2, mc = self.thresholds()
@@ -181,8 +182,34 @@ class ProjectiveICP:
         self.last_accepted = int(acc.item())
         return out
 
+    def estimateTransformDevice(self, intr, curr_pyr, ncurr_pyr, prev_pyr, nprev_pyr, depth_variant=False):
+        """The same loop as ONE enqueue (dfusion_icp_estimate): sums, 6x6 solve and pose update all on the GPU, one read-back at the
+        end.  Returns (ok, affine 4x4 f32 curr -> prev)."""
+        n = self.getUsedLevelsNum()
+        levels = (capi.DfIcpLevel * n)()
+        esz = 2 if depth_variant else 16
+        for l in range(n):
+            rows, cols = nprev_pyr[l].shape[:2]
+            levels[l] = capi.DfIcpLevel(curr_pyr[l].data_ptr(), cols * esz, ncurr_pyr[l].data_ptr(), cols * 16, prev_pyr[l].data_ptr(), cols * esz,
+                                        nprev_pyr[l].data_ptr(), cols * 16, cols, rows, self.iters_[l])
+        rows0, cols0 = nprev_pyr[0].shape[:2]
+        need = capi.lib().dfusion_icp_workspace_floats(cols0, rows0) + 27
+        dev = nprev_pyr[0].device
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 27 * 1200 + 27), dtype=torch.float32, device=dev)
+        state = torch.empty(13, dtype=torch.float32, device=dev)
+        d2, mc = self.thresholds()
+        capi.check(capi.lib().dfusion_icp_estimate(levels, n, 1 if depth_variant else 0, intr.as_proj(), d2, mc, _ptr(self._ws), _ptr(state),
+                                                   _stream()), "dfusion_icp_estimate")
+        st = state.cpu().numpy()
+        affine = np.eye(4, dtype=F32)
+        affine[:3, :3] = st[:9].reshape(3, 3)
+        affine[:3, 3] = st[9:12]
+        return bool(st[12] != 0), affine
+
     def estimateTransform(self, intr, curr_pyr, ncurr_pyr, prev_pyr, nprev_pyr, depth_variant=False):
-        """projective_icp.cpp:129-213.  Returns (ok, affine 4x4 f32 curr -> prev)."""
+        """projective_icp.cpp:129-213 with the reference's control flow (one host solve per iteration).  Returns (ok, affine 4x4 f32
+        curr -> prev)."""
         affine = np.eye(4, dtype=F32)
         for level in range(self.getUsedLevelsNum() - 1, -1, -1):
             li = intr_level(intr, level)                           # setLevelIntr, projective_icp.cpp:17-23

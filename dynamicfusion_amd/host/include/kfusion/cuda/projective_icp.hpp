@@ -27,6 +27,9 @@ namespace kfusion
             void setAngleThreshold(float angle);
             void setIterationsNum(const std::vector<int>& iters);
             int getUsedLevelsNum() const;
+            /// true (default): the whole Gauss-Newton loop is one enqueue with the 6x6 solve on the GPU; false: the reference's control
+            /// flow (stream synchronise + host solve per iteration).  Poses agree to ~1e-6.
+            void setDeviceLoop(bool on) { device_loop_ = on; }
 
             /** masked depth: "if depth(y,x) is not zero, then normals(y,x) surely is not qnan" */
             virtual bool estimateTransform(Affine3f& affine, const Intr& intr, const DepthPyr& dcurr, const NormalsPyr ncurr, const DepthPyr dprev, const NormalsPyr nprev);
@@ -37,6 +40,7 @@ namespace kfusion
             std::vector<int> iters_;
             float angle_thres_;
             float dist_thres_;
+            bool device_loop_ = true;
             DeviceArray<float> buffer_;                      // partial sums + the 27 results
         };
     }

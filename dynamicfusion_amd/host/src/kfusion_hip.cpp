@@ -510,6 +510,25 @@ bool ProjectiveICP::iterate(Affine3f& affine, const Intr& intr, const void* cons
     const float dist2_thres = dist_thres_ * dist_thres_;               // ComputeIcpHelper ctor, projective_icp.cpp:11-15
     const float min_cosine = std::cos(angle_thres_);
     affine = Affine3f::Identity();
+    if (device_loop_ && LEVELS > 0) {
+        // the whole loop as one enqueue: sums, 6x6 solve and pose update stay on the GPU (no per-iteration stream synchronise)
+        DfIcpLevel lv[MAX_PYRAMID_LEVELS];
+        for (int l = 0; l < LEVELS; ++l) {
+            lv[l].curr = curr[l]; lv[l].curr_pitch = curr_step[l]; lv[l].ncurr = (const float*)ncurr[l].ptr(); lv[l].ncurr_pitch = ncurr[l].step();
+            lv[l].prev = prev[l]; lv[l].prev_pitch = prev_step[l]; lv[l].nprev = (const float*)nprev[l].ptr(); lv[l].nprev_pitch = nprev[l].step();
+            lv[l].cols = nprev[l].cols(); lv[l].rows = nprev[l].rows(); lv[l].iters = iters_[l];
+        }
+        const size_t need = (size_t)dfusion_icp_workspace_floats(lv[0].cols, lv[0].rows) + 27 + 16;
+        if (buffer_.size() < need) buffer_.create(need);
+        float* state_dev = buffer_.ptr() + (need - 16);
+        const float in[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
+        KF_DF(dfusion_icp_estimate(lv, LEVELS, depth_variant ? 1 : 0, in, dist2_thres, min_cosine, buffer_.ptr(), state_dev, nullptr));
+        float st[13];
+        KF_HIP(hipMemcpy(st, state_dev, sizeof(st), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 9; ++i) affine.R.val[i] = st[i];
+        for (int i = 0; i < 3; ++i) affine.t[i] = st[9 + i];
+        return st[12] != 0.f;
+    }
     for (int level_index = LEVELS - 1; level_index >= 0; --level_index) {
         const Normals& n = nprev[level_index];
         const int rows = n.rows(), cols = n.cols();

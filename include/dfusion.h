@@ -279,6 +279,23 @@ int dfusion_icp_sums_depth(const uint16_t *dcurr_dev, size_t dcurr_pitch, const 
                            const float aff[12], const float intr[4], float dist2_thres, float min_cosine, float *workspace_dev,
                            float *sums_dev, int *accepted_dev, dfStream stream);
 
+/* ProjectiveICP::estimateTransform (projective_icp.cpp:129-213) as ONE enqueue: for every pyramid level from the coarsest,
+ * `iters` times { correspondences + 27 sums (as dfusion_icp_sums_*), 6x6 solve, Tinc * estimate } with the estimate kept in
+ * device memory -- no host round trip per iteration (the reference synchronises a stream and solves on the host each time).
+ *   levels[l]     images of pyramid level l (curr / prev are float4 points, or u16 depth when depth_variant != 0)
+ *   intr          level-0 intrinsics {fx, fy, cx, cy}; level l uses intr / 2^l (setLevelIntr)
+ *   workspace_dev dfusion_icp_workspace_floats(level-0 cols, rows) + 27 floats
+ *   state_dev     13 floats out: curr -> prev estimate {R[9] row-major, t[3]} and ok (1, or 0 once a normal matrix was singular:
+ *                 |det| < 1e-15 or NaN -- estimateTransform returns false there)
+ * The 6x6 solve is LU with partial pivoting in double (cv::solve DECOMP_SVD in the reference; OpenCV is not in its tree).    */
+typedef struct DfIcpLevel {
+    const void *curr; size_t curr_pitch; const float *ncurr; size_t ncurr_pitch;
+    const void *prev; size_t prev_pitch; const float *nprev; size_t nprev_pitch;
+    int cols, rows, iters;
+} DfIcpLevel;
+int dfusion_icp_estimate(const DfIcpLevel *levels, int n_levels, int depth_variant, const float intr[4], float dist2_thres,
+                         float min_cosine, float *workspace_dev, float *state_dev, dfStream stream);
+
 /* ---- measurement helper: plain device copy used as the MEASURED HBM roofline denominator ---- */
 int dfusion_copy_bandwidth_probe(void *dst_dev, const void *src_dev, size_t bytes, dfStream stream);
 /* read-only stream of `bytes` (sink4_dev: 4 writable device bytes): the measured denominator for scan kernels */

@@ -83,6 +83,9 @@ def test_icp_sums_and_trajectory_match_oracle(cfg):
     ok_g, aff_g = icp.estimateTransform(intr, gv1, gn1, gv0, gn0)
     ok_c, aff_c, hist = icp_loop(lambda lv, li, a: O.icp_sums(cv1[lv], cn1[lv], cv0[lv], cn0[lv], synth.aff12(a), li, d2t, mc)[0], intr_np)
     assert ok_g and ok_c and np.array_equal(bits(aff_g), bits(aff_c))
+    # the single-enqueue loop (solve + pose update on the device, LU instead of numpy's LAPACK solve): same pose to ~1e-5
+    ok_d, aff_d = icp.estimateTransformDevice(intr, gv1, gn1, gv0, gn0)
+    assert ok_d and np.abs(aff_d - aff_g).max() < 5e-5      # the roll about the scene's symmetry axis is ill-conditioned and amplifies the solver difference
     true = synth.affine_mul(synth.affine_inv(synth.camera_pose(cfg, 0)), synth.camera_pose(cfg, 6))
     assert np.abs(aff_g[:3, 3] - true[:3, 3]).max() < 1e-2 and np.abs(aff_g[:3, 2] - true[:3, 2]).max() < 1e-2   # sanity vs ground truth
 
@@ -107,6 +110,8 @@ def test_icp_depth_variant_and_degenerate_input():
     icp1 = frontend.ProjectiveICP(); icp1.setIterationsNum([3])
     ok, _ = icp1.estimateTransform(intr, [z], [up4(n1)], [upload_u16(m0)], [up4(n0)], depth_variant=True)
     assert ok is False
+    ok, aff = icp1.estimateTransformDevice(intr, [z], [up4(n1)], [upload_u16(m0)], [up4(n0)], depth_variant=True)
+    assert ok is False and np.array_equal(aff, np.eye(4, dtype=F32))
     # argument validation
     assert capi.lib().dfusion_bilateral_filter(z.data_ptr(), 2 * cfg.cols, z.data_ptr(), 2 * cfg.cols, cfg.cols, cfg.rows, 7, 4.5, 0.04, None) == 100001
     assert capi.lib().dfusion_icp_workspace_floats(640, 480) == 27 * 1200
