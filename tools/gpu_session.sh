@@ -16,3 +16,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ
   tail -1 gpurun_out/pmc_$tag.log
 done
 find gpurun_out/prof gpurun_out/pmc -name "*.csv" | head -20
+echo "== kinfu frame profile"
+bash tools/kinfu_profile.sh > gpurun_out/kinfu_profile.log 2>&1; grep "ms/frame" gpurun_out/kinfu_profile.log | cut -c1-160
+python tools/kinfu_probe.py > gpurun_out/kinfu_probe.log 2>&1; cat gpurun_out/kinfu_probe.log | cut -c1-170
