@@ -93,6 +93,15 @@ class TsdfVolume:
             self.data_ = torch.empty((self.z_store_n, Y, X), dtype=torch.int32, device=self.device)
             self.clear()
 
+    def owning_stored_planes(self):
+        """A second handle on the SAME device blob whose `own` range is the whole stored range (own planes + halos): integrating
+        through it makes a Z-slab shard compute its halo planes itself instead of receiving them from its neighbours."""
+        import copy
+        v = copy.copy(self)
+        v.slab_ = (self.z_store0, self.z_store_n, 0)
+        v.z_own0, v.z_own_n = self.z_store0, self.z_store_n
+        return v
+
     def getDims(self):
         return self.dims_
 

@@ -13,7 +13,7 @@ from test_gpu_parity import MID, SMALL, make_gpu_volume, make_gpu_warp
 pytestmark = pytest.mark.gpu
 
 
-def run_sharded(sc, world, frames, k=None):
+def run_sharded(sc, world, frames, k=None, recompute_halo=False):
     cfg = sc.cfg
     intr = Intr(*cfg.intr)
     Z = cfg.dims[2]
@@ -27,8 +27,8 @@ def run_sharded(sc, world, frames, k=None):
         wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
         d = upload_u16(sc.dists[f])
         for v in vols:
-            v.integrate_warped(d, sc.cam_poses[f], intr, wf)
-        for r in range(world - 1):                       # halo exchange between Z neighbours r <-> r+1
+            (v.owning_stored_planes() if recompute_halo else v).integrate_warped(d, sc.cam_poses[f], intr, wf)
+        for r in range(0 if recompute_halo else world - 1):   # halo exchange between Z neighbours r <-> r+1 (not needed when recomputed)
             a, b = vols[r], vols[r + 1]
             a_hi = a.z_own0 + a.z_own_n - a.z_store0     # local index one past a's last own plane
             b_lo = b.z_own0 - b.z_store0
@@ -62,8 +62,9 @@ def run_sharded(sc, world, frames, k=None):
     return vols, acc[0], acc[1], best
 
 
+@pytest.mark.parametrize("recompute_halo", [False, True], ids=["halo-exchange", "halo-recompute"])
 @pytest.mark.parametrize("cfg,world", [(SMALL, 2), (SMALL, 4), (MID, 4)], ids=["64x2", "64x4", "128x4"])
-def test_slab_pipeline_equals_unsharded(cfg, world):
+def test_slab_pipeline_equals_unsharded(cfg, world, recompute_halo):
     frames = 2
     sc = Scene(cfg, n_frames=frames)
     intr = Intr(*cfg.intr)
@@ -77,7 +78,7 @@ def test_slab_pipeline_equals_unsharded(cfg, world):
     fk = torch.empty((cfg.rows, cfg.cols), dtype=torch.int32, device="cuda")
     full.raycast(sc.cam_poses[frames - 1], intr, fp, fn, keys=fk)
 
-    vols, mp, mn, best = run_sharded(sc, world, frames)
+    vols, mp, mn, best = run_sharded(sc, world, frames, recompute_halo=recompute_halo)
     ref = full.data()
     for v in vols:                                        # own planes AND exchanged halos equal the unsharded volume
         assert torch.equal(v.data(), ref[v.z_store0:v.z_store0 + v.z_store_n])

@@ -39,7 +39,7 @@ def _unsharded(sc):
     return vol, p, n
 
 
-def _worker(rank, world, port):
+def _worker(rank, world, port, recompute_halo):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -50,6 +50,7 @@ def _worker(rank, world, port):
         z0, zn = sharded.slab_range(Z, rank, world)
         lo, hi = max(0, z0 - halo), min(Z, z0 + zn + halo)
         slab = O.make_slab(lo, hi - lo, z0, zn)
+        slab_int = O.make_slab(lo, hi - lo, lo, hi - lo) if recompute_halo else slab     # own := stored planes for the integrate
         vol = np.zeros((hi - lo, Y, X), np.uint32)
         vol_t = torch.from_numpy(vol.view(np.int32))                    # shares memory with `vol`
         pts = nrm = None
@@ -60,8 +61,9 @@ def _worker(rank, world, port):
             sharded.broadcast_bytes(dq, 0)                                      # ... and the solver's node transforms
             dists = O.compute_dists(depth.numpy().view(np.uint16), sc.intr)
             O.integrate_warped(dists, vol, sc.ovol(vol), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)), sc.intr,
-                               sc.pos, dq.numpy(), sc.sigma, CFG.k, slab=slab)
-            sharded.exchange_halos(vol_t, lo, z0, zn, Z, halo, rank, world)
+                               sc.pos, dq.numpy(), sc.sigma, CFG.k, slab=slab_int)
+            if not recompute_halo:
+                sharded.exchange_halos(vol_t, lo, z0, zn, Z, halo, rank, world)
 
             def march():
                 k, vx = O.raycast_march(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.reproj, CFG.cols, CFG.rows,
@@ -80,7 +82,7 @@ def _worker(rank, world, port):
             pts, nrm = sharded.raycast_sharded(march, select, shade, rank, world)
         # every rank checks its slab (own + halo planes) against the unsharded volume; rank 0 checks the merged cast
         full, fp, fn = _unsharded(sc)
-        assert np.array_equal(vol, full[lo:hi]), "rank %d: slab (incl. exchanged halos) differs from the unsharded volume" % rank
+        assert np.array_equal(vol, full[lo:hi]), "rank %d: slab (incl. halos) differs from the unsharded volume" % rank
         if rank == 0:
             gp, gn = pts.numpy(), nrm.numpy()
             assert np.array_equal(gp.view(np.uint32), fp.view(np.uint32)), "merged ray-cast vertices differ"
@@ -92,9 +94,12 @@ def _worker(rank, world, port):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("recompute_halo", [False, True], ids=["halo-exchange", "halo-recompute"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_zslab_pipeline_over_gloo(world):
-    mp.spawn(_worker, args=(world, _free_port()), nprocs=world, join=True)
+def test_zslab_pipeline_over_gloo(world, recompute_halo):
+    """halo-recompute: every rank integrates its halo planes itself (the integrate is a pure function of the broadcast inputs, so
+    the planes come out bit-identical with the neighbour's) -- no halo collective at all; what bench.py does."""
+    mp.spawn(_worker, args=(world, _free_port(), recompute_halo), nprocs=world, join=True)
 
 
 def test_single_rank_is_a_no_op_path():
