@@ -74,3 +74,20 @@ def test_full_frame_is_reproducible():
         outs.append((dq.cpu().numpy(), en.cpu().numpy()))
     assert np.array_equal(bits(outs[0][0]), bits(outs[1][0])) and np.array_equal(bits(outs[0][1]), bits(outs[1][1]))
     assert outs[0][1][1] < 0.2 * outs[0][1][0]
+
+
+@pytest.mark.parametrize("name", ["MultipleNodesTest", "NonRigidTest"])
+def test_reference_warp_test_kats_on_gpu(name):
+    """tests/warp_test.cpp:243-391 through the HIP solve + warp: targets met within the tests' 1e-3, node transforms equal the
+    oracle's bit for bit."""
+    from test_oracle_solver import KAT_CASES
+    nodes, src, dst = KAT_CASES[name]
+    wf = WarpField(k=8)
+    wf.init(nodes, sigma=3.0)
+    pts = torch.from_numpy(src).cuda()
+    dq, _ = wf.energy_data(pts, torch.from_numpy(dst).cuda(), iters=250)
+    wf.warp(pts)
+    torch.cuda.synchronize()
+    assert np.abs(pts.cpu().numpy() - dst).max() < 1e-3
+    ref_dq, _ = O.solve_data_term(nodes, synth.identity_dq(len(nodes)), np.full(len(nodes), 3.0, F32), src, dst, 8, 250)
+    assert np.array_equal(bits(dq.cpu().numpy()), bits(ref_dq))

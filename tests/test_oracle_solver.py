@@ -2,6 +2,7 @@
 reference's own solver tests (tests/ceres_warp_test.cpp: after energy_data + warp the source vertices sit on the targets
 within 1e-3) and by a float64 least-squares solution."""
 import numpy as np
+import pytest
 
 import oracle_lib as O
 from dynamicfusion_amd import synth
@@ -56,3 +57,70 @@ def test_matches_float64_least_squares_and_skips_nan_points():
     assert np.abs(W @ t_out[:, 1:].astype(np.float64) - W @ T64).max() < 2e-4
     # rotations untouched, identity here
     assert np.array_equal(out[:, :4], dq[:, :4])
+
+
+# ---- the remaining known-answer tests of the reference's solver suites (max_error = 1e-3 in all of them)
+FIVE_SRC = F32([[-3, -3, -3], [-2, -2, -2], [0, 0, 0], [2, 2, 2], [3, 3, 3]])
+FIVE_DST = F32([[-2.95, -2.95, -2.95], [-1.95, -1.95, -1.95], [0.05, 0.05, 0.05], [2.05, 2.05, 2.05], [3.05, 3.05, 3.05]])
+NODES12 = F32([[1, 1, 1], [1, 2, -1], [1, -2, 1], [1, -1, -1], [-1, 1, 5], [-1, 1, -1], [-1, -1, 1], [-1, -1, -1], [2, -3, -1], [-3, -3, -2],
+               [2, -3, 3], [2, 2, 4]])
+SIX_SRC = F32([[-3, -3, -3], [-2, -2, -2], [0, 0, 0], [2, 2, 2], [3, 3, 3], [3, 3, 3]])
+KAT_CASES = {
+    # tests/warp_test.cpp:243-317
+    "MultipleNodesTest": (NODES12, SIX_SRC, F32([[-2.95, -2.95, -2.95], [-1.95, -1.95, -1.95], [0.1, 0.1, 0.1], [2, 2, 2], [3.05, 3.05, 3.05],
+                                                 [3.05, 3.05, 3.05]])),
+    # tests/warp_test.cpp:320-391
+    "NonRigidTest": (NODES12[:9], SIX_SRC, F32([[-2.95, -3.0, -2.95], [-1.95, -1.95, -2.0], [0.1, 0.1, 0.1], [2, 2.5, 2], [3.05, 3.05, 3.05],
+                                                [3.05, 3.05, 3.05]])),
+}
+
+
+def kat_solve_warp(solve, warp, nodes, src, dst, iters=250):
+    """init (sigma = 3, identity transforms) -> data-term solve -> warp(src); iters = the tests' linearIter."""
+    sigma = np.full(len(nodes), 3.0, F32)
+    dq = solve(nodes, synth.identity_dq(len(nodes)), sigma, src, dst, 8, iters)
+    return dq, warp(nodes, dq, sigma, src)
+
+
+def _o_solve(nodes, dq, sigma, src, dst, k, iters):
+    return O.solve_data_term(nodes, dq, sigma, src, dst, k, iters)[0]
+
+
+def _o_warp(nodes, dq, sigma, pts):
+    return O.warp_points(nodes, dq, sigma, pts, np.tile(F32([0, 0, 1]), (len(pts), 1)), 8)[0]
+
+
+@pytest.mark.parametrize("name", sorted(KAT_CASES))
+def test_reference_warp_test_kats(name):
+    nodes, src, dst = KAT_CASES[name]
+    _, warped = kat_solve_warp(_o_solve, _o_warp, nodes, src, dst)
+    assert np.abs(warped - dst).max() < 1e-3
+
+
+def _ls_optimum_max_error(nodes, sigma, src, dst):
+    """max |canonical + W T* - live| for the float64 least-squares optimum T* of the data term."""
+    idx, d2 = O.knn(nodes, src, 8)
+    w = np.exp(-d2.astype(np.float64) / (2 * float(sigma[0]) ** 2))
+    W = np.zeros((len(src), len(nodes)))
+    for j in range(8):
+        np.add.at(W, (np.arange(len(src)), idx[:, j]), w[:, j])
+    d = (dst - src).astype(np.float64)
+    T = np.linalg.lstsq(W, d, rcond=None)[0]
+    return np.abs(W @ T - d).max()
+
+
+def test_reference_WarpAndReverseTest():                     # tests/ceres_warp_test.cpp:120-210, tests/warp_test.cpp:147-240
+    """Five points on the cube diagonal against the 8 corner nodes: by symmetry the nodes fall into 4 weight classes, so the 5
+    constraints per axis over-determine the data term and its optimum misses the targets by 6e-3 -- the reference's ASSERT_NEAR
+    (1e-3) cannot hold for its own energy here.  What is checked instead: the solve reaches that least-squares optimum, forward and
+    (starting from the deformed field) backward."""
+    sigma = np.full(8, 3.0, F32)
+    best_fwd = _ls_optimum_max_error(CUBE, sigma, FIVE_SRC, FIVE_DST)
+    assert 1e-3 < best_fwd < 1e-2
+    dq1 = _o_solve(CUBE, synth.identity_dq(8), sigma, FIVE_SRC, FIVE_DST, 8, 250)
+    assert np.abs(_o_warp(CUBE, dq1, sigma, FIVE_SRC) - FIVE_DST).max() < best_fwd + 1e-4
+    # reverse, starting from the deformed field.  In exact arithmetic this direction can be fitted exactly, but only through a
+    # near-null direction of W (translations of the order of 1e3): fp32 conjugate gradients (and any damped solver) stop at the
+    # same 6e-3 as the forward pass.  The points come back to within that of where they started (0.05 away before the solve).
+    dq2 = _o_solve(CUBE, dq1, sigma, FIVE_DST, FIVE_SRC, 8, 250)
+    assert np.abs(_o_warp(CUBE, dq2, sigma, FIVE_DST) - FIVE_SRC).max() < best_fwd + 1e-3
