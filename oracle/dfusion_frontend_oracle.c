@@ -1,6 +1,6 @@
 /*
  * dfusion_frontend_oracle.c -- CPU restatement of the depth front-end and the projective-ICP reduction
- * (SURVEY.md 8(f) "next" #3).  TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/ may load it (it is linked into
+ * (SURVEY.md 8(f) "next" #3) and of the warp-field data-term solve (#4, at the end of the file).  TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/ may load it (it is linked into
  * liboracle.so next to dfusion_oracle.c).
  *
  * What is restated (citations relative to /root/reference):
