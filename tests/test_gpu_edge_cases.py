@@ -1,0 +1,115 @@
+"""Edge cases of the hot path on the GPU against the oracle: empty inputs, all-invalid / saturated depth, weight saturation,
+ragged (odd) image sizes, volumes that are not multiples of the tile sizes, argument validation."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from dynamicfusion_amd import Intr, TsdfVolume, WarpField, capi, compute_dists, download_u16, synth, upload_u16
+from scene import Scene, compare_volumes
+from test_gpu_parity import make_gpu_volume, make_gpu_warp
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+DF_E_INVALID = 100001
+
+
+def test_empty_point_sets_are_no_ops():
+    sc = Scene(synth.Config(32, 1.0, cols=64, rows=48, nodes=20, k=4), n_frames=1)
+    wf = make_gpu_warp(sc)
+    z3 = torch.zeros((0, 3), dtype=torch.float32, device="cuda")
+    L = capi.lib()
+    assert L.dfusion_knn(wf.handle, 4, z3.data_ptr(), 0, None, None, None) in (0, DF_E_INVALID)      # nothing to write
+    idx, d2 = wf.KNN(torch.zeros((1, 3), device="cuda"))
+    assert idx.shape == (1, 4)
+    assert L.dfusion_warp_points(wf.handle, 4, torch.zeros((1, 3), device="cuda").data_ptr(), None, 0, capi.floats(synth.aff12(np.eye(4, dtype=F32))), None) == 0
+    d = upload_u16(sc.dists[0])
+    assert L.dfusion_project_and_remove(d.data_ptr(), 128, d.clone().data_ptr(), 128, 64, 48, torch.zeros((1, 4), device="cuda").data_ptr(), 0,
+                                        capi.floats(sc.intr), None, None, None) == 0
+    vol = make_gpu_volume(sc)
+    vol.integrate(d, sc.cam_poses[0], Intr(*sc.cfg.intr))
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    buf = torch.zeros((1, 4), dtype=torch.float32, device="cuda")
+    capi.check(L.dfusion_extract_cloud(vol.c_volume(), None, capi.floats(synth.aff12(sc.pose)), buf.data_ptr(), 0, cnt.data_ptr(), None))
+    _, n_ref = O.extract_cloud(sc.ovol(vol.download()), synth.aff12(sc.pose), 1 << 20)
+    assert int(cnt.item()) == n_ref > 0 and not buf.any()                         # capacity 0: counted, nothing written
+
+
+def test_all_invalid_and_saturated_depth():
+    cfg = synth.Config(32, 1.0, cols=64, rows=48, nodes=20, k=4)
+    sc = Scene(cfg, n_frames=1)
+    intr = Intr(*cfg.intr)
+    for depth in (np.zeros((48, 64), np.uint16), np.full((48, 64), 65535, np.uint16)):
+        g = download_u16(compute_dists(upload_u16(depth), intr))
+        assert np.array_equal(g, O.compute_dists(depth, sc.intr))                 # 65535 mm * lambda overflows half -> inf bits, same on both
+        vol = make_gpu_volume(sc)
+        n = torch.zeros(1, dtype=torch.int64, device="cuda")
+        vol.integrate(upload_u16(g), sc.cam_poses[0], intr, n_updated=n)
+        ref = sc.new_volume()
+        n_ref = O.integrate(g, ref, sc.ovol(ref), synth.aff12(sc.vol2cam(0)), sc.intr)
+        assert int(n.item()) == n_ref and compare_volumes(vol.download(), ref)["bits_mismatch"] == 0
+        wf = make_gpu_warp(sc)
+        vol.integrate_warped(upload_u16(g), sc.cam_poses[0], intr, wf)
+        O.integrate_warped(g, ref, sc.ovol(ref), synth.aff12(sc.pose), synth.aff12(sc.world2cam(0)), sc.intr, sc.pos, sc.dqs[0], sc.sigma, cfg.k)
+        assert compare_volumes(vol.download(), ref)["bits_mismatch"] == 0
+
+
+def test_weight_saturates_at_max_weight():
+    cfg = synth.Config(32, 1.0, cols=64, rows=48, nodes=20, k=4)
+    sc = Scene(cfg, n_frames=1)
+    intr = Intr(*cfg.intr)
+    vol = make_gpu_volume(sc); vol.setMaxWeight(3)
+    ref = sc.new_volume(); ov = O.make_volume(ref, cfg.dims, sc.vs, sc.trunc, 3)
+    wf = make_gpu_warp(sc)
+    d = upload_u16(sc.dists[0])
+    for _ in range(3):
+        vol.integrate(d, sc.cam_poses[0], intr)
+        O.integrate(sc.dists[0], ref, ov, synth.aff12(sc.vol2cam(0)), sc.intr)
+    for _ in range(3):
+        vol.integrate_warped(d, sc.cam_poses[0], intr, wf)
+        O.integrate_warped(sc.dists[0], ref, ov, synth.aff12(sc.pose), synth.aff12(sc.world2cam(0)), sc.intr, sc.pos, sc.dqs[0], sc.sigma, cfg.k)
+    got = vol.download()
+    assert compare_volumes(got, ref)["bits_mismatch"] == 0 and int((got >> 16).max()) == 3
+
+
+@pytest.mark.parametrize("dims,cols,rows", [((36, 20, 44), 67, 45), ((64, 40, 24), 33, 31)], ids=["36x20x44", "64x40x24"])
+def test_ragged_volumes_and_images(dims, cols, rows):
+    """Volumes that are not multiples of the sweep tile (32 x 16 x 8) or the 8^3 brick, odd image sizes."""
+    cfg = synth.Config(dims, 1.0, cols=cols, rows=rows, nodes=30, k=8)
+    sc = Scene(cfg, n_frames=2)
+    intr = Intr(*cfg.intr)
+    vol = make_gpu_volume(sc)
+    wf = make_gpu_warp(sc)
+    ref = sc.new_volume()
+    for f in range(2):
+        wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+        vol.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, wf)
+        O.integrate_warped(sc.dists[f], ref, sc.ovol(ref), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)), sc.intr, sc.pos, sc.dqs[f], sc.sigma, cfg.k)
+    assert compare_volumes(vol.download(), ref)["bits_mismatch"] == 0
+    pts = torch.empty((rows, cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
+    vol.raycast(sc.cam_poses[1], intr, pts, nrm)
+    rp, rn, _, _ = O.raycast_points(sc.ovol(ref), synth.aff12(sc.cam2vol(1)), sc.rinv(1), sc.reproj, cols, rows, cfg.raycast_step_factor,
+                                    cfg.gradient_delta_factor)
+    assert np.array_equal(pts.cpu().numpy().view(np.uint32), rp.view(np.uint32)) and np.array_equal(nrm.cpu().numpy().view(np.uint32), rn.view(np.uint32))
+    cloud = vol.fetchCloud().cpu().numpy()
+    rc, n = O.extract_cloud(sc.ovol(ref), synth.aff12(sc.pose), 1 << 20)
+    order = lambda a: a[np.lexsort(np.ascontiguousarray(a).view(np.uint32).T[::-1])]
+    assert n == len(cloud) and np.array_equal(order(cloud).view(np.uint32), order(rc).view(np.uint32))
+
+
+def test_argument_validation():
+    L = capi.lib()
+    with pytest.raises(ValueError):
+        TsdfVolume((30, 32, 32))                                                   # dims[0] % 4
+    v = TsdfVolume((32, 32, 32))
+    bad = capi.DfVolume(None, (capi.C.c_int * 3)(32, 32, 32), (capi.C.c_float * 3)(0.01, 0.01, 0.01), 0.03, 64)
+    assert L.dfusion_clear(bad, None, None) == DF_E_INVALID                        # null data
+    d = torch.zeros((8, 8), dtype=torch.int16, device="cuda")
+    assert L.dfusion_compute_dists(d.data_ptr(), 16, d.data_ptr(), 16, 0, 8, Intr(1, 1, 0, 0).as_proj(), None) == DF_E_INVALID
+    slab = capi.DfSlab(8, 8, 4, 8)                                                 # own range outside the stored range
+    assert L.dfusion_clear(v.c_volume(), capi.C.byref(slab), None) == DF_E_INVALID
+    wf = WarpField(k=4); wf.init(np.zeros((4, 3), F32), sigma=1.0)
+    assert L.dfusion_warp_set_nodes(wf.handle, d.data_ptr(), d.data_ptr(), d.data_ptr(), 70000, None) == DF_E_INVALID   # ids are 16-bit
+    assert L.dfusion_warp_solve_data_term(wf.handle, 4, d.data_ptr(), d.data_ptr(), 0, 10, 0.0, None, None, None) == DF_E_INVALID
+    assert L.dfusion_icp_estimate(None, 1, 0, Intr(1, 1, 0, 0).as_proj(), 0.01, 0.9, d.data_ptr(), d.data_ptr(), None) == DF_E_INVALID
+    assert L.dfusion_error_string(DF_E_INVALID) and L.dfusion_error_string(100002) and L.dfusion_abi_version() == 1
