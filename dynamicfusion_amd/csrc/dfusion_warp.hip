@@ -1044,6 +1044,18 @@ __device__ __forceinline__ void tab_raw_load(const DfWarpedArgs& a, size_t tv, D
     r.idx = reinterpret_cast<const uint2*>(a.knn_tab)[tv];
     r.w0 = reinterpret_cast<const float4*>(a.w_tab)[tv];
 }
+// the same with the record index split into a wave-uniform base and a 32-bit lane offset
+__device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<8>& r)
+{
+    r.idx = (reinterpret_cast<const uint4*>(a.knn_tab) + rec)[lane];
+    r.w0 = (reinterpret_cast<const float4*>(a.w_tab) + rec)[lane];
+    r.w1 = (reinterpret_cast<const float4*>(a.w_tab) + a.tab_nvox + rec)[lane];
+}
+__device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<4>& r)
+{
+    r.idx = (reinterpret_cast<const uint2*>(a.knn_tab) + rec)[lane];
+    r.w0 = (reinterpret_cast<const float4*>(a.w_tab) + rec)[lane];
+}
 __device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<8>& r, int (&bi)[8], float (&wt)[8])
 {
     bi[0] = r.idx.x & 0xffff; bi[1] = r.idx.x >> 16; bi[2] = r.idx.y & 0xffff; bi[3] = r.idx.y >> 16;
@@ -1100,9 +1112,21 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
         };
         // prefetch distance is TWO batches (two packed register sets, used alternately): the tables of batch b+2 are
         // requested in the middle of batch b and consumed at the start of batch b+2, a whole blend later.
+        // table address = (workgroup-uniform record index: tile column + tile layer + plane in tile) + (loop-invariant 32-bit lane
+        // offset inside the tile plane): the uniform part stays in SGPRs and the loads take the saddr + voffset form instead of
+        // a 64-bit VALU address per load
+        const unsigned lane_vox = (unsigned)(yc * a.X + xc);
+        const unsigned lane_tab = (unsigned)((yc % DF_TAB_TY) * DF_TAB_TX + (xc % DF_TAB_TX));
+        const size_t tile_col = (size_t)(yc / DF_TAB_TY) * a.tab_ntx + (size_t)(xc / DF_TAB_TX);      // == (ty, tx) of the workgroup: uniform
+        const size_t tile_col_u = (size_t)__builtin_amdgcn_readfirstlane((int)tile_col);
         auto load_batch = [&](DfTabRaw<K> (&S)[2], int l, int z0) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) tab_raw_load(a, df_tab_index(a, xc, yc, min(z0 + u, layer_ze(l) - 1)), S[u]);
+            for (int u = 0; u < 2; ++u) {
+                const int zl = min(z0 + u, layer_ze(l) - 1) - a.tab_z0;
+                const size_t rec = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty * a.tab_ntx + tile_col_u) * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ) +
+                                   (size_t)(zl % DF_TAB_TZ) * (DF_TAB_TX * DF_TAB_TY);
+                tab_raw_load_at(a, rec, lane_tab, S[u]);
+            }
         };
         int l = __ffs(alive) - 1, z0 = layer_zb(l);
         int l1, z1; advance(l, z0, &l1, &z1);
@@ -1121,7 +1145,7 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 inz[u] = in_xy && z0 + u < ze;
-                vp[u] = a.vol + (size_t)(min(z0 + u, ze - 1) - a.z_store0) * plane + (size_t)yc * a.X + xc;
+                vp[u] = (a.vol + (size_t)(min(z0 + u, ze - 1) - a.z_store0) * plane) + lane_vox;     // uniform plane base + lane offset
                 vox[u] = *vp[u];
             }
             // (2) blend -> transform -> project, then the dists gathers (clamped address, always valid)
@@ -1137,7 +1161,7 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
                 ok[u] = inz[u] & (vc[u].z > 0.f) & (pu >= 0.f) & (pv >= 0.f) & (pu < (float)a.P.cols) & (pv < (float)a.P.rows);   // :82,:86
                 const int ui = (int)fminf(fmaxf(pu, 0.f), (float)(a.P.cols - 1));
                 const int vi = (int)fminf(fmaxf(pv, 0.f), (float)(a.P.rows - 1));
-                dpb[u] = *(const uint16_t*)((const char*)a.P.dists + (size_t)vi * a.P.pitch + 2 * (size_t)ui);   // :85
+                dpb[u] = *(const uint16_t*)((const char*)a.P.dists + ((unsigned)vi * (unsigned)a.P.pitch + 2u * (unsigned)ui));   // :85 (image < 4 GiB)
             }
             __builtin_amdgcn_sched_barrier(0);
             // (3) tables of batch b+2 into the set just consumed.  Unconditional (a dummy re-read at the end): a branch here
