@@ -53,6 +53,7 @@ HOST_DIR = os.path.join(PKG_DIR, "host")
 HOST_LIB = os.path.join(HOST_DIR, "libkfusion_hip.so")
 HOST_APP = os.path.join(HOST_DIR, "headless_frame")
 HOST_KINFU_APP = os.path.join(HOST_DIR, "kinfu_headless")
+HOST_WARP_TESTS = os.path.join(HOST_DIR, "warp_tests")
 
 
 def build_host(force=False, verbose=False):
@@ -61,9 +62,10 @@ def build_host(force=False, verbose=False):
     src = os.path.join(HOST_DIR, "src", "kfusion_hip.cpp")
     app = os.path.join(HOST_DIR, "apps", "headless_frame.cpp")
     app2 = os.path.join(HOST_DIR, "apps", "kinfu_headless.cpp")
-    deps = [src, app, app2, LIB_PATH] + [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(HOST_DIR, "include")) for f in fs]
-    if not force and all(os.path.exists(f) for f in (HOST_LIB, HOST_APP, HOST_KINFU_APP)) and \
-            min(os.path.getmtime(f) for f in (HOST_LIB, HOST_APP, HOST_KINFU_APP)) >= max(os.path.getmtime(d) for d in deps):
+    app3 = os.path.join(HOST_DIR, "apps", "warp_tests.cpp")
+    deps = [src, app, app2, app3, LIB_PATH] + [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(HOST_DIR, "include")) for f in fs]
+    if not force and all(os.path.exists(f) for f in (HOST_LIB, HOST_APP, HOST_KINFU_APP, HOST_WARP_TESTS)) and \
+            min(os.path.getmtime(f) for f in (HOST_LIB, HOST_APP, HOST_KINFU_APP, HOST_WARP_TESTS)) >= max(os.path.getmtime(d) for d in deps):
         return HOST_LIB, HOST_APP
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     common = ["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HOST_DIR, "include"),
@@ -71,7 +73,8 @@ def build_host(force=False, verbose=False):
     link = ["-L", PKG_DIR, "-ldfusion_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64"]
     cmds = [common + ["-fPIC", "-shared", src, "-o", HOST_LIB] + link + ["-Wl,-rpath,$ORIGIN/.."],
             common + [app, "-o", HOST_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
-            common + [app2, "-o", HOST_KINFU_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
+            common + [app2, "-o", HOST_KINFU_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
+            common + [app3, "-o", HOST_WARP_TESTS, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
     for c in cmds:
         if verbose:
             print(" ".join(c))

@@ -215,3 +215,12 @@ def test_cxx_kinfu_tracks_the_camera(tmp_path):
     O.integrate(O.compute_dists(depths[0], sc.intr), ref, sc.ovol(ref), synth.aff12(cxx_mul(cxx_inv(np.eye(4, dtype=F32)), pose)), sc.intr)
     s = compare_volumes(vol, ref)
     assert s["bits_mismatch"] == 0, s
+
+
+def test_cxx_reference_warp_test_suites():
+    """The reference's own solver tests (tests/ceres_warp_test.cpp, tests/warp_test.cpp) compiled against the C++ mirror: same
+    WarpField calls and inputs, same 1e-3 bound (WarpAndReverseTest: the data term's least-squares optimum, see the source)."""
+    build.build_host()
+    r = subprocess.run([build.HOST_WARP_TESTS], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and r.stdout.count("OK") == 5, r.stdout + r.stderr
