@@ -60,9 +60,10 @@ def measured_copy_gbps(nbytes=1 << 30, iters=10):
     return 2.0 * nbytes / (ms * 1e-3) / 1e9        # read + write bytes
 
 
-def cpu_baseline(cfg, sc_inputs, vol_u32, budget_planes=4):
-    """Oracle ("port") timed on the host cores on a BOUNDED sample of the same frame: integrate_warped on
-    `budget_planes` Z planes of the volume (scaled to all planes) + the full 640x480 ray-cast."""
+def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=12.0):
+    """Oracle ("port") timed on the host cores on a BOUNDED sample of the same frame: integrate_warped on a band of Z planes in the
+    middle of the volume (scaled to all planes) + the full ray-cast.  The band is sized by a 4-plane probe so that the sample is
+    about `target_s` seconds of CPU work whatever the core count."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_lib as O
     depth, _, pose, cam_pose, pos, sigma, dq = sc_inputs
@@ -71,14 +72,24 @@ def cpu_baseline(cfg, sc_inputs, vol_u32, budget_planes=4):
     vs = np.array([np.float32(cfg.size) / np.float32(d) for d in cfg.dims], np.float32)
     trunc = float(max(np.float32(cfg.trunc_dist), np.float32(2.1) * vs.max()))
     X, Y, Z = cfg.dims
-    z0 = Z // 2
-    slab = O.make_slab(z0, budget_planes, z0, budget_planes)
-    sample = np.ascontiguousarray(vol_u32[z0:z0 + budget_planes]).copy()
-    ov = O.make_volume(sample, cfg.dims, vs, trunc, cfg.max_weight)
     world2cam = synth.affine_inv(cam_pose)
-    t0 = time.time()
-    O.integrate_warped(dists, sample, ov, synth.aff12(pose), synth.aff12(world2cam), intr, pos, dq, sigma, cfg.k, slab=slab)
-    t_int = (time.time() - t0) * (Z / budget_planes)
+
+    def timed_band(n_planes):
+        z0 = (Z - n_planes) // 2
+        slab = O.make_slab(z0, n_planes, z0, n_planes)
+        sample = np.ascontiguousarray(vol_u32[z0:z0 + n_planes]).copy()
+        ov = O.make_volume(sample, cfg.dims, vs, trunc, cfg.max_weight)
+        t0 = time.time()
+        O.integrate_warped(dists, sample, ov, synth.aff12(pose), synth.aff12(world2cam), intr, pos, dq, sigma, cfg.k, slab=slab)
+        return time.time() - t0
+
+    budget_planes, t_band = 4, timed_band(4)
+    for _ in range(2):                                      # grow the band until it is about target_s of work (or the whole volume)
+        if t_band >= 0.5 * target_s or budget_planes >= Z:
+            break
+        budget_planes = int(min(Z, max(budget_planes + 4, 4 * round(budget_planes * target_s / max(t_band, 1e-3) / 4))))
+        t_band = timed_band(budget_planes)
+    t_int = t_band * (Z / budget_planes)
     full = O.make_volume(vol_u32, cfg.dims, vs, trunc, cfg.max_weight)
     cam2vol = synth.affine_mul(synth.affine_inv(pose), cam_pose)
     rinv = np.linalg.inv(cam2vol[:3, :3].astype(np.float64)).astype(np.float32)
@@ -87,8 +98,8 @@ def cpu_baseline(cfg, sc_inputs, vol_u32, budget_planes=4):
     O.raycast_points(full, synth.aff12(cam2vol), rinv, reproj, cfg.cols, cfg.rows, cfg.raycast_step_factor, cfg.gradient_delta_factor)
     t_ray = time.time() - t0
     return {"value": 1.0 / (t_int + t_ray), "unit": "frames/s", "cores": int(O.lib().orc_num_threads()), "kind": "port",
-            "sample": "oracle (OpenMP, brute-force k-NN) integrate_warped on %d of %d Z planes scaled x%d (est %.1f s/frame) "
-                      "+ full %dx%d raycast (%.2f s)" % (budget_planes, Z, Z // budget_planes, t_int, cfg.cols, cfg.rows, t_ray)}
+            "sample": "oracle (OpenMP, brute-force k-NN) integrate_warped on %d of %d Z planes in %.1f s, scaled x%.1f (est %.1f s/frame) "
+                      "+ full %dx%d raycast (%.2f s)" % (budget_planes, Z, t_band, Z / budget_planes, t_int, cfg.cols, cfg.rows, t_ray)}
 
 
 def kinfu_frame_ms(cfg, frames=12):
