@@ -2,7 +2,7 @@
 // frames from a file to kfusion::KinFu::operator() and records what the demo would display -- the camera pose per frame.
 //   kinfu_headless <cols> <rows> <frames> <dims> <size_m> <in.bin> <out.bin> [warped|host|warped-host]
 //   (warped: per-voxel warped integrate instead of surface_fusion; host: the reference's host-staged data flow; nosolver: skip the
-//   warp data-term solve)
+//   warp data-term solve; depth: the reference's USE_DEPTH build -- depth pyramids and masked-depth ICP)
 // in.bin : intrinsics fx fy cx cy f32[4], then per frame depth u16[rows*cols] (mm).
 // out.bin: per frame { tracked i32 (operator()'s return value), pose f32[12] (R row-major, t) }, then the extracted surface
 //          count u64 and the volume u32[dims^3].
@@ -19,7 +19,7 @@ using namespace kfusion;
 
 int main(int argc, char** argv)
 {
-    if (argc != 8 && argc != 9) { std::fprintf(stderr, "usage: %s cols rows frames dims size in.bin out.bin [warped|host|nosolver, '-' separated]\n", argv[0]); return 2; }
+    if (argc != 8 && argc != 9) { std::fprintf(stderr, "usage: %s cols rows frames dims size in.bin out.bin [warped|host|nosolver|depth, '-' separated]\n", argv[0]); return 2; }
     const int cols = std::atoi(argv[1]), rows = std::atoi(argv[2]), frames = std::atoi(argv[3]), dims = std::atoi(argv[4]);
     const float size = (float)std::atof(argv[5]);
     FILE* in = std::fopen(argv[6], "rb");
@@ -37,6 +37,7 @@ int main(int argc, char** argv)
     p.warped_fusion = mode.find("warped") != std::string::npos;
     p.device_resident = mode.find("host") == std::string::npos;
     if (mode.find("nosolver") != std::string::npos) p.warp_solver_iterations = 0;
+    p.use_depth_pyramids = mode.find("depth") != std::string::npos;
     KinFu kinfu(p);
 
     FILE* out = std::fopen(argv[7], "wb");

@@ -35,6 +35,7 @@ namespace kfusion
         // extensions
         int max_warp_nodes = 65535;
         bool warped_fusion = false;
+        bool use_depth_pyramids = false; // the reference's USE_DEPTH build (internal.hpp:6, commented out there): depth + normals pyramids, masked depth ICP
         bool device_resident = true;   // keep dynamicfusion()'s point sets on the GPU (no host staging); false = the reference's data flow
         int warp_solver_iterations = 40;  // conjugate-gradient steps of the warp data term per frame, 0 = off (Opt is capped at linearIter = 100,
                                           // kinfu.cpp:118; on the synthetic sequence the energy has converged to 4 digits by 40)
@@ -79,5 +80,6 @@ namespace kfusion
         cuda::Cloud df_cloud_; cuda::Normals df_normals_;
         cuda::DeviceArray<float> df_points3_, df_normals3_, df_live3_;
         cuda::DeviceArray<Point> df_warped4_;
+        cuda::Normals df_live_normals_;
     };
 }

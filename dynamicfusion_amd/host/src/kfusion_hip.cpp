@@ -676,7 +676,12 @@ bool KinFu::operator()(const cuda::Depth& depth, const cuda::Image& /*image*/)  
     cuda::depthBilateralFilter(depth, curr_.depth_pyr[0], p.bilateral_kernel_size, p.bilateral_sigma_spatial, p.bilateral_sigma_depth);
     if (p.icp_truncate_depth_dist > 0) cuda::depthTruncation(curr_.depth_pyr[0], p.icp_truncate_depth_dist);
     for (int i = 1; i < LEVELS; ++i) cuda::depthBuildPyramid(curr_.depth_pyr[i - 1], curr_.depth_pyr[i], p.bilateral_sigma_depth);
-    for (int i = 0; i < LEVELS; ++i) cuda::computePointNormals(p.intr(i), curr_.depth_pyr[i], curr_.points_pyr[i], curr_.normals_pyr[i]);
+    for (int i = 0; i < LEVELS; ++i) {
+        if (p.use_depth_pyramids) cuda::computeNormalsAndMaskDepth(p.intr(i), curr_.depth_pyr[i], curr_.normals_pyr[i]);   // #if defined USE_DEPTH, :236-237
+        else cuda::computePointNormals(p.intr(i), curr_.depth_pyr[i], curr_.points_pyr[i], curr_.normals_pyr[i]);          // :239
+    }
+    if (p.use_depth_pyramids)   // dynamicfusion() is handed curr_.points_pyr[0] in either build (:283): keep it valid
+        cuda::computePointNormals(p.intr(0), curr_.depth_pyr[0], curr_.points_pyr[0], df_live_normals_);
     cuda::waitAllDefaultStream();
 
     if (frame_counter_ == 0) {                                          // :246-265
@@ -696,23 +701,31 @@ bool KinFu::operator()(const cuda::Depth& depth, const cuda::Image& /*image*/)  
         std::vector<Vec3f> seeds;
         for (size_t i = 0; i < cloud.size(); i += step) seeds.push_back(Vec3f(cloud[i].x, cloud[i].y, cloud[i].z));
         if (seeds.size() >= (size_t)warp_->k()) warp_->init(seeds);
-        curr_.points_pyr.swap(prev_.points_pyr);
-        curr_.points_pyr.swap(first_.points_pyr);
+        if (p.use_depth_pyramids) { curr_.depth_pyr.swap(prev_.depth_pyr); curr_.depth_pyr.swap(first_.depth_pyr); }        // :254-256
+        else { curr_.points_pyr.swap(prev_.points_pyr); curr_.points_pyr.swap(first_.points_pyr); }                         // :258-259
         curr_.normals_pyr.swap(prev_.normals_pyr);
         curr_.normals_pyr.swap(first_.normals_pyr);
         return ++frame_counter_, false;
     }
 
     Affine3f affine;                                                    // curr -> prev
-    if (!icp_->estimateTransform(affine, p.intr, curr_.points_pyr, curr_.normals_pyr, prev_.points_pyr, prev_.normals_pyr))
-        return reset(), false;
+    const bool ok = p.use_depth_pyramids
+        ? icp_->estimateTransform(affine, p.intr, curr_.depth_pyr, curr_.normals_pyr, prev_.depth_pyr, prev_.normals_pyr)      // :272
+        : icp_->estimateTransform(affine, p.intr, curr_.points_pyr, curr_.normals_pyr, prev_.points_pyr, prev_.normals_pyr);   // :274
+    if (!ok) return reset(), false;
     poses_.push_back(poses_.back() * affine);                           // curr -> global
     cuda::Depth d = curr_.depth_pyr[0];
     dynamicfusion(d, curr_.points_pyr[0], curr_.normals_pyr[0]);
 
-    volume_->raycast(poses_.back(), p.intr, prev_.points_pyr[0], prev_.normals_pyr[0]);    // :296-299
-    for (int i = 1; i < LEVELS; ++i)
-        cuda::resizePointsNormals(prev_.points_pyr[i - 1], prev_.normals_pyr[i - 1], prev_.points_pyr[i], prev_.normals_pyr[i]);
+    if (p.use_depth_pyramids) {                                         // :292-295
+        volume_->raycast(poses_.back(), p.intr, prev_.depth_pyr[0], prev_.normals_pyr[0]);
+        for (int i = 1; i < LEVELS; ++i)
+            cuda::resizeDepthNormals(prev_.depth_pyr[i - 1], prev_.normals_pyr[i - 1], prev_.depth_pyr[i], prev_.normals_pyr[i]);
+    } else {                                                            // :296-299
+        volume_->raycast(poses_.back(), p.intr, prev_.points_pyr[0], prev_.normals_pyr[0]);
+        for (int i = 1; i < LEVELS; ++i)
+            cuda::resizePointsNormals(prev_.points_pyr[i - 1], prev_.normals_pyr[i - 1], prev_.points_pyr[i], prev_.normals_pyr[i]);
+    }
     cuda::waitAllDefaultStream();
     return ++frame_counter_, true;
 }
