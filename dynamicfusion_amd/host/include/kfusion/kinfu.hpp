@@ -14,31 +14,40 @@
 
 namespace kfusion
 {
+    // The knobs of the pipeline, field for field those of the reference's KinFuParams (kinfu.hpp:15-48), followed by the extensions
+    // of this implementation.  Units: pixels, metres, radians, frames.
     struct KinFuParams
     {
-        static KinFuParams default_params();                   // kinfu.cpp:55-89
-        static KinFuParams default_params_dynamicfusion();     // kinfu.cpp:15-50
+        static KinFuParams default_params();                   // 512^3 / 3 m volume, fx = fy = 525                    kinfu.cpp:55-89
+        static KinFuParams default_params_dynamicfusion();     // 256^3 / 1 m volume, fx = fy = 570.342 (what demo.cpp uses)  :15-50
 
+        // sensor
         int cols, rows;
         Intr intr;
-        Vec3i volume_dims;
-        Vec3f volume_size;
-        Affine3f volume_pose;
+        // TSDF volume
+        Vec3i volume_dims;                   // voxels per axis (dims[0] % 32 == 0)
+        Vec3f volume_size;                   // metres per axis
+        Affine3f volume_pose;                // volume -> world
+        float tsdf_trunc_dist;               // clamped to >= 2.1 voxels by TsdfVolume::setTruncDist
+        int tsdf_max_weight;
+        float tsdf_min_camera_movement;      // unused by the pipeline, as in the reference
+        float raycast_step_factor, gradient_delta_factor;      // in voxel sizes
+        // depth front-end
         float bilateral_sigma_depth, bilateral_sigma_spatial;
         int bilateral_kernel_size;
-        float icp_truncate_depth_dist, icp_dist_thres, icp_angle_thres;
-        std::vector<int> icp_iter_num;
-        float tsdf_min_camera_movement, tsdf_trunc_dist;
-        int tsdf_max_weight;
-        float raycast_step_factor, gradient_delta_factor;
-        Vec3f light_pose;
-        // extensions
-        int max_warp_nodes = 65535;
-        bool warped_fusion = false;
-        bool use_depth_pyramids = false; // the reference's USE_DEPTH build (internal.hpp:6, commented out there): depth + normals pyramids, masked depth ICP
-        bool device_resident = true;   // keep dynamicfusion()'s point sets on the GPU (no host staging); false = the reference's data flow
-        int warp_solver_iterations = 40;  // conjugate-gradient steps of the warp data term per frame, 0 = off (Opt is capped at linearIter = 100,
-                                          // kinfu.cpp:118; on the synthetic sequence the energy has converged to 4 digits by 40)
+        float icp_truncate_depth_dist;       // 0 = no truncation
+        // tracker
+        float icp_dist_thres, icp_angle_thres;
+        std::vector<int> icp_iter_num;       // per pyramid level, finest first
+        Vec3f light_pose;                    // rendering only (out of scope here)
+
+        // ---- extensions (defaults reproduce the reference's observable behaviour unless noted)
+        int max_warp_nodes = 65535;          // node ids are 16-bit: the stride-50 sampling of the seed cloud widens if it must
+        bool warped_fusion = false;          // true: per-voxel warped integrate (the north-star kernel) instead of surface_fusion
+        bool use_depth_pyramids = false;     // the reference's USE_DEPTH build (internal.hpp:6): depth pyramids + masked-depth ICP
+        bool device_resident = true;         // dynamicfusion() keeps its point sets on the GPU; false = the reference's host staging
+        int warp_solver_iterations = 40;     // CG steps of the warp data term per frame, 0 = off (Opt's cap is linearIter = 100,
+                                             // kinfu.cpp:118; the synthetic sequence has converged to 4 digits by 40)
     };
 
     class KinFu
