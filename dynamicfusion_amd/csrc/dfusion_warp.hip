@@ -1076,8 +1076,12 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
     __syncthreads();
 
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int x = tx * DF_ROW_TX + (threadIdx.x & (DF_ROW_TX - 1));
-    const int y = ty * DF_LDS_TY + (threadIdx.x >> 5);
+    // lane -> column of the 32 x 16 footprint: a wave owns an 8 x 8 patch (4 patches across, 2 down), not a 32 x 2 strip -- the
+    // same 8 cache lines per table load, but a compact footprint, so that the voxels of a wave fall on the same side of the frustum
+    // and of the observed surface more often
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int x = tx * DF_ROW_TX + (wv & 3) * 8 + (ln & 7);
+    const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (ln >> 3);
     const bool in_xy = x < a.X && y < a.Y;
     const int xc = min(x, a.X - 1), yc = min(y, a.Y - 1);                 // clamped: out-of-volume lanes read valid entries, write nothing
     const size_t plane = (size_t)a.X * a.Y;
