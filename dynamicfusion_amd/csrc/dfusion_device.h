@@ -75,16 +75,79 @@ __device__ __forceinline__ quat q_scale(float s, quat a) { quat r; r.w = s * a.w
 __device__ __forceinline__ quat q_add(quat a, quat b) { quat r; r.w = a.w + b.w; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; return r; }
 // dual_quaternion.hpp:120-125
 __device__ __forceinline__ quat dq_get_translation(quat rot, quat dual) { return q_mul(q_scale(2.f, dual), q_conj(q_normalize(rot))); }
-// dual_quaternion.hpp:204-210 + quaternion.hpp:124-130
-__device__ __forceinline__ f3 dq_transform(quat rot, quat dual, f3 p)
+// dual_quaternion.hpp:204-210 + quaternion.hpp:124-130, given rn = normalize(real)
+__device__ __forceinline__ f3 dq_transform_rn(quat rn, quat dual, f3 p)
 {
-    quat rn = q_normalize(rot);                       // shared by getTranslation() and rotate()
     quat t = q_mul(q_scale(2.f, dual), q_conj(rn));
     f3 qv = mk3(rn.x, rn.y, rn.z);
     f3 inner = add3(cross3(qv, p), scale3(p, rn.w));
     p = add3(p, cross3(scale3(qv, 2.f), inner));
     return add3(p, mk3(t.x, t.y, t.z));
 }
+__device__ __forceinline__ f3 dq_transform(quat rot, quat dual, f3 p)
+{
+    return dq_transform_rn(q_normalize(rot), dual, p);          // one normalize shared by getTranslation() and rotate()
+}
+
+// ---------------------------------------------------------------- short forms of the correctly rounded operations
+// The warped sweep is VALU-issue bound, and a third of its instructions are the generic expansions of sqrtf, the f64
+// division and the f64 scaling inside q_normalize.  On a restricted domain each has a shorter sequence with THE SAME
+// result bits; callers test the domain wave-wide (df_wave_all) and fall back to the generic form otherwise.
+//
+// sqrtf for finite x >= 2^-96: the compiler's own expansion (v_sqrt_f32, then step to the neighbour below / above when
+// the residual says so) without its input scaling for tiny x and its zero / inf / NaN pass-through.
+__device__ __forceinline__ bool df_sqrt_short_ok(float x) { return (x >= 0x1p-96f) & (x < __builtin_inff()); }
+__device__ __forceinline__ float df_sqrt_short(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+    float r = (rd <= 0.f) ? sd : s;
+    r = (ru > 0.f) ? su : r;
+    return r;
+}
+// 1.0 / (double)n for a normal, finite f32 n > 0: the f64 division's Newton-Raphson core (v_rcp_f64, two refinements, one
+// correction of the quotient) without v_div_scale / v_div_fixup, which only act on operands near the ends of the f64
+// exponent range -- unreachable from an f32.
+__device__ __forceinline__ double df_rcp_short(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double rem = __builtin_fma(-d, r, 1.0);     // quotient q = 1.0 * r
+    return __builtin_fma(rem, r, r);
+}
+__device__ __forceinline__ float q_sumsq(quat a) { return (a.w * a.w) + (a.x * a.x) + (a.y * a.y) + (a.z * a.z); }
+__device__ __forceinline__ quat q_scale_f64(double inv, quat a)
+{
+    quat r;
+    r.w = (float)(inv * (double)a.w); r.x = (float)(inv * (double)a.x);
+    r.y = (float)(inv * (double)a.y); r.z = (float)(inv * (double)a.z);
+    return r;
+}
+// q_normalize with the short reciprocal.  Domain: everything.  For a normal, finite norm it is the same division; for norm 0, inf
+// or NaN both forms make every component of the result (and, through the second normalize and the transform, of the warped
+// position) non-finite -- the generic one via 1.0 / 0 = inf, (float)(inf * c) = inf or NaN, the short one via rcp(0) = inf,
+// fma(-0, inf, 1) = NaN -- and a non-finite position fails the reference's vc.z > 0 test either way: the voxel is not updated.
+// (The norm is never denormal: sqrtf of the smallest positive f32 is 2^-74.5.)
+__device__ __forceinline__ quat q_normalize_rcp_short(quat a) { return q_scale_f64(df_rcp_short((double)sqrtf(q_sumsq(a))), a); }
+// q_normalize of an (almost) unit quaternion: s = 1 + d with |d| <= 2^-20 (d = s - 1 is exact).  In f64,
+//   sqrt(s) = 1 + d/2 - d^2/8 + O(d^3):  1 + d/2 is a multiple of 2^-25 and d^2/8 one of 2^-51, so the first three terms are exact
+//   in f64, lie >= 2^-51 off every f32 rounding boundary when d != 0 while the dropped terms are < 2^-63  =>  the f32 rounding of
+//   that f64 value IS the correctly rounded sqrtf(s);
+//   1/n = 1 - e + e^2 - O(e^3) for n = 1 + e (e = n - 1 exact, a multiple of 2^-24): 1 - e + e^2 is exact in f64 and the dropped
+//   terms are < 2^-63, far inside half an f64 ulp  =>  it IS the correctly rounded 1.0 / (double)n.
+__device__ __forceinline__ bool q_near_unit_ok(float s) { return fabsf(s - 1.f) <= 0x1p-20f; }
+__device__ __forceinline__ quat q_normalize_near_unit(quat a, float s)
+{
+    const double d = (double)(s - 1.f);
+    const float n = (float)__builtin_fma(-0.125 * d, d, __builtin_fma(0.5, d, 1.0));
+    const double e = (double)(n - 1.f);
+    return q_scale_f64(__builtin_fma(e, e, 1.0 - e), a);
+}
+__device__ __forceinline__ bool df_wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
 // warp_field.cpp:238-241 (double exp overload, see oracle header)
 __device__ __forceinline__ float dqb_weight(float d2, float sigma) { return (float)exp((double)(-d2 / (2 * sigma * sigma))); }
 // knn_point_cloud.hpp:25-31

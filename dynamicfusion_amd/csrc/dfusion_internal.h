@@ -57,6 +57,7 @@ struct DfWarpField {
     uint16_t* knn_tab; size_t knn_tab_cap;      // elements (uint16)
     int tab_z0, tab_zn, tab_k; bool tab_valid;
     float* w_tab; size_t w_tab_cap; bool w_tab_valid;   // per-voxel blend weights (optional, DF_INDEX_WEIGHT_TABLE)
+    float* tile_wmax; size_t tile_wmax_cap;             // per table tile: max over its voxels of the weight sum (with w_tab)
     // device scalars for the conservative brick cull: [0] max |t_i|, [1] max sin(theta_i/2), [2] max dists
     float* bounds_dev;
     // scratch of dfusion_warp_solve_data_term (grown on demand)

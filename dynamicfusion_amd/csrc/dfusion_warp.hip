@@ -39,27 +39,32 @@ __global__ __launch_bounds__(256) void df_pack_nodes_kernel(const float* __restr
 }
 
 // Conservative per-node displacement ingredients for brick culling: max |t_i| and max sin(theta_i/2)
-// over nodes.  bounds[0] = max |t|, bounds[1] = max sin(half angle), bounds[1] = 2 (=> no culling) if
+// over nodes.  bounds[0] = max |t|, bounds[3] = max |rotation quaternion| (for the zero-weight tile test), bounds[1] = max
+// sin(half angle), bounds[1] = 2 (=> no culling) if
 // any rotation has w < 0 or is not finite (the hemisphere argument of the bound needs w >= 0).
 __global__ __launch_bounds__(256) void df_node_bounds_kernel(const float4* __restrict__ rot, const float4* __restrict__ node_t,
                                                              int M, float* __restrict__ bounds)
 {
     int j = blockIdx.x * 256 + threadIdx.x;
-    float tn = 0.f, sh = 0.f;
+    float tn = 0.f, sh = 0.f, rn = 0.f;
     if (j < M) {
         float4 t = node_t[j], r = rot[j];
         tn = sqrtf(t.y * t.y + t.z * t.z + t.w * t.w);          // (x,y,z) of the quaternion are .y .z .w of the float4
         float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+        rn = (n == n) ? n : 3.0e38f;                            // >= every |component| of the rotation quaternion
         float vn = sqrtf(r.y * r.y + r.z * r.z + r.w * r.w);
         sh = vn / n;
         if (!(r.x >= 0.f) || !(n > 0.f) || !(sh == sh) || !(tn == tn)) { sh = 2.f; }
         if (!(tn == tn)) tn = 3.0e38f;
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { tn = fmaxf(tn, __shfl_xor(tn, o, 64)); sh = fmaxf(sh, __shfl_xor(sh, o, 64)); }
+    for (int o = 32; o >= 1; o >>= 1) {
+        tn = fmaxf(tn, __shfl_xor(tn, o, 64)); sh = fmaxf(sh, __shfl_xor(sh, o, 64)); rn = fmaxf(rn, __shfl_xor(rn, o, 64));
+    }
     if ((threadIdx.x & 63) == 0) {
         atomicMax((unsigned int*)&bounds[0], __float_as_uint(tn));   // non-negative floats order as uints
         atomicMax((unsigned int*)&bounds[1], __float_as_uint(sh));
+        atomicMax((unsigned int*)&bounds[3], __float_as_uint(rn));
     }
 }
 
@@ -80,7 +85,7 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     if (!wf) return DF_OK;
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
-    (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids);
+    (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids); (void)hipFree(wf->tile_wmax);
     free(wf);
     return DF_OK;
 }
@@ -105,7 +110,7 @@ static int df_warp_pack(DfWarpField* wf, const float* pos, const float* dq, cons
     hipLaunchKernelGGL(df_pack_nodes_kernel, dim3((wf->M + 255) / 256), dim3(256), 0, st, pos, dq, sigma, wf->M,
                        wf->pos_sigma, wf->rot, wf->dual, wf->node_t);
     DF_LAUNCH_CHECK();
-    DF_HIP(hipMemsetAsync(wf->bounds_dev, 0, 2 * sizeof(float), st));
+    DF_HIP(hipMemsetAsync(wf->bounds_dev, 0, 4 * sizeof(float), st));     // [2] (max dists) is rewritten by every integrate
     hipLaunchKernelGGL(df_node_bounds_kernel, dim3((wf->M + 255) / 256), dim3(256), 0, st, wf->rot, wf->node_t, wf->M,
                        wf->bounds_dev);
     DF_LAUNCH_CHECK();
@@ -185,29 +190,38 @@ __device__ __forceinline__ void dqb_blend_w(const DfWarpView& W, const float (&w
 // without register shuffles (left to itself it paired (w,z),(x,y) and spent ~65 v_mov per voxel re-pairing the LDS
 // words).  Element-wise IEEE mul then add, exactly the scalar sequence of :211-212.
 typedef float df_v2f __attribute__((ext_vector_type(2)));
+struct DfBlendSums { df_v2f t01, t23, r01, r23; };      // sum w_i * node_t_i and sum w_i * rot_i as (w,x),(y,z) halves
 template <int K>
-__device__ __forceinline__ void dqb_blend_lds(const float4* s_node, const float (&wt)[K], const int (&bi)[K], quat* rot_out,
-                                              quat* dual_out)
+__device__ __forceinline__ DfBlendSums dqb_sums_lds(const float4* s_node, const float (&wt)[K], const int (&bi)[K])
 {
-    df_v2f t01 = {0.f, 0.f}, t23 = {0.f, 0.f}, r01 = {0.f, 0.f}, r23 = {0.f, 0.f};
+    DfBlendSums S;
+    S.t01 = S.t23 = S.r01 = S.r23 = df_v2f{0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         const float4* nd = s_node + 2 * bi[i];
         const float4 r4 = nd[0], t4 = nd[1];
         const df_v2f ww = {wt[i], wt[i]};
         const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
-        t01 = t01 + ww * ta; t23 = t23 + ww * tb;     // :211
-        r01 = r01 + ww * ra; r23 = r23 + ww * rb;     // :212
+        S.t01 = S.t01 + ww * ta; S.t23 = S.t23 + ww * tb;     // :211
+        S.r01 = S.r01 + ww * ra; S.r23 = S.r23 + ww * rb;     // :212
     }
+    return S;
+}
+template <int K>
+__device__ __forceinline__ void dqb_blend_lds(const float4* s_node, const float (&wt)[K], const int (&bi)[K], quat* rot_out,
+                                              quat* dual_out)
+{
+    const DfBlendSums S = dqb_sums_lds<K>(s_node, wt, bi);
     quat tsum, rsum;
-    tsum.w = t01.x; tsum.x = t01.y; tsum.y = t23.x; tsum.z = t23.y;
-    rsum.w = r01.x; rsum.x = r01.y; rsum.y = r23.x; rsum.z = r23.y;
+    tsum.w = S.t01.x; tsum.x = S.t01.y; tsum.y = S.t23.x; tsum.z = S.t23.y;
+    rsum.w = S.r01.x; rsum.x = S.r01.y; rsum.y = S.r23.x; rsum.z = S.r23.y;
     rsum = q_normalize(rsum);                         // :214
     quat half;
     half.w = 0.5f * tsum.w; half.x = 0.5f * tsum.x; half.y = 0.5f * tsum.y; half.z = 0.5f * tsum.z;
     *rot_out = rsum;
     *dual_out = q_mul(half, rsum);                    // dual_quaternion.hpp:59-63
 }
+
 // weights from squared distances: WarpField::weighting (warp_field.cpp:238-241) per neighbour
 template <int K>
 __device__ __forceinline__ void dqb_weights(const DfWarpView& W, const float (&bd)[K], const int (&bi)[K], float (&wt)[K])
@@ -696,7 +710,15 @@ struct DfWarpedArgs {
     //   w_tab    K float weights per voxel, stored as K/4 float4 PLANES of tab_nvox entries each, so that a wave of
     //            x-adjacent lanes reads 1 KiB contiguous per instruction
     uint16_t* knn_tab; float* w_tab; int tab_z0; size_t tab_nvox; int tab_ntx, tab_nty;
+    // max over the voxels of each table tile of sum_i w_i (written by the table build, frame-invariant); null = no zero-weight test
+    float* tile_wmax;
 };
+// A tile is ZERO-WEIGHT for a frame when tile_wmax * max_j |rot_j| < 2^-76: every component of every voxel's blend sum
+// sum_i w_i rot_i is then below 2^-75 in magnitude (the 2x margin covers the rounding of the sums), its square below 2^-150
+// rounds to 0 in f32, the norm is 0, the reference's 1.0 / norm is inf, inf * c is inf or NaN, the second normalize makes every
+// component NaN and the NaN position fails vc.z > 0 (tsdf_volume.cu:86): no voxel of the tile can update.  Far from every
+// node (> 10 sigma) that is the normal case, and such tiles are skipped without reading their tables.
+#define DF_ZERO_WEIGHT 1.3234890e-23f      // 2^-76
 
 // table entry of voxel (x, y, z): tiles of 32(x) x 16(y) x 8(z) voxels, tile-major; inside a tile z, then y, then x --
 // a wave of the sweep (32 x-lanes x 2 y rows) reads 64 consecutive entries, a workgroup plane 512.
@@ -888,8 +910,30 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
     float wt0[K], wt1[K];
     if constexpr (BUILD) {
         const size_t tv0 = df_tab_index(a, x, y, z0), tv1 = df_tab_index(a, x, y, z1);
+        float wsum = 0.f;
         if (act0) { knn_tab_store<K>(a.knn_tab, tv0, bi0); if (a.w_tab) { dqb_weights<K>(W, bd0, bi0, wt0); w_tab_store<K>(a.w_tab, a.tab_nvox, tv0, wt0); } }
         if (act1) { knn_tab_store<K>(a.knn_tab, tv1, bi1); if (a.w_tab) { dqb_weights<K>(W, bd1, bi1, wt1); w_tab_store<K>(a.w_tab, a.tab_nvox, tv1, wt1); } }
+        if (a.w_tab && a.tile_wmax) {                       // a brick lies inside one table tile (8 | 32, 16, 8; table planes are brick-aligned)
+            if (act0) {
+                float s0 = 0.f;
+#pragma unroll
+                for (int i = 0; i < K; ++i) s0 += wt0[i];
+                wsum = !(s0 == s0) ? 3.0e38f : s0;
+            }
+            if (act1) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < K; ++i) s1 += wt1[i];
+                wsum = fmaxf(wsum, !(s1 == s1) ? 3.0e38f : s1);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) wsum = fmaxf(wsum, __shfl_xor(wsum, o, 64));
+            if ((threadIdx.x & 63) == 0) {
+                const int zl = bzz * DF_BRICK - a.tab_z0;
+                const size_t tile = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty + (byy * DF_BRICK) / DF_TAB_TY) * a.tab_ntx + (bxx * DF_BRICK) / DF_TAB_TX;
+                atomicMax((unsigned int*)&a.tile_wmax[tile], __float_as_uint(wsum));      // non-negative floats order as uints
+            }
+        }
     } else {
         unsigned int my_upd = 0;
         if (act0) {
@@ -1044,17 +1088,26 @@ __device__ __forceinline__ void tab_raw_load(const DfWarpedArgs& a, size_t tv, D
     r.idx = reinterpret_cast<const uint2*>(a.knn_tab)[tv];
     r.w0 = reinterpret_cast<const float4*>(a.w_tab)[tv];
 }
+// A pointer the whole wave agrees on, moved to scalar registers: address = SGPR base + 32-bit lane offset is then one
+// instruction operand (global_load ... v_off, s[base]) instead of a 64-bit add per lane and a VGPR pair per address.
+template <typename T>
+__device__ __forceinline__ T* df_wave_uniform(T* p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
 // the same with the record index split into a wave-uniform base and a 32-bit lane offset
 __device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<8>& r)
 {
-    r.idx = (reinterpret_cast<const uint4*>(a.knn_tab) + rec)[lane];
-    r.w0 = (reinterpret_cast<const float4*>(a.w_tab) + rec)[lane];
-    r.w1 = (reinterpret_cast<const float4*>(a.w_tab) + a.tab_nvox + rec)[lane];
+    r.idx = df_wave_uniform(reinterpret_cast<const uint4*>(a.knn_tab) + rec)[lane];
+    r.w0 = df_wave_uniform(reinterpret_cast<const float4*>(a.w_tab) + rec)[lane];
+    r.w1 = df_wave_uniform(reinterpret_cast<const float4*>(a.w_tab) + a.tab_nvox + rec)[lane];
 }
 __device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<4>& r)
 {
-    r.idx = (reinterpret_cast<const uint2*>(a.knn_tab) + rec)[lane];
-    r.w0 = (reinterpret_cast<const float4*>(a.w_tab) + rec)[lane];
+    r.idx = df_wave_uniform(reinterpret_cast<const uint2*>(a.knn_tab) + rec)[lane];
+    r.w0 = df_wave_uniform(reinterpret_cast<const float4*>(a.w_tab) + rec)[lane];
 }
 __device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<8>& r, int (&bi)[8], float (&wt)[8])
 {
@@ -1068,7 +1121,7 @@ __device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<4>& r, int (&bi)[4
     wt[0] = r.w0.x; wt[1] = r.w0.y; wt[2] = r.w0.z; wt[3] = r.w0.w;
 }
 
-template <int K>
+template <int K, int U>
 __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
@@ -1100,14 +1153,18 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
                                                   ((float)(ty * DF_LDS_TY) + 0.5f * (DF_LDS_TY - 1)) * a.vsy,
                                                   ((float)((lt0 + l) * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
             culled = df_tile_culled(a, c);
+            if (a.tile_wmax) {                                             // zero-weight tile (DF_ZERO_WEIGHT): nothing in it can update
+                const size_t tile = ((size_t)(lt0 + l - a.tab_z0 / DF_TAB_TZ) * a.tab_nty + ty) * a.tab_ntx + tx;
+                culled |= a.tile_wmax[tile] * a.cull[3] < DF_ZERO_WEIGHT;
+            }
         }
         if (!culled) alive |= 1u << l;
     }
     unsigned int my_upd = 0;
     if (alive) {
-        // batch sequence: 2 planes per batch inside a layer, then the first batch of the next alive layer; l < 0 = none
+        // batch sequence: U planes per batch inside a layer, then the first batch of the next alive layer; l < 0 = none
         auto advance = [&](int l, int z0, int* nl, int* nz0) {
-            *nl = l; *nz0 = z0 + 2;
+            *nl = l; *nz0 = z0 + U;
             if (*nz0 >= layer_ze(l)) {
                 const unsigned rem = alive >> (l + 1);
                 *nl = rem ? l + 1 + (__ffs(rem) - 1) : -1;
@@ -1123,9 +1180,9 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
         const unsigned lane_tab = (unsigned)((yc % DF_TAB_TY) * DF_TAB_TX + (xc % DF_TAB_TX));
         const size_t tile_col = (size_t)(yc / DF_TAB_TY) * a.tab_ntx + (size_t)(xc / DF_TAB_TX);      // == (ty, tx) of the workgroup: uniform
         const size_t tile_col_u = (size_t)__builtin_amdgcn_readfirstlane((int)tile_col);
-        auto load_batch = [&](DfTabRaw<K> (&S)[2], int l, int z0) {
+        auto load_batch = [&](DfTabRaw<K> (&S)[U], int l, int z0) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int zl = min(z0 + u, layer_ze(l) - 1) - a.tab_z0;
                 const size_t rec = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty * a.tab_ntx + tile_col_u) * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ) +
                                    (size_t)(zl % DF_TAB_TZ) * (DF_TAB_TX * DF_TAB_TY);
@@ -1134,32 +1191,41 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
         };
         int l = __ffs(alive) - 1, z0 = layer_zb(l);
         int l1, z1; advance(l, z0, &l1, &z1);
-        DfTabRaw<K> S0[2], S1[2];
+        DfTabRaw<K> S0[U], S1[U];
         load_batch(S0, l, z0);
         load_batch(S1, l1 >= 0 ? l1 : l, l1 >= 0 ? z1 : z0);               // dummy re-read when there is no second batch
 
         // one batch: consumes S (tables of batch (l, z0)), then refills S with the tables of batch (l2, z2)
-        auto step = [&](DfTabRaw<K> (&S)[2], int l, int z0, int l2, int z2) {
+        auto step = [&](DfTabRaw<K> (&S)[U], int l, int z0, int l2, int z2) {
             const int ze = layer_ze(l);
-            int bi[2][K]; float wt[2][K];
+            int bi[U][K]; float wt[U][K];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) tab_raw_unpack(S[u], bi[u], wt[u]);
+            for (int u = 0; u < U; ++u) tab_raw_unpack(S[u], bi[u], wt[u]);
             // (1) voxel words of this batch (unconditional; clamped plane for the tail)
-            uint32_t* vp[2]; uint32_t vox[2]; bool inz[2];
+            uint32_t* vp[U]; uint32_t vox[U]; bool inz[U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 inz[u] = in_xy && z0 + u < ze;
-                vp[u] = (a.vol + (size_t)(min(z0 + u, ze - 1) - a.z_store0) * plane) + lane_vox;     // uniform plane base + lane offset
+                vp[u] = df_wave_uniform(a.vol + (size_t)(min(z0 + u, ze - 1) - a.z_store0) * plane) + lane_vox;     // uniform plane base + lane offset
                 vox[u] = *vp[u];
             }
-            // (2) blend -> transform -> project, then the dists gathers (clamped address, always valid)
-            f3 vc[2]; bool ok[2]; uint16_t dpb[2];
+            // (2) blend -> transform -> project, then the dists gathers (clamped address, always valid).  The normalisations and the
+            // square root take their short forms (dfusion_device.h: same bits on a restricted domain) when the whole wave is inside
+            // the domain.
+            f3 vc[U]; bool ok[U]; uint16_t dpb[U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const f3 q = aff_mul(a.vol2world, mk3(fxv, fyv, (float)(z0 + u) * a.vsz));   // canonical position
-                quat rot, dual;
-                dqb_blend_lds<K>(s_nodes, wt[u], bi[u], &rot, &dual);
-                vc[u] = aff_mul(a.world2cam, dq_transform(rot, dual, q));
+                const DfBlendSums B = dqb_sums_lds<K>(s_nodes, wt[u], bi[u]);
+                quat rsum, half, rn;
+                rsum.w = B.r01.x; rsum.x = B.r01.y; rsum.y = B.r23.x; rsum.z = B.r23.y;
+                half.w = 0.5f * B.t01.x; half.x = 0.5f * B.t01.y; half.y = 0.5f * B.t23.x; half.z = 0.5f * B.t23.y;
+                const quat rot = q_normalize_rcp_short(rsum);                                 // :214
+                const quat dual = q_mul(half, rot);                                           // dual_quaternion.hpp:59-63
+                const float s2 = q_sumsq(rot);
+                if (__builtin_expect(df_wave_all(q_near_unit_ok(s2)), 1)) rn = q_normalize_near_unit(rot, s2);
+                else rn = q_normalize(rot);                      // blend sums so small that their squares were denormal: rot is not unit
+                vc[u] = aff_mul(a.world2cam, dq_transform_rn(rn, dual, q));
                 const float pu = fmaf(a.P.fx, vc[u].x / vc[u].z, a.P.cx);                     // device.hpp:35
                 const float pv = fmaf(a.P.fy, vc[u].y / vc[u].z, a.P.cy);                     // device.hpp:36
                 ok[u] = inz[u] & (vc[u].z > 0.f) & (pu >= 0.f) & (pv >= 0.f) & (pu < (float)a.P.cols) & (pv < (float)a.P.rows);   // :82,:86
@@ -1174,9 +1240,13 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
             __builtin_amdgcn_sched_barrier(0);
             // (4) finish the sample (:85-93), fuse (:97-103), store
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const float Dp = h2f_bits(dpb[u]);
-                const float sdf = Dp - sqrtf(dot3(vc[u], vc[u]));                             // :89
+                const float v2 = dot3(vc[u], vc[u]);
+                float vn;
+                if (__builtin_expect(df_wave_all(df_sqrt_short_ok(v2)), 1)) vn = df_sqrt_short(v2);
+                else vn = sqrtf(v2);                                                         // (NaN positions of zero-weight voxels come here)
+                const float sdf = Dp - vn;                                                    // :89
                 const bool upd = ok[u] & (Dp != 0.f) & (sdf >= -a.P.trunc);                   // :86, :91
                 if (upd) {
                     *vp[u] = tsdf_fuse(vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight);   // :93
@@ -1277,6 +1347,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         a.cam_scale = (float)((fabs(fro - 1.7320508075688772) < 1e-3) ? 1.001 : fro * 1.001);
         a.tile_r = (float)(r * 1.001 + 1e-6);
         a.cull = wf->bounds_dev;
+        if (use_w && !(flags & DF_WARP_NO_ZERO_SKIP)) a.tile_wmax = wf->tile_wmax;
     }
 
     DfWarpView W = df_view(wf);
@@ -1291,8 +1362,8 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         const size_t lds = (size_t)wf->M * 32;
         typedef void (*lds_kernel_t)(const DfWarpedArgs, const DfWarpView, int);
         lds_kernel_t kern = nullptr;
-        if (use_w && k == 8 && !(flags & DF_WARP_NO_PIPELINE)) kern = df_warp_rows_pipe_kernel<8>;
-        else if (use_w && k == 4 && !(flags & DF_WARP_NO_PIPELINE)) kern = df_warp_rows_pipe_kernel<4>;
+        if (use_w && k == 8 && !(flags & DF_WARP_NO_PIPELINE)) kern = df_warp_rows_pipe_kernel<8, 2>;
+        else if (use_w && k == 4 && !(flags & DF_WARP_NO_PIPELINE)) kern = df_warp_rows_pipe_kernel<4, 2>;
         else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
         else { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, false, 1>)); }
         DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1335,9 +1406,19 @@ static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab
         DF_HIP(hipMalloc((void**)&wf->w_tab, need * sizeof(float)));
         wf->w_tab_cap = need;
     }
+    const size_t ntile = (size_t)ntx * nty * (tzn / DF_TAB_TZ);
+    if (weights) {
+        if (ntile > wf->tile_wmax_cap) {
+            (void)hipFree(wf->tile_wmax); wf->tile_wmax = nullptr; wf->tile_wmax_cap = 0;
+            DF_HIP(hipMalloc((void**)&wf->tile_wmax, ntile * sizeof(float)));
+            wf->tile_wmax_cap = ntile;
+        }
+        DF_HIP(hipMemsetAsync(wf->tile_wmax, 0, ntile * sizeof(float), st));
+    }
     DfWarpedArgs a;
     memset(&a, 0, sizeof(a));
     a.w_tab = weights ? wf->w_tab : nullptr;
+    a.tile_wmax = weights ? wf->tile_wmax : nullptr;
     a.X = v.dims[0]; a.Y = v.dims[1]; a.Z = v.dims[2];
     a.z_store0 = tz0; a.z_own0 = tz0; a.z_own_n = tzn;        // every voxel of the covered bricks gets an entry
     a.vsx = v.voxel_size[0]; a.vsy = v.voxel_size[1]; a.vsz = v.voxel_size[2];

@@ -75,6 +75,8 @@ enum {
 #define DF_WARP_NO_LDS 8u    /* gather node transforms from global memory (the path taken when the
                                 node table exceeds the 160 KiB LDS, M > 5120); validation switch  */
 #define DF_WARP_NO_PIPELINE 16u /* batched instead of software-pipelined table loads; validation switch */
+#define DF_WARP_NO_ZERO_SKIP 32u /* also sweep tiles whose blend weights are all so small that the reference's
+                                 normalisation divides by zero (they cannot update); validation switch  */
 /* flags for dfusion_warp_build_index */
 #define DF_INDEX_VOXEL_TABLE 1u /* also cache the exact k-NN of EVERY voxel of the slab in HBM:
                                    k * 2 bytes per voxel (2 GiB at 512^3, k = 8) -- the per-frame

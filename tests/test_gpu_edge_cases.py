@@ -138,3 +138,33 @@ def test_every_neighbour_count_matches_oracle(k):
         vol = make_gpu_volume(sc)
         vol.integrate_warped(d, sc.cam_poses[0], intr, wf, **kw)
         assert compare_volumes(vol.download(), ref)["bits_mismatch"] == 0, kw
+
+
+@pytest.mark.parametrize("k,sigma", [(8, 0.012), (4, 0.02), (8, 0.03)])
+def test_vanishing_blend_weights_match_oracle(k, sigma):
+    """Small sigma: most of the volume is many sigma away from every node, so the sweep meets, from the nodes outwards, normal blend
+    sums, sums whose squares are denormal (the rotation comes out un-normalised and the near-unit short form must step aside), and
+    sums whose squares vanish (norm 0 -> the reference divides by zero -> NaN position -> no update; whole tiles of those are skipped
+    from the table build's weight bound).  The whole volume against the oracle, with and without the skip, update counts included."""
+    cfg = synth.Config(64, 1.0, cols=96, rows=72, nodes=60, k=k)
+    sc = Scene(cfg, n_frames=2)
+    sc.sigma = np.full_like(sc.sigma, sigma)
+    intr = Intr(*cfg.intr)
+    wf = WarpField(k=k)
+    wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
+    ref = sc.new_volume()
+    vols = [make_gpu_volume(sc) for _ in range(3)]
+    kws = [dict(), dict(zero_skip=False), dict(cull=False, pipelined=False)]
+    n_ref = 0
+    n = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in vols]
+    for f in range(2):
+        wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+        n_ref += O.integrate_warped(sc.dists[f], ref, sc.ovol(ref), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)), sc.intr, sc.pos, sc.dqs[f],
+                                    sc.sigma, k)
+        for v, kw, c in zip(vols, kws, n):
+            v.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, wf, n_updated=c, **kw)
+    w = ref >> 16
+    assert 0 < int((w > 0).sum()) < ref.size // 2            # some voxels near the nodes update, most of the volume cannot
+    for v, kw, c in zip(vols, kws, n):
+        assert compare_volumes(v.download(), ref)["bits_mismatch"] == 0, kw
+        assert int(c.item()) == n_ref, kw
