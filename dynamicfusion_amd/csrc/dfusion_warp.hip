@@ -801,12 +801,13 @@ __device__ __forceinline__ void w_tab_load(const float* tab, size_t nvox, size_t
 // lies within rho = cam_scale*(tile_r + delta) of cc = world2cam * c.  No voxel of the tile can update if that ball
 // is entirely behind the camera, entirely outside one image-frustum side plane, or entirely farther than
 // max_dist + trunc from the camera centre.
-__device__ __forceinline__ bool df_tile_culled(const DfWarpedArgs& a, f3 c)
+// wk >= sum_i w_i of every voxel of the tile: (float)k always (w_i <= 1), the table build's per-tile bound where there is one
+__device__ __forceinline__ bool df_tile_culled(const DfWarpedArgs& a, f3 c, float wk)
 {
     const float max_t = a.cull[0], sin_half = a.cull[1], max_dist = a.cull[2];
     if (!(sin_half <= 1.0f && max_t < 1.0e30f)) return false;
     const float cn = sqrtf(dot3(c, c));
-    const float delta = 2.f * sin_half * (cn + a.tile_r) + a.kf * max_t;
+    const float delta = 2.f * sin_half * (cn + a.tile_r) + wk * max_t;
     const float rho = a.cam_scale * (a.tile_r + delta) * 1.002f + 1e-3f;
     const f3 cc = aff_mul(a.world2cam, c);
     bool out = false;
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
     if (!BUILD && a.cull) {
         const f3 c = aff_mul(a.vol2world, mk3(((float)(bxx * DF_BRICK) + 3.5f) * a.vsx, ((float)(byy * DF_BRICK) + 3.5f) * a.vsy,
                                               ((float)(bzz * DF_BRICK) + 3.5f) * a.vsz));
-        if (df_tile_culled(a, c)) return;                           // block-uniform
+        if (df_tile_culled(a, c, a.kf)) return;                           // block-uniform
     }
 
     const bool in_xy = x < a.X && y < a.Y;
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(256, UNROLL) void df_warp_rows_kernel(const DfWarpe
         const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX) + 0.5f * (DF_ROW_TX - 1)) * a.vsx,
                                               ((float)(ty * DF_ROW_TY) + 0.5f * (DF_ROW_TY - 1)) * a.vsy,
                                               ((float)(zt * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
-        if (df_tile_culled(a, c)) return;                               // block-uniform
+        if (df_tile_culled(a, c, a.kf)) return;                               // block-uniform
     }
     const int x = tx * DF_ROW_TX + (threadIdx.x & (DF_ROW_TX - 1));
     const int y = ty * DF_ROW_TY + (threadIdx.x >> 5);
@@ -1025,7 +1026,7 @@ __global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArg
             const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX) + 0.5f * (DF_ROW_TX - 1)) * a.vsx,
                                                   ((float)(ty * DF_LDS_TY) + 0.5f * (DF_LDS_TY - 1)) * a.vsy,
                                                   ((float)(zt * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
-            if (df_tile_culled(a, c)) continue;                           // block-uniform
+            if (df_tile_culled(a, c, a.kf)) continue;                           // block-uniform
         }
         if (!in_xy) continue;
         // NB planes per batch: all table loads of the batch are issued back to back (NB * 3 KiB in flight per wave),
@@ -1144,21 +1145,25 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
     auto layer_zb = [&](int l) { return max((lt0 + l) * DF_ROW_TZ, a.z_own0); };
     auto layer_ze = [&](int l) { return min((lt0 + l + 1) * DF_ROW_TZ, own1); };
 
-    unsigned alive = 0;                                                    // block-uniform: layers that are in range and not culled
-    for (int l = 0; l < DF_LDS_ZT; ++l) {
-        if (layer_zb(l) >= layer_ze(l)) continue;
-        bool culled = false;
-        if (a.cull) {
+    // block-uniform: layers that are in range and not culled.  Lane l of every wave judges layer l (the verdict costs ~150
+    // instructions -- eight of them one after the other in all lanes was 7 % of the kernel's VALU work), a ballot collects them.
+    unsigned alive;
+    {
+        const int l = ln & (DF_LDS_ZT - 1);
+        bool keep = layer_zb(l) < layer_ze(l);
+        if (keep && a.cull) {
             const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX) + 0.5f * (DF_ROW_TX - 1)) * a.vsx,
                                                   ((float)(ty * DF_LDS_TY) + 0.5f * (DF_LDS_TY - 1)) * a.vsy,
                                                   ((float)((lt0 + l) * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
-            culled = df_tile_culled(a, c);
-            if (a.tile_wmax) {                                             // zero-weight tile (DF_ZERO_WEIGHT): nothing in it can update
-                const size_t tile = ((size_t)(lt0 + l - a.tab_z0 / DF_TAB_TZ) * a.tab_nty + ty) * a.tab_ntx + tx;
-                culled |= a.tile_wmax[tile] * a.cull[3] < DF_ZERO_WEIGHT;
+            float wk = a.kf;
+            if (a.tile_wmax) {
+                const float wmax = a.tile_wmax[((size_t)(lt0 + l - a.tab_z0 / DF_TAB_TZ) * a.tab_nty + ty) * a.tab_ntx + tx];
+                keep = !(wmax * a.cull[3] < DF_ZERO_WEIGHT);              // zero-weight tile: nothing in it can update
+                wk = fminf(wk, wmax * 1.0001f);                            // |sum w_i t_i| <= (sum w_i) max |t_i|: far from the nodes the blend barely translates
             }
+            keep = keep && !df_tile_culled(a, c, wk);
         }
-        if (!culled) alive |= 1u << l;
+        alive = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)__builtin_amdgcn_ballot_w64(keep) & ((1u << DF_LDS_ZT) - 1u)));
     }
     unsigned int my_upd = 0;
     if (alive) {
