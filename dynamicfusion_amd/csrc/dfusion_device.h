@@ -147,6 +147,66 @@ __device__ __forceinline__ quat q_normalize_near_unit(quat a, float s)
     const double e = (double)(n - 1.f);
     return q_scale_f64(__builtin_fma(e, e, 1.0 - e), a);
 }
+// ---- quaternion products on (w,x),(y,z) register pairs: 8 v_pk_mul_f32 + 6 v_pk_add_f32.  Every product and every sum of
+// q_mul above, in the same association -- ((p0 +- p1) +- p2) +- p3 per component -- with the operand halves picked by op_sel and
+// the signs by neg_lo / neg_hi (a sign flip of an operand: exact).  The compiler's own pairing of the scalar form needs 23
+// instructions, a third of them moves.  CONJ_B: b is used as conj(b) (quaternion.hpp:124, every x/y/z operand of b negated).
+typedef float df_v2f __attribute__((ext_vector_type(2)));
+struct quat2 { df_v2f wx, yz; };
+__device__ __forceinline__ quat2 q_pairs(quat a) { quat2 r; r.wx = df_v2f{a.w, a.x}; r.yz = df_v2f{a.y, a.z}; return r; }
+__device__ __forceinline__ quat q_unpair(quat2 a) { quat r; r.w = a.wx.x; r.x = a.wx.y; r.y = a.yz.x; r.z = a.yz.y; return r; }
+__device__ __forceinline__ quat2 q_mul_pk(quat2 a, quat2 b)
+{
+    quat2 r; df_v2f p1, p2, p3, q1, q2, q3;
+    asm("v_pk_mul_f32 %[rwx], %[awx], %[bwx] op_sel_hi:[0,1]\n\t"                 // (aw bw, aw bx)
+        "v_pk_mul_f32 %[p1], %[awx], %[bwx] op_sel:[1,1] op_sel_hi:[1,0]\n\t"     // (ax bx, ax bw)
+        "v_pk_mul_f32 %[p2], %[ayz], %[byz] op_sel_hi:[0,1]\n\t"                  // (ay by, ay bz)
+        "v_pk_mul_f32 %[p3], %[ayz], %[byz] op_sel:[1,1] op_sel_hi:[1,0]\n\t"     // (az bz, az by)
+        "v_pk_mul_f32 %[ryz], %[awx], %[byz] op_sel_hi:[0,1]\n\t"                 // (aw by, aw bz)
+        "v_pk_mul_f32 %[q1], %[awx], %[byz] op_sel:[1,1] op_sel_hi:[1,0]\n\t"     // (ax bz, ax by)
+        "v_pk_mul_f32 %[q2], %[ayz], %[bwx] op_sel_hi:[0,1]\n\t"                  // (ay bw, ay bx)
+        "v_pk_mul_f32 %[q3], %[ayz], %[bwx] op_sel:[1,1] op_sel_hi:[1,0]\n\t"     // (az bx, az bw)
+        "v_pk_add_f32 %[rwx], %[rwx], %[p1] neg_lo:[0,1]\n\t"                     // w: - ax bx   x: + ax bw
+        "v_pk_add_f32 %[ryz], %[ryz], %[q1] neg_lo:[0,1]\n\t"                     // y: - ax bz   z: + ax by
+        "v_pk_add_f32 %[rwx], %[rwx], %[p2] neg_lo:[0,1]\n\t"                     // w: - ay by   x: + ay bz
+        "v_pk_add_f32 %[ryz], %[ryz], %[q2] neg_hi:[0,1]\n\t"                     // y: + ay bw   z: - ay bx
+        "v_pk_add_f32 %[rwx], %[rwx], %[p3] neg_lo:[0,1] neg_hi:[0,1]\n\t"        // w: - az bz   x: - az by
+        "v_pk_add_f32 %[ryz], %[ryz], %[q3]"                                       // y: + az bx   z: + az bw
+        : [rwx] "=&v"(r.wx), [ryz] "=&v"(r.yz), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3)
+        : [awx] "v"(a.wx), [ayz] "v"(a.yz), [bwx] "v"(b.wx), [byz] "v"(b.yz));
+    return r;
+}
+__device__ __forceinline__ quat2 q_mul_conj_pk(quat2 a, quat2 b)
+{
+    quat2 r; df_v2f p1, p2, p3, q1, q2, q3;
+    asm("v_pk_mul_f32 %[rwx], %[awx], %[bwx] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"                          // (aw bw, aw (-bx))
+        "v_pk_mul_f32 %[p1], %[awx], %[bwx] op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"              // (ax (-bx), ax bw)
+        "v_pk_mul_f32 %[p2], %[ayz], %[byz] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"              // (ay (-by), ay (-bz))
+        "v_pk_mul_f32 %[p3], %[ayz], %[byz] op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" // (az (-bz), az (-by))
+        "v_pk_mul_f32 %[ryz], %[awx], %[byz] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"             // (aw (-by), aw (-bz))
+        "v_pk_mul_f32 %[q1], %[awx], %[byz] op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" // (ax (-bz), ax (-by))
+        "v_pk_mul_f32 %[q2], %[ayz], %[bwx] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"                           // (ay bw, ay (-bx))
+        "v_pk_mul_f32 %[q3], %[ayz], %[bwx] op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"              // (az (-bx), az bw)
+        "v_pk_add_f32 %[rwx], %[rwx], %[p1] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[ryz], %[ryz], %[q1] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[rwx], %[rwx], %[p2] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %[ryz], %[ryz], %[q2] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[rwx], %[rwx], %[p3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[ryz], %[ryz], %[q3]"
+        : [rwx] "=&v"(r.wx), [ryz] "=&v"(r.yz), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3)
+        : [awx] "v"(a.wx), [ayz] "v"(a.yz), [bwx] "v"(b.wx), [byz] "v"(b.yz));
+    return r;
+}
+// dq_transform_rn with the two quaternion products on register pairs (dual = 0.5 * tsum * rot is formed by the caller the same way)
+__device__ __forceinline__ f3 dq_transform_rn_pk(quat rn, quat2 dual, f3 p)
+{
+    quat2 d2; d2.wx = dual.wx * 2.f; d2.yz = dual.yz * 2.f;                              // q_scale(2, dual)
+    const quat2 t = q_mul_conj_pk(d2, q_pairs(rn));
+    f3 qv = mk3(rn.x, rn.y, rn.z);
+    f3 inner = add3(cross3(qv, p), scale3(p, rn.w));
+    p = add3(p, cross3(scale3(qv, 2.f), inner));
+    return add3(p, mk3(t.wx.y, t.yz.x, t.yz.y));
+}
 __device__ __forceinline__ bool df_wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
 // warp_field.cpp:238-241 (double exp overload, see oracle header)
 __device__ __forceinline__ float dqb_weight(float d2, float sigma) { return (float)exp((double)(-d2 / (2 * sigma * sigma))); }

@@ -189,7 +189,6 @@ __device__ __forceinline__ void dqb_blend_w(const DfWarpView& W, const float (&w
 // kept as two float2 halves in MEMORY order ((w,x),(y,z)): the backend maps them 1:1 onto v_pk_mul_f32 / v_pk_add_f32
 // without register shuffles (left to itself it paired (w,z),(x,y) and spent ~65 v_mov per voxel re-pairing the LDS
 // words).  Element-wise IEEE mul then add, exactly the scalar sequence of :211-212.
-typedef float df_v2f __attribute__((ext_vector_type(2)));
 struct DfBlendSums { df_v2f t01, t23, r01, r23; };      // sum w_i * node_t_i and sum w_i * rot_i as (w,x),(y,z) halves
 template <int K>
 __device__ __forceinline__ DfBlendSums dqb_sums_lds(const float4* s_node, const float (&wt)[K], const int (&bi)[K])
@@ -1121,12 +1120,58 @@ __device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<4>& r, int (&bi)[4
     bi[0] = r.idx.x & 0xffff; bi[1] = r.idx.x >> 16; bi[2] = r.idx.y & 0xffff; bi[3] = r.idx.y >> 16;
     wt[0] = r.w0.x; wt[1] = r.w0.y; wt[2] = r.w0.z; wt[3] = r.w0.w;
 }
+// Byte offset of node `word` (0 = low, 1 = high 16 bits of v) in the interleaved LDS node table: index * 32 in ONE instruction
+// (SDWA selects the 16-bit word as the shift's operand; and + shift / bfe + shift otherwise, two per index, 16 per voxel).
+__device__ __forceinline__ unsigned df_node_off_lo(unsigned v)
+{
+    unsigned r;
+    asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ unsigned df_node_off_hi(unsigned v)
+{
+    unsigned r;
+    asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ void tab_raw_offsets(const DfTabRaw<8>& r, unsigned (&bo)[8], float (&wt)[8])
+{
+    bo[0] = df_node_off_lo(r.idx.x); bo[1] = df_node_off_hi(r.idx.x); bo[2] = df_node_off_lo(r.idx.y); bo[3] = df_node_off_hi(r.idx.y);
+    bo[4] = df_node_off_lo(r.idx.z); bo[5] = df_node_off_hi(r.idx.z); bo[6] = df_node_off_lo(r.idx.w); bo[7] = df_node_off_hi(r.idx.w);
+    wt[0] = r.w0.x; wt[1] = r.w0.y; wt[2] = r.w0.z; wt[3] = r.w0.w; wt[4] = r.w1.x; wt[5] = r.w1.y; wt[6] = r.w1.z; wt[7] = r.w1.w;
+}
+__device__ __forceinline__ void tab_raw_offsets(const DfTabRaw<4>& r, unsigned (&bo)[4], float (&wt)[4])
+{
+    bo[0] = df_node_off_lo(r.idx.x); bo[1] = df_node_off_hi(r.idx.x); bo[2] = df_node_off_lo(r.idx.y); bo[3] = df_node_off_hi(r.idx.y);
+    wt[0] = r.w0.x; wt[1] = r.w0.y; wt[2] = r.w0.z; wt[3] = r.w0.w;
+}
+// dqb_sums_lds with the nodes given as byte offsets into the workgroup's LDS.  The node table is the kernel's only LDS object (the
+// dynamic array), so it starts at LDS address 0 and the offset IS the address -- df_warp_rows_pipe_kernel checks that.
+typedef float df_v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) df_v4f df_lds_cf4;
+template <int K>
+__device__ __forceinline__ DfBlendSums dqb_sums_lds_off(const float (&wt)[K], const unsigned (&bo)[K])
+{
+    DfBlendSums S;
+    S.t01 = S.t23 = S.r01 = S.r23 = df_v2f{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        df_lds_cf4* nd = (df_lds_cf4*)(size_t)bo[i];
+        const df_v4f r4 = nd[0], t4 = nd[1];
+        const df_v2f ww = {wt[i], wt[i]};
+        const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
+        S.t01 = S.t01 + ww * ta; S.t23 = S.t23 + ww * tb;     // :211
+        S.r01 = S.r01 + ww * ra; S.r23 = S.r23 + ww * rb;     // :212
+    }
+    return S;
+}
 
 template <int K, int U>
 __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
     for (int j = threadIdx.x; j < W.M; j += 512) { s_nodes[2 * j] = W.rot[j]; s_nodes[2 * j + 1] = W.node_t[j]; }
+    if ((unsigned)(size_t)(df_lds_cf4*)s_nodes != 0u) __builtin_trap();  // dqb_sums_lds_off addresses the table from LDS address 0
     __syncthreads();
 
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -1203,9 +1248,9 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
         // one batch: consumes S (tables of batch (l, z0)), then refills S with the tables of batch (l2, z2)
         auto step = [&](DfTabRaw<K> (&S)[U], int l, int z0, int l2, int z2) {
             const int ze = layer_ze(l);
-            int bi[U][K]; float wt[U][K];
+            unsigned bo[U][K]; float wt[U][K];
 #pragma unroll
-            for (int u = 0; u < U; ++u) tab_raw_unpack(S[u], bi[u], wt[u]);
+            for (int u = 0; u < U; ++u) tab_raw_offsets(S[u], bo[u], wt[u]);
             // (1) voxel words of this batch (unconditional; clamped plane for the tail)
             uint32_t* vp[U]; uint32_t vox[U]; bool inz[U];
 #pragma unroll
@@ -1221,16 +1266,16 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const f3 q = aff_mul(a.vol2world, mk3(fxv, fyv, (float)(z0 + u) * a.vsz));   // canonical position
-                const DfBlendSums B = dqb_sums_lds<K>(s_nodes, wt[u], bi[u]);
-                quat rsum, half, rn;
+                const DfBlendSums B = dqb_sums_lds_off<K>(wt[u], bo[u]);
+                quat rsum, rn; quat2 half;
                 rsum.w = B.r01.x; rsum.x = B.r01.y; rsum.y = B.r23.x; rsum.z = B.r23.y;
-                half.w = 0.5f * B.t01.x; half.x = 0.5f * B.t01.y; half.y = 0.5f * B.t23.x; half.z = 0.5f * B.t23.y;
+                half.wx = B.t01 * 0.5f; half.yz = B.t23 * 0.5f;
                 const quat rot = q_normalize_rcp_short(rsum);                                 // :214
-                const quat dual = q_mul(half, rot);                                           // dual_quaternion.hpp:59-63
+                const quat2 dual = q_mul_pk(half, q_pairs(rot));                              // dual_quaternion.hpp:59-63
                 const float s2 = q_sumsq(rot);
                 if (__builtin_expect(df_wave_all(q_near_unit_ok(s2)), 1)) rn = q_normalize_near_unit(rot, s2);
                 else rn = q_normalize(rot);                      // blend sums so small that their squares were denormal: rot is not unit
-                vc[u] = aff_mul(a.world2cam, dq_transform_rn(rn, dual, q));
+                vc[u] = aff_mul(a.world2cam, dq_transform_rn_pk(rn, dual, q));
                 const float pu = fmaf(a.P.fx, vc[u].x / vc[u].z, a.P.cx);                     // device.hpp:35
                 const float pv = fmaf(a.P.fy, vc[u].y / vc[u].z, a.P.cy);                     // device.hpp:36
                 ok[u] = inz[u] & (vc[u].z > 0.f) & (pu >= 0.f) & (pv >= 0.f) & (pu < (float)a.P.cols) & (pv < (float)a.P.rows);   // :82,:86
