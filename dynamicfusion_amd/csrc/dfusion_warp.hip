@@ -1211,6 +1211,7 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
         alive = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)__builtin_amdgcn_ballot_w64(keep) & ((1u << DF_LDS_ZT) - 1u)));
     }
     unsigned int my_upd = 0;
+    const unsigned pitch24 = (unsigned)a.P.pitch;                          // rows, pitch < 2^24 (checked by the launcher): 24-bit multiply
     if (alive) {
         // batch sequence: U planes per batch inside a layer, then the first batch of the next alive layer; l < 0 = none
         auto advance = [&](int l, int z0, int* nl, int* nz0) {
@@ -1270,7 +1271,11 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
                 quat rsum, rn; quat2 half;
                 rsum.w = B.r01.x; rsum.x = B.r01.y; rsum.y = B.r23.x; rsum.z = B.r23.y;
                 half.wx = B.t01 * 0.5f; half.yz = B.t23 * 0.5f;
-                const quat rot = q_normalize_rcp_short(rsum);                                 // :214
+                const float s1 = q_sumsq(rsum);
+                float n1;
+                if (__builtin_expect(df_wave_all(df_sqrt_short_ok(s1)), 1)) n1 = df_sqrt_short(s1);
+                else n1 = sqrtf(s1);                             // far from the nodes: tiny, denormal or zero sums
+                const quat rot = q_scale_f64(df_rcp_short((double)n1), rsum);                 // :214 (see q_normalize_rcp_short)
                 const quat2 dual = q_mul_pk(half, q_pairs(rot));                              // dual_quaternion.hpp:59-63
                 const float s2 = q_sumsq(rot);
                 if (__builtin_expect(df_wave_all(q_near_unit_ok(s2)), 1)) rn = q_normalize_near_unit(rot, s2);
@@ -1281,7 +1286,7 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
                 ok[u] = inz[u] & (vc[u].z > 0.f) & (pu >= 0.f) & (pv >= 0.f) & (pu < (float)a.P.cols) & (pv < (float)a.P.rows);   // :82,:86
                 const int ui = (int)fminf(fmaxf(pu, 0.f), (float)(a.P.cols - 1));
                 const int vi = (int)fminf(fmaxf(pv, 0.f), (float)(a.P.rows - 1));
-                dpb[u] = *(const uint16_t*)((const char*)a.P.dists + ((unsigned)vi * (unsigned)a.P.pitch + 2u * (unsigned)ui));   // :85 (image < 4 GiB)
+                dpb[u] = *(const uint16_t*)((const char*)a.P.dists + (__umul24((unsigned)vi, pitch24) + 2u * (unsigned)ui));   // :85
             }
             __builtin_amdgcn_sched_barrier(0);
             // (3) tables of batch b+2 into the set just consumed.  Unconditional (a dummy re-read at the end): a branch here
@@ -1412,8 +1417,9 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         const size_t lds = (size_t)wf->M * 32;
         typedef void (*lds_kernel_t)(const DfWarpedArgs, const DfWarpView, int);
         lds_kernel_t kern = nullptr;
-        if (use_w && k == 8 && !(flags & DF_WARP_NO_PIPELINE)) kern = df_warp_rows_pipe_kernel<8, 2>;
-        else if (use_w && k == 4 && !(flags & DF_WARP_NO_PIPELINE)) kern = df_warp_rows_pipe_kernel<4, 2>;
+        const bool pipe_ok = use_w && !(flags & DF_WARP_NO_PIPELINE) && pitch < (1u << 24) && rows < (1 << 24);   // its 24-bit row * pitch
+        if (pipe_ok && k == 8) kern = df_warp_rows_pipe_kernel<8, 2>;
+        else if (pipe_ok && k == 4) kern = df_warp_rows_pipe_kernel<4, 2>;
         else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
         else { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, false, 1>)); }
         DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
