@@ -709,6 +709,7 @@ struct DfWarpedArgs {
     //   w_tab    K float weights per voxel, stored as K/4 float4 PLANES of tab_nvox entries each, so that a wave of
     //            x-adjacent lanes reads 1 KiB contiguous per instruction
     uint16_t* knn_tab; float* w_tab; int tab_z0; size_t tab_nvox; int tab_ntx, tab_nty;
+    int zt;                        // pipelined sweep: tile layers per workgroup (1..16)
     // max over the voxels of each table tile of sum_i w_i (written by the table build, frame-invariant); null = no zero-weight test
     float* tile_wmax;
 };
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(256, UNROLL) void df_warp_rows_kernel(const DfWarpe
 // 512-thread workgroup stages rot + node_t of ALL nodes in LDS once and walks DF_LDS_ZT tile layers; gathers become
 // ds_read_b128 (256 B/clk/CU, identical addresses broadcast).  Two such workgroups fill a CU (160 KiB LDS, 16 waves).
 #define DF_LDS_TY 16
-#define DF_LDS_ZT 8          // tile layers (of DF_ROW_TZ planes) walked per workgroup
+#define DF_LDS_ZT 8          // tile layers (of DF_ROW_TZ planes) walked per workgroup (batched kernel; the pipelined one takes a.zt)
 
 template <int K, bool HAS_W, int NB>
 __global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
@@ -1185,7 +1186,7 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
     const int xc = min(x, a.X - 1), yc = min(y, a.Y - 1);                 // clamped: out-of-volume lanes read valid entries, write nothing
     const size_t plane = (size_t)a.X * a.Y;
     const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
-    const int lt0 = a.bz0 + blockIdx.y * DF_LDS_ZT;                        // first tile layer of this workgroup
+    const int lt0 = a.bz0 + blockIdx.y * a.zt;                        // first tile layer of this workgroup
     const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
     auto layer_zb = [&](int l) { return max((lt0 + l) * DF_ROW_TZ, a.z_own0); };
     auto layer_ze = [&](int l) { return min((lt0 + l + 1) * DF_ROW_TZ, own1); };
@@ -1194,8 +1195,8 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
     // instructions -- eight of them one after the other in all lanes was 7 % of the kernel's VALU work), a ballot collects them.
     unsigned alive;
     {
-        const int l = ln & (DF_LDS_ZT - 1);
-        bool keep = layer_zb(l) < layer_ze(l);
+        const int l = ln & 15;
+        bool keep = l < a.zt && layer_zb(l) < layer_ze(l);
         if (keep && a.cull) {
             const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX) + 0.5f * (DF_ROW_TX - 1)) * a.vsx,
                                                   ((float)(ty * DF_LDS_TY) + 0.5f * (DF_LDS_TY - 1)) * a.vsy,
@@ -1208,7 +1209,7 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
             }
             keep = keep && !df_tile_culled(a, c, wk);
         }
-        alive = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)__builtin_amdgcn_ballot_w64(keep) & ((1u << DF_LDS_ZT) - 1u)));
+        alive = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)__builtin_amdgcn_ballot_w64(keep) & 0xffffu));
     }
     unsigned int my_upd = 0;
     const unsigned pitch24 = (unsigned)a.P.pitch;                          // rows, pitch < 2^24 (checked by the launcher): 24-bit multiply
@@ -1413,11 +1414,15 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
         a.bz0 = zt_lo;
         if (a.cull) a.tile_r = (float)(df_tile_radius(vol2world, DF_ROW_TX, DF_LDS_TY, DF_ROW_TZ, v) * 1.001 + 1e-6);
-        dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + DF_LDS_ZT - 1) / DF_LDS_ZT));
         const size_t lds = (size_t)wf->M * 32;
         typedef void (*lds_kernel_t)(const DfWarpedArgs, const DfWarpView, int);
         lds_kernel_t kern = nullptr;
         const bool pipe_ok = use_w && !(flags & DF_WARP_NO_PIPELINE) && pitch < (1u << 24) && rows < (1 << 24);   // its 24-bit row * pitch
+        // tile layers per workgroup: long walks amortise the LDS fill and the pipeline ramp, short ones even out the last round of
+        // workgroups on the 256 CUs (measured: 4 layers best at 256^3 = 1024 workgroups, 8 at 512^3, 16 at 1024^3 = 16384)
+        const long long cols_layers = (long long)tiles_x * tiles_y * (zt_hi - zt_lo + 1);
+        a.zt = !pipe_ok ? DF_LDS_ZT : cols_layers <= 8192 ? 4 : cols_layers <= 65536 ? 8 : 16;
+        dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + a.zt - 1) / a.zt));
         if (pipe_ok && k == 8) kern = df_warp_rows_pipe_kernel<8, 2>;
         else if (pipe_ok && k == 4) kern = df_warp_rows_pipe_kernel<4, 2>;
         else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
