@@ -1191,15 +1191,17 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
     auto layer_zb = [&](int l) { return max((lt0 + l) * DF_ROW_TZ, a.z_own0); };
     auto layer_ze = [&](int l) { return min((lt0 + l + 1) * DF_ROW_TZ, own1); };
 
-    // block-uniform: layers that are in range and not culled.  Lane l of every wave judges layer l (the verdict costs ~150
+    // wave-uniform: layers that are in range and whose 8 x 8 x 8 voxels of this wave are not culled (the waves of a workgroup walk
+    // their own batch sequences; nothing in the sweep synchronises them).  Lane l judges layer l (the verdict costs ~150
     // instructions -- eight of them one after the other in all lanes was 7 % of the kernel's VALU work), a ballot collects them.
     unsigned alive;
     {
         const int l = ln & 15;
         bool keep = l < a.zt && layer_zb(l) < layer_ze(l);
         if (keep && a.cull) {
-            const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX) + 0.5f * (DF_ROW_TX - 1)) * a.vsx,
-                                                  ((float)(ty * DF_LDS_TY) + 0.5f * (DF_LDS_TY - 1)) * a.vsy,
+            // the wave's own 8 x 8 x 8 voxels of the layer, not the workgroup's 32 x 16 x 8: a third of the radius
+            const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX + (wv & 3) * 8) + 3.5f) * a.vsx,
+                                                  ((float)(ty * DF_LDS_TY + (wv >> 2) * 8) + 3.5f) * a.vsy,
                                                   ((float)((lt0 + l) * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
             float wk = a.kf;
             if (a.tile_wmax) {
@@ -1413,11 +1415,12 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_LDS_TY - 1) / DF_LDS_TY;
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
         a.bz0 = zt_lo;
-        if (a.cull) a.tile_r = (float)(df_tile_radius(vol2world, DF_ROW_TX, DF_LDS_TY, DF_ROW_TZ, v) * 1.001 + 1e-6);
+        const bool pipe_ok = use_w && !(flags & DF_WARP_NO_PIPELINE) && pitch < (1u << 24) && rows < (1 << 24);   // its 24-bit row * pitch
+        if (a.cull) a.tile_r = (float)(df_tile_radius(vol2world, pipe_ok && (k == 8 || k == 4) ? 8 : DF_ROW_TX, pipe_ok && (k == 8 || k == 4) ? 8 : DF_LDS_TY,
+                                                      DF_ROW_TZ, v) * 1.001 + 1e-6);
         const size_t lds = (size_t)wf->M * 32;
         typedef void (*lds_kernel_t)(const DfWarpedArgs, const DfWarpView, int);
         lds_kernel_t kern = nullptr;
-        const bool pipe_ok = use_w && !(flags & DF_WARP_NO_PIPELINE) && pitch < (1u << 24) && rows < (1 << 24);   // its 24-bit row * pitch
         // tile layers per workgroup: long walks amortise the LDS fill and the pipeline ramp, short ones even out the last round of
         // workgroups on the 256 CUs (measured: 4 layers best at 256^3 = 1024 workgroups, 8 at 512^3, 16 at 1024^3 = 16384)
         const long long cols_layers = (long long)tiles_x * tiles_y * (zt_hi - zt_lo + 1);
