@@ -12,7 +12,7 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libdfusion_hip.so")
 
-SOURCES = ["dfusion_volume.hip", "dfusion_warp.hip", "dfusion_raycast.hip", "dfusion_frontend.hip", "dfusion_solver.hip"]
+SOURCES = ["dfusion_volume.hip", "dfusion_warp.hip", "dfusion_raycast.hip", "dfusion_frontend.hip", "dfusion_solver.hip", "dfusion_selftest.hip"]
 HEADERS = ["dfusion_device.h", "dfusion_internal.h", os.path.join(REPO_DIR, "include", "dfusion.h")]
 
 # -ffp-contract=off: fused multiply-adds only where the reference writes __fmaf_rn (explicit fmaf);

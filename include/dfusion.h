@@ -195,6 +195,12 @@ int dfusion_warp_build_index(DfWarpField *wf, DfVolume geometry, const DfSlab *s
 /* Introspection of the k-NN index (blocking): total candidate-list entries, number of 8^3 bricks, k it was built for. */
 int dfusion_warp_index_info(const DfWarpField *wf, unsigned long long *total_entries, unsigned int *n_bricks, int *k_built);
 
+/* Device self-test of the sweep's short arithmetic forms (dfusion_device.h) against the generic ones they replace; no reference
+ * counterpart, used by the parity tests.  counts_dev[5] (device) receives mismatch counts: [0] short sqrtf over every f32 of its
+ * domain, [1] short f64 reciprocal over every positive normal f32, [2] packed quaternion products on n_random random pairs
+ * (specials included), [3] near-unit normalisation on the normalised quaternions among them, [4] how many of those there were.   */
+int dfusion_selftest_exact_forms(unsigned long long n_random, unsigned long long *counts_dev, dfStream stream);
+
 /* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k],
  * ascending distance, ties -> lower node index.                                               */
 int dfusion_knn(DfWarpField *wf, int k, const float *queries_dev, int N, int *idx_dev, float *d2_dev, dfStream stream);

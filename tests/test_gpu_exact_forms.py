@@ -1,0 +1,20 @@
+"""The warped sweep replaces sqrtf, the f64 reciprocal inside Quaternion::normalize and the quaternion products by shorter
+instruction sequences that are claimed to give THE SAME BITS (dynamicfusion_amd/csrc/dfusion_device.h).  The library checks those
+claims on the device over the whole domain of each form (dfusion_selftest_exact_forms); this test runs the check."""
+import pytest
+import torch
+
+from dynamicfusion_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_short_forms_equal_generic_forms_on_every_input():
+    counts = torch.zeros(5, dtype=torch.int64, device="cuda")
+    capi.check(capi.lib().dfusion_selftest_exact_forms(1 << 27, counts.data_ptr(), None))
+    torch.cuda.synchronize()
+    sqrt_bad, rcp_bad, qmul_bad, unit_bad, unit_seen = [int(c) for c in counts.cpu()]
+    assert sqrt_bad == 0          # every finite f32 >= 2^-96 (1.8e9 values)
+    assert rcp_bad == 0           # every positive normal f32 as the f64 denominator (2.1e9 values)
+    assert qmul_bad == 0          # 2 x 1.3e8 random quaternion products, zeros / infinities / NaNs / denormals included
+    assert unit_bad == 0 and unit_seen > (1 << 24)      # second normalisation of already normalised quaternions
