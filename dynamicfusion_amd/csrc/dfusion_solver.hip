@@ -66,38 +66,66 @@ __global__ __launch_bounds__(256) void df_sv_offsets_kernel(const unsigned int* 
 }
 
 // ---- u = W p : per point, slot order
+// K > 0: compile-time neighbour count, so that the 2K entry loads and 3K gathers of a point are all in flight before the first sum
+// (with a run-time k the loop issues and waits entry by entry); K = 0: any k.  Same sums in the same order either way.
+template <int K>
 __global__ __launch_bounds__(256) void df_sv_w_apply_kernel(const float* __restrict__ w, const unsigned int* __restrict__ keys, int N, int k,
                                                             int M, const float* __restrict__ p, float* __restrict__ u)
 {
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= N) return;
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int j = 0; j < k; ++j) {
-        const int e = v * k + j;
-        const unsigned int n = keys[e];
-        if (n < (unsigned int)M) {
-            const float wj = w[e];
-            sx = sx + wj * p[3 * n]; sy = sy + wj * p[3 * n + 1]; sz = sz + wj * p[3 * n + 2];
+    if constexpr (K > 0) {
+        unsigned int n[K]; float wj[K], px[K], py[K], pz[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) { n[j] = keys[v * K + j]; wj[j] = w[v * K + j]; }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const unsigned int nc = min(n[j], (unsigned int)(M - 1));            // clamped gather; the entry is skipped below if n >= M
+            px[j] = p[3 * nc]; py[j] = p[3 * nc + 1]; pz[j] = p[3 * nc + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (n[j] < (unsigned int)M) { sx = sx + wj[j] * px[j]; sy = sy + wj[j] * py[j]; sz = sz + wj[j] * pz[j]; }
+    } else {
+        for (int j = 0; j < k; ++j) {
+            const int e = v * k + j;
+            const unsigned int n = keys[e];
+            if (n < (unsigned int)M) {
+                const float wj = w[e];
+                sx = sx + wj * p[3 * n]; sy = sy + wj * p[3 * n + 1]; sz = sz + wj * p[3 * n + 2];
+            }
         }
     }
     u[3 * v] = sx; u[3 * v + 1] = sy; u[3 * v + 2] = sz;
 }
 
+// ---- node-major copies of the entries' point ids and weights (once per solve; the W^T kernel then reads them in list order)
+__global__ __launch_bounds__(256) void df_sv_sorted_kernel(const unsigned int* __restrict__ sorted_vals, const float* __restrict__ w, int E, int k,
+                                                           unsigned int* __restrict__ sorted_pt, float* __restrict__ sorted_w)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    const unsigned int e = sorted_vals[i];
+    sorted_pt[i] = e / (unsigned int)k;
+    sorted_w[i] = w[e];
+}
+
 // ---- out = W^T u (+ lambda * p) : one 256-thread workgroup per node over its (ascending-point-order) entry list.
 // Thread t sums entries t, t + 256, ... ; the 256 partials are combined by the tree (t, t + s), s = 128 .. 1 (s >= 64 through
 // LDS, s <= 32 with __shfl_down inside wave 0) -- a fixed order, restated in the oracle.
-__global__ __launch_bounds__(256) void df_sv_wt_apply_kernel(const unsigned int* __restrict__ off, const unsigned int* __restrict__ sorted_vals,
-                                                             const float* __restrict__ w, int k, int M, const float* __restrict__ u,
+__global__ __launch_bounds__(256) void df_sv_wt_apply_kernel(const unsigned int* __restrict__ off, const unsigned int* __restrict__ sorted_pt,
+                                                             const float* __restrict__ sorted_w, int M, const float* __restrict__ u,
                                                              float lambda, const float* __restrict__ p, float* __restrict__ out)
 {
     __shared__ float lds[3 * 128];
     const int n = blockIdx.x, t = threadIdx.x, wv = t >> 6, l = t & 63;
     const unsigned int b = off[n], e_end = off[n + 1];
     float s[3] = {0.f, 0.f, 0.f};
+    // the entry's point id and weight sit in list order (df_sv_sorted_kernel), so a trip is one coalesced read + the u gather
     for (unsigned int i = b + t; i < e_end; i += 256) {
-        const unsigned int e = sorted_vals[i];
-        const unsigned int v = e / (unsigned int)k;
-        const float we = w[e];
+        const unsigned int v = sorted_pt[i];
+        const float we = sorted_w[i];
         s[0] = s[0] + we * u[3 * v]; s[1] = s[1] + we * u[3 * v + 1]; s[2] = s[2] + we * u[3 * v + 2];
     }
     if (wv >= 2) { for (int c = 0; c < 3; ++c) lds[c * 128 + (t - 128)] = s[c]; }
@@ -204,6 +232,67 @@ __global__ __launch_bounds__(SV_BLOCK) void df_sv_step_kernel(const float* __res
     }
 }
 
+// df_sv_step_kernel for M <= EPT * SV_BLOCK: x, r, p, q are read once and stay in registers between the three passes (the passes of
+// the kernel above each wait for their own global loads).  Same element -> thread assignment, same sums, same trees.
+template <int EPT>
+__global__ __launch_bounds__(SV_BLOCK) void df_sv_step_reg_kernel(const float* __restrict__ q, int M, float* __restrict__ x, float* __restrict__ r,
+                                                                  float* __restrict__ p, float* __restrict__ scal)
+{
+    __shared__ float lds[3 * SV_BLOCK];
+    float pv[EPT][3], qv[EPT][3], rv[EPT][3], xv[EPT][3];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int n = threadIdx.x + j * SV_BLOCK;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool in = n < M;
+            pv[j][c] = in ? p[3 * n + c] : 0.f; qv[j][c] = in ? q[3 * n + c] : 0.f;
+            rv[j][c] = in ? r[3 * n + c] : 0.f; xv[j][c] = in ? x[3 * n + c] : 0.f;
+        }
+    }
+    float pq[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (threadIdx.x + j * SV_BLOCK < M)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pq[c] = pq[c] + pv[j][c] * qv[j][c];
+    sv_block_sum3(pq, lds);
+    float alpha[3], rr_old[3];
+    for (int c = 0; c < 3; ++c) {
+        rr_old[c] = scal[c];
+        alpha[c] = (pq[c] > 0.f && rr_old[c] > 0.f) ? rr_old[c] / pq[c] : 0.f;
+    }
+    float rr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (threadIdx.x + j * SV_BLOCK < M)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                xv[j][c] = xv[j][c] + alpha[c] * pv[j][c];
+                rv[j][c] = rv[j][c] - alpha[c] * qv[j][c];
+                rr[c] = rr[c] + rv[j][c] * rv[j][c];
+            }
+    sv_block_sum3(rr, lds);
+    float beta[3];
+    for (int c = 0; c < 3; ++c) beta[c] = (alpha[c] != 0.f && rr_old[c] > 0.f) ? rr[c] / rr_old[c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int n = threadIdx.x + j * SV_BLOCK;
+        if (n < M)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { x[3 * n + c] = xv[j][c]; r[3 * n + c] = rv[j][c]; p[3 * n + c] = rv[j][c] + beta[c] * pv[j][c]; }
+    }
+    if (threadIdx.x == 0) {
+        float active = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float keep = (alpha[c] != 0.f && rr[c] > SV_REL_TOL2 * scal[6 + c]) ? rr[c] : 0.f;
+            scal[c] = keep;
+            active += keep > 0.f ? 1.f : 0.f;
+        }
+        scal[3] = active;
+    }
+}
+
 // ---- energy = sum_v |e_v|^2 (single workgroup, same tree)
 __global__ __launch_bounds__(SV_BLOCK) void df_sv_energy_kernel(const float* __restrict__ e, int N, float* __restrict__ out)
 {
@@ -257,7 +346,7 @@ extern "C" int dfusion_warp_solve_data_term(DfWarpField* wf, int k, const float*
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_idx = take(E * 4), o_d2 = take(E * 4), o_w = take(E * 4), o_keys = take(E * 4), o_vals = take(E * 4), o_skeys = take(E * 4),
-                 o_svals = take(E * 4), o_e0 = take((size_t)N * 12), o_u = take((size_t)N * 12), o_off = take(((size_t)M + 2) * 4),
+                 o_svals = take(E * 4), o_spt = take(E * 4), o_sw = take(E * 4), o_e0 = take((size_t)N * 12), o_u = take((size_t)N * 12), o_off = take(((size_t)M + 2) * 4),
                  o_x = take((size_t)M * 12), o_r = take((size_t)M * 12), o_p = take((size_t)M * 12), o_q = take((size_t)M * 12),
                  o_scal = take(64), o_dq = take((size_t)M * 32);
     size_t sort_bytes = 0;
@@ -270,6 +359,7 @@ extern "C" int dfusion_warp_solve_data_term(DfWarpField* wf, int k, const float*
     int* idx = (int*)(ws + o_idx); float* d2 = (float*)(ws + o_d2); float* w = (float*)(ws + o_w);
     unsigned int* keys = (unsigned int*)(ws + o_keys); unsigned int* vals = (unsigned int*)(ws + o_vals);
     unsigned int* skeys = (unsigned int*)(ws + o_skeys); unsigned int* svals = (unsigned int*)(ws + o_svals);
+    unsigned int* spt = (unsigned int*)(ws + o_spt); float* sw = (float*)(ws + o_sw);
     float* e0 = (float*)(ws + o_e0); float* u = (float*)(ws + o_u); unsigned int* offs = (unsigned int*)(ws + o_off);
     float* x = (float*)(ws + o_x); float* r = (float*)(ws + o_r); float* p = (float*)(ws + o_p); float* q = (float*)(ws + o_q);
     float* scal = (float*)(ws + o_scal); float* dq = (float*)(ws + o_dq);
@@ -282,17 +372,21 @@ extern "C" int dfusion_warp_solve_data_term(DfWarpField* wf, int k, const float*
     DF_HIP(hipcub::DeviceRadixSort::SortPairs(ws + o_sort, sort_bytes, keys, skeys, vals, svals, (int)E, 0, 17, st));   // stable
     hipLaunchKernelGGL(df_sv_offsets_kernel, dim3((unsigned)((E + 1 + 255) / 256)), dim3(256), 0, st, skeys, (int)E, M, offs);
     DF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(df_sv_sorted_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, svals, w, (int)E, k, spt, sw);
+    DF_LAUNCH_CHECK();
     if (energy) { hipLaunchKernelGGL(df_sv_energy_kernel, dim3(1), dim3(SV_BLOCK), 0, st, e0, N, scal + 4); DF_LAUNCH_CHECK(); }
+    auto step = M <= 2 * SV_BLOCK ? df_sv_step_reg_kernel<2> : M <= 5 * SV_BLOCK ? df_sv_step_reg_kernel<5> : M <= 8 * SV_BLOCK ? df_sv_step_reg_kernel<8> : df_sv_step_kernel;
+    auto w_apply = k == 8 ? df_sv_w_apply_kernel<8> : k == 4 ? df_sv_w_apply_kernel<4> : df_sv_w_apply_kernel<0>;
     // r0 = W^T e0 ; p0 = r0 ; x0 = 0
     const dim3 gW(M);
-    hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, svals, w, k, M, e0, 0.f, (const float*)nullptr, r);
+    hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, spt, sw, M, e0, 0.f, (const float*)nullptr, r);
     DF_LAUNCH_CHECK();
     hipLaunchKernelGGL(df_sv_init_kernel, dim3(1), dim3(SV_BLOCK), 0, st, r, M, x, p, scal);
     DF_LAUNCH_CHECK();
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(df_sv_w_apply_kernel, gN, dim3(256), 0, st, w, keys, N, k, M, p, u);
-        hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, svals, w, k, M, u, lambda, p, q);
-        hipLaunchKernelGGL(df_sv_step_kernel, dim3(1), dim3(SV_BLOCK), 0, st, q, M, x, r, p, scal);
+        hipLaunchKernelGGL(w_apply, gN, dim3(256), 0, st, w, keys, N, k, M, p, u);
+        hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, spt, sw, M, u, lambda, p, q);
+        hipLaunchKernelGGL(step, dim3(1), dim3(SV_BLOCK), 0, st, q, M, x, r, p, scal);
         DF_LAUNCH_CHECK();
         if ((it & 15) == 15 && it + 1 < iters) {            // converged components are frozen (further steps are exact no-ops): stop launching
             float active = 1.f;
@@ -302,7 +396,7 @@ extern "C" int dfusion_warp_solve_data_term(DfWarpField* wf, int k, const float*
         }
     }
     if (energy) {
-        hipLaunchKernelGGL(df_sv_w_apply_kernel, gN, dim3(256), 0, st, w, keys, N, k, M, x, u);
+        hipLaunchKernelGGL(w_apply, gN, dim3(256), 0, st, w, keys, N, k, M, x, u);
         hipLaunchKernelGGL(df_sv_residual_kernel, dim3((unsigned)((3 * (size_t)N + 255) / 256)), dim3(256), 0, st, e0, u, 3 * N, u);
         hipLaunchKernelGGL(df_sv_energy_kernel, dim3(1), dim3(SV_BLOCK), 0, st, u, N, scal + 5);
         DF_LAUNCH_CHECK();
