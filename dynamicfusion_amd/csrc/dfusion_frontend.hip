@@ -489,33 +489,52 @@ extern "C" int dfusion_icp_sums_depth(const uint16_t* dcurr, size_t dcurr_pitch,
 // (LU with partial pivoting in double -- the arithmetic of the host mirror's solve6), applies the determinant test, builds Tinc by
 // Rodrigues and composes it into the estimate that lives in device memory; the next iteration's kernels read it from there.
 // state = {affine R[9], t[3], ok (1 / 0)}.  Once ok == 0 (|det| < 1e-15 or NaN, :152-156) the estimate is frozen.
-__global__ void df_icp_solve_kernel(const float* __restrict__ sums, float* __restrict__ state)
+__global__ __launch_bounds__(64) void df_icp_solve_kernel(const float* __restrict__ sums, float* __restrict__ state)
 {
-    // the augmented matrix lives in LDS: the pivot search indexes it dynamically, which in registers would spill to scratch
+    // One wave.  The augmented matrix lives in LDS (the pivot search indexes it dynamically); lane (i, j) = (lane / 8, lane % 8)
+    // owns element M[i][j] during the elimination, so a pivot step is one parallel update instead of up to 35 dependent LDS
+    // round trips -- each element still sees exactly the operations of the serial loop (f = M[i][c] / M[c][c]; M[i][j] -= f * M[c][j]).
     __shared__ double M[6][7];
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (state[12] == 0.f) return;
-    {
+    __shared__ int s_flag[2];                                  // [0] pivot row, [1] 1 = singular
+    __shared__ double s_det;
+    const int lane = threadIdx.x, li = lane >> 3, lj = lane & 7;
+    if (state[12] == 0.f) return;                              // uniform: frozen estimate
+    if (lane == 0) {
         int shift = 0;
         for (int i = 0; i < 6; ++i)
             for (int j = i; j < 7; ++j) {
                 const double value = (double)sums[shift++];
                 if (j == 6) M[i][6] = value; else { M[i][j] = value; M[j][i] = value; }
             }
+        s_det = 1.0; s_flag[1] = 0;
     }
-    double det = 1.0;
-    bool singular = false;
-    for (int c = 0; c < 6 && !singular; ++c) {
-        int p = c;
-        for (int i = c + 1; i < 6; ++i) if (fabs(M[i][c]) > fabs(M[p][c])) p = i;
-        if (M[p][c] == 0.0 || M[p][c] != M[p][c]) { det = (M[p][c] != M[p][c]) ? M[p][c] : 0.0; singular = true; break; }
-        if (p != c) { for (int j = 0; j < 7; ++j) { const double tmp = M[p][j]; M[p][j] = M[c][j]; M[c][j] = tmp; } det = -det; }
-        det *= M[c][c];
-        for (int i = c + 1; i < 6; ++i) {
-            const double f = M[i][c] / M[c][c];
-            for (int j = c; j < 7; ++j) M[i][j] -= f * M[c][j];
+    __syncthreads();
+    for (int c = 0; c < 6; ++c) {
+        if (lane == 0) {
+            int p = c;
+            for (int i = c + 1; i < 6; ++i) if (fabs(M[i][c]) > fabs(M[p][c])) p = i;
+            if (M[p][c] == 0.0 || M[p][c] != M[p][c]) { s_det = (M[p][c] != M[p][c]) ? M[p][c] : 0.0; s_flag[1] = 1; }
+            s_flag[0] = p;
         }
+        __syncthreads();
+        if (s_flag[1]) break;                                  // uniform
+        const int p = s_flag[0];
+        double a_p = 0.0, a_c = 0.0;
+        if (p != c && lane < 7) { a_p = M[p][lane]; a_c = M[c][lane]; }
+        __syncthreads();
+        if (p != c && lane < 7) { M[p][lane] = a_c; M[c][lane] = a_p; }
+        __syncthreads();
+        if (lane == 0) { if (p != c) s_det = -s_det; s_det *= M[c][c]; }
+        const bool mine = li > c && li < 6 && lj >= c && lj < 7;
+        double f = 0.0, mcj = 0.0, mij = 0.0;
+        if (mine) { f = M[li][c] / M[c][c]; mcj = M[c][lj]; mij = M[li][lj]; }
+        __syncthreads();
+        if (mine) M[li][lj] = mij - f * mcj;
+        __syncthreads();
     }
+    if (lane != 0) return;
+    const bool singular = s_flag[1] != 0;
+    const double det = s_det;
     if (singular || fabs(det) < 1e-15 || det != det) { state[12] = 0.f; return; }
     float r[6];
     for (int i = 5; i >= 0; --i) {
