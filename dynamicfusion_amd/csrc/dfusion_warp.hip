@@ -1090,25 +1090,33 @@ __device__ __forceinline__ void tab_raw_load(const DfWarpedArgs& a, size_t tv, D
     r.w0 = reinterpret_cast<const float4*>(a.w_tab)[tv];
 }
 // A pointer the whole wave agrees on, moved to scalar registers: address = SGPR base + 32-bit lane offset is then one
-// instruction operand (global_load ... v_off, s[base]) instead of a 64-bit add per lane and a VGPR pair per address.
+// instruction operand (global_load ... v_off, s[base]) instead of a 64-bit add per lane and a VGPR pair per address.  The
+// result is typed as a GLOBAL (address space 1) pointer: rebuilt from integers it would otherwise be a generic one, its accesses
+// FLAT instructions, and a pending FLAT load makes the compiler wait with vmcnt(0) -- which drains the table prefetch.
+typedef float df_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int df_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int df_v2u __attribute__((ext_vector_type(2)));
+template <typename T> using df_global_ptr = __attribute__((address_space(1))) T*;
 template <typename T>
-__device__ __forceinline__ T* df_wave_uniform(T* p)
+__device__ __forceinline__ df_global_ptr<T> df_wave_uniform(T* p)
 {
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return (T*)(((unsigned long long)hi << 32) | lo);
+    return (df_global_ptr<T>)(((unsigned long long)hi << 32) | lo);
 }
 // the same with the record index split into a wave-uniform base and a 32-bit lane offset
 __device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<8>& r)
 {
-    r.idx = df_wave_uniform(reinterpret_cast<const uint4*>(a.knn_tab) + rec)[lane];
-    r.w0 = df_wave_uniform(reinterpret_cast<const float4*>(a.w_tab) + rec)[lane];
-    r.w1 = df_wave_uniform(reinterpret_cast<const float4*>(a.w_tab) + a.tab_nvox + rec)[lane];
+    const df_v4u i4 = df_wave_uniform(reinterpret_cast<const df_v4u*>(a.knn_tab) + rec)[lane];
+    const df_v4f a4 = df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec)[lane];
+    const df_v4f b4 = df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + a.tab_nvox + rec)[lane];
+    r.idx = make_uint4(i4.x, i4.y, i4.z, i4.w); r.w0 = make_float4(a4.x, a4.y, a4.z, a4.w); r.w1 = make_float4(b4.x, b4.y, b4.z, b4.w);
 }
 __device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<4>& r)
 {
-    r.idx = df_wave_uniform(reinterpret_cast<const uint2*>(a.knn_tab) + rec)[lane];
-    r.w0 = df_wave_uniform(reinterpret_cast<const float4*>(a.w_tab) + rec)[lane];
+    const df_v2u i2 = df_wave_uniform(reinterpret_cast<const df_v2u*>(a.knn_tab) + rec)[lane];
+    const df_v4f a4 = df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec)[lane];
+    r.idx = make_uint2(i2.x, i2.y); r.w0 = make_float4(a4.x, a4.y, a4.z, a4.w);
 }
 __device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<8>& r, int (&bi)[8], float (&wt)[8])
 {
@@ -1148,7 +1156,6 @@ __device__ __forceinline__ void tab_raw_offsets(const DfTabRaw<4>& r, unsigned (
 }
 // dqb_sums_lds with the nodes given as byte offsets into the workgroup's LDS.  The node table is the kernel's only LDS object (the
 // dynamic array), so it starts at LDS address 0 and the offset IS the address -- df_warp_rows_pipe_kernel checks that.
-typedef float df_v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) df_v4f df_lds_cf4;
 template <int K>
 __device__ __forceinline__ DfBlendSums dqb_sums_lds_off(const float (&wt)[K], const unsigned (&bo)[K])
@@ -1249,6 +1256,25 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
         load_batch(S0, l, z0);
         load_batch(S1, l1 >= 0 ? l1 : l, l1 >= 0 ? z1 : z0);               // dummy re-read when there is no second batch
 
+        // The end of a batch's sample (:85-93: compare with the dists value, fuse, store) is carried into the NEXT batch: the dists
+        // gather is the last thing a voxel's chain issues, so finishing the batch at once waits for it with nothing left to do in the
+        // wave; a batch later it has long arrived.  `pend` is what the finish needs (6 VGPRs); an empty one (ok = false) stores nothing.
+        struct { float vn[U]; uint16_t dpb[U]; uint32_t vox[U]; int z[U]; bool ok[U]; } pend;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { pend.vn[u] = 0.f; pend.dpb[u] = 0; pend.vox[u] = 0u; pend.z[u] = a.z_store0; pend.ok[u] = false; }
+        auto finish_pending = [&]() {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float Dp = h2f_bits(pend.dpb[u]);
+                const float sdf = Dp - pend.vn[u];                                            // :89
+                const bool upd = pend.ok[u] & (Dp != 0.f) & (sdf >= -a.P.trunc);              // :86, :91
+                if (upd) {
+                    df_global_ptr<uint32_t> vp = df_wave_uniform(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane) + lane_vox;
+                    *vp = tsdf_fuse(pend.vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight);   // :93
+                    ++my_upd;
+                }
+            }
+        };
         // one batch: consumes S (tables of batch (l, z0)), then refills S with the tables of batch (l2, z2)
         auto step = [&](DfTabRaw<K> (&S)[U], int l, int z0, int l2, int z2) {
             const int ze = layer_ze(l);
@@ -1256,12 +1282,12 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
 #pragma unroll
             for (int u = 0; u < U; ++u) tab_raw_offsets(S[u], bo[u], wt[u]);
             // (1) voxel words of this batch (unconditional; clamped plane for the tail)
-            uint32_t* vp[U]; uint32_t vox[U]; bool inz[U];
+            uint32_t vox[U]; bool inz[U]; int zv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 inz[u] = in_xy && z0 + u < ze;
-                vp[u] = df_wave_uniform(a.vol + (size_t)(min(z0 + u, ze - 1) - a.z_store0) * plane) + lane_vox;     // uniform plane base + lane offset
-                vox[u] = *vp[u];
+                zv[u] = min(z0 + u, ze - 1);
+                vox[u] = *(df_wave_uniform(a.vol + (size_t)(zv[u] - a.z_store0) * plane) + lane_vox);      // uniform plane base + lane offset
             }
             // (2) blend -> transform -> project, then the dists gathers (clamped address, always valid).  The normalisations and the
             // square root take their short forms (dfusion_device.h: same bits on a restricted domain) when the whole wave is inside
@@ -1291,25 +1317,21 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
                 const int vi = (int)fminf(fmaxf(pv, 0.f), (float)(a.P.rows - 1));
                 dpb[u] = *(const uint16_t*)((const char*)a.P.dists + (__umul24((unsigned)vi, pitch24) + 2u * (unsigned)ui));   // :85
             }
+            // (2b) the previous batch's compare / fuse / store: its gathers were issued a whole batch ago
+            finish_pending();
             __builtin_amdgcn_sched_barrier(0);
             // (3) tables of batch b+2 into the set just consumed.  Unconditional (a dummy re-read at the end): a branch here
             // would make the compiler assume the loads may not have been issued and wait for most of the prefetch.
             load_batch(S, l2 >= 0 ? l2 : l, l2 >= 0 ? z2 : z0);
             __builtin_amdgcn_sched_barrier(0);
-            // (4) finish the sample (:85-93), fuse (:97-103), store
+            // (4) |vc| of this batch (:89); the rest of the sample waits in `pend`
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float Dp = h2f_bits(dpb[u]);
                 const float v2 = dot3(vc[u], vc[u]);
                 float vn;
                 if (__builtin_expect(df_wave_all(df_sqrt_short_ok(v2)), 1)) vn = df_sqrt_short(v2);
                 else vn = sqrtf(v2);                                                         // (NaN positions of zero-weight voxels come here)
-                const float sdf = Dp - vn;                                                    // :89
-                const bool upd = ok[u] & (Dp != 0.f) & (sdf >= -a.P.trunc);                   // :86, :91
-                if (upd) {
-                    *vp[u] = tsdf_fuse(vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight);   // :93
-                    ++my_upd;
-                }
+                pend.vn[u] = vn; pend.dpb[u] = dpb[u]; pend.vox[u] = vox[u]; pend.z[u] = zv[u]; pend.ok[u] = ok[u];
             }
         };
         for (;;) {
@@ -1323,6 +1345,7 @@ __global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpe
             if (l2 < 0) break;
             l = l2; z0 = z2; l1 = l3; z1 = z3;
         }
+        finish_pending();                                                   // the last batch
     }
     df_count_updates(a, my_upd);
 }
