@@ -1174,19 +1174,25 @@ __device__ __forceinline__ DfBlendSums dqb_sums_lds_off(const float (&wt)[K], co
     return S;
 }
 
-template <int K, int U>
-__global__ __launch_bounds__(512, 4) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
+// WGT = 512: one 32 x 16 tile column per workgroup, two workgroups per CU while the node table is <= 80 KiB (2560 nodes).
+// WGT = 1024: two x-adjacent tile columns share one node table, for the larger tables that leave room for only one workgroup per CU:
+// 16 waves (4 per SIMD) instead of 8.
+template <int K, int U, int WGT>
+__global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
-    for (int j = threadIdx.x; j < W.M; j += 512) { s_nodes[2 * j] = W.rot[j]; s_nodes[2 * j + 1] = W.node_t[j]; }
+    for (int j = threadIdx.x; j < W.M; j += WGT) { s_nodes[2 * j] = W.rot[j]; s_nodes[2 * j + 1] = W.node_t[j]; }
     if ((unsigned)(size_t)(df_lds_cf4*)s_nodes != 0u) __builtin_trap();  // dqb_sums_lds_off addresses the table from LDS address 0
     __syncthreads();
 
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    constexpr int TPW = WGT / 512;                                         // tile columns per workgroup
+    const int groups_x = (tiles_x + TPW - 1) / TPW;
+    const int tx = (blockIdx.x % groups_x) * TPW + (int)(threadIdx.x >> 9), ty = blockIdx.x / groups_x;   // wave-uniform
+    if (tx >= tiles_x) return;                                             // odd tile count: the second half of the last group is idle
     // lane -> column of the 32 x 16 footprint: a wave owns an 8 x 8 patch (4 patches across, 2 down), not a 32 x 2 strip -- the
     // same 8 cache lines per table load, but a compact footprint, so that the voxels of a wave fall on the same side of the frustum
     // and of the observed surface more often
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int wv = (threadIdx.x >> 6) & 7, ln = threadIdx.x & 63;
     const int x = tx * DF_ROW_TX + (wv & 3) * 8 + (ln & 7);
     const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (ln >> 3);
     const bool in_xy = x < a.X && y < a.Y;
@@ -1449,12 +1455,14 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         const long long cols_layers = (long long)tiles_x * tiles_y * (zt_hi - zt_lo + 1);
         a.zt = !pipe_ok ? DF_LDS_ZT : cols_layers <= 8192 ? 4 : cols_layers <= 65536 ? 8 : 16;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + a.zt - 1) / a.zt));
-        if (pipe_ok && k == 8) kern = df_warp_rows_pipe_kernel<8, 2>;
-        else if (pipe_ok && k == 4) kern = df_warp_rows_pipe_kernel<4, 2>;
+        const bool wide = pipe_ok && (k == 8 || k == 4) && lds > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads
+        if (wide) grid.x = (unsigned)(((tiles_x + 1) / 2) * tiles_y);
+        if (pipe_ok && k == 8) kern = wide ? df_warp_rows_pipe_kernel<8, 2, 1024> : df_warp_rows_pipe_kernel<8, 2, 512>;
+        else if (pipe_ok && k == 4) kern = wide ? df_warp_rows_pipe_kernel<4, 2, 1024> : df_warp_rows_pipe_kernel<4, 2, 512>;
         else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
         else { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, false, 1>)); }
         DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kern<<<grid, dim3(512), lds, st>>>(a, W, tiles_x);
+        kern<<<grid, dim3(wide ? 1024 : 512), lds, st>>>(a, W, tiles_x);
     } else if (use_tab) {
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_ROW_TY - 1) / DF_ROW_TY;
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
