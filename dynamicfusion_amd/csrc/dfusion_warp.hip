@@ -710,6 +710,7 @@ struct DfWarpedArgs {
     //            x-adjacent lanes reads 1 KiB contiguous per instruction
     uint16_t* knn_tab; float* w_tab; int tab_z0; size_t tab_nvox; int tab_ntx, tab_nty;
     int zt;                        // pipelined sweep: tile layers per workgroup (1..16)
+    int v2w_identity;              // vol2world.R is exactly the identity (set by the launcher)
     // max over the voxels of each table tile of sum_i w_i (written by the table build, frame-invariant); null = no zero-weight test
     float* tile_wmax;
 };
@@ -1177,7 +1178,7 @@ __device__ __forceinline__ DfBlendSums dqb_sums_lds_off(const float (&wt)[K], co
 // WGT = 512: one 32 x 16 tile column per workgroup, two workgroups per CU while the node table is <= 80 KiB (2560 nodes).
 // WGT = 1024: two x-adjacent tile columns share one node table, for the larger tables that leave room for only one workgroup per CU:
 // 16 waves (4 per SIMD) instead of 8.
-template <int K, int U, int WGT>
+template <int K, int U, int WGT, bool V2W_IDENTITY>
 __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
@@ -1301,7 +1302,13 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
             f3 vc[U]; bool ok[U]; uint16_t dpb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const f3 q = aff_mul(a.vol2world, mk3(fxv, fyv, (float)(z0 + u) * a.vsz));   // canonical position
+                // canonical position.  With an axis-aligned volume (R = I exactly -- the reference's default pose is a pure
+                // translation) the nested FMAs of R * p return p itself: fma(1, x, fma(0, y, 0 * z)) = x for the finite, non-negative grid
+                // coordinates, so only the translation is left to add.
+                const f3 pv3 = mk3(fxv, fyv, (float)(z0 + u) * a.vsz);
+                f3 q;
+                if constexpr (V2W_IDENTITY) q = add3(pv3, mk3(a.vol2world.t[0], a.vol2world.t[1], a.vol2world.t[2]));
+                else q = aff_mul(a.vol2world, pv3);
                 const DfBlendSums B = dqb_sums_lds_off<K>(wt[u], bo[u]);
                 quat rsum, rn; quat2 half;
                 rsum.w = B.r01.x; rsum.x = B.r01.y; rsum.y = B.r23.x; rsum.z = B.r23.y;
@@ -1407,6 +1414,10 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     a.z_store0 = s.z_store0; a.z_own0 = s.z_own0; a.z_own_n = s.z_own_n;
     a.vsx = v.voxel_size[0]; a.vsy = v.voxel_size[1]; a.vsz = v.voxel_size[2];
     a.vol2world = df_aff(vol2world); a.world2cam = df_aff(world2cam);
+    {
+        static const float I9[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        a.v2w_identity = memcmp(vol2world, I9, sizeof(I9)) == 0;     // bitwise: -0 entries do not qualify
+    }
     a.P.dists = dists; a.P.pitch = pitch; a.P.cols = cols; a.P.rows = rows;
     a.P.fx = proj[0]; a.P.fy = proj[1]; a.P.cx = proj[2]; a.P.cy = proj[3];
     a.P.trunc = v.trunc_dist; a.P.trunc_inv = 1.f / v.trunc_dist; a.P.max_weight = v.max_weight;
@@ -1457,8 +1468,13 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + a.zt - 1) / a.zt));
         const bool wide = pipe_ok && (k == 8 || k == 4) && lds > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads
         if (wide) grid.x = (unsigned)(((tiles_x + 1) / 2) * tiles_y);
-        if (pipe_ok && k == 8) kern = wide ? df_warp_rows_pipe_kernel<8, 2, 1024> : df_warp_rows_pipe_kernel<8, 2, 512>;
-        else if (pipe_ok && k == 4) kern = wide ? df_warp_rows_pipe_kernel<4, 2, 1024> : df_warp_rows_pipe_kernel<4, 2, 512>;
+        const bool vi = a.v2w_identity != 0;
+        if (pipe_ok && k == 8)
+            kern = wide ? (vi ? df_warp_rows_pipe_kernel<8, 2, 1024, true> : df_warp_rows_pipe_kernel<8, 2, 1024, false>)
+                        : (vi ? df_warp_rows_pipe_kernel<8, 2, 512, true> : df_warp_rows_pipe_kernel<8, 2, 512, false>);
+        else if (pipe_ok && k == 4)
+            kern = wide ? (vi ? df_warp_rows_pipe_kernel<4, 2, 1024, true> : df_warp_rows_pipe_kernel<4, 2, 1024, false>)
+                        : (vi ? df_warp_rows_pipe_kernel<4, 2, 512, true> : df_warp_rows_pipe_kernel<4, 2, 512, false>);
         else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
         else { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, false, 1>)); }
         DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
