@@ -1326,8 +1326,9 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
                 const float pu = fmaf(a.P.fx, vc[u].x / vc[u].z, a.P.cx);                     // device.hpp:35
                 const float pv = fmaf(a.P.fy, vc[u].y / vc[u].z, a.P.cy);                     // device.hpp:36
                 ok[u] = inz[u] & (vc[u].z > 0.f) & (pu >= 0.f) & (pv >= 0.f) & (pu < (float)a.P.cols) & (pv < (float)a.P.rows);   // :82,:86
-                const int ui = (int)fminf(fmaxf(pu, 0.f), (float)(a.P.cols - 1));
-                const int vi = (int)fminf(fmaxf(pv, 0.f), (float)(a.P.rows - 1));
+                // clamped pixel (one v_med3_f32 each; a NaN coordinate gives some in-range pixel, and such a voxel is not `ok` anyway)
+                const int ui = (int)__builtin_amdgcn_fmed3f(pu, 0.f, (float)(a.P.cols - 1));
+                const int vi = (int)__builtin_amdgcn_fmed3f(pv, 0.f, (float)(a.P.rows - 1));
                 dpb[u] = *(const uint16_t*)((const char*)a.P.dists + (__umul24((unsigned)vi, pitch24) + 2u * (unsigned)ui));   // :85
             }
             // (2b) the previous batch's compare / fuse / store: its gathers were issued a whole batch ago
