@@ -343,7 +343,8 @@ def main():
     # kernel that ran + its per-voxel cache footprint; PMC traffic comes from the committed rocprofv3 --pmc passes
     lds_ok = cfg.nodes * 32 <= 160 * 1024
     if lds_ok and cfg.k in (4, 8):
-        kernel_name = "df_warp_rows_pipe_kernel<%d, 2, %d>" % (cfg.k, 1024 if cfg.nodes * 32 > 80 * 1024 else 512)
+        axis_aligned = bool(np.array_equal(np.asarray(cfg.volume_pose, np.float32).reshape(4, 4)[:3, :3], np.eye(3, dtype=np.float32)))
+        kernel_name = "df_warp_rows_pipe_kernel<%d, 2, %d, %s>" % (cfg.k, 1024 if cfg.nodes * 32 > 80 * 1024 else 512, "true" if axis_aligned else "false")
     elif lds_ok:
         kernel_name = "df_warp_rows_lds_kernel<%d, true, 2>" % cfg.k
     else:
