@@ -15,7 +15,8 @@
 //                                       a fixed tree -- no float atomics, so the result is reproducible (and bit-comparable
 //                                       with the restatement in oracle/dfusion_frontend_oracle.c);
 //   dot products / vector updates     : one 1024-thread workgroup (M <= 65535), fixed tree.
-// Nothing returns to the host between iterations.
+// Nothing returns to the host between iterations: once every component has converged (scal[3] == 0) the kernels of the remaining
+// steps return at once.
 #include <hipcub/hipcub.hpp>
 #include "dfusion_internal.h"
 
@@ -70,8 +71,12 @@ __global__ __launch_bounds__(256) void df_sv_offsets_kernel(const unsigned int* 
 // (with a run-time k the loop issues and waits entry by entry); K = 0: any k.  Same sums in the same order either way.
 template <int K>
 __global__ __launch_bounds__(256) void df_sv_w_apply_kernel(const float* __restrict__ w, const unsigned int* __restrict__ keys, int N, int k,
-                                                            int M, const float* __restrict__ p, float* __restrict__ u)
+                                                            int M, const float* __restrict__ p, float* __restrict__ u,
+                                                            const float* __restrict__ active)
 {
+    // `active` (nullable): scal[3], the number of CG components still iterating.  Once it is 0 every further step is an exact no-op
+    // (alpha = beta = 0), so the kernels of the remaining steps return at once -- the host enqueues all steps without looking.
+    if (active && *active == 0.f) return;
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= N) return;
     float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -116,9 +121,11 @@ __global__ __launch_bounds__(256) void df_sv_sorted_kernel(const unsigned int* _
 // LDS, s <= 32 with __shfl_down inside wave 0) -- a fixed order, restated in the oracle.
 __global__ __launch_bounds__(256) void df_sv_wt_apply_kernel(const unsigned int* __restrict__ off, const unsigned int* __restrict__ sorted_pt,
                                                              const float* __restrict__ sorted_w, int M, const float* __restrict__ u,
-                                                             float lambda, const float* __restrict__ p, float* __restrict__ out)
+                                                             float lambda, const float* __restrict__ p, float* __restrict__ out,
+                                                             const float* __restrict__ active)
 {
     __shared__ float lds[3 * 128];
+    if (active && *active == 0.f) return;                               // see df_sv_w_apply_kernel
     const int n = blockIdx.x, t = threadIdx.x, wv = t >> 6, l = t & 63;
     const unsigned int b = off[n], e_end = off[n + 1];
     float s[3] = {0.f, 0.f, 0.f};
@@ -198,6 +205,7 @@ __global__ __launch_bounds__(SV_BLOCK) void df_sv_step_kernel(const float* __res
                                                               float* __restrict__ p, float* __restrict__ scal)
 {
     __shared__ float lds[3 * SV_BLOCK];
+    if (scal[3] == 0.f) return;                                         // all components frozen: the step would change nothing
     float pq[3] = {0.f, 0.f, 0.f};
     for (int n = threadIdx.x; n < M; n += SV_BLOCK)
         for (int c = 0; c < 3; ++c) pq[c] = pq[c] + p[3 * n + c] * q[3 * n + c];
@@ -239,6 +247,7 @@ __global__ __launch_bounds__(SV_BLOCK) void df_sv_step_reg_kernel(const float* _
                                                                   float* __restrict__ p, float* __restrict__ scal)
 {
     __shared__ float lds[3 * SV_BLOCK];
+    if (scal[3] == 0.f) return;                                         // all components frozen: the step would change nothing
     float pv[EPT][3], qv[EPT][3], rv[EPT][3], xv[EPT][3];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
@@ -379,24 +388,18 @@ extern "C" int dfusion_warp_solve_data_term(DfWarpField* wf, int k, const float*
     auto w_apply = k == 8 ? df_sv_w_apply_kernel<8> : k == 4 ? df_sv_w_apply_kernel<4> : df_sv_w_apply_kernel<0>;
     // r0 = W^T e0 ; p0 = r0 ; x0 = 0
     const dim3 gW(M);
-    hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, spt, sw, M, e0, 0.f, (const float*)nullptr, r);
+    hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, spt, sw, M, e0, 0.f, (const float*)nullptr, r, (const float*)nullptr);
     DF_LAUNCH_CHECK();
     hipLaunchKernelGGL(df_sv_init_kernel, dim3(1), dim3(SV_BLOCK), 0, st, r, M, x, p, scal);
     DF_LAUNCH_CHECK();
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL(w_apply, gN, dim3(256), 0, st, w, keys, N, k, M, p, u);
-        hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, spt, sw, M, u, lambda, p, q);
+        hipLaunchKernelGGL(w_apply, gN, dim3(256), 0, st, w, keys, N, k, M, p, u, (const float*)(scal + 3));
+        hipLaunchKernelGGL(df_sv_wt_apply_kernel, gW, dim3(256), 0, st, offs, spt, sw, M, u, lambda, p, q, (const float*)(scal + 3));
         hipLaunchKernelGGL(step, dim3(1), dim3(SV_BLOCK), 0, st, q, M, x, r, p, scal);
         DF_LAUNCH_CHECK();
-        if ((it & 15) == 15 && it + 1 < iters) {            // converged components are frozen (further steps are exact no-ops): stop launching
-            float active = 1.f;
-            DF_HIP(hipMemcpyAsync(&active, scal + 3, sizeof(float), hipMemcpyDeviceToHost, st));
-            DF_HIP(hipStreamSynchronize(st));
-            if (active == 0.f) break;
-        }
     }
     if (energy) {
-        hipLaunchKernelGGL(w_apply, gN, dim3(256), 0, st, w, keys, N, k, M, x, u);
+        hipLaunchKernelGGL(w_apply, gN, dim3(256), 0, st, w, keys, N, k, M, x, u, (const float*)nullptr);
         hipLaunchKernelGGL(df_sv_residual_kernel, dim3((unsigned)((3 * (size_t)N + 255) / 256)), dim3(256), 0, st, e0, u, 3 * N, u);
         hipLaunchKernelGGL(df_sv_energy_kernel, dim3(1), dim3(SV_BLOCK), 0, st, u, N, scal + 5);
         DF_LAUNCH_CHECK();
