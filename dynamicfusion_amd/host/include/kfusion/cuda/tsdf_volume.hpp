@@ -78,7 +78,8 @@ private:
     float max_weight_;                                                     // a float in the reference too (tsdf_volume.hpp:86)
     float gradient_delta_factor_, raycast_step_factor_;
     DeviceArray<Point> cloud_buffer_, cloud_;
-    DeviceArray<Normal> normal_buffer_;
+    DeviceArray<Normal> normal_buffer_;                                    // grows, never shrinks: cloud_.size() entries are valid
+    mutable DeviceArray<unsigned long long> extract_count_;                // fetchCloud's device counter, allocated once
     mutable std::vector<Point> cloud_host_;
     mutable std::vector<Normal> normal_host_;
     mutable bool cloud_host_stale_ = false, normal_host_stale_ = false;

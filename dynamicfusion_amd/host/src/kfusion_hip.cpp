@@ -200,7 +200,8 @@ DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>& cloud_buffer) cons
     enum { DEFAULT_CLOUD_BUFFER_SIZE = 256 * 256 * 256 };                   // :184
     if (cloud_buffer.empty()) cloud_buffer.create(DEFAULT_CLOUD_BUFFER_SIZE);
     float aff[12]; affine_to_aff12(pose_, aff);
-    DeviceArray<unsigned long long> count(1);
+    if (extract_count_.empty()) extract_count_.create(1);                   // (a hipMalloc + hipFree per frame otherwise: ~0.1 ms)
+    DeviceArray<unsigned long long>& count = extract_count_;
     KF_HIP(hipMemset(count.ptr(), 0, sizeof(unsigned long long)));
     KF_DF(dfusion_extract_cloud(c_volume(*this), nullptr, aff, (float*)cloud_buffer.ptr(), cloud_buffer.size(), count.ptr(), nullptr));
     unsigned long long n = 0;
@@ -227,7 +228,15 @@ void TsdfVolume::compute_points()
 
 void TsdfVolume::compute_normals()
 {
-    fetchNormals(cloud_, normal_buffer_);
+    // fetchNormals(cloud_, normal_buffer_) without its per-frame reallocation (the cloud size changes every frame): the buffer only
+    // grows, the first cloud_.size() normals are the current ones
+    if (normal_buffer_.size() < cloud_.size()) normal_buffer_.create(cloud_.size() + cloud_.size() / 4 + 1024);
+    if (cloud_.size()) {
+        float aff[12]; affine_to_aff12(pose_, aff);
+        const Mat3f ri = pose_.rotation().inv();                            // :214 inv(DECOMP_SVD)
+        KF_DF(dfusion_extract_normals(c_volume(*this), nullptr, aff, ri.val, (const float*)cloud_.ptr(), cloud_.size(), gradient_delta_factor_,
+                                      (float*)normal_buffer_.ptr(), nullptr));
+    }
     normal_host_stale_ = true;
 }
 
@@ -245,7 +254,7 @@ const std::vector<Normal>& TsdfVolume::get_normal_host() const
 {
     if (normal_host_stale_) {
         normal_host_.resize(cloud_.size());
-        if (cloud_.size()) normal_buffer_.download(normal_host_.data());
+        if (cloud_.size()) KF_HIP(hipMemcpy(normal_host_.data(), normal_buffer_.ptr(), cloud_.size() * sizeof(Normal), hipMemcpyDeviceToHost));
         normal_host_stale_ = false;
     }
     return normal_host_;
