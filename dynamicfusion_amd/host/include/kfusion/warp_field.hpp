@@ -33,8 +33,11 @@ namespace kfusion
         /// warp_field.cpp:68-88: one identity node per point, dg_w = 3 (NaN points skipped -- the reference
         /// leaves zero-position, zero-weight nodes in their place; fixed)
         void init(const std::vector<Vec3f>& first_frame);
-        const std::vector<deformation_node>* getNodes() const { return &nodes_; }
-        std::vector<deformation_node>* getNodes() { return &nodes_; }
+        /// the host node store; after a GPU solve (energy_data) the transforms are fetched from the device on the first access
+        const std::vector<deformation_node>* getNodes() const { pullNodes(); return &nodes_; }
+        std::vector<deformation_node>* getNodes() { pullNodes(); return &nodes_; }
+        /// number of nodes, without touching the transforms (no device round trip)
+        size_t nodeCount() const { return nodes_.size(); }
         /// push host-side node edits (positions or transforms) to the device; `positions_changed` invalidates the k-NN index
         void commit(bool positions_changed);
 
@@ -71,7 +74,10 @@ namespace kfusion
         /// brick candidate lists are built, which is all point queries (KNN, warp, energy_data) need
         void ensureIndex(const cuda::TsdfVolume& volume, bool tables = true) const;
     private:
-        std::vector<deformation_node> nodes_;
+        void pullNodes() const;                              // device transforms -> nodes_ when a solve has made them newer
+        mutable std::vector<deformation_node> nodes_;
+        mutable cuda::DeviceArray<float> solve_dq_, solve_energy_;   // outputs of the last energy_data (kept: no per-frame allocation)
+        mutable bool nodes_stale_ = false;
         Affine3f warp_to_live_;
         int k_;
         DfWarpField* handle_;

@@ -326,7 +326,7 @@ WarpField::~WarpField() { dfusion_warp_destroy(handle_); }
 
 void WarpField::init(const std::vector<Vec3f>& first_frame)
 {
-    nodes_.clear();
+    nodes_.clear(); nodes_stale_ = false;
     for (const Vec3f& p : first_frame) {
         if (std::isnan(p[0])) continue;
         deformation_node n;
@@ -340,6 +340,7 @@ void WarpField::init(const std::vector<Vec3f>& first_frame)
 
 void WarpField::commit(bool positions_changed)
 {
+    pullNodes();                                           // (edits were made through getNodes(), which had pulled already)
     const size_t M = nodes_.size();
     std::vector<float> dq(M * 8);
     for (size_t i = 0; i < M; ++i) std::memcpy(&dq[8 * i], nodes_[i].transform.raw(), 32);
@@ -360,12 +361,21 @@ void WarpField::energy_data(const cuda::DeviceArray<float>& canonical_vertices, 
 {
     const size_t M = nodes_.size();
     if (!M || n <= 0) return;
-    DeviceArray<float> d_dq(M * 8), d_energy(2);
-    KF_DF(dfusion_warp_solve_data_term(handle_, k_, canonical_vertices.ptr(), live_vertices.ptr(), n, solver_iters_, solver_lambda_, d_dq.ptr(),
-                                       track_energy_ ? d_energy.ptr() : nullptr, nullptr));
+    solve_dq_.create(M * 8); solve_energy_.create(2);      // no-ops after the first frame
+    KF_DF(dfusion_warp_solve_data_term(handle_, k_, canonical_vertices.ptr(), live_vertices.ptr(), n, solver_iters_, solver_lambda_, solve_dq_.ptr(),
+                                       track_energy_ ? solve_energy_.ptr() : nullptr, nullptr));
+    if (track_energy_) solve_energy_.download(last_energy_);
+    nodes_stale_ = true;                                   // the host node store follows (updateWarp, optimisation.hpp:211-218) -- when it is looked at
+}
+
+void WarpField::pullNodes() const
+{
+    if (!nodes_stale_) return;
+    nodes_stale_ = false;
+    const size_t M = nodes_.size();
+    if (!M || solve_dq_.size() != M * 8) return;
     std::vector<float> dq(M * 8);
-    d_dq.download(dq.data());                              // the host node store follows (updateWarp, optimisation.hpp:211-218)
-    if (track_energy_) d_energy.download(last_energy_);
+    solve_dq_.download(dq.data());                         // (synchronises with the solve)
     for (size_t i = 0; i < M; ++i) std::memcpy((void*)nodes_[i].transform.raw(), &dq[8 * i], 32);
 }
 
@@ -742,7 +752,7 @@ bool KinFu::operator()(const cuda::Depth& depth, const cuda::Image& /*image*/)  
 void KinFu::dynamicfusion(cuda::Depth& depth, cuda::Cloud live_frame, cuda::Normals /*current_normals*/)   // kinfu.cpp:344-400
 {
     const Affine3f camera_pose = poses_.back();
-    if (warp_->getNodes()->size() < (size_t)warp_->k()) {               // no usable warp field (empty first frame): plain KinFu fusion
+    if (warp_->nodeCount() < (size_t)warp_->k()) {                      // no usable warp field (empty first frame): plain KinFu fusion
         cuda::Dists dists; cuda::computeDists(depth, dists, params_.intr);
         volume_->integrate(dists, camera_pose, params_.intr);
         return;
