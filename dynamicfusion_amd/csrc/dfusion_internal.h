@@ -64,4 +64,5 @@ struct DfWarpField {
     void* solver_ws; size_t solver_ws_cap;
     // points an indexed k-NN / warp pass left to the scan kernel: [0] count, [1..] ids
     int* pt_ids; size_t pt_ids_cap;
+    int pt_image_cols;                                 // dfusion_warp_set_point_tiling: 0 = point queries in linear order
 };

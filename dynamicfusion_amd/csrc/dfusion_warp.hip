@@ -312,7 +312,7 @@ template <int K, int MODE>
 __global__ __launch_bounds__(64) void df_points_index_kernel(DfWarpView W, DfPointIndex G, const float* __restrict__ queries, int N,
                                                              int* __restrict__ idx_out, float* __restrict__ d2_out,
                                                              float* __restrict__ points, float* __restrict__ normals, DfAff to_live,
-                                                             int* __restrict__ out_ids, int* __restrict__ out_count)
+                                                             int* __restrict__ out_ids, int* __restrict__ out_count, int image_cols)
 {
     // One wave64 per workgroup (so __syncthreads is a wave-level barrier and every loop below is wave-uniform).  Neighbouring
     // query points (pixels) mostly share a brick: the wave visits its DISTINCT bricks one after the other, stages each brick's
@@ -321,7 +321,14 @@ __global__ __launch_bounds__(64) void df_points_index_kernel(DfWarpView W, DfPoi
     __shared__ float4 s_pos[64];
     __shared__ int s_id[64];
     const int lane = threadIdx.x;
-    const int i = blockIdx.x * 64 + lane;
+    // image_cols > 0 (dfusion_warp_set_point_tiling): the points are the pixels of an image that wide and a wave takes an 8 x 8 pixel
+    // tile instead of 64 consecutive pixels of a row -- 3 distinct bricks per wave instead of 8 on a 640 x 480 ray-cast cloud, and every
+    // brick visit is a chain of dependent loads plus a ranking pass in which only that brick's lanes work.  Same results per point.
+    int i = blockIdx.x * 64 + lane;
+    if (image_cols > 0) {
+        const int tiles = image_cols >> 3, ty = blockIdx.x / tiles, tx = blockIdx.x - ty * tiles;
+        i = (ty * 8 + (lane >> 3)) * image_cols + tx * 8 + (lane & 7);
+    }
     const bool active = i < N;
     f3 q = mk3(0.f, 0.f, 0.f);
     const float* src = MODE == 0 ? queries : points;
@@ -479,6 +486,20 @@ static bool df_point_index(const DfWarpField* wf, int k, DfPointIndex* G)
     return wf->brick_thr != nullptr;
 }
 
+// the image width to tile point queries by, if the hint applies to this query (whole 8 x 8 tiles), else 0 = linear order
+static int df_point_tiling(const DfWarpField* wf, int N)
+{
+    const int c = wf->pt_image_cols;
+    return (c >= 8 && (c & 7) == 0 && N % (8 * c) == 0) ? c : 0;
+}
+
+extern "C" int dfusion_warp_set_point_tiling(DfWarpField* wf, int image_cols)
+{
+    if (!wf || image_cols < 0) return DF_E_INVALID;
+    wf->pt_image_cols = image_cols;
+    return DF_OK;
+}
+
 extern "C" int dfusion_knn(DfWarpField* wf, int k, const float* queries, int N, int* idx, float* d2, dfStream stream)
 {
     if (!wf || !queries || !idx || !d2 || N < 0 || wf->M < k || k < 1) return DF_E_INVALID;
@@ -490,7 +511,7 @@ extern "C" int dfusion_knn(DfWarpField* wf, int k, const float* queries, int N, 
         int rc = df_point_fallback_reserve(wf, N, (hipStream_t)stream);
         if (rc) return rc;
         DF_DISPATCH_K(k, df_points_index_kernel<K, 0><<<dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
-                             W, G, queries, N, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_ids + 1, wf->pt_ids));
+                             W, G, queries, N, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_ids + 1, wf->pt_ids, df_point_tiling(wf, N)));
         DF_DISPATCH_K(k, df_points_wave_kernel<K, 0><<<dim3(2048), dim3(256), 0, (hipStream_t)stream>>>(
                              W, queries, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_ids + 1, wf->pt_ids));
     } else
@@ -512,7 +533,7 @@ extern "C" int dfusion_warp_points(DfWarpField* wf, int k, float* points, float*
         int rc = df_point_fallback_reserve(wf, N, (hipStream_t)stream);
         if (rc) return rc;
         DF_DISPATCH_K(k, df_points_index_kernel<K, 1><<<dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
-                             W, G, (const float*)nullptr, N, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_ids + 1, wf->pt_ids));
+                             W, G, (const float*)nullptr, N, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_ids + 1, wf->pt_ids, df_point_tiling(wf, N)));
         DF_DISPATCH_K(k, df_points_wave_kernel<K, 1><<<dim3(2048), dim3(256), 0, (hipStream_t)stream>>>(
                              W, (const float*)nullptr, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_ids + 1, wf->pt_ids));
     } else

@@ -759,6 +759,7 @@ void KinFu::dynamicfusion(cuda::Depth& depth, cuda::Cloud live_frame, cuda::Norm
     }
     const size_t n = (size_t)depth.rows() * depth.cols();
     warp_->ensureIndex(*volume_, params_.warped_fusion);                // brick lists: exact k-NN of the points below without scanning all nodes
+    KF_DF(dfusion_warp_set_point_tiling(warp_->handle(), depth.cols()));  // the point sets below are images: 8 x 8 pixel tiles per wave
     if (params_.device_resident) {
         // kinfu.cpp:346-393 with every point set kept on the GPU: raycast -> canonical = inverse_pose * point (and the float4 ->
         // float3 repack) -> warp twice (as the reference does, :387 and :391) -> psdf / removal -> fusion

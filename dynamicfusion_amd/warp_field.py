@@ -97,6 +97,12 @@ class WarpField:
                    "dfusion_warp_points")
 
     # ---- WarpField::energy_data (warp_field.cpp:117-163) / WarpFieldOptimiser::optimiseWarpData: the data term, on the GPU
+
+    def set_point_tiling(self, image_cols):
+        """Locality hint (include/dfusion.h dfusion_warp_set_point_tiling): point queries are row-major images `image_cols` wide and are
+        processed in 8x8 pixel tiles per wave; 0 = off.  Results do not change."""
+        capi.check(capi.lib().dfusion_warp_set_point_tiling(self.handle, int(image_cols)), "dfusion_warp_set_point_tiling")
+
     def energy_data(self, canonical_dev, live_dev, iters=100, lam=0.0, k=None):
         """Least-squares update of the node translations so that canonical + sum_i w_i T_i meets live (device [N,3] tensors).
         Returns (dq [M,8] device tensor of the updated transforms, energy [before, after] device tensor)."""

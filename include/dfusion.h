@@ -195,6 +195,12 @@ int dfusion_warp_build_index(DfWarpField *wf, DfVolume geometry, const DfSlab *s
 /* Introspection of the k-NN index (blocking): total candidate-list entries, number of 8^3 bricks, k it was built for. */
 int dfusion_warp_index_info(const DfWarpField *wf, unsigned long long *total_entries, unsigned int *n_bricks, int *k_built);
 
+/* Locality hint for dfusion_knn / dfusion_warp_points (and the solver's k-NN): the query points are the pixels of an image
+ * `image_cols` wide in row-major order (the ray-cast cloud KinFu::dynamicfusion warps, kinfu.cpp:353-391).  Queries whose count is a
+ * whole number of 8-row bands are then processed in 8 x 8 pixel tiles per wave instead of 64-pixel row segments; results are
+ * identical, only faster (fewer distinct index bricks per wave).  0 switches it off (default).                                   */
+int dfusion_warp_set_point_tiling(DfWarpField *wf, int image_cols);
+
 /* Device self-test of the sweep's short arithmetic forms (dfusion_device.h) against the generic ones they replace; no reference
  * counterpart, used by the parity tests.  counts_dev[5] (device) receives mismatch counts: [0] short sqrtf over every f32 of its
  * domain, [1] short f64 reciprocal over every positive normal f32, [2] packed quaternion products on n_random random pairs

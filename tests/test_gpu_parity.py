@@ -383,3 +383,12 @@ def test_point_queries_through_the_brick_index_equal_brute_force(cfg):
     ri, rd = O.knn(sc.pos, np.nan_to_num(q[:3000], nan=0.3), cfg.k)
     i2, d2 = wf.KNN(torch.from_numpy(np.nan_to_num(q[:3000], nan=0.3)).cuda())
     assert np.array_equal(i2.cpu().numpy(), ri) and np.array_equal(d2.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+    # the 8x8-tile processing order (a hint for image-ordered point sets) changes nothing: 49920 = 24 bands of 8 rows x 260 columns...
+    for cols, m in ((208, 49920), (640, 46080), (200, 50000)):          # ...whole bands, whole bands, NOT a multiple of 8 rows (hint ignored)
+        wf.set_point_tiling(cols)
+        i3, d3 = wf.KNN(dq[:m].contiguous())
+        p3, n3 = dq[:m].clone(), torch.from_numpy(nrm[:m]).cuda()
+        wf.warp(p3, n3)
+        assert torch.equal(i3, i0[:m]) and torch.equal(d3.view(torch.int32), d0[:m].view(torch.int32))
+        assert torch.equal(p3.view(torch.int32), p0[:m].view(torch.int32)) and torch.equal(n3.view(torch.int32), n0[:m].view(torch.int32))
+    wf.set_point_tiling(0)
