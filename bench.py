@@ -266,6 +266,12 @@ def main():
 
     ms_int = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ms_ray = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    # per-frame spread (integrate + ray-cast between HIP events on the launch stream) and the reference-shaped frame
+    # (KinFu::dynamicfusion integrates once and ray-casts twice)
+    per_frame = np.array([e[0].elapsed_time(e[2]) for e in ev], np.float64)
+    frame_stats = {"integrate+raycast_ms": {"p10": float(np.percentile(per_frame, 10)), "median": float(np.median(per_frame)),
+                                            "p90": float(np.percentile(per_frame, 90))},
+                   "reference_shaped_ms": ms_int + 2.0 * ms_ray}
 
     # ---- algorithmic bytes of one integrate launch: 8*N_upd + 2*W*H + 48*M.
     # N_upd counted by the kernel itself (parity-checked against the oracle's count in tests/), untimed pass.
@@ -379,6 +385,7 @@ def main():
                        "halo": "integrated redundantly by every rank, no halo collective" if world > 1 else None,
                        "frame": "set_transforms + compute_dists + integrate_warped + raycast_points"},
             "kernel_ms": {"integrate_warped": ms_int, "raycast(+merge)": ms_ray, "index_build_once_s": t_index},
+            "frame_stats": frame_stats,
             "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src,
