@@ -95,9 +95,14 @@ def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=12.0):
     rinv = np.linalg.inv(cam2vol[:3, :3].astype(np.float64)).astype(np.float32)
     reproj = np.array([np.float32(1) / np.float32(cfg.intr[0]), np.float32(1) / np.float32(cfg.intr[1]), cfg.intr[2], cfg.intr[3]], np.float32)
     t0 = time.time()
-    O.raycast_points(full, synth.aff12(cam2vol), rinv, reproj, cfg.cols, cfg.rows, cfg.raycast_step_factor, cfg.gradient_delta_factor)
+    _, _, _, rc_stats = O.raycast_points(full, synth.aff12(cam2vol), rinv, reproj, cfg.cols, cfg.rows, cfg.raycast_step_factor,
+                                         cfg.gradient_delta_factor)
     t_ray = time.time() - t0
+    # SURVEY.md 8(d) algorithmic bytes of the ray-cast: 4 B per nearest-voxel fetch (steps + 1 per ray), 256 B per hit (2 + 6 trilinear
+    # evaluations x 8 taps x 4 B), 32 B per pixel of output -- steps and hits counted by the oracle on the same volume and pose
+    rc_bytes = 4.0 * (float(rc_stats[0]) + cfg.cols * cfg.rows) + 256.0 * float(rc_stats[1]) + 32.0 * cfg.cols * cfg.rows
     return {"value": 1.0 / (t_int + t_ray), "unit": "frames/s", "cores": int(O.lib().orc_num_threads()), "kind": "port",
+            "raycast_algorithmic_bytes": rc_bytes, "raycast_steps": int(rc_stats[0]), "raycast_hits": int(rc_stats[1]),
             "sample": "oracle (OpenMP, brute-force k-NN) integrate_warped on %d of %d Z planes in %.1f s, scaled x%.1f (est %.1f s/frame) "
                       "+ full %dx%d raycast (%.2f s)" % (budget_planes, Z, t_band, Z / budget_planes, t_int, cfg.cols, cfg.rows, t_ray)}
 
@@ -399,6 +404,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             vol_host = vol.download()
             out["cpu_baseline"] = cpu_baseline(cfg, (depths_np[0], None, cfg.volume_pose, cam_poses[0], pos, sigma, dqs_np[0]), vol_host)
+            rcb = out["cpu_baseline"].pop("raycast_algorithmic_bytes")
+            out["raycast"] = {"kernel": "df_raycast_kernel<0>", "ms": ms_ray, "algorithmic_bytes": rcb,
+                              "steps": out["cpu_baseline"].pop("raycast_steps"), "hits": out["cpu_baseline"].pop("raycast_hits"),
+                              "achieved_GBps": rcb / (ms_ray * 1e-3) / 1e9,
+                              "note": "gather-latency bound (one dependent 4-byte fetch per march step); reported, no roofline target (SURVEY 8d)"}
             try:
                 wf.set_transforms(dqs[0])
                 rw = reference_warp_baseline(cfg, pts, pos, sigma, dqs_np[0], wf)
