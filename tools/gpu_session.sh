@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 echo "== pytest gpu"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tee gpurun_out/pytest_gpu.log | tail -3
 echo "== bench 512"; timeout 900 python bench.py --steps 40 --warmup 5 2>&1 | tee gpurun_out/bench.log | tail -2
 echo "== bench 256"; timeout 300 python bench.py --steps 40 --warmup 5 --config 256 2>&1 | tee gpurun_out/bench_256.log | tail -2
+echo "== bench N=2 code path on one GPU (gloo stand-in for RCCL)"; timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/bench_multi_smoke.py --gpus 2 --steps 3 --warmup 1 --no-extras 2>&1 | tail -1 | cut -c1-300 | tee gpurun_out/bench_multi_smoke.log
 echo "== rocprof kernel trace"
 rm -rf gpurun_out/prof gpurun_out/pmc
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kinfu > $R/gpurun_out/rocprof.log 2>&1)
