@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rigid", action="store_true", help="(kept for old command lines; the extra kernels are timed by default)")
+    ap.add_argument("--halo", choices=["recompute", "exchange"], default="recompute",
+                    help="N>1: how a rank gets its neighbours' boundary planes for the ray-cast -- recompute them (default: every rank "
+                         "integrates its halo planes too, no collective) or exchange them after the integrate (paired isend/irecv over RCCL, "
+                         "the north star's wording; one more collective per frame, 2*H fewer planes to sweep)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (rigid_integrate, extract_cloud, kinfu_frame)")
     ap.add_argument("--no-kinfu", action="store_true", help="skip the kinfu_frame extra (it runs a child process; use under profilers)")
     return ap.parse_args()
@@ -204,7 +208,7 @@ def main():
 
     # N > 1: every rank also integrates its halo planes (a pure function of the broadcast inputs: bit-identical with the neighbour's
     # planes), so the frame has NO halo collective; `vol_int` is the same blob seen as owner of all its stored planes.
-    vol_int = vol.owning_stored_planes() if world > 1 else vol
+    vol_int = vol.owning_stored_planes() if (world > 1 and args.halo == "recompute") else vol
     wf = WarpField(k=cfg.k, device=dev)
     wf.init(pos, sigma=sigma, transforms=dqs_np[0])
     t0 = time.time()
@@ -240,6 +244,8 @@ def main():
         if timed_idx is not None: ev[timed_idx][0].record()
         vol_int.integrate_warped(dists, cam_poses[f], intr, wf, sync=False)
         if timed_idx is not None: ev[timed_idx][1].record()
+        if world > 1 and args.halo == "exchange":
+            sharded.exchange_halos(vol.data(), vol.z_store0, vol.z_own0, vol.z_own_n, Z, halo, rank, world)
         if world > 1:
             out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, vertex, rank),
                                           lambda mk, vx: vol.raycast_select(mk, vx, rank),
@@ -387,7 +393,8 @@ def main():
             "config": {"workload": cfg.name, "volume_dims": list(cfg.dims), "volume_size_m": cfg.size,
                        "depth": [cfg.cols, cfg.rows], "warp_nodes": cfg.nodes, "k": cfg.k,
                        "parallelism": "zslab%d" % world if world > 1 else "single", "halo_planes": halo if world > 1 else 0,
-                       "halo": "integrated redundantly by every rank, no halo collective" if world > 1 else None,
+                       "halo": (("integrated redundantly by every rank, no halo collective" if args.halo == "recompute" else
+                                 "exchanged after the integrate (paired isend/irecv of %d planes per side)" % halo) if world > 1 else None),
                        "frame": "set_transforms + compute_dists + integrate_warped + raycast_points"},
             "kernel_ms": {"integrate_warped": ms_int, "raycast(+merge)": ms_ray, "index_build_once_s": t_index},
             "frame_stats": frame_stats,
