@@ -1126,18 +1126,20 @@ __device__ __forceinline__ df_global_ptr<T> df_wave_uniform(T* p)
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return (df_global_ptr<T>)(((unsigned long long)hi << 32) | lo);
 }
+// the per-voxel tables are read once per frame and never again before 5 GB of other data have gone by: non-temporal loads (`nt`)
+#define DF_TAB_LD(p) __builtin_nontemporal_load(p)
 // the same with the record index split into a wave-uniform base and a 32-bit lane offset
 __device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<8>& r)
 {
-    const df_v4u i4 = df_wave_uniform(reinterpret_cast<const df_v4u*>(a.knn_tab) + rec)[lane];
-    const df_v4f a4 = df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec)[lane];
-    const df_v4f b4 = df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + a.tab_nvox + rec)[lane];
+    const df_v4u i4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4u*>(a.knn_tab) + rec) + lane);
+    const df_v4f a4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec) + lane);
+    const df_v4f b4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + a.tab_nvox + rec) + lane);
     r.idx = make_uint4(i4.x, i4.y, i4.z, i4.w); r.w0 = make_float4(a4.x, a4.y, a4.z, a4.w); r.w1 = make_float4(b4.x, b4.y, b4.z, b4.w);
 }
 __device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<4>& r)
 {
-    const df_v2u i2 = df_wave_uniform(reinterpret_cast<const df_v2u*>(a.knn_tab) + rec)[lane];
-    const df_v4f a4 = df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec)[lane];
+    const df_v2u i2 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v2u*>(a.knn_tab) + rec) + lane);
+    const df_v4f a4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec) + lane);
     r.idx = make_uint2(i2.x, i2.y); r.w0 = make_float4(a4.x, a4.y, a4.z, a4.w);
 }
 __device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<8>& r, int (&bi)[8], float (&wt)[8])
