@@ -1311,13 +1311,12 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
             unsigned bo[U][K]; float wt[U][K];
 #pragma unroll
             for (int u = 0; u < U; ++u) tab_raw_offsets(S[u], bo[u], wt[u]);
-            // (1) voxel words of this batch (unconditional; clamped plane for the tail)
-            uint32_t vox[U]; bool inz[U]; int zv[U];
+            // (1) planes of this batch (clamped for the tail)
+            bool inz[U]; int zv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 inz[u] = in_xy && z0 + u < ze;
                 zv[u] = min(z0 + u, ze - 1);
-                vox[u] = *(df_wave_uniform(a.vol + (size_t)(zv[u] - a.z_store0) * plane) + lane_vox);      // uniform plane base + lane offset
             }
             // (2) blend -> transform -> project, then the dists gathers (clamped address, always valid).  The normalisations and the
             // square root take their short forms (dfusion_device.h: same bits on a restricted domain) when the whole wave is inside
@@ -1368,7 +1367,11 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
                 float vn;
                 if (__builtin_expect(df_wave_all(df_sqrt_short_ok(v2)), 1)) vn = df_sqrt_short(v2);
                 else vn = sqrtf(v2);                                                         // (NaN positions of zero-weight voxels come here)
-                pend.vn[u] = vn; pend.dpb[u] = dpb[u]; pend.vox[u] = vox[u]; pend.z[u] = zv[u]; pend.ok[u] = ok[u];
+                // the voxel word is only needed if the voxel projects into the image (the finish is a batch away: time enough), and
+                // whole 32-byte runs of lanes that do not are not fetched at all
+                uint32_t vw = 0u;
+                if (ok[u]) vw = *(df_wave_uniform(a.vol + (size_t)(zv[u] - a.z_store0) * plane) + lane_vox);   // uniform plane base + lane offset
+                pend.vn[u] = vn; pend.dpb[u] = dpb[u]; pend.vox[u] = vw; pend.z[u] = zv[u]; pend.ok[u] = ok[u];
             }
         };
         for (;;) {
