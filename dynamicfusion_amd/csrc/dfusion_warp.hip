@@ -1167,34 +1167,53 @@ __device__ __forceinline__ unsigned df_node_off_hi(unsigned v)
     asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(v));
     return r;
 }
-__device__ __forceinline__ void tab_raw_offsets(const DfTabRaw<8>& r, unsigned (&bo)[8], float (&wt)[8])
-{
-    bo[0] = df_node_off_lo(r.idx.x); bo[1] = df_node_off_hi(r.idx.x); bo[2] = df_node_off_lo(r.idx.y); bo[3] = df_node_off_hi(r.idx.y);
-    bo[4] = df_node_off_lo(r.idx.z); bo[5] = df_node_off_hi(r.idx.z); bo[6] = df_node_off_lo(r.idx.w); bo[7] = df_node_off_hi(r.idx.w);
-    wt[0] = r.w0.x; wt[1] = r.w0.y; wt[2] = r.w0.z; wt[3] = r.w0.w; wt[4] = r.w1.x; wt[5] = r.w1.y; wt[6] = r.w1.z; wt[7] = r.w1.w;
-}
-__device__ __forceinline__ void tab_raw_offsets(const DfTabRaw<4>& r, unsigned (&bo)[4], float (&wt)[4])
-{
-    bo[0] = df_node_off_lo(r.idx.x); bo[1] = df_node_off_hi(r.idx.x); bo[2] = df_node_off_lo(r.idx.y); bo[3] = df_node_off_hi(r.idx.y);
-    wt[0] = r.w0.x; wt[1] = r.w0.y; wt[2] = r.w0.z; wt[3] = r.w0.w;
-}
-// dqb_sums_lds with the nodes given as byte offsets into the workgroup's LDS.  The node table is the kernel's only LDS object (the
+// The blend below addresses the nodes by byte offsets into the workgroup's LDS.  The node table is the kernel's only LDS object (the
 // dynamic array), so it starts at LDS address 0 and the offset IS the address -- df_warp_rows_pipe_kernel checks that.
 typedef const __attribute__((address_space(3))) df_v4f df_lds_cf4;
-template <int K>
-__device__ __forceinline__ DfBlendSums dqb_sums_lds_off(const float (&wt)[K], const unsigned (&bo)[K])
+// w.lo * q and w.hi * q on both halves of q: the weight is picked out of its register PAIR by op_sel (the table record delivers the
+// weights two to a pair), instead of being copied into a {w, w} pair first -- 12 v_mov per voxel at k = 8.
+__device__ __forceinline__ df_v2f df_pk_mul_lo(df_v2f w, df_v2f q)
+{
+    df_v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(q));
+    return r;
+}
+__device__ __forceinline__ df_v2f df_pk_mul_hi(df_v2f w, df_v2f q)
+{
+    df_v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "v"(q));
+    return r;
+}
+// the blend sums straight from a packed table record: node offsets and weights are taken out of the loaded registers where they are used
+__device__ __forceinline__ void df_blend_pair(DfBlendSums& S, unsigned idx2, df_v2f wp)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        df_lds_cf4* nd = (df_lds_cf4*)(size_t)(h == 0 ? df_node_off_lo(idx2) : df_node_off_hi(idx2));
+        const df_v4f r4 = nd[0], t4 = nd[1];
+        const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
+        if (h == 0) {
+            S.t01 = S.t01 + df_pk_mul_lo(wp, ta); S.t23 = S.t23 + df_pk_mul_lo(wp, tb);     // :211
+            S.r01 = S.r01 + df_pk_mul_lo(wp, ra); S.r23 = S.r23 + df_pk_mul_lo(wp, rb);     // :212
+        } else {
+            S.t01 = S.t01 + df_pk_mul_hi(wp, ta); S.t23 = S.t23 + df_pk_mul_hi(wp, tb);
+            S.r01 = S.r01 + df_pk_mul_hi(wp, ra); S.r23 = S.r23 + df_pk_mul_hi(wp, rb);
+        }
+    }
+}
+__device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<8>& r)
 {
     DfBlendSums S;
     S.t01 = S.t23 = S.r01 = S.r23 = df_v2f{0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        df_lds_cf4* nd = (df_lds_cf4*)(size_t)bo[i];
-        const df_v4f r4 = nd[0], t4 = nd[1];
-        const df_v2f ww = {wt[i], wt[i]};
-        const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
-        S.t01 = S.t01 + ww * ta; S.t23 = S.t23 + ww * tb;     // :211
-        S.r01 = S.r01 + ww * ra; S.r23 = S.r23 + ww * rb;     // :212
-    }
+    df_blend_pair(S, r.idx.x, df_v2f{r.w0.x, r.w0.y}); df_blend_pair(S, r.idx.y, df_v2f{r.w0.z, r.w0.w});
+    df_blend_pair(S, r.idx.z, df_v2f{r.w1.x, r.w1.y}); df_blend_pair(S, r.idx.w, df_v2f{r.w1.z, r.w1.w});
+    return S;
+}
+__device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<4>& r)
+{
+    DfBlendSums S;
+    S.t01 = S.t23 = S.r01 = S.r23 = df_v2f{0.f, 0.f};
+    df_blend_pair(S, r.idx.x, df_v2f{r.w0.x, r.w0.y}); df_blend_pair(S, r.idx.y, df_v2f{r.w0.z, r.w0.w});
     return S;
 }
 
@@ -1206,7 +1225,7 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
     for (int j = threadIdx.x; j < W.M; j += WGT) { s_nodes[2 * j] = W.rot[j]; s_nodes[2 * j + 1] = W.node_t[j]; }
-    if ((unsigned)(size_t)(df_lds_cf4*)s_nodes != 0u) __builtin_trap();  // dqb_sums_lds_off addresses the table from LDS address 0
+    if ((unsigned)(size_t)(df_lds_cf4*)s_nodes != 0u) __builtin_trap();  // the blend addresses the table from LDS address 0
     __syncthreads();
 
     constexpr int TPW = WGT / 512;                                         // tile columns per workgroup
@@ -1308,9 +1327,6 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
         // one batch: consumes S (tables of batch (l, z0)), then refills S with the tables of batch (l2, z2)
         auto step = [&](DfTabRaw<K> (&S)[U], int l, int z0, int l2, int z2) {
             const int ze = layer_ze(l);
-            unsigned bo[U][K]; float wt[U][K];
-#pragma unroll
-            for (int u = 0; u < U; ++u) tab_raw_offsets(S[u], bo[u], wt[u]);
             // (1) planes of this batch (clamped for the tail)
             bool inz[U]; int zv[U];
 #pragma unroll
@@ -1331,7 +1347,7 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
                 f3 q;
                 if constexpr (V2W_IDENTITY) q = add3(pv3, mk3(a.vol2world.t[0], a.vol2world.t[1], a.vol2world.t[2]));
                 else q = aff_mul(a.vol2world, pv3);
-                const DfBlendSums B = dqb_sums_lds_off<K>(wt[u], bo[u]);
+                const DfBlendSums B = dqb_sums_lds_rec(S[u]);
                 quat rsum, rn; quat2 half;
                 rsum.w = B.r01.x; rsum.x = B.r01.y; rsum.y = B.r23.x; rsum.z = B.r23.y;
                 half.wx = B.t01 * 0.5f; half.yz = B.t23 * 0.5f;
