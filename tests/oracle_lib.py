@@ -41,8 +41,17 @@ def build(force=False):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
 
 
+    refcu = os.path.join(ORACLE_DIR, "_ref", "libdfref_cu.so")
+    deps = [os.path.join(ORACLE_DIR, f) for f in ("ref_cu_glue.cpp", "gen_ref_cu.sh", "cuda_shim/cuda_runtime_api.h",
+                                                   "cuda_shim/cuda_shim_runtime.cpp")]
+    if os.path.isdir("/root/reference/kfusion/src/cuda") and (
+            force or not os.path.exists(refcu) or os.path.getmtime(refcu) < max(os.path.getmtime(d) for d in deps)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "ref_cu"], stdout=subprocess.DEVNULL)
+
+
 _lib = None
 _ref = None
+_refcu = None
 
 
 def lib():
@@ -166,6 +175,93 @@ def ref():
         R.ref_nanoflann_version.restype = C.c_int
         _ref = R
     return _ref
+
+
+def have_refcu():
+    build()
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libdfref_cu.so"))
+
+
+def refcu():
+    """The reference's own CUDA kernels (tsdf_volume.cu, imgproc.cu, proj_icp.cu) compiled for the host through
+    oracle/cuda_shim (oracle/_ref/libdfref_cu.so, `make -C oracle ref_cu`)."""
+    global _refcu
+    if _refcu is None:
+        build()
+        R = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libdfref_cu.so"))
+        u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+        i, f = C.c_int, C.c_float
+        R.refcu_clear.argtypes = [Volume]
+        R.refcu_integrate.argtypes = [u16p, i, i, Volume, f32p, f32p]
+        R.refcu_raycast_points.argtypes = [Volume, f32p, f32p, f32p, i, i, f, f, f32p, f32p]
+        R.refcu_raycast_depth.argtypes = [Volume, f32p, f32p, f32p, i, i, f, f, u16p, f32p]
+        R.refcu_project_and_remove.argtypes = [u16p, i, i, f32p, i, i, f32p]
+        R.refcu_extract_normals.argtypes = [Volume, f32p, f32p, f32p, C.c_uint64, f, f32p]
+        R.refcu_extract_cloud.argtypes = [Volume, f32p, f32p, C.c_uint64]
+        R.refcu_extract_cloud.restype = C.c_uint64
+        R.refcu_compute_dists.argtypes = [u16p, i, i, f32p, u16p]
+        R.refcu_bilateral.argtypes = [u16p, i, i, i, f, f, u16p]
+        R.refcu_truncate_depth.argtypes = [u16p, i, i, f]
+        R.refcu_depth_pyramid.argtypes = [u16p, i, i, f, u16p]
+        R.refcu_compute_normals_mask_depth.argtypes = [u16p, i, i, f32p, f32p]
+        R.refcu_compute_point_normals.argtypes = [u16p, i, i, f32p, f32p, f32p]
+        R.refcu_resize_depth_normals.argtypes = [u16p, f32p, i, i, u16p, f32p]
+        R.refcu_resize_points_normals.argtypes = [f32p, f32p, i, i, f32p, f32p]
+        R.refcu_render_points.argtypes = [f32p, f32p, i, i, f32p, f32p, u8p]
+        R.refcu_render_depth.argtypes = [u16p, f32p, i, i, f32p, f32p, u8p]
+        R.refcu_render_tangent_colors.argtypes = [f32p, i, i, u8p]
+        R.refcu_icp_sums_points.argtypes = [f32p, f32p, f32p, f32p, i, i, f32p, f32p, f, f, f32p]
+        for n in dir(R):
+            pass
+        for name in ("refcu_clear", "refcu_integrate", "refcu_raycast_points", "refcu_raycast_depth", "refcu_project_and_remove",
+                     "refcu_extract_normals", "refcu_compute_dists", "refcu_bilateral", "refcu_truncate_depth", "refcu_depth_pyramid",
+                     "refcu_compute_normals_mask_depth", "refcu_compute_point_normals", "refcu_resize_depth_normals",
+                     "refcu_resize_points_normals", "refcu_render_points", "refcu_render_depth", "refcu_render_tangent_colors",
+                     "refcu_icp_sums_points"):
+            getattr(R, name).restype = None
+        _refcu = R
+    return _refcu
+
+
+# ---- the reference's own kernels, numpy level (same argument conventions as the oracle helpers below) ---------------
+def refcu_compute_dists(depth_u16, intr):
+    d = _u16(depth_u16); rows, cols = d.shape
+    out = np.zeros_like(d)
+    refcu().refcu_compute_dists(d, rows, cols, f32(intr), out)
+    return out
+
+
+def refcu_integrate(dists, volume, vol2cam, intr):
+    rows, cols = dists.shape
+    refcu().refcu_integrate(_u16(dists), rows, cols, volume, f32(vol2cam).reshape(-1), f32(intr))
+
+
+def refcu_raycast_points(volume, cam2vol, Rinv, intr, cols, rows, step_factor, delta_factor):
+    pts = np.empty((rows, cols, 4), np.float32); nrm = np.empty((rows, cols, 4), np.float32)
+    refcu().refcu_raycast_points(volume, f32(cam2vol).reshape(-1), f32(Rinv).reshape(-1), f32(intr), rows, cols, step_factor, delta_factor,
+                                 pts.reshape(-1), nrm.reshape(-1))
+    return pts, nrm
+
+
+def refcu_raycast_depth(volume, cam2vol, Rinv, intr, cols, rows, step_factor, delta_factor):
+    dep = np.empty((rows, cols), np.uint16); nrm = np.empty((rows, cols, 4), np.float32)
+    refcu().refcu_raycast_depth(volume, f32(cam2vol).reshape(-1), f32(Rinv).reshape(-1), f32(intr), rows, cols, step_factor, delta_factor,
+                                dep, nrm.reshape(-1))
+    return dep, nrm
+
+
+def refcu_extract_cloud(volume, aff, capacity):
+    pts = np.zeros((capacity, 4), np.float32)
+    n = int(refcu().refcu_extract_cloud(volume, f32(aff).reshape(-1), pts.reshape(-1), capacity))
+    return pts[:min(n, capacity)], n
+
+
+def refcu_extract_normals(volume, aff, Rinv, points, gradient_delta_factor):
+    points = np.ascontiguousarray(points, np.float32)
+    out = np.empty_like(points)
+    refcu().refcu_extract_normals(volume, f32(aff).reshape(-1), f32(Rinv).reshape(-1), points.reshape(-1), points.shape[0],
+                                  gradient_delta_factor, out.reshape(-1))
+    return out
 
 
 # ------------------------------------------------------------------ numpy-level helpers

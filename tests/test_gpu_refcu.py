@@ -1,0 +1,82 @@
+"""GPU parity against the reference's OWN CUDA kernels (not the restatement): the HIP path through the C-ABI vs
+  * tests/golden/refcu_64.npz -- vectors produced by kfusion/src/cuda/tsdf_volume.cu + imgproc.cu compiled for the host
+    (tests/golden/make_golden_refcu.py), always available;
+  * oracle/_ref/libdfref_cu.so run live on the box's CPU (the prebuilt library travels with the snapshot), at 128^3 / 640x480.
+Bit-for-bit."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from dynamicfusion_amd import Intr, compute_dists, download_u16, synth, upload_u16
+from test_gpu_parity import make_gpu_volume
+from test_oracle_refcu import GOLDEN, bits, make_scene
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def gpu_frames(sc, cfg, frames):
+    intr = Intr(*cfg.intr)
+    vol = make_gpu_volume(sc)
+    for f in range(frames):
+        d = compute_dists(upload_u16(sc.depths[f]), intr)
+        torch.cuda.synchronize()
+        assert np.array_equal(download_u16(d), sc.dists[f])
+        vol.integrate(d, sc.cam_poses[f], intr)
+    return vol, intr
+
+
+def gpu_raycast(vol, sc, cfg, intr, f):
+    pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
+    nrm = torch.empty_like(pts)
+    vol.raycast(sc.cam_poses[f], intr, pts, nrm)
+    dep = torch.empty((cfg.rows, cfg.cols), dtype=torch.int16, device="cuda")
+    nrm2 = torch.empty_like(pts)
+    vol.raycast(sc.cam_poses[f], intr, dep, nrm2)
+    torch.cuda.synchronize()
+    return pts.cpu().numpy(), nrm.cpu().numpy(), dep.cpu().numpy().view(np.uint16), nrm2.cpu().numpy()
+
+
+def test_hip_equals_committed_reference_golden():
+    g = np.load(GOLDEN)
+    cfg, sc = make_scene(64, rotated=True)
+    assert np.array_equal(sc.pose, g["pose"]) and np.array_equal(np.stack(sc.dists), g["dists"])
+    vol, intr = gpu_frames(sc, cfg, 3)
+    assert np.array_equal(vol.download(), g["volume"])                       # tsdf_volume.cu:51-108 on the CPU vs HIP
+    p, n, d, _ = gpu_raycast(vol, sc, cfg, intr, 2)
+    assert np.array_equal(bits(p), g["points_bits"]) and np.array_equal(bits(n), g["normals_bits"])
+    assert np.array_equal(d, g["depth"])
+    cloud = vol.fetchCloud()
+    assert int(cloud.shape[0]) == int(g["cloud_count"])
+
+
+@pytest.mark.skipif(not O.have_refcu(), reason="oracle/_ref/libdfref_cu.so did not travel")
+def test_hip_equals_reference_kernels_live_128():
+    cfg, sc = make_scene(128, rotated=True, cols=640, rows=480)
+    vol, intr = gpu_frames(sc, cfg, 3)
+    ref = sc.new_volume()
+    for f in range(3):
+        O.refcu_integrate(sc.dists[f], sc.ovol(ref), synth.aff12(sc.vol2cam(f)), sc.intr)
+    assert (ref >> 16).max() == 3
+    assert np.array_equal(vol.download(), ref)
+    tail = (cfg.cols, cfg.rows, cfg.raycast_step_factor, cfg.gradient_delta_factor)
+    for f in (0, 2):
+        p, n, d, dn = gpu_raycast(vol, sc, cfg, intr, f)
+        rp, rn = O.refcu_raycast_points(sc.ovol(ref), synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.intr, *tail)
+        rd, rdn = O.refcu_raycast_depth(sc.ovol(ref), synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.intr, *tail)
+        assert np.isfinite(rp[..., 0]).sum() > 0.3 * cfg.cols * cfg.rows
+        assert np.array_equal(bits(p), bits(rp)) and np.array_equal(bits(n), bits(rn))
+        assert np.array_equal(d, rd) and np.array_equal(bits(dn), bits(rdn))
+    # FullScan6 + extract_normals_kernel: same point set, same normals
+    cloud = vol.fetchCloud()
+    normals = vol.fetchNormals(cloud)
+    torch.cuda.synchronize()
+    rc, count = O.refcu_extract_cloud(sc.ovol(ref), synth.aff12(sc.pose), 1 << 22)
+    assert count == cloud.shape[0]
+    key = lambda a: np.sort(np.ascontiguousarray(bits(a)[:, :3]).view([("x", "u4"), ("y", "u4"), ("z", "u4")]).reshape(-1), order=("x", "y", "z"))
+    c = cloud.cpu().numpy()
+    assert np.array_equal(key(c), key(rc))
+    rinv = np.linalg.inv(sc.pose[:3, :3].astype(np.float64)).astype(F32)
+    rn = O.refcu_extract_normals(sc.ovol(ref), synth.aff12(sc.pose), rinv, c, cfg.gradient_delta_factor)
+    assert np.array_equal(bits(normals.cpu().numpy())[:, :3], bits(rn)[:, :3])
