@@ -13,8 +13,9 @@
  *   integrate (rigid)    kfusion/src/cuda/tsdf_volume.cu:51-112, host :141-161
  *   raycast              kfusion/src/cuda/tsdf_volume.cu:202-474
  *   extract cloud/normals kfusion/src/cuda/tsdf_volume.cu:511-710,714-795
- *   k-NN                 kfusion/src/warp_field.cpp:247-251 + knn_point_cloud.hpp:16-32
- *                        (nanoflann v1.2.3 exact L2, ascending; brute force here)
+ *   k-NN                 kfusion/src/warp_field.cpp:247-251 + knn_point_cloud.hpp:16-32 + the vendored
+ *                        nanoflann v1.2.3 (kd-tree build, visit order and result set restated, so that exact
+ *                        distance ties resolve as in the reference)
  *   weighting            kfusion/src/warp_field.cpp:238-241
  *   DQB                  kfusion/src/warp_field.cpp:203-217
  *   DualQuaternion math  kfusion/src/utils/dual_quaternion.hpp:59-63,120-125,204-210
@@ -37,7 +38,6 @@
  * Deliberate deviations (each is also a documented policy of the HIP path):
  *   - NaN pixel coordinates in integrate => skip (reference relies on texture border).
  *   - fetch_tsdf index is clamped to the stored range (reference reads unchecked).
- *   - k-NN ties: lower node index first (nanoflann: first found in tree order).
  *   - exp() in weighting is the double overload (what gcc 5 / Ubuntu 16.04, the
  *     reference's platform, resolves `exp(float)` to with <cmath> only), then cast to float.
  *   - (ushort)(z*1000) in the depth raycast saturates to [0,65535].
@@ -274,8 +274,206 @@ static inline float knn_dist2(const float *q, const float *p)
     return d0 * d0 + d1 * d1 + d2 * d2;
 }
 
-/* exact k smallest, ascending; ties -> lower index first (strict < insertion, index order scan);
- * nanoflann.hpp:110-131 addPoint semantics minus tree order. */
+/* ---------------------------------------------------------------- nanoflann v1.2.3, restated
+ * kfusion/include/nanoflann/nanoflann.hpp as the reference instantiates it (warp_field.hpp:13-17, warp_field.cpp:20,23,247-251):
+ * KDTreeSingleIndexAdaptor<L2_Simple_Adaptor<float, PointCloud>, PointCloud, 3>, leaf_max_size 10, KNNResultSet<float>,
+ * SearchParams(10) (eps = 0).  The k nearest are unique only up to EXACT distance ties; which of two equidistant nodes is
+ * returned (and blended) is decided by the order the tree visits them and by KNNResultSet::addPoint keeping the first found,
+ * so the build (divideTree / middleSplit_ / planeSplit, :1042-1176) and the search (searchLevel :1200-1254, addPoint :110-131)
+ * are restated statement by statement, float arithmetic included.  Pinned against the reference's own header compiled
+ * unmodified (oracle/_ref, tests/test_oracle_golden.py) on random and on gridded (tie-heavy) node sets. */
+#define NF_LEAF_MAX 10                                   /* KDTreeSingleIndexAdaptorParams(10), warp_field.cpp:20 */
+typedef struct { int child1, child2; int left, right; int divfeat; float divlow, divhigh; } nf_node;
+typedef struct { float low, high; } nf_interval;
+typedef struct {
+    const float *pos; int M;
+    int *vind; nf_node *nodes; int n_nodes, cap_nodes;
+    nf_interval root_bbox[3];
+    int root;
+} nf_tree;
+
+static inline float nf_get(const nf_tree *t, int idx, int c) { return t->pos[3 * idx + c]; }       /* kdtree_get_pt */
+
+static void nf_min_max(const nf_tree *t, const int *ind, int count, int element, float *min_elem, float *max_elem)   /* :1094-1103 */
+{
+    *min_elem = nf_get(t, ind[0], element);
+    *max_elem = nf_get(t, ind[0], element);
+    for (int i = 1; i < count; ++i) {
+        float val = nf_get(t, ind[i], element);
+        if (val < *min_elem) *min_elem = val;
+        if (val > *max_elem) *max_elem = val;
+    }
+}
+
+/* :1151-1176 (IndexType is size_t there: the `right &&` / `!right` tests keep the unsigned index from wrapping) */
+static void nf_plane_split(const nf_tree *t, int *ind, int count, int cutfeat, float cutval, int *lim1, int *lim2)
+{
+    size_t left = 0, right = (size_t)count - 1;
+    for (;;) {
+        while (left <= right && nf_get(t, ind[left], cutfeat) < cutval) ++left;
+        while (right && left <= right && nf_get(t, ind[right], cutfeat) >= cutval) --right;
+        if (left > right || !right) break;
+        int tmp = ind[left]; ind[left] = ind[right]; ind[right] = tmp;
+        ++left; --right;
+    }
+    *lim1 = (int)left;
+    right = (size_t)count - 1;
+    for (;;) {
+        while (left <= right && nf_get(t, ind[left], cutfeat) <= cutval) ++left;
+        while (right && left <= right && nf_get(t, ind[right], cutfeat) > cutval) --right;
+        if (left > right || !right) break;
+        int tmp = ind[left]; ind[left] = ind[right]; ind[right] = tmp;
+        ++left; --right;
+    }
+    *lim2 = (int)left;
+}
+
+static void nf_middle_split(const nf_tree *t, int *ind, int count, int *index, int *cutfeat, float *cutval, const nf_interval *bbox)   /* :1105-1140 */
+{
+    const float EPS = 0.00001f;
+    float max_span = bbox[0].high - bbox[0].low;
+    for (int i = 1; i < 3; ++i) {
+        float span = bbox[i].high - bbox[i].low;
+        if (span > max_span) max_span = span;
+    }
+    float max_spread = -1;
+    *cutfeat = 0;
+    for (int i = 0; i < 3; ++i) {
+        float span = bbox[i].high - bbox[i].low;
+        if (span > (1 - EPS) * max_span) {
+            float min_elem, max_elem;
+            nf_min_max(t, ind, count, i, &min_elem, &max_elem);
+            float spread = max_elem - min_elem;
+            if (spread > max_spread) { *cutfeat = i; max_spread = spread; }
+        }
+    }
+    float split_val = (bbox[*cutfeat].low + bbox[*cutfeat].high) / 2;
+    float min_elem, max_elem;
+    nf_min_max(t, ind, count, *cutfeat, &min_elem, &max_elem);
+    if (split_val < min_elem) *cutval = min_elem;
+    else if (split_val > max_elem) *cutval = max_elem;
+    else *cutval = split_val;
+    int lim1, lim2;
+    nf_plane_split(t, ind, count, *cutfeat, *cutval, &lim1, &lim2);
+    if (lim1 > count / 2) *index = lim1;
+    else if (lim2 < count / 2) *index = lim2;
+    else *index = count / 2;
+}
+
+static int nf_divide(nf_tree *t, int left, int right, nf_interval *bbox)                          /* divideTree :1042-1091 */
+{
+    int me = t->n_nodes++;
+    nf_node *node = &t->nodes[me];
+    if ((right - left) <= NF_LEAF_MAX) {
+        node->child1 = node->child2 = -1;
+        node->left = left; node->right = right;
+        for (int i = 0; i < 3; ++i) { bbox[i].low = nf_get(t, t->vind[left], i); bbox[i].high = nf_get(t, t->vind[left], i); }
+        for (int k = left + 1; k < right; ++k)
+            for (int i = 0; i < 3; ++i) {
+                if (bbox[i].low > nf_get(t, t->vind[k], i)) bbox[i].low = nf_get(t, t->vind[k], i);
+                if (bbox[i].high < nf_get(t, t->vind[k], i)) bbox[i].high = nf_get(t, t->vind[k], i);
+            }
+    } else {
+        int idx, cutfeat; float cutval;
+        nf_middle_split(t, t->vind + left, right - left, &idx, &cutfeat, &cutval, bbox);
+        node->divfeat = cutfeat;
+        nf_interval left_bbox[3], right_bbox[3];
+        memcpy(left_bbox, bbox, sizeof(left_bbox));
+        left_bbox[cutfeat].high = cutval;
+        int c1 = nf_divide(t, left, left + idx, left_bbox);
+        memcpy(right_bbox, bbox, sizeof(right_bbox));
+        right_bbox[cutfeat].low = cutval;
+        int c2 = nf_divide(t, left + idx, right, right_bbox);
+        node = &t->nodes[me];
+        node->child1 = c1; node->child2 = c2;
+        node->divlow = left_bbox[cutfeat].high;
+        node->divhigh = right_bbox[cutfeat].low;
+        for (int i = 0; i < 3; ++i) {
+            bbox[i].low = right_bbox[i].low < left_bbox[i].low ? right_bbox[i].low : left_bbox[i].low;      /* std::min(a,b): b<a ? b : a */
+            bbox[i].high = left_bbox[i].high < right_bbox[i].high ? right_bbox[i].high : left_bbox[i].high; /* std::max(a,b): a<b ? b : a */
+        }
+    }
+    return me;
+}
+
+static nf_tree *nf_build(const float *pos, int M)                                                  /* buildIndex :855-866 */
+{
+    nf_tree *t = (nf_tree *)calloc(1, sizeof(nf_tree));
+    t->pos = pos; t->M = M;
+    t->vind = (int *)malloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
+    for (int i = 0; i < M; ++i) t->vind[i] = i;                                                    /* init_vind */
+    t->cap_nodes = 2 * M + 2;
+    t->nodes = (nf_node *)calloc((size_t)t->cap_nodes, sizeof(nf_node));
+    t->root = -1;
+    if (M == 0) return t;
+    for (int i = 0; i < 3; ++i) t->root_bbox[i].low = t->root_bbox[i].high = nf_get(t, 0, i);      /* computeBoundingBox :1010-1032 */
+    for (int k = 1; k < M; ++k)
+        for (int i = 0; i < 3; ++i) {
+            if (nf_get(t, k, i) < t->root_bbox[i].low) t->root_bbox[i].low = nf_get(t, k, i);
+            if (nf_get(t, k, i) > t->root_bbox[i].high) t->root_bbox[i].high = nf_get(t, k, i);
+        }
+    t->root = nf_divide(t, 0, M, t->root_bbox);
+    return t;
+}
+static void nf_free(nf_tree *t) { if (t) { free(t->vind); free(t->nodes); free(t); } }
+
+typedef struct { int *indices; float *dists; int capacity, count; } nf_result;                      /* KNNResultSet :78-137 */
+static inline void nf_add_point(nf_result *r, float dist, int index)                               /* addPoint :110-131 */
+{
+    int i;
+    for (i = r->count; i > 0; --i) {
+        if (r->dists[i - 1] > dist) {
+            if (i < r->capacity) { r->dists[i] = r->dists[i - 1]; r->indices[i] = r->indices[i - 1]; }
+        } else break;
+    }
+    if (i < r->capacity) { r->dists[i] = dist; r->indices[i] = index; }
+    if (r->count < r->capacity) r->count++;
+}
+
+static void nf_search_level(const nf_tree *t, nf_result *rs, const float *vec, int node_i, float mindistsq, float *dists)   /* :1200-1254 */
+{
+    const nf_node *node = &t->nodes[node_i];
+    if (node->child1 < 0 && node->child2 < 0) {
+        float worst_dist = rs->dists[rs->capacity - 1];                                             /* worstDist(), read once per leaf */
+        for (int i = node->left; i < node->right; ++i) {
+            const int index = t->vind[i];
+            float dist = knn_dist2(vec, t->pos + 3 * index);
+            if (dist < worst_dist) nf_add_point(rs, dist, index);
+        }
+        return;
+    }
+    int idx = node->divfeat;
+    float val = vec[idx];
+    float diff1 = val - node->divlow;
+    float diff2 = val - node->divhigh;
+    int best, other; float cut_dist;
+    if ((diff1 + diff2) < 0) { best = node->child1; other = node->child2; cut_dist = (val - node->divhigh) * (val - node->divhigh); }
+    else { best = node->child2; other = node->child1; cut_dist = (val - node->divlow) * (val - node->divlow); }
+    nf_search_level(t, rs, vec, best, mindistsq, dists);
+    float dst = dists[idx];
+    mindistsq = mindistsq + cut_dist - dst;
+    dists[idx] = cut_dist;
+    if (mindistsq * 1.0f <= rs->dists[rs->capacity - 1]) nf_search_level(t, rs, vec, other, mindistsq, dists);   /* epsError = 1 + 0 */
+    dists[idx] = dst;
+}
+
+/* findNeighbors :903-917 after resultSet.init (:92-99).  M >= k is a precondition. */
+static inline void knn_tree(const nf_tree *t, const float q[3], int k, int *idx, float *d2)
+{
+    nf_result rs = {idx, d2, k, 0};
+    d2[k - 1] = 3.402823466e+38f;                                                                   /* numeric_limits<float>::max() */
+    if (t->M == 0) return;
+    float dists[3] = {0.f, 0.f, 0.f};
+    float distsq = 0.f;
+    for (int i = 0; i < 3; ++i) {                                                                   /* computeInitialDistances :1179-1196 */
+        if (q[i] < t->root_bbox[i].low) { dists[i] = (q[i] - t->root_bbox[i].low) * (q[i] - t->root_bbox[i].low); distsq += dists[i]; }
+        if (q[i] > t->root_bbox[i].high) { dists[i] = (q[i] - t->root_bbox[i].high) * (q[i] - t->root_bbox[i].high); distsq += dists[i]; }
+    }
+    nf_search_level(t, &rs, q, t->root, distsq, dists);
+}
+
+/* exhaustive scan in node-index order, strict '<' insertion (ties -> lower index).  Kept only as an independent check of the
+ * tree search on tie-free data (tests) -- the oracle's answers come from knn_tree. */
 static inline void knn_brute(const float *pos, int M, const float q[3], int k, int *idx, float *d2)
 {
     int count = 0;
@@ -291,8 +489,31 @@ static inline void knn_brute(const float *pos, int M, const float q[3], int k, i
 
 ORC_API void orc_knn(const float *pos, int M, const float *queries, int N, int k, int *idx_out, float *d2_out)
 {
+    nf_tree *t = nf_build(pos, M);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) knn_tree(t, queries + 3 * i, k, idx_out + (size_t)i * k, d2_out + (size_t)i * k);
+    nf_free(t);
+}
+ORC_API void orc_knn_brute(const float *pos, int M, const float *queries, int N, int k, int *idx_out, float *d2_out)
+{
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < N; ++i) knn_brute(pos, M, queries + 3 * i, k, idx_out + (size_t)i * k, d2_out + (size_t)i * k);
+}
+/* tree shape for tests: depth, leaf count, and vind (the permutation the build leaves behind) */
+ORC_API void orc_nanoflann_tree_info(const float *pos, int M, int *vind_out, int *n_nodes, int *depth_out)
+{
+    nf_tree *t = nf_build(pos, M);
+    if (vind_out) memcpy(vind_out, t->vind, sizeof(int) * (size_t)M);
+    if (n_nodes) *n_nodes = t->n_nodes;
+    if (depth_out) {
+        int best = 0;
+        int *stack = (int *)malloc(sizeof(int) * 2 * (size_t)(t->n_nodes + 1)); int sp = 0;
+        if (t->root >= 0) { stack[sp++] = t->root; stack[sp++] = 1; }
+        while (sp) { int d = stack[--sp], n = stack[--sp]; if (d > best) best = d;
+            if (t->nodes[n].child1 >= 0) { stack[sp++] = t->nodes[n].child1; stack[sp++] = d + 1; stack[sp++] = t->nodes[n].child2; stack[sp++] = d + 1; } }
+        free(stack); *depth_out = best;
+    }
+    nf_free(t);
 }
 
 /* warp_field.cpp:238-241 */
@@ -334,10 +555,10 @@ static void node_translations(const float *dq, int M, float *node_t)
 }
 
 /* DQB-warp one point (warp_field.cpp:187-188): returns DQB(p).transform(p) */
-static inline f3 warp_point(const float *pos, const float *dq, const float *node_t, const float *sigma, int M, int k, f3 p)
+static inline f3 warp_point(const nf_tree *tree, const float *dq, const float *node_t, const float *sigma, int k, f3 p)
 {
     int idx[16]; float d2[16]; float q[3] = {p.x, p.y, p.z};
-    knn_brute(pos, M, q, k, idx, d2);
+    knn_tree(tree, q, k, idx, d2);
     quat rot, dual; dqb_blend(dq, node_t, sigma, k, idx, d2, &rot, &dual);
     return dq_transform(rot, dual, p);
 }
@@ -357,13 +578,14 @@ ORC_API void orc_warp_points(const float *pos, const float *dq, const float *sig
 {
     float *node_t = (float *)malloc((size_t)M * 16);
     node_translations(dq, M, node_t);
+    nf_tree *tree = nf_build(pos, M);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < N; ++i) {
         float *p = points + 3 * (size_t)i;
         float *n = normals ? normals + 3 * (size_t)i : 0;
         if (isnan(p[0]) || (n && isnan(n[0]))) continue;
         int idx[16]; float d2[16];
-        knn_brute(pos, M, p, k, idx, d2);
+        knn_tree(tree, p, k, idx, d2);
         quat rot, dual; dqb_blend(dq, node_t, sigma, k, idx, d2, &rot, &dual);
         f3 pw = cv_affine_mul(warp_to_live, dq_transform(rot, dual, mk3(p[0], p[1], p[2])));
         p[0] = pw.x; p[1] = pw.y; p[2] = pw.z;
@@ -372,6 +594,7 @@ ORC_API void orc_warp_points(const float *pos, const float *dq, const float *sig
             n[0] = nw.x; n[1] = nw.y; n[2] = nw.z;
         }
     }
+    nf_free(tree);
     free(node_t);
 }
 
@@ -381,13 +604,15 @@ ORC_API void orc_dqb(const float *pos, const float *dq, const float *sigma, int 
 {
     float *node_t = (float *)malloc((size_t)M * 16);
     node_translations(dq, M, node_t);
+    nf_tree *tree = nf_build(pos, M);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < N; ++i) {
         int idx[16]; float d2[16];
-        knn_brute(pos, M, points + 3 * (size_t)i, k, idx, d2);
+        knn_tree(tree, points + 3 * (size_t)i, k, idx, d2);
         quat rot, dual; dqb_blend(dq, node_t, sigma, k, idx, d2, &rot, &dual);
         memcpy(out_dq + 8 * (size_t)i, &rot, 16); memcpy(out_dq + 8 * (size_t)i + 4, &dual, 16);
     }
+    nf_free(tree);
     free(node_t);
 }
 
@@ -405,6 +630,7 @@ ORC_API uint64_t orc_integrate_warped(const uint16_t *dists, size_t pitch, int c
     uint16_t *base = (uint16_t *)v.data;
     float *node_t = (float *)malloc((size_t)M * 16);
     node_translations(dq, M, node_t);
+    nf_tree *tree = nf_build(pos, M);
     uint64_t n_upd = 0;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : n_upd)
     for (int z = s.z_own0; z < s.z_own0 + s.z_own_n; ++z)
@@ -412,11 +638,12 @@ ORC_API uint64_t orc_integrate_warped(const uint16_t *dists, size_t pitch, int c
             for (int x = 0; x < X; ++x) {
                 f3 vx = mk3((float)x * v.voxel_size[0], (float)y * v.voxel_size[1], (float)z * v.voxel_size[2]);
                 f3 xc = aff_mul(vol2world, vx);
-                f3 xw = warp_point(pos, dq, node_t, sigma, M, k, xc);
+                f3 xw = warp_point(tree, dq, node_t, sigma, k, xc);
                 f3 vc = aff_mul(world2cam, xw);
                 uint16_t *vox = base + 2 * ((size_t)x + (size_t)y * X + (size_t)(z - s.z_store0) * X * Y);
                 n_upd += tsdf_update(vox, vc, dists, pitch, cols, rows, proj, v.trunc_dist, trunc_inv, v.max_weight);
             }
+    nf_free(tree);
     free(node_t);
     return n_upd;
 }

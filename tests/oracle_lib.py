@@ -74,6 +74,10 @@ def lib():
                                            f32p, f32p, f32p, f32p, C.c_int, C.c_int]
         L.orc_knn.restype = None
         L.orc_knn.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p, f32p]
+        L.orc_knn_brute.restype = None
+        L.orc_knn_brute.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p, f32p]
+        L.orc_nanoflann_tree_info.restype = None
+        L.orc_nanoflann_tree_info.argtypes = [f32p, C.c_int, i32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_dqb.restype = None
         L.orc_dqb.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_int, f32p]
         L.orc_warp_points.restype = None
@@ -368,12 +372,14 @@ def project_and_remove(dists, points, proj, remove=True, want_ro=True):
     return pts, out, ro, int(n)
 
 
-def knn(pos, queries, k, use_ref=False):
+def knn(pos, queries, k, use_ref=False, brute=False):
+    """use_ref: the reference's own nanoflann (oracle/_ref); brute: exhaustive index-order scan (ties -> lower index);
+    default: the oracle's restatement of nanoflann (tie order of the reference)."""
     pos, queries = f32(pos), f32(queries)
     n = queries.shape[0]
     idx = np.empty((n, k), np.int32)
     d2 = np.empty((n, k), np.float32)
-    fn = ref().ref_knn if use_ref else lib().orc_knn
+    fn = ref().ref_knn if use_ref else (lib().orc_knn_brute if brute else lib().orc_knn)
     fn(pos.reshape(-1), pos.shape[0], queries.reshape(-1), n, k, idx.reshape(-1), d2.reshape(-1))
     return idx, d2
 

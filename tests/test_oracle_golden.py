@@ -6,8 +6,8 @@
      (tests/golden/make_golden.py -> oracle/_ref/libdfref.so);
   3. where /root/reference is present (the build container), live against oracle/_ref.
 
-integrate / raycast / compute_dists / clear have NO reference tests or vectors ("parity unpinned"):
-they are pinned by source restatement only and by the self-consistency tests in test_oracle_properties.py.
+integrate / raycast / compute_dists / clear / extract / front-end / ICP: pinned against the reference's own CUDA kernels
+compiled for the host -- tests/test_oracle_refcu.py.
 """
 import os
 
@@ -88,11 +88,28 @@ def test_knn_golden():
         idx, d2 = O.knn(g["pos"], g["queries"], k)
         assert np.array_equal(idx, g[ki])
         assert np.array_equal(bits(d2), bits(g[kd]))
-    # nanoflann_test.cpp fixture: 8 cube corners, k = 8 -> every query returns all 8 nodes; distances
-    # (sorted) are identical, the order inside exact-tie groups is tree order in nanoflann and node index here.
+    # nanoflann_test.cpp fixture: 8 cube corners, k = 8 -> every query returns all 8 nodes, equidistant ones in nanoflann's
+    # tree order (the oracle restates the tree, so the index lists are identical, not just the sets)
     idx, d2 = O.knn(g["corners"], g["corner_queries"], 8)
     assert np.array_equal(bits(d2), bits(g["corner_d2"]))
-    assert np.array_equal(np.sort(idx, 1), np.sort(g["corner_idx"], 1))
+    assert np.array_equal(idx, g["corner_idx"])
+
+
+@pytest.mark.parametrize("name", ["grid", "surface", "dups"])
+def test_knn_tie_order_golden(name):
+    """Exact distance ties resolve as in the reference's nanoflann (tests/golden/make_golden_ties.py): gridded nodes and
+    queries, the bench's pixel-grid surface construction, duplicated nodes."""
+    g = np.load(os.path.join(GOLD, "knn_ties.npz"))
+    pos, q = g[name + "_pos"], g[name + "_q"]
+    for k in (4, 8):
+        idx, d2 = O.knn(pos, q, k)
+        assert np.array_equal(idx, g["%s_idx%d" % (name, k)].astype(np.int32))
+        assert np.array_equal(bits(d2), bits(g["%s_d2_%d" % (name, k)]))
+        bi, bd = O.knn(pos, q, k, brute=True)                  # the sets really are tie-heavy: index order disagrees
+        assert np.array_equal(bits(bd), bits(d2)) and (bi != idx).any(1).sum() > 100
+    if name == "surface":
+        wp, _ = O.warp_points(pos, g["surface_dq"], g["surface_sigma"], q, None, 8)
+        assert np.array_equal(bits(wp), bits(g["surface_warp8"]))
 
 
 @pytest.mark.parametrize("tag", ["s3", "s015"])
@@ -123,3 +140,21 @@ def test_live_against_reference_headers():
         i2, d2 = O.knn(pos, q, k, use_ref=True)
         assert np.array_equal(i1, i2) and np.array_equal(bits(d1), bits(d2))
         assert np.array_equal(bits(O.dqb(pos, dq, sigma, q, k)), bits(O.dqb(pos, dq, sigma, q, k, use_ref=True)))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/kfusion/src/utils"), reason="reference checkout absent")
+@pytest.mark.parametrize("M,n", [(11, 6), (100, 12), (1000, 24), (4913, 40)])
+def test_live_tie_order_against_reference_nanoflann(M, n):
+    """Gridded node sets of several sizes (tree depths 1..10), gridded + random queries inside and outside the bounding box."""
+    rng = np.random.RandomState(M)
+    side = int(np.ceil(M ** (1 / 3)))
+    g = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(F32) * F32(0.5)
+    pos = g[rng.permutation(len(g))[:M]]
+    q = np.stack(np.meshgrid(*[np.arange(-2, n)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(F32) * F32(0.25 * side / (n - 4) * 2)
+    q = np.concatenate([q, rng.uniform(-1, side * 0.5 + 1, (2000, 3)).astype(F32)])
+    for k in (1, 3, 8):
+        if M < k:
+            continue
+        i1, d1 = O.knn(pos, q, k)
+        i2, d2 = O.knn(pos, q, k, use_ref=True)
+        assert np.array_equal(i1, i2) and np.array_equal(bits(d1), bits(d2))
