@@ -41,7 +41,7 @@ struct DfWarpView {
     const uint16_t* brick_list;
     const float* brick_thr;    // [nb] list radius: nodes outside brick b's list are farther than this from its centre
     int bx, by, bz;            // brick grid over the GLOBAL volume
-    DfNfView nf;               // nanoflann's tree over the nodes: decides exact distance ties (dfusion_nanoflann.h)
+    DfNfView nf;               // nanoflann's tree over the nodes: orders exactly equidistant nodes (dfusion_nanoflann.h)
 };
 
 struct DfWarpField {
@@ -66,9 +66,7 @@ struct DfWarpField {
     void* solver_ws; size_t solver_ws_cap;
     // points an indexed k-NN / warp pass left to the scan kernel: [0] count, [1..] ids
     int* pt_ids; size_t pt_ids_cap;
-    int* pt_tie;                                       // same shape, inside the pt_ids allocation: points with an exact distance tie
-    unsigned long long* tie_mask; size_t tie_mask_cap;  // per 8^3 brick, 8 words: voxels of the last brick sweep with an exact distance tie
     int pt_image_cols;                                 // dfusion_warp_set_point_tiling: 0 = point queries in linear order
     // replica of the reference's nanoflann tree over the node positions (rebuilt by dfusion_warp_set_nodes)
-    DfNfNode* nf_nodes; uint16_t* nf_vind; size_t nf_nodes_cap, nf_vind_cap; float nf_blo[3], nf_bhi[3]; bool nf_ok; int nf_depth;
+    DfNfNode* nf_nodes; uint16_t* nf_vpos; size_t nf_nodes_cap, nf_vpos_cap; bool nf_ok; int nf_depth;
 };

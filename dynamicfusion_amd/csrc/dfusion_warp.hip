@@ -86,7 +86,7 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
     (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids); (void)hipFree(wf->tile_wmax);
-    (void)hipFree(wf->nf_nodes); (void)hipFree(wf->nf_vind); (void)hipFree(wf->tie_mask);
+    (void)hipFree(wf->nf_nodes); (void)hipFree(wf->nf_vpos);
     free(wf);
     return DF_OK;
 }
@@ -120,7 +120,7 @@ static int df_warp_pack(DfWarpField* wf, const float* pos, const float* dq, cons
 
 // buildKDTree (warp_field.cpp:275-282): nanoflann's tree over the node positions, replayed on the host (the build is sequential in
 // nanoflann too -- the partition order depends on every swap) from the positions just packed on the device; M <= 65535 nodes, a
-// few hundred microseconds.  The tree only arbitrates exact distance ties (dfusion_nanoflann.h).
+// few hundred microseconds.  The tree only orders exactly equidistant nodes (dfusion_nanoflann.h).
 static int df_warp_build_tie_tree(DfWarpField* wf, hipStream_t st)
 {
     const int M = wf->M;
@@ -130,21 +130,21 @@ static int df_warp_build_tie_tree(DfWarpField* wf, hipStream_t st)
     DF_HIP(hipStreamSynchronize(st));
     for (size_t i = 0; i < (size_t)M * 4; ++i) if ((i & 3) != 3 && !(host[i] == host[i])) return DF_OK;     // NaN position: no tree
     DfNfBuild B;
-    if (!B.build(host.data(), M, wf->nf_blo, wf->nf_bhi)) return DF_OK;                                     // too deep: index-order ties
+    B.build(host.data(), M);
     if (B.nodes.size() > wf->nf_nodes_cap) {
         (void)hipFree(wf->nf_nodes); wf->nf_nodes = nullptr; wf->nf_nodes_cap = 0;
         DF_HIP(hipMalloc((void**)&wf->nf_nodes, B.nodes.size() * sizeof(DfNfNode)));
         wf->nf_nodes_cap = B.nodes.size();
     }
-    if ((size_t)M > wf->nf_vind_cap) {
-        (void)hipFree(wf->nf_vind); wf->nf_vind = nullptr; wf->nf_vind_cap = 0;
-        DF_HIP(hipMalloc((void**)&wf->nf_vind, (size_t)M * sizeof(uint16_t)));
-        wf->nf_vind_cap = (size_t)M;
+    if ((size_t)M > wf->nf_vpos_cap) {
+        (void)hipFree(wf->nf_vpos); wf->nf_vpos = nullptr; wf->nf_vpos_cap = 0;
+        DF_HIP(hipMalloc((void**)&wf->nf_vpos, (size_t)M * sizeof(uint16_t)));
+        wf->nf_vpos_cap = (size_t)M;
     }
-    std::vector<uint16_t> v16((size_t)M);
-    for (int i = 0; i < M; ++i) v16[i] = (uint16_t)B.vind[i];
+    std::vector<uint16_t> vpos((size_t)M);
+    for (int i = 0; i < M; ++i) vpos[B.vind[i]] = (uint16_t)i;
     DF_HIP(hipMemcpyAsync(wf->nf_nodes, B.nodes.data(), B.nodes.size() * sizeof(DfNfNode), hipMemcpyHostToDevice, st));
-    DF_HIP(hipMemcpyAsync(wf->nf_vind, v16.data(), (size_t)M * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    DF_HIP(hipMemcpyAsync(wf->nf_vpos, vpos.data(), (size_t)M * sizeof(uint16_t), hipMemcpyHostToDevice, st));
     DF_HIP(hipStreamSynchronize(st));                        // the host vectors go out of scope
     wf->nf_depth = B.depth;
     wf->nf_ok = true;
@@ -172,20 +172,20 @@ extern "C" int dfusion_warp_set_transforms(DfWarpField* wf, const float* dq, dfS
 }
 
 // ====================================================================================== top-k in registers
-// Sorted insert with strict '<': ranks by distance only.  The k smallest DISTANCES are what nanoflann returns; the node LIST is
-// unique only if no two candidates that matter are exactly equidistant -- `tie` is raised whenever a candidate arrives whose
-// distance equals one already in the list (that covers a tie inside the list and a tie at rank k: the earlier of two equidistant
-// nodes is still listed when the later one arrives, unless k strictly closer nodes pushed it out, and then neither matters).
-// A raised flag sends the query to knn_resolve_ties, which answers it in nanoflann's own tree order.
+// What nanoflann returns (KNNResultSet::addPoint nanoflann.hpp:110-131 fed in searchLevel's order :1200-1254): the first k nodes by
+// (distance, order in which THIS query's tree walk meets them).  Candidates arrive here in some other order (node index, brick
+// list), so the sorted insert ranks by distance with strict '<' and, only when two distances are EQUAL, asks
+// df_nf_visited_before (dfusion_nanoflann.h) which node the reference's walk meets first.  The common case costs K compares more
+// than a plain insert; the equal-distance branch (nodes mirrored about a voxel / pixel plane, duplicated nodes) is a short
+// stackless walk down the tree replica.  Without a tree (T.nodes == null) equal distances keep arrival order.
 template <int K>
-__device__ __forceinline__ void topk_insert(float (&bd)[K], int (&bi)[K], float d, int j, bool& tie)
+__device__ __forceinline__ void topk_insert(float (&bd)[K], int (&bi)[K], float d, int j, const DfNfView& T, f3 q)
 {
     if (d <= bd[K - 1]) {
         bool eq = false;
 #pragma unroll
         for (int i = 0; i < K; ++i) eq = eq || (bd[i] == d);
-        tie = tie || eq;
-        if (d < bd[K - 1]) {
+        if (!eq) {                                           // (then d < bd[K - 1])
             bd[K - 1] = d; bi[K - 1] = j;
 #pragma unroll
             for (int i = K - 1; i > 0; --i) {
@@ -194,6 +194,23 @@ __device__ __forceinline__ void topk_insert(float (&bd)[K], int (&bi)[K], float 
                     int ti = bi[i]; bi[i] = bi[i - 1]; bi[i - 1] = ti;
                 }
             }
+        } else {
+            // position = entries strictly closer + equidistant entries the reference meets before j
+            int pos = 0;
+#pragma unroll 1
+            for (int i = 0; i < K; ++i) {
+                float di = bd[0]; int ji = bi[0];
+#pragma unroll
+                for (int t = 1; t < K; ++t) { di = (i == t) ? bd[t] : di; ji = (i == t) ? bi[t] : ji; }   // register select, no scratch
+                if (di < d) ++pos;
+                else if (di == d && (!T.nodes || df_nf_visited_before(T, q.x, q.y, q.z, ji, j))) ++pos;
+            }
+#pragma unroll
+            for (int i = K - 1; i > 0; --i)
+                if (i > pos) { bd[i] = bd[i - 1]; bi[i] = bi[i - 1]; }
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+                if (i == pos) { bd[i] = d; bi[i] = j; }
         }
     }
 }
@@ -211,17 +228,6 @@ __device__ __forceinline__ void topk_insert(float (&bd)[K], int (&bi)[K], float 
             }
         }
     }
-}
-// The reference's answer for a query with an exact distance tie: nanoflann's search replayed (dfusion_nanoflann.h).  Without a
-// tree (NaN node positions, pathological depth) the distance-ranked list with ties in scan order stands.
-template <int K>
-__device__ __forceinline__ void knn_resolve_ties(const DfWarpView& W, f3 q, float (&bd)[K], int (&bi)[K])
-{
-    if (!W.nf.nodes) return;
-    const DfNfResult<K> r = df_nf_search<K>(W.nf.nodes, W.nf.vind, W.pos_sigma, W.nf.blo[0], W.nf.blo[1], W.nf.blo[2], W.nf.bhi[0],
-                                            W.nf.bhi[1], W.nf.bhi[2], q.x, q.y, q.z);
-#pragma unroll
-    for (int i = 0; i < K; ++i) { bd[i] = r.d[i]; bi[i] = r.i[i]; }
 }
 template <int K>
 __device__ __forceinline__ void topk_init(float (&bd)[K], int (&bi)[K])
@@ -344,14 +350,11 @@ __device__ __forceinline__ void df_point_finish(const DfWarpView& W, int i, f3 q
     }
 }
 
-// Queries whose distance-ranked list met an exact tie are not finished by the kernel that found them: their ids go to a list
-// (tie_ids, counter tie_count) and df_points_tie_kernel answers them in nanoflann's tree order afterwards.  That keeps the tree
-// walk -- a stack in scratch memory -- out of the kernels every query runs through.
 template <int K, int MODE /* 0 = knn out, 1 = warp points */>
 __global__ __launch_bounds__(256) void df_points_kernel(DfWarpView W, const float* __restrict__ queries, int N,
                                                         int* __restrict__ idx_out, float* __restrict__ d2_out,
                                                         float* __restrict__ points, float* __restrict__ normals,
-                                                        DfAff to_live, int* __restrict__ tie_ids, int* __restrict__ tie_count)
+                                                        DfAff to_live)
 {
     __shared__ float4 s_pos[DF_PT_CHUNK];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -361,7 +364,6 @@ __global__ __launch_bounds__(256) void df_points_kernel(DfWarpView W, const floa
     if (active) q = mk3(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2]);
     float bd[K]; int bi[K];
     topk_init<K>(bd, bi);
-    bool tie = false;
     for (int base = 0; base < W.M; base += DF_PT_CHUNK) {
         const int n = min(DF_PT_CHUNK, W.M - base);
         __syncthreads();
@@ -369,11 +371,10 @@ __global__ __launch_bounds__(256) void df_points_kernel(DfWarpView W, const floa
         __syncthreads();
         for (int c = 0; c < n; ++c) {
             const float4 p = s_pos[c];
-            topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), base + c, tie);
+            topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), base + c, W.nf, q);
         }
     }
     if (!active) return;
-    if (tie && W.nf.nodes) { tie_ids[atomicAdd(tie_count, 1)] = i; return; }
     df_point_finish<K, MODE>(W, i, q, bd, bi, idx_out, d2_out, points, normals, to_live);
 }
 
@@ -388,8 +389,7 @@ template <int K, int MODE>
 __global__ __launch_bounds__(64) void df_points_index_kernel(DfWarpView W, DfPointIndex G, const float* __restrict__ queries, int N,
                                                              int* __restrict__ idx_out, float* __restrict__ d2_out,
                                                              float* __restrict__ points, float* __restrict__ normals, DfAff to_live,
-                                                             int* __restrict__ out_ids, int* __restrict__ out_count, int image_cols,
-                                                             int* __restrict__ tie_ids, int* __restrict__ tie_count)
+                                                             int* __restrict__ out_ids, int* __restrict__ out_count, int image_cols)
 {
     // One wave64 per workgroup (so __syncthreads is a wave-level barrier and every loop below is wave-uniform).  Neighbouring
     // query points (pixels) mostly share a brick: the wave visits its DISTINCT bricks one after the other, stages each brick's
@@ -412,7 +412,6 @@ __global__ __launch_bounds__(64) void df_points_index_kernel(DfWarpView W, DfPoi
     if (active) q = mk3(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2]);
     float bd[K]; int bi[K];
     topk_init<K>(bd, bi);
-    bool tie = false;
     const bool is_nan = (q.x != q.x) || (q.y != q.y) || (q.z != q.z);
     int brick = -1;                                        // -1: nothing to search (inactive / NaN)
     float dq = 0.f;                                        // distance to the centre of the brick that is searched
@@ -450,7 +449,7 @@ __global__ __launch_bounds__(64) void df_points_index_kernel(DfWarpView W, DfPoi
             if (mine)
                 for (int c = 0; c < n; ++c) {
                     const float4 p = s_pos[c];
-                    topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), s_id[c], tie);
+                    topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), s_id[c], W.nf, q);
                 }
         }
     }
@@ -465,21 +464,18 @@ __global__ __launch_bounds__(64) void df_points_index_kernel(DfWarpView W, DfPoi
         if (outside) out_ids[atomicAdd(out_count, 1)] = i;
     }
     if (!active || outside) return;
-    // (the candidate list holds every node that can tie at rank k: |n - c_B| <= d(q, n) + r_B <= D_k(c_B) + 2 r_B)
-    if (tie && W.nf.nodes) { tie_ids[atomicAdd(tie_count, 1)] = i; return; }
     df_point_finish<K, MODE>(W, i, q, bd, bi, idx_out, d2_out, points, normals, to_live);
 }
 
 // Second pass of the indexed query: ONE WAVE per listed point.  The lanes split the nodes (lane, lane + 64, ...), each keeps its own
 // top-K, and the wave merges them with K pops of the lexicographic minimum (distance, node index) -- the order of a serial scan in
-// node-index order with strict '<' insertion, ties to the lower index.  A serial scan by one lane takes ~0.5 ms whatever the number
+// node-index order with strict '<' insertion, equal distances in the reference's tree order.  A serial scan by one lane takes ~0.5 ms whatever the number
 // of points (it is the depth of df_points_kernel); this takes M / 64 steps.
 template <int K, int MODE>
 __global__ __launch_bounds__(256) void df_points_wave_kernel(DfWarpView W, const float* __restrict__ queries, int* __restrict__ idx_out,
                                                              float* __restrict__ d2_out, float* __restrict__ points,
                                                              float* __restrict__ normals, DfAff to_live, const int* __restrict__ ids,
-                                                             const int* __restrict__ id_count, int* __restrict__ tie_ids,
-                                                             int* __restrict__ tie_count)
+                                                             const int* __restrict__ id_count)
 {
     const int lane = threadIdx.x & 63;
     const int n_ids = *id_count;
@@ -489,19 +485,24 @@ __global__ __launch_bounds__(256) void df_points_wave_kernel(DfWarpView W, const
         const f3 q = mk3(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2]);
         float bd[K]; int bi[K];
         topk_init<K>(bd, bi);
-        bool tie = false;                                   // ties inside a lane's share; ties across lanes show up at the merge
         for (int j = lane; j < W.M; j += 64) {
             const float4 p = W.pos_sigma[j];
-            topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), j, tie);
+            topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), j, W.nf, q);
         }
         float rd[K]; int ri[K];
 #pragma unroll
         for (int r = 0; r < K; ++r) {
             const float m = wave_min_f32(bd[0]);
-            tie = tie || (__popcll(__ballot(bd[0] == m)) > 1);     // two lanes hold the same distance
-            int cand = (bd[0] == m) ? bi[0] : 0x7fffffff;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+            // the lanes whose head is at the minimum distance: the one whose node the reference's walk meets first wins
+            // (wave-uniform loop over the set bits; one bit unless distances tie)
+            unsigned long long who = __ballot(bd[0] == m);
+            int cand = __shfl(bi[0], __ffsll((long long)who) - 1, 64);
+            who &= who - 1;
+            while (who) {
+                const int other = __shfl(bi[0], __ffsll((long long)who) - 1, 64);
+                who &= who - 1;
+                if (W.nf.nodes ? df_nf_visited_before(W.nf, q.x, q.y, q.z, other, cand) : other < cand) cand = other;
+            }
             rd[r] = m; ri[r] = cand;
             if (bd[0] == m && bi[0] == cand) {              // the owner pops its head
 #pragma unroll
@@ -509,31 +510,7 @@ __global__ __launch_bounds__(256) void df_points_wave_kernel(DfWarpView W, const
                 bd[K - 1] = __uint_as_float(0x7f800000u); bi[K - 1] = -1;
             }
         }
-        tie = tie || (wave_min_f32(bd[0]) == rd[K - 1]);     // the (k+1)-th distance equals the k-th
-        tie = __ballot(tie) != 0ull;
-        if (lane == 0) {
-            if (tie && W.nf.nodes) tie_ids[atomicAdd(tie_count, 1)] = i;
-            else df_point_finish<K, MODE>(W, i, q, rd, ri, idx_out, d2_out, points, normals, to_live);
-        }
-    }
-}
-
-// The listed (tied) queries, one lane each: nanoflann's own search (dfusion_nanoflann.h), then the usual finish.
-template <int K, int MODE>
-__global__ __launch_bounds__(64) void df_points_tie_kernel(DfWarpView W, const float* __restrict__ queries, int* __restrict__ idx_out,
-                                                           float* __restrict__ d2_out, float* __restrict__ points,
-                                                           float* __restrict__ normals, DfAff to_live, const int* __restrict__ ids,
-                                                           const int* __restrict__ id_count)
-{
-    const int n_ids = *id_count;
-    for (int slot = blockIdx.x * 64 + threadIdx.x; slot < n_ids; slot += gridDim.x * 64) {
-        const int i = ids[slot];
-        const float* src = MODE == 0 ? queries : points;
-        const f3 q = mk3(src[3 * (size_t)i], src[3 * (size_t)i + 1], src[3 * (size_t)i + 2]);
-        float bd[K]; int bi[K];
-        topk_init<K>(bd, bi);
-        knn_resolve_ties<K>(W, q, bd, bi);
-        df_point_finish<K, MODE>(W, i, q, bd, bi, idx_out, d2_out, points, normals, to_live);
+        if (lane == 0) df_point_finish<K, MODE>(W, i, q, rd, ri, idx_out, d2_out, points, normals, to_live);
     }
 }
 
@@ -542,8 +519,7 @@ static DfWarpView df_view(const DfWarpField* wf)
     DfWarpView W;
     W.pos_sigma = wf->pos_sigma; W.rot = wf->rot; W.dual = wf->dual; W.node_t = wf->node_t; W.M = wf->M;
     W.brick_off = wf->brick_off; W.brick_list = wf->brick_list; W.brick_thr = wf->brick_thr; W.bx = wf->bx; W.by = wf->by; W.bz = wf->bz;
-    W.nf.nodes = wf->nf_ok ? wf->nf_nodes : nullptr; W.nf.vind = wf->nf_vind;
-    for (int c = 0; c < 3; ++c) { W.nf.blo[c] = wf->nf_blo[c]; W.nf.bhi[c] = wf->nf_bhi[c]; }
+    W.nf.nodes = wf->nf_ok ? wf->nf_nodes : nullptr; W.nf.vpos = wf->nf_vpos;
     return W;
 }
 
@@ -574,17 +550,14 @@ extern "C" int dfusion_warp_index_info(const DfWarpField* wf, unsigned long long
 
 // the brick lists serve point queries when an index for >= k neighbours exists (a list built for k_built >= k contains the k nearest)
 // [0] = count, [1..] = ids of the points the indexed pass left to the scan; zeroed per call
-// (a second list of the same shape follows it: the points with an exact distance tie, for df_points_tie_kernel)
 static int df_point_fallback_reserve(DfWarpField* wf, int N, hipStream_t st)
 {
     if ((size_t)N + 1 > wf->pt_ids_cap) {
         (void)hipFree(wf->pt_ids); wf->pt_ids = nullptr; wf->pt_ids_cap = 0;
-        DF_HIP(hipMalloc((void**)&wf->pt_ids, 2 * ((size_t)N + 1) * sizeof(int)));
+        DF_HIP(hipMalloc((void**)&wf->pt_ids, ((size_t)N + 1) * sizeof(int)));
         wf->pt_ids_cap = (size_t)N + 1;
     }
-    wf->pt_tie = wf->pt_ids + wf->pt_ids_cap;
     DF_HIP(hipMemsetAsync(wf->pt_ids, 0, sizeof(int), st));
-    DF_HIP(hipMemsetAsync(wf->pt_tie, 0, sizeof(int), st));
     return DF_OK;
 }
 
@@ -619,20 +592,16 @@ extern "C" int dfusion_knn(DfWarpField* wf, int k, const float* queries, int N, 
     DfWarpView W = df_view(wf);
     DfAff ident; memset(&ident, 0, sizeof(ident));
     DfPointIndex G;
-    int rc = df_point_fallback_reserve(wf, N, (hipStream_t)stream);
-    if (rc) return rc;
     if (df_point_index(wf, k, &G)) {
+        int rc = df_point_fallback_reserve(wf, N, (hipStream_t)stream);
+        if (rc) return rc;
         DF_DISPATCH_K(k, df_points_index_kernel<K, 0><<<dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
-                             W, G, queries, N, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_ids + 1, wf->pt_ids, df_point_tiling(wf, N),
-                             wf->pt_tie + 1, wf->pt_tie));
+                             W, G, queries, N, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_ids + 1, wf->pt_ids, df_point_tiling(wf, N)));
         DF_DISPATCH_K(k, df_points_wave_kernel<K, 0><<<dim3(2048), dim3(256), 0, (hipStream_t)stream>>>(
-                             W, queries, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_ids + 1, wf->pt_ids, wf->pt_tie + 1, wf->pt_tie));
+                             W, queries, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_ids + 1, wf->pt_ids));
     } else
     DF_DISPATCH_K(k, df_points_kernel<K, 0><<<dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
-                         W, queries, N, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_tie + 1, wf->pt_tie));
-    if (W.nf.nodes)
-        DF_DISPATCH_K(k, df_points_tie_kernel<K, 0><<<dim3(256), dim3(64), 0, (hipStream_t)stream>>>(
-                             W, queries, idx, d2, (float*)nullptr, (float*)nullptr, ident, wf->pt_tie + 1, wf->pt_tie));
+                         W, queries, N, idx, d2, (float*)nullptr, (float*)nullptr, ident));
     DF_LAUNCH_CHECK();
     return DF_OK;
 }
@@ -645,20 +614,16 @@ extern "C" int dfusion_warp_points(DfWarpField* wf, int k, float* points, float*
     DfWarpView W = df_view(wf);
     DfAff live = df_aff(warp_to_live);
     DfPointIndex G;
-    int rc = df_point_fallback_reserve(wf, N, (hipStream_t)stream);
-    if (rc) return rc;
     if (df_point_index(wf, k, &G)) {
+        int rc = df_point_fallback_reserve(wf, N, (hipStream_t)stream);
+        if (rc) return rc;
         DF_DISPATCH_K(k, df_points_index_kernel<K, 1><<<dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream>>>(
-                             W, G, (const float*)nullptr, N, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_ids + 1, wf->pt_ids, df_point_tiling(wf, N),
-                             wf->pt_tie + 1, wf->pt_tie));
+                             W, G, (const float*)nullptr, N, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_ids + 1, wf->pt_ids, df_point_tiling(wf, N)));
         DF_DISPATCH_K(k, df_points_wave_kernel<K, 1><<<dim3(2048), dim3(256), 0, (hipStream_t)stream>>>(
-                             W, (const float*)nullptr, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_ids + 1, wf->pt_ids, wf->pt_tie + 1, wf->pt_tie));
+                             W, (const float*)nullptr, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_ids + 1, wf->pt_ids));
     } else
     DF_DISPATCH_K(k, df_points_kernel<K, 1><<<dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
-                         W, (const float*)nullptr, N, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_tie + 1, wf->pt_tie));
-    if (W.nf.nodes)
-        DF_DISPATCH_K(k, df_points_tie_kernel<K, 1><<<dim3(256), dim3(64), 0, (hipStream_t)stream>>>(
-                             W, (const float*)nullptr, (int*)nullptr, (float*)nullptr, points, normals, live, wf->pt_tie + 1, wf->pt_tie));
+                         W, (const float*)nullptr, N, (int*)nullptr, (float*)nullptr, points, normals, live));
     DF_LAUNCH_CHECK();
     return DF_OK;
 }
@@ -854,8 +819,6 @@ struct DfWarpedArgs {
     int v2w_identity;              // vol2world.R is exactly the identity (set by the launcher)
     // max over the voxels of each table tile of sum_i w_i (written by the table build, frame-invariant); null = no zero-weight test
     float* tile_wmax;
-    // brick sweeps: 8 words per brick of the launch, voxels left to df_brick_tie_kernel (exact distance ties); null = no marking
-    unsigned long long* tie_mask;
 };
 // A tile is ZERO-WEIGHT for a frame when tile_wmax * max_j |rot_j| < 2^-76: every component of every voxel's blend sum
 // sum_i w_i rot_i is then below 2^-75 in magnitude (the 2x margin covers the rounding of the sums), its square below 2^-150
@@ -995,44 +958,6 @@ __device__ __forceinline__ void df_count_updates(const DfWarpedArgs& a, unsigned
     }
 }
 
-// what a brick sweep does with the k nearest nodes of voxel (x, y, z), canonical position q.  BUILD: table records (+ the voxel's
-// weight sum folded into *wsum for the tile bound); otherwise weights -> blend -> TSDF update, returns 1 if the voxel updated.
-template <int K, bool BUILD>
-__device__ __forceinline__ unsigned int df_brick_voxel_finish(const DfWarpedArgs& a, const DfWarpView& W, int x, int y, int z, f3 q,
-                                                              const float (&bd)[K], const int (&bi)[K], float* wsum)
-{
-    float wt[K];
-    if constexpr (BUILD) {
-        const size_t tv = df_tab_index(a, x, y, z);
-        knn_tab_store<K>(a.knn_tab, tv, bi);
-        if (a.w_tab) {
-            dqb_weights<K>(W, bd, bi, wt);
-            w_tab_store<K>(a.w_tab, a.tab_nvox, tv, wt);
-            float s0 = 0.f;
-#pragma unroll
-            for (int i = 0; i < K; ++i) s0 += wt[i];
-            *wsum = fmaxf(*wsum, !(s0 == s0) ? 3.0e38f : s0);
-        }
-        return 0u;
-    } else {
-        dqb_weights<K>(W, bd, bi, wt);
-        const size_t plane = (size_t)a.X * a.Y;
-        return df_warp_update<K>(a, W, q, wt, bi, a.vol + (size_t)(z - a.z_store0) * plane + (size_t)y * a.X + x);
-    }
-}
-// per table tile: max over its voxels of the weight sum (a brick lies inside one tile: 8 | 32, 16, 8; table planes are brick-aligned)
-__device__ __forceinline__ void df_brick_wmax(const DfWarpedArgs& a, int bxx, int byy, int bzz, float wsum)
-{
-    if (!(a.w_tab && a.tile_wmax)) return;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) wsum = fmaxf(wsum, __shfl_xor(wsum, o, 64));
-    if ((threadIdx.x & 63) == 0) {
-        const int zl = bzz * DF_BRICK - a.tab_z0;
-        const size_t tile = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty + (byy * DF_BRICK) / DF_TAB_TY) * a.tab_ntx + (bxx * DF_BRICK) / DF_TAB_TX;
-        atomicMax((unsigned int*)&a.tile_wmax[tile], __float_as_uint(wsum));      // non-negative floats order as uints
-    }
-}
-
 // ---- brick kernel: exact k-NN from the brick candidate lists (through LDS), one 256-thread workgroup per 8^3 brick.
 // BUILD = false: fused with the TSDF update -- no per-voxel memory ("lean" path, re-ranks ~150 candidates per voxel per frame).
 // BUILD = true : writes the per-voxel k-NN (and weight) tables instead; run when node POSITIONS change, not per frame.
@@ -1055,13 +980,7 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
     if (!BUILD && a.cull) {
         const f3 c = aff_mul(a.vol2world, mk3(((float)(bxx * DF_BRICK) + 3.5f) * a.vsx, ((float)(byy * DF_BRICK) + 3.5f) * a.vsy,
                                               ((float)(bzz * DF_BRICK) + 3.5f) * a.vsz));
-        if (df_tile_culled(a, c, a.kf)) {                                  // block-uniform
-            if (a.tie_mask && (t & 63) == 0) {
-                unsigned long long* mw = a.tie_mask + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
-                mw[lz] = 0ull; mw[lz + 4] = 0ull;
-            }
-            return;
-        }
+        if (df_tile_culled(a, c, a.kf)) return;                           // block-uniform
     }
 
     const bool in_xy = x < a.X && y < a.Y;
@@ -1076,7 +995,6 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
     float bd0[K], bd1[K]; int bi0[K], bi1[K];
     topk_init<K>(bd0, bi0);
     topk_init<K>(bd1, bi1);
-    bool tie0 = false, tie1 = false;
     const uint32_t off = W.brick_off[b];
     const uint32_t cnt = W.brick_off[b + 1] - off;
     for (uint32_t base = 0; base < cnt; base += DF_CAND_CHUNK) {
@@ -1091,53 +1009,51 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
         for (int c = 0; c < n; ++c) {
             const float4 p = s_pos[c];                 // broadcast ds_read_b128
             const int j = s_idx[c];
-            topk_insert<K>(bd0, bi0, knn_dist2(q0, p.x, p.y, p.z), j, tie0);
-            topk_insert<K>(bd1, bi1, knn_dist2(q1, p.x, p.y, p.z), j, tie1);
+            topk_insert<K>(bd0, bi0, knn_dist2(q0, p.x, p.y, p.z), j, W.nf, q0);
+            topk_insert<K>(bd1, bi1, knn_dist2(q1, p.x, p.y, p.z), j, W.nf, q1);
         }
     }
-    // Exact distance ties (voxels on a symmetry plane of the node set, duplicated nodes): the reference's tree order decides, and
-    // that walk lives in df_brick_tie_kernel -- here such voxels are only marked (8 words per brick, bit = y * 8 + x of plane z).
-    const bool t0 = tie0 && act0 && W.nf.nodes, t1 = tie1 && act1 && W.nf.nodes;
-    if (a.tie_mask) {
-        const unsigned long long m0 = __ballot(t0), m1 = __ballot(t1);
-        if ((t & 63) == 0) {
-            unsigned long long* mw = a.tie_mask + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
-            mw[lz] = m0; mw[lz + 4] = m1;
-        }
-    }
-    float wsum = 0.f;
-    unsigned int my_upd = 0;
-    if (act0 && !t0) my_upd += df_brick_voxel_finish<K, BUILD>(a, W, x, y, z0, q0, bd0, bi0, &wsum);
-    if (act1 && !t1) my_upd += df_brick_voxel_finish<K, BUILD>(a, W, x, y, z1, q1, bd1, bi1, &wsum);
-    if constexpr (BUILD) df_brick_wmax(a, bxx, byy, bzz, wsum);
-    else df_count_updates(a, my_upd);
-}
 
-// The voxels a brick sweep marked: one wave per brick, lane = (y, x) of a plane; nanoflann's own search, then the same finish.
-template <int K, bool BUILD>
-__global__ __launch_bounds__(64) void df_brick_tie_kernel(const DfWarpedArgs a, const DfWarpView W)
-{
-    const int lane = threadIdx.x;
-    const unsigned long long* mw = a.tie_mask + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
-    const unsigned long long mine = lane < 8 ? mw[lane] : 0ull;
-    if (__ballot(mine != 0ull) == 0ull) return;
-    const int bxx = blockIdx.x % W.bx, byy = blockIdx.x / W.bx, bzz = a.bz0 + blockIdx.y;
-    const int x = bxx * DF_BRICK + (lane & 7), y = byy * DF_BRICK + (lane >> 3);
-    float wsum = 0.f;
-    unsigned int my_upd = 0;
-    for (int w = 0; w < 8; ++w) {
-        const unsigned int lo = __shfl((unsigned int)mine, w, 64), hi = __shfl((unsigned int)(mine >> 32), w, 64);
-        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-        if (!((m >> lane) & 1ull)) continue;
-        const int z = bzz * DF_BRICK + w;
-        const f3 q = aff_mul(a.vol2world, mk3((float)x * a.vsx, (float)y * a.vsy, (float)z * a.vsz));
-        float bd[K]; int bi[K];
-        topk_init<K>(bd, bi);
-        knn_resolve_ties<K>(W, q, bd, bi);
-        my_upd += df_brick_voxel_finish<K, BUILD>(a, W, x, y, z, q, bd, bi, &wsum);
+    const size_t plane = (size_t)a.X * a.Y;
+    float wt0[K], wt1[K];
+    if constexpr (BUILD) {
+        const size_t tv0 = df_tab_index(a, x, y, z0), tv1 = df_tab_index(a, x, y, z1);
+        float wsum = 0.f;
+        if (act0) { knn_tab_store<K>(a.knn_tab, tv0, bi0); if (a.w_tab) { dqb_weights<K>(W, bd0, bi0, wt0); w_tab_store<K>(a.w_tab, a.tab_nvox, tv0, wt0); } }
+        if (act1) { knn_tab_store<K>(a.knn_tab, tv1, bi1); if (a.w_tab) { dqb_weights<K>(W, bd1, bi1, wt1); w_tab_store<K>(a.w_tab, a.tab_nvox, tv1, wt1); } }
+        if (a.w_tab && a.tile_wmax) {                       // a brick lies inside one table tile (8 | 32, 16, 8; table planes are brick-aligned)
+            if (act0) {
+                float s0 = 0.f;
+#pragma unroll
+                for (int i = 0; i < K; ++i) s0 += wt0[i];
+                wsum = !(s0 == s0) ? 3.0e38f : s0;
+            }
+            if (act1) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < K; ++i) s1 += wt1[i];
+                wsum = fmaxf(wsum, !(s1 == s1) ? 3.0e38f : s1);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) wsum = fmaxf(wsum, __shfl_xor(wsum, o, 64));
+            if ((threadIdx.x & 63) == 0) {
+                const int zl = bzz * DF_BRICK - a.tab_z0;
+                const size_t tile = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty + (byy * DF_BRICK) / DF_TAB_TY) * a.tab_ntx + (bxx * DF_BRICK) / DF_TAB_TX;
+                atomicMax((unsigned int*)&a.tile_wmax[tile], __float_as_uint(wsum));      // non-negative floats order as uints
+            }
+        }
+    } else {
+        unsigned int my_upd = 0;
+        if (act0) {
+            dqb_weights<K>(W, bd0, bi0, wt0);
+            my_upd += df_warp_update<K>(a, W, q0, wt0, bi0, a.vol + (size_t)(z0 - a.z_store0) * plane + (size_t)y * a.X + x);
+        }
+        if (act1) {
+            dqb_weights<K>(W, bd1, bi1, wt1);
+            my_upd += df_warp_update<K>(a, W, q1, wt1, bi1, a.vol + (size_t)(z1 - a.z_store0) * plane + (size_t)y * a.X + x);
+        }
+        df_count_updates(a, my_upd);
     }
-    if constexpr (BUILD) df_brick_wmax(a, bxx, byy, bzz, wsum);
-    else df_count_updates(a, my_upd);
 }
 
 // ---- row-tile kernel: the per-frame sweep when the per-voxel tables are cached in HBM.
@@ -1606,20 +1522,6 @@ static double df_tile_radius(const float vol2world[12], double nx, double ny, do
     return r;
 }
 
-// mask words for a brick sweep of n_bricks bricks (every brick's words are written by the sweep itself)
-static int df_tie_mask_reserve(DfWarpField* wf, size_t n_bricks, DfWarpedArgs* a)
-{
-    a->tie_mask = nullptr;
-    if (!wf->nf_ok) return DF_OK;
-    if (n_bricks * 8 > wf->tie_mask_cap) {
-        (void)hipFree(wf->tie_mask); wf->tie_mask = nullptr; wf->tie_mask_cap = 0;
-        DF_HIP(hipMalloc((void**)&wf->tie_mask, n_bricks * 8 * sizeof(unsigned long long)));
-        wf->tie_mask_cap = n_bricks * 8;
-    }
-    a->tie_mask = wf->tie_mask;
-    return DF_OK;
-}
-
 extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
                                         const float vol2world[12], const float world2cam[12], const float proj[4],
                                         DfWarpField* wf, int k, unsigned flags, unsigned long long* n_updated, dfStream stream)
@@ -1719,10 +1621,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         const int bz_lo = s.z_own0 / DF_BRICK, bz_hi = (s.z_own0 + s.z_own_n - 1) / DF_BRICK;
         a.bz0 = bz_lo;
         dim3 grid((unsigned)(W.bx * W.by), (unsigned)(bz_hi - bz_lo + 1));
-        int rc = df_tie_mask_reserve(wf, (size_t)grid.x * grid.y, &a);
-        if (rc) return rc;
         DF_DISPATCH_K(k, df_warp_brick_kernel<K, false><<<grid, dim3(256), 0, st>>>(a, W));
-        if (a.tie_mask) DF_DISPATCH_K(k, df_brick_tie_kernel<K, false><<<grid, dim3(64), 0, st>>>(a, W));
     }
     DF_LAUNCH_CHECK();
     return DF_OK;
@@ -1769,10 +1668,7 @@ static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab
     a.knn_tab = wf->knn_tab; a.tab_z0 = tz0; a.tab_nvox = nvox; a.tab_ntx = ntx; a.tab_nty = nty; a.bz0 = bz_lo;
     DfWarpView W = df_view(wf);
     dim3 grid((unsigned)(W.bx * W.by), (unsigned)(bz_hi - bz_lo + 1));
-    int rc = df_tie_mask_reserve(wf, (size_t)grid.x * grid.y, &a);
-    if (rc) return rc;
     DF_DISPATCH_K(k, df_warp_brick_kernel<K, true><<<grid, dim3(256), 0, st>>>(a, W));
-    if (a.tie_mask) DF_DISPATCH_K(k, df_brick_tie_kernel<K, true><<<grid, dim3(64), 0, st>>>(a, W));
     DF_LAUNCH_CHECK();
     DF_HIP(hipStreamSynchronize(st));
     wf->tab_z0 = tz0; wf->tab_zn = tzn; wf->tab_k = k; wf->tab_valid = true; wf->w_tab_valid = weights;
