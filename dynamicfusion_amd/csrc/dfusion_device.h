@@ -259,6 +259,51 @@ __device__ __forceinline__ bool tsdf_sample_nb(const DfIntegrateParams& P, f3 vc
     *tsdf_out = fminf(1.f, sdf * P.trunc_inv);            // :93
     return ok;
 }
+// The same sample on a restricted domain, for sweeps that have established it for a whole run of voxels (the rigid sweep does, per
+// sub-chunk and per wave): 2^-20 <= |vc.x|, |vc.y| <= 2^30 and 0.05 <= vc.z <= 2^30, dists image below 2 GiB (32-bit offsets).
+// There the correctly rounded operations have shorter sequences WITH THE SAME BITS:
+//   * x / z and y / z share the refined reciprocal.  hipcc's f32 division is v_div_scale (x2), v_rcp, one Newton step on the
+//     reciprocal, quotient, two residual corrections (the last inside v_div_fmas), v_div_fixup.  With every exponent this far from
+//     the ends of the range v_div_scale returns its operand unchanged (it acts on denormal / huge denominators, on quotients near
+//     the denormal range and on numerators below 2^-103), v_div_fmas is a plain fma and v_div_fixup passes the finite, normal
+//     quotient through -- what remains is the sequence below, 13 instructions for both quotients instead of 22;
+//   * sqrtf as df_sqrt_short (argument >= vc.z^2 >= 2^-9);
+//   * the pixel clamp by v_med3_f32 (no NaN can reach it), the dists address in 32 bits.
+// dfusion_selftest_sample_forms compares it with tsdf_sample_nb on random in-domain positions.
+__device__ __forceinline__ float df_div_shared(float n, float d, float r)       // n / d given r = df_rcp_refined(d)
+{
+    float q = n * r;
+    q = fmaf(fmaf(-d, q, n), r, q);
+    return fmaf(fmaf(-d, q, n), r, q);
+}
+__device__ __forceinline__ float df_rcp_refined(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ bool tsdf_sample_domain_ok(f3 a, f3 b)               // both ends of a run along which vc moves monotonically
+{
+    const float lo = 0x1p-20f, hi = 0x1p30f;
+    const bool x_ok = (a.x * b.x > 0.f) & (fminf(fabsf(a.x), fabsf(b.x)) >= lo) & (fmaxf(fabsf(a.x), fabsf(b.x)) <= hi);
+    const bool y_ok = (a.y * b.y > 0.f) & (fminf(fabsf(a.y), fabsf(b.y)) >= lo) & (fmaxf(fabsf(a.y), fabsf(b.y)) <= hi);
+    const bool z_ok = (fminf(a.z, b.z) >= 0.05f) & (fmaxf(a.z, b.z) <= hi);
+    return x_ok & y_ok & z_ok;
+}
+__device__ __forceinline__ bool tsdf_sample_fast(const DfIntegrateParams& P, f3 vc, float* tsdf_out)
+{
+    const float r = df_rcp_refined(vc.z);
+    const float u = fmaf(P.fx, df_div_shared(vc.x, vc.z, r), P.cx);        // device.hpp:35
+    const float v = fmaf(P.fy, df_div_shared(vc.y, vc.z, r), P.cy);        // device.hpp:36
+    bool ok = (u >= 0.f) & (v >= 0.f) & (u < (float)P.cols) & (v < (float)P.rows);   // :82 (:86's vc.z > 0 holds on the domain)
+    const uint32_t ui = (uint32_t)(int)__builtin_amdgcn_fmed3f(u, 0.f, (float)(P.cols - 1));
+    const uint32_t vi = (uint32_t)(int)__builtin_amdgcn_fmed3f(v, 0.f, (float)(P.rows - 1));
+    const uint32_t off = vi * (uint32_t)P.pitch + 2u * ui;
+    const float Dp = h2f_bits(*(const uint16_t*)((const char*)P.dists + off));       // :85
+    const float sdf = Dp - df_sqrt_short(dot3(vc, vc));    // :89
+    ok = ok & (Dp != 0.f) & (sdf >= -P.trunc);             // :86, :91
+    *tsdf_out = fminf(1.f, sdf * P.trunc_inv);             // :93
+    return ok;
+}
 // :97-103
 __device__ __forceinline__ uint32_t tsdf_fuse(uint32_t vox, float tsdf, int max_weight)
 {

@@ -207,8 +207,14 @@ int dfusion_warp_set_point_tiling(DfWarpField *wf, int image_cols);
  * (specials included), [3] near-unit normalisation on the normalised quaternions among them, [4] how many of those there were.   */
 int dfusion_selftest_exact_forms(unsigned long long n_random, unsigned long long *counts_dev, dfStream stream);
 
-/* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k],
- * ascending distance, ties -> lower node index.                                               */
+/* Validation switches of dfusion_integrate, so that tests can assert the volumes are identical with and without them (process-wide,
+ * default 3; no reference counterpart).  bit 0: the behind-the-surface test (a conservative, result-identical skip of voxels that
+ * lie more than trunc_dist behind every depth value they can be compared with; per-frame max-pyramid of dists); bit 1: the short
+ * forms of the correctly rounded divisions / square root on runs of voxels whose coordinates are inside their domain.              */
+int dfusion_debug_rigid(int flags);
+
+/* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k], ascending distance; exactly
+ * equidistant nodes in the order the reference's nanoflann walk meets them (nanoflann.hpp:110-131,1200-1254).                    */
 int dfusion_knn(DfWarpField *wf, int k, const float *queries_dev, int N, int *idx_dev, float *d2_dev, dfStream stream);
 
 /* WarpField::warp (warp_field.cpp:180-195) on device: points/normals [N*3] in place

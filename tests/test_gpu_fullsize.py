@@ -128,9 +128,18 @@ def test_full_size_properties_and_sampled_oracle(name):
     gp, gn = fp.cpu().numpy(), fn.cpu().numpy()
     assert np.array_equal(bits(gp), bits(rp)) and np.array_equal(bits(gn), bits(rn))
 
-    # ---- rigid: slab-sharded == unsharded at full size (replayed vc accumulation)
+    # ---- rigid: slab-sharded == unsharded at full size (replayed vc accumulation); behind-the-surface skip on == off
     r_full = setup(cfg)
     r_full.integrate(dists[0], sc.cam_poses[0], intr)
+    from dynamicfusion_amd import capi
+    try:
+        capi.check(capi.lib().dfusion_debug_rigid(0))
+        r_nocull = setup(cfg)
+        r_nocull.integrate(dists[0], sc.cam_poses[0], intr)
+    finally:
+        capi.check(capi.lib().dfusion_debug_rigid(3))
+    assert torch.equal(r_nocull.data(), r_full.data())
+    del r_nocull
     zs, zn = sharded.slab_range(Z, 5, 8)
     r_slab = setup(cfg, slab=(zs, zn, 0))
     r_slab.integrate(dists[0], sc.cam_poses[0], intr)

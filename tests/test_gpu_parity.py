@@ -96,6 +96,33 @@ def test_integrate_rigid_bit_exact(cfg):
     assert w.max() == 3
 
 
+@pytest.mark.parametrize("cfg", [SMALL, MID], ids=["64", "128"])
+def test_integrate_rigid_depth_cull_is_result_identical(cfg):
+    """The behind-the-surface skip of the rigid sweep (max-pyramid of dists, conservative per 16-plane sub-chunk) must not change
+    a single bit: 3 frames with it, 3 frames without, plus an all-invalid and a one-pixel depth image."""
+    sc = Scene(cfg, n_frames=3, with_nodes=False)
+    intr = Intr(*cfg.intr)
+    L = capi.lib()
+    vols = []
+    try:
+        for flags in (3, 0, 1, 2):                       # bit 0: depth cull, bit 1: short arithmetic forms
+            capi.check(L.dfusion_debug_rigid(flags))
+            vol = make_gpu_volume(sc)
+            n_upd = torch.zeros(1, dtype=torch.int64, device="cuda")
+            for f in range(3):
+                vol.integrate(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, n_updated=n_upd)
+            empty = np.zeros_like(sc.dists[0])
+            vol.integrate(upload_u16(empty), sc.cam_poses[0], intr, n_updated=n_upd)          # Dp == 0 everywhere: nothing updates
+            one = empty.copy(); one[cfg.rows // 2, cfg.cols // 2] = sc.dists[0][cfg.rows // 2, cfg.cols // 2]
+            vol.integrate(upload_u16(one), sc.cam_poses[0], intr, n_updated=n_upd)
+            vols.append((vol.download(), int(n_upd.item())))
+    finally:
+        capi.check(L.dfusion_debug_rigid(3))
+    for other in vols[1:]:
+        assert np.array_equal(vols[0][0], other[0]) and vols[0][1] == other[1]
+    assert (vols[0][0] >> 16).max() == 4
+
+
 def test_integrate_rigid_slabs_equal_full():
     """Z-slab sharding of the rigid sweep replays vc += zstep and is bit-identical with the full sweep."""
     sc = Scene(SMALL, n_frames=1, with_nodes=False)
