@@ -64,10 +64,12 @@ def measured_copy_gbps(nbytes=1 << 30, iters=10):
     return 2.0 * nbytes / (ms * 1e-3) / 1e9        # read + write bytes
 
 
-def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=12.0):
-    """Oracle ("port") timed on the host cores on a BOUNDED sample of the same frame: integrate_warped on a band of Z planes in the
-    middle of the volume (scaled to all planes) + the full ray-cast.  The band is sized by a 4-plane probe so that the sample is
-    about `target_s` seconds of CPU work whatever the core count."""
+def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=10.0):
+    """The reference-style CPU path timed on the host cores on a BOUNDED sample of the same frame: per-voxel warped
+    integrate through the reference's OWN nanoflann k-NN + DQB + transform classes (oracle/_ref, one tree / result set per OpenMP
+    thread -- the reference's WarpField is single-threaded and not re-entrant) on a band of Z planes in the middle of the volume,
+    scaled to all planes, + the full ray-cast (oracle restatement, pinned to the reference's kernel).  kind = "reference".
+    Also reported: the same band on ONE thread (how the reference itself would run it) and the oracle port (restated nanoflann)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_lib as O
     depth, _, pose, cam_pose, pos, sigma, dq = sc_inputs
@@ -77,23 +79,34 @@ def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=12.0):
     trunc = float(max(np.float32(cfg.trunc_dist), np.float32(2.1) * vs.max()))
     X, Y, Z = cfg.dims
     world2cam = synth.affine_inv(cam_pose)
+    have_ref = O.have_ref()
 
-    def timed_band(n_planes):
+    def timed_band(n_planes, mode, threads=0):
         z0 = (Z - n_planes) // 2
-        slab = O.make_slab(z0, n_planes, z0, n_planes)
         sample = np.ascontiguousarray(vol_u32[z0:z0 + n_planes]).copy()
-        ov = O.make_volume(sample, cfg.dims, vs, trunc, cfg.max_weight)
         t0 = time.time()
-        O.integrate_warped(dists, sample, ov, synth.aff12(pose), synth.aff12(world2cam), intr, pos, dq, sigma, cfg.k, slab=slab)
-        return time.time() - t0
+        if mode == "reference":
+            _, used = O.ref_integrate_warped(dists, sample, cfg.dims, vs, trunc, cfg.max_weight, synth.aff12(pose), synth.aff12(world2cam), intr,
+                                             pos, dq, sigma, cfg.k, z0, z0, n_planes, threads=threads)
+        else:
+            ov = O.make_volume(sample, cfg.dims, vs, trunc, cfg.max_weight)
+            O.integrate_warped(dists, sample, ov, synth.aff12(pose), synth.aff12(world2cam), intr, pos, dq, sigma, cfg.k,
+                               slab=O.make_slab(z0, n_planes, z0, n_planes))
+            used = int(O.lib().orc_num_threads())
+        return time.time() - t0, used
 
-    budget_planes, t_band = 4, timed_band(4)
-    for _ in range(2):                                      # grow the band until it is about target_s of work (or the whole volume)
-        if t_band >= 0.5 * target_s or budget_planes >= Z:
-            break
-        budget_planes = int(min(Z, max(budget_planes + 4, 4 * round(budget_planes * target_s / max(t_band, 1e-3) / 4))))
-        t_band = timed_band(budget_planes)
-    t_int = t_band * (Z / budget_planes)
+    def sized_band(mode, budget_s):
+        planes, (t, used) = 4, timed_band(4, mode)
+        for _ in range(2):                                  # grow the band until it is about budget_s of work (or the whole volume)
+            if t >= 0.5 * budget_s or planes >= Z:
+                break
+            planes = int(min(Z, max(planes + 4, 4 * round(planes * budget_s / max(t, 1e-3) / 4))))
+            t, used = timed_band(planes, mode)
+        return planes, t, used
+
+    kind = "reference" if have_ref else "port"
+    planes, t_band, cores = sized_band(kind, target_s)
+    t_int = t_band * (Z / planes)
     full = O.make_volume(vol_u32, cfg.dims, vs, trunc, cfg.max_weight)
     cam2vol = synth.affine_mul(synth.affine_inv(pose), cam_pose)
     rinv = np.linalg.inv(cam2vol[:3, :3].astype(np.float64)).astype(np.float32)
@@ -105,10 +118,21 @@ def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=12.0):
     # SURVEY.md 8(d) algorithmic bytes of the ray-cast: 4 B per nearest-voxel fetch (steps + 1 per ray), 256 B per hit (2 + 6 trilinear
     # evaluations x 8 taps x 4 B), 32 B per pixel of output -- steps and hits counted by the oracle on the same volume and pose
     rc_bytes = 4.0 * (float(rc_stats[0]) + cfg.cols * cfg.rows) + 256.0 * float(rc_stats[1]) + 32.0 * cfg.cols * cfg.rows
-    return {"value": 1.0 / (t_int + t_ray), "unit": "frames/s", "cores": int(O.lib().orc_num_threads()), "kind": "port",
-            "raycast_algorithmic_bytes": rc_bytes, "raycast_steps": int(rc_stats[0]), "raycast_hits": int(rc_stats[1]),
-            "sample": "oracle (OpenMP, brute-force k-NN) integrate_warped on %d of %d Z planes in %.1f s, scaled x%.1f (est %.1f s/frame) "
-                      "+ full %dx%d raycast (%.2f s)" % (budget_planes, Z, t_band, Z / budget_planes, t_int, cfg.cols, cfg.rows, t_ray)}
+    out = {"value": 1.0 / (t_int + t_ray), "unit": "frames/s", "cores": cores, "kind": kind,
+           "raycast_algorithmic_bytes": rc_bytes, "raycast_steps": int(rc_stats[0]), "raycast_hits": int(rc_stats[1]),
+           "sample": "per-voxel warped integrate through the reference's own nanoflann + DQB classes (oracle/_ref, OpenMP, one tree per thread) on "
+                     "%d of %d Z planes in %.1f s on %d threads, scaled x%.1f (est %.2f s/frame) + full %dx%d ray-cast (%.2f s)"
+                     % (planes, Z, t_band, cores, Z / planes, t_int, cfg.cols, cfg.rows, t_ray)}
+    if have_ref:
+        # one thread, as the reference's own (non-re-entrant) WarpField would run it: one plane is ~0.2-0.5 s
+        t1, _ = timed_band(2, "reference", threads=1)
+        out["single_thread"] = {"value": 1.0 / (t1 * Z / 2 + t_ray * cores), "unit": "frames/s", "cores": 1,
+                                "sample": "same path on 1 thread, 2 of %d planes in %.2f s (est %.0f s/frame integrate; ray-cast scaled by the thread count)" % (Z, t1, t1 * Z / 2)}
+        # the oracle port (restated nanoflann, what the parity tests run), a short band
+        p_planes, p_t, p_cores = sized_band("port", 3.0)
+        out["port"] = {"value": 1.0 / (p_t * Z / p_planes + t_ray), "unit": "frames/s", "cores": p_cores,
+                       "sample": "oracle restatement on %d planes in %.1f s" % (p_planes, p_t)}
+    return out
 
 
 def reference_warp_baseline(cfg, pts_dev, pos, sigma, dq, wf):
@@ -350,6 +374,33 @@ def main():
                                   "achieved_GBps": b_e / (ms_e * 1e-3) / 1e9, "frac_of_peak": b_e / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                   "measured_read_GBps": read_gbps}
         del buf, src
+        # ---- what the per-voxel caches buy and cost: the timed frame leaves the k-NN search and the weights in the
+        # 48 B/voxel cache, which is valid while node POSITIONS stand (the reference's node set is static after init; the solver
+        # only writes transforms).  A frame after the node set changed pays the rebuild first; the lean path never caches.
+        try:
+            reb = []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                wf.set_nodes(*wf._keep)                   # positions "changed": tree replica + invalidated index
+                wf.ensure_index(vol_int, cfg.k)           # brick lists + per-voxel k-NN / weight tables
+                vol.integrate_warped(dists, cam_poses[0], intr, wf, sync=False)
+                vol.raycast(cam_poses[0], intr, pts, nrm)
+                torch.cuda.synchronize(); reb.append((time.perf_counter() - t0) * 1e3)
+            extra["frame_nodes_changed_ms"] = {"ms": float(np.median(reb)), "what": "set_nodes (incl. the nanoflann tree replica, built on the host) + brick index "
+                                               "+ per-voxel k-NN / weight tables rebuilt + the frame itself; wall clock, median of 3"}
+            lean = WarpField(k=cfg.k, device=dev, voxel_table=False)
+            lean.init(pos, sigma=sigma, transforms=dqs_np[0])
+            lean.ensure_index(vol, cfg.k)
+            vol.integrate_warped(dists, cam_poses[0], intr, lean, sync=False)
+            e0.record()
+            for i in range(5):
+                vol.integrate_warped(dists, cam_poses[i % F], intr, lean, sync=False)
+            e1.record(); torch.cuda.synchronize()
+            extra["lean_path_ms"] = {"integrate_warped_ms": e0.elapsed_time(e1) / 5, "what": "no per-voxel cache (brick candidate lists only, ~80 MB): exact top-k "
+                                     "over ~150 candidates per voxel and the weights' exp() every frame (df_warp_brick_kernel)"}
+            del lean
+        except Exception as e:
+            extra["frame_nodes_changed_ms"] = {"error": repr(e)[:200]}
         # one whole KinFu::operator() frame (front-end, ICP, dynamicfusion, ray-cast) through the C++ mirror, for context
         if not args.no_kinfu:
             try:

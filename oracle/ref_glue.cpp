@@ -12,6 +12,11 @@
                       // as on the reference's platform (gcc 5 / Ubuntu 16.04), see static_assert below.
 #include <cstring>
 #include <cstdint>
+#include <cstddef>
+#include <immintrin.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <type_traits>
 #include <vector>
 #include <kfusion/types.hpp>            // oracle/cv_shim
@@ -165,5 +170,68 @@ void ref_dq_transform(const float dq[8], float p[3])
 { DQ d = dq_from_raw(dq); Vec3f v(p[0], p[1], p[2]); d.transform(v); p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; }
 
 int ref_nanoflann_version(void) { return NANOFLANN_VERSION; }
+
+// ---- the reference-style CPU path for the north-star kernel: per-voxel warped integrate with the reference's OWN
+// nanoflann k-NN + DQB + DualQuaternion::transform (one Warp -- tree, result set, scratch vectors -- PER THREAD: the reference's
+// WarpField keeps them in globals, warp_field.cpp:11-15, and is not re-entrant), OpenMP over Z planes.  The TSDF update after the
+// warp is the ~20 lines of TsdfIntegrator::operator() from the projection on (tsdf_volume.cu:77-104) in plain C++ (that kernel
+// is pinned separately, oracle/ref_cu_glue.cpp).  Planes [z0, z0 + zn) of a volume whose blob starts at plane z_store0.
+// threads <= 0: all host cores.  Returns the number of updated voxels.
+unsigned long long ref_integrate_warped(const unsigned short* dists, size_t pitch, int cols, int rows, unsigned short* vol,
+                                        int X, int Y, int z_store0, int z0, int zn, const float vs[3], float trunc, int max_weight,
+                                        const float vol2world[12], const float world2cam[12], const float proj[4],
+                                        const float* pos, const float* dq, const float* sigma, int M, int k, int threads,
+                                        int* threads_used)
+{
+    const float trunc_inv = 1.f / trunc;
+    unsigned long long n_upd = 0;
+    int used = 1;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads) reduction(+ : n_upd)
+#endif
+    {
+        Warp w(pos, dq, sigma, M, k);
+#ifdef _OPENMP
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for collapse(2) schedule(dynamic, 4)
+#endif
+        for (int z = z0; z < z0 + zn; ++z)
+            for (int y = 0; y < Y; ++y)
+                for (int x = 0; x < X; ++x) {
+                    const float vx = (float)x * vs[0], vy = (float)y * vs[1], vz = (float)z * vs[2];
+                    // Aff3f * v (device.hpp:71-74): three fma-nested dots + t
+                    const float* A = vol2world;
+                    Vec3f p(fmaf(A[0], vx, fmaf(A[1], vy, A[2] * vz)) + A[9], fmaf(A[3], vx, fmaf(A[4], vy, A[5] * vz)) + A[10],
+                            fmaf(A[6], vx, fmaf(A[7], vy, A[8] * vz)) + A[11]);
+                    DQ d = w.DQB(p);                                            // warp_field.cpp:203-217 (nanoflann inside)
+                    d.transform(p);                                             // warp_field.cpp:188
+                    const float* C = world2cam;
+                    const float cx_ = fmaf(C[0], p[0], fmaf(C[1], p[1], C[2] * p[2])) + C[9];
+                    const float cy_ = fmaf(C[3], p[0], fmaf(C[4], p[1], C[5] * p[2])) + C[10];
+                    const float cz_ = fmaf(C[6], p[0], fmaf(C[7], p[1], C[8] * p[2])) + C[11];
+                    const float u = fmaf(proj[0], cx_ / cz_, proj[2]);          // device.hpp:35
+                    const float v = fmaf(proj[1], cy_ / cz_, proj[3]);          // device.hpp:36
+                    if (!(u >= 0 && v >= 0 && u < (float)cols && v < (float)rows)) continue;   // tsdf_volume.cu:82
+                    const unsigned short* row = (const unsigned short*)((const char*)dists + (size_t)(int)v * pitch);
+                    const float Dp = _cvtsh_ss(row[(int)u]);                    // :85
+                    if (Dp == 0 || cz_ <= 0) continue;                          // :86
+                    const float sdf = Dp - sqrtf(fmaf(cx_, cx_, fmaf(cy_, cy_, cz_ * cz_)));   // :89
+                    if (sdf >= -trunc) {                                        // :91
+                        const float tsdf = fminf(1.f, sdf * trunc_inv);
+                        unsigned short* vox = vol + 2 * ((size_t)x + (size_t)y * X + (size_t)(z - z_store0) * X * Y);
+                        const int wp = vox[1];
+                        const float fp = _cvtsh_ss(vox[0]);
+                        const float fn = fmaf(fp, (float)wp, tsdf) / (float)(wp + 1);           // :99
+                        vox[0] = _cvtss_sh(fn, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+                        vox[1] = (unsigned short)(wp + 1 < max_weight ? wp + 1 : max_weight);
+                        ++n_upd;
+                    }
+                }
+    }
+    if (threads_used) *threads_used = used;
+    return n_upd;
+}
 
 }  // extern "C"

@@ -177,6 +177,10 @@ def ref():
         R.ref_dq_transform.restype = None
         R.ref_dq_transform.argtypes = [f32p, f32p]
         R.ref_nanoflann_version.restype = C.c_int
+        R.ref_integrate_warped.restype = C.c_uint64
+        R.ref_integrate_warped.argtypes = [u16p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p,
+                                           C.c_float, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(C.c_int)]
         _ref = R
     return _ref
 
@@ -307,6 +311,19 @@ def integrate_warped(dists, vol_u32, volume, vol2world, world2cam, proj, pos, dq
     return int(lib().orc_integrate_warped(dists, cols * 2, cols, rows, volume, C.byref(slab) if slab else None,
                                           f32(vol2world).reshape(-1), f32(world2cam).reshape(-1), f32(proj),
                                           pos.reshape(-1), dq.reshape(-1), sigma, pos.shape[0], k))
+
+
+def ref_integrate_warped(dists, vol_u32, dims, vs, trunc, max_weight, vol2world, world2cam, proj, pos, dq, sigma, k, z_store0, z0, zn,
+                         threads=0):
+    """Per-voxel warped integrate through the reference's own nanoflann / DQB classes (oracle/_ref), OpenMP with one tree per
+    thread.  vol_u32: [z_store_n, Y, X] blob starting at plane z_store0.  Returns (n_updated, threads_used)."""
+    rows, cols = dists.shape
+    used = C.c_int(0)
+    n = ref().ref_integrate_warped(np.ascontiguousarray(dists), cols * 2, cols, rows, vol_u32.ctypes.data, int(dims[0]), int(dims[1]),
+                                   int(z_store0), int(z0), int(zn), f32(vs), float(np.float32(trunc)), int(max_weight),
+                                   f32(vol2world).reshape(-1), f32(world2cam).reshape(-1), f32(proj), f32(pos).reshape(-1),
+                                   f32(dq).reshape(-1), f32(sigma), int(len(pos)), int(k), int(threads), C.byref(used))
+    return int(n), used.value
 
 
 def raycast_points(volume, cam2vol, Rinv, reproj, cols, rows, step_factor, delta_factor, slab=None, want_keys=False):
