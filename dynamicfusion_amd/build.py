@@ -54,6 +54,7 @@ HOST_LIB = os.path.join(HOST_DIR, "libkfusion_hip.so")
 HOST_APP = os.path.join(HOST_DIR, "headless_frame")
 HOST_KINFU_APP = os.path.join(HOST_DIR, "kinfu_headless")
 HOST_WARP_TESTS = os.path.join(HOST_DIR, "warp_tests")
+HOST_DEMO_CALLS = os.path.join(HOST_DIR, "demo_calls")
 
 
 def build_host(force=False, verbose=False):
@@ -63,9 +64,10 @@ def build_host(force=False, verbose=False):
     app = os.path.join(HOST_DIR, "apps", "headless_frame.cpp")
     app2 = os.path.join(HOST_DIR, "apps", "kinfu_headless.cpp")
     app3 = os.path.join(HOST_DIR, "apps", "warp_tests.cpp")
-    deps = [src, app, app2, app3, LIB_PATH] + [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(HOST_DIR, "include")) for f in fs]
-    if not force and all(os.path.exists(f) for f in (HOST_LIB, HOST_APP, HOST_KINFU_APP, HOST_WARP_TESTS)) and \
-            min(os.path.getmtime(f) for f in (HOST_LIB, HOST_APP, HOST_KINFU_APP, HOST_WARP_TESTS)) >= max(os.path.getmtime(d) for d in deps):
+    app4 = os.path.join(HOST_DIR, "apps", "demo_calls.cpp")
+    deps = [src, app, app2, app3, app4, LIB_PATH] + [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(HOST_DIR, "include")) for f in fs]
+    outs = (HOST_LIB, HOST_APP, HOST_KINFU_APP, HOST_WARP_TESTS, HOST_DEMO_CALLS)
+    if not force and all(os.path.exists(f) for f in outs) and min(os.path.getmtime(f) for f in outs) >= max(os.path.getmtime(d) for d in deps):
         return HOST_LIB, HOST_APP
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     common = ["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(HOST_DIR, "include"),
@@ -74,7 +76,8 @@ def build_host(force=False, verbose=False):
     cmds = [common + ["-fPIC", "-shared", src, "-o", HOST_LIB] + link + ["-Wl,-rpath,$ORIGIN/.."],
             common + [app, "-o", HOST_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
             common + [app2, "-o", HOST_KINFU_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
-            common + [app3, "-o", HOST_WARP_TESTS, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
+            common + [app3, "-o", HOST_WARP_TESTS, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
+            common + [app4, "-o", HOST_DEMO_CALLS, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
     for c in cmds:
         if verbose:
             print(" ".join(c))

@@ -47,6 +47,7 @@ SYMBOLS = [
     "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
     "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate",
     "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_debug_rigid",
+    "dfusion_render_image_points", "dfusion_render_image_depth", "dfusion_render_tangent_colors",
 ]
 
 

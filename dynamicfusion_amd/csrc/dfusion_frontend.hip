@@ -22,6 +22,7 @@ __device__ __forceinline__ void st4(float* b, size_t pitch, int y, int x, float4
 // Reprojector::operator() device.hpp:42-47 / ComputeIcpHelper::reproj proj_icp.cu:39-44
 struct FeIntr { float fx, fy, cx, cy, finvx, finvy; };
 __device__ __forceinline__ f3 fe_reproj(const FeIntr& I, float u, float v, float z) { return mk3(z * (u - I.cx) * I.finvx, z * (v - I.cy) * I.finvy, z); }
+static f3 mk3h(const float v[3]) { f3 r; r.x = v[0]; r.y = v[1]; r.z = v[2]; return r; }
 static FeIntr fe_intr(const float intr[4])
 {
     FeIntr I; I.fx = intr[0]; I.fy = intr[1]; I.cx = intr[2]; I.cy = intr[3]; I.finvx = 1.f / intr[0]; I.finvy = 1.f / intr[1];   // precomp.cpp:55
@@ -252,6 +253,93 @@ extern "C" int dfusion_resize_points_normals(const float* points, size_t points_
     const int dc = src_cols / 2, dr = src_rows / 2;
     hipLaunchKernelGGL(df_resize_points_normals_kernel, FE_GRID(dc, dr), dim3(256), 0, (hipStream_t)stream, points, points_pitch, normals,
                        normals_pitch, points_out, points_out_pitch, normals_out, normals_out_pitch, dc, dr);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ renderImage / renderTangentColors
+// device::renderImage (x2) and renderTangentColors (imgproc.cu:420-583): the Phong view KinFu::renderImage hands to the demo.
+// One lane per pixel, 4-byte BGRA stores.  __powf(x, 20) -> (float)pow((double)x, 20.0) and rsqrt -> 1 / sqrtf on both sides of
+// the parity tests (oracle/dfusion_frontend_oracle.c, and the reference's own kernel through oracle/cuda_shim).
+__device__ __forceinline__ float fe_saturate(float a) { return a != a ? 0.f : fminf(fmaxf(a, 0.f), 1.f); }
+__device__ __forceinline__ uint32_t fe_shade(bool have, f3 P, f3 N, f3 light, int y, int rows)
+{
+    f3 color;
+    if (!have) {
+        const f3 bgr1 = mk3(4.f / 255.f, 2.f / 255.f, 2.f / 255.f), bgr2 = mk3(236.f / 255.f, 120.f / 255.f, 120.f / 255.f);
+        const float w = (float)y / (float)rows;
+        color = add3(scale3(bgr1, 1.f - w), scale3(bgr2, w));                                       // :439-444
+    } else {
+        const f3 L = normalized3(sub3(light, P));
+        const f3 V = normalized3(sub3(mk3(0.f, 0.f, 0.f), P));
+        const f3 R = normalized3(sub3(scale3(scale3(N, 2.f), dot3(N, L)), L));                     // 2 * N * dot(N, L) - L
+        // Ix = Ax*Ka*Dx + Lx*Kd*Dx * max(0, N.L) + Lx*Ks*Sx * max(0, R.V)^20 with Ax = Dx = Sx = Lx = 1, Ka = .3, Kd = .5, Ks = .2
+        const float Ix = 0.3f + 0.5f * fmaxf(0.f, dot3(N, L)) + 0.2f * (float)pow((double)fmaxf(0.f, dot3(R, V)), 20.0);
+        color = mk3(Ix, Ix, Ix);
+    }
+    const uint32_t b = (uint32_t)(fe_saturate(color.x) * 255.f), g = (uint32_t)(fe_saturate(color.y) * 255.f), r = (uint32_t)(fe_saturate(color.z) * 255.f);
+    return b | (g << 8) | (r << 16);
+}
+template <bool DEPTH>
+__global__ __launch_bounds__(256) void df_render_kernel(const void* __restrict__ src, size_t spitch, const float* __restrict__ normals,
+                                                        size_t npitch, int cols, int rows, FeIntr I, f3 light, uint32_t* __restrict__ image,
+                                                        size_t ipitch)
+{
+    FE_XY;
+    if (x >= cols || y >= rows) return;
+    const float4 n = ld4(normals, npitch, y, x);
+    bool have; f3 P;
+    if (DEPTH) {
+        const int d = *(const uint16_t*)((const char*)src + (size_t)y * spitch + 2 * (size_t)x);
+        have = d != 0;
+        const float z = (float)d * 0.001f;
+        P = mk3(z * ((float)x - I.cx) * I.finvx, z * ((float)y - I.cy) * I.finvy, z);              // Reprojector, device.hpp:42-48
+    } else {
+        const float4 p = ld4((const float*)src, spitch, y, x);
+        have = !isnan(p.x);
+        P = mk3(p.x, p.y, p.z);
+    }
+    *(uint32_t*)((char*)image + (size_t)y * ipitch + 4 * (size_t)x) = fe_shade(have, P, mk3(n.x, n.y, n.z), light, y, rows);
+}
+__global__ __launch_bounds__(256) void df_tangent_colors_kernel(const float* __restrict__ normals, size_t npitch, int cols, int rows,
+                                                                uint32_t* __restrict__ image, size_t ipitch)
+{
+    FE_XY;
+    if (x >= cols || y >= rows) return;
+    const float4 n = ld4(normals, npitch, y, x);
+    // (unsigned char)(float) of the reference: truncation; saturating / NaN -> 0 here as in the GPU conversion it compiles to
+    const float r = (5.f - n.x * 3.5f) * 25.5f, g = (5.f - n.y * 2.5f) * 25.5f, b = (5.f - n.z * 3.5f) * 25.5f;
+    const uint32_t rb = (uint32_t)(r != r ? 0.f : fminf(fmaxf(r, 0.f), 255.f)), gb = (uint32_t)(g != g ? 0.f : fminf(fmaxf(g, 0.f), 255.f)),
+                   bb = (uint32_t)(b != b ? 0.f : fminf(fmaxf(b, 0.f), 255.f));
+    *(uint32_t*)((char*)image + (size_t)y * ipitch + 4 * (size_t)x) = bb | (gb << 8) | (rb << 16);  // make_uchar4(b, g, r, 0)
+}
+
+extern "C" int dfusion_render_image_points(const float* points, size_t points_pitch, const float* normals, size_t normals_pitch, int cols,
+                                           int rows, const float light_pose[3], unsigned char* image, size_t image_pitch, dfStream stream)
+{
+    if (!points || !normals || !light_pose || !image || cols <= 0 || rows <= 0) return DF_E_INVALID;
+    FeIntr I; I.fx = I.fy = 1.f; I.cx = I.cy = 0.f; I.finvx = I.finvy = 1.f;
+    hipLaunchKernelGGL((df_render_kernel<false>), FE_GRID(cols, rows), dim3(256), 0, (hipStream_t)stream, (const void*)points, points_pitch, normals,
+                       normals_pitch, cols, rows, I, mk3h(light_pose), (uint32_t*)image, image_pitch);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+extern "C" int dfusion_render_image_depth(const uint16_t* depth, size_t depth_pitch, const float* normals, size_t normals_pitch, int cols,
+                                          int rows, const float intr[4], const float light_pose[3], unsigned char* image, size_t image_pitch,
+                                          dfStream stream)
+{
+    if (!depth || !normals || !intr || !light_pose || !image || cols <= 0 || rows <= 0) return DF_E_INVALID;
+    hipLaunchKernelGGL((df_render_kernel<true>), FE_GRID(cols, rows), dim3(256), 0, (hipStream_t)stream, (const void*)depth, depth_pitch, normals,
+                       normals_pitch, cols, rows, fe_intr(intr), mk3h(light_pose), (uint32_t*)image, image_pitch);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+extern "C" int dfusion_render_tangent_colors(const float* normals, size_t normals_pitch, int cols, int rows, unsigned char* image,
+                                             size_t image_pitch, dfStream stream)
+{
+    if (!normals || !image || cols <= 0 || rows <= 0) return DF_E_INVALID;
+    hipLaunchKernelGGL(df_tangent_colors_kernel, FE_GRID(cols, rows), dim3(256), 0, (hipStream_t)stream, normals, normals_pitch, cols, rows,
+                       (uint32_t*)image, image_pitch);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }

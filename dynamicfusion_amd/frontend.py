@@ -91,6 +91,32 @@ def resizePointsNormals(points, normals):
     return p, n
 
 
+def renderImage(src, normals, intr, light_pose, image=None):
+    """kfusion::cuda::renderImage (imgproc.cpp:152-186): Phong view of a points image (float32 [rows, cols, 4]) or a depth image
+    (int16 [rows, cols]) with its normals; image: uint8 [rows, cols, 4] BGRA (device)."""
+    rows, cols = normals.shape[:2]
+    if image is None:
+        image = torch.empty((rows, cols, 4), dtype=torch.uint8, device=normals.device)
+    light = capi.floats(light_pose)
+    if src.dtype == torch.float32:
+        capi.check(capi.lib().dfusion_render_image_points(_ptr(src), cols * 16, _ptr(normals), cols * 16, cols, rows, light, _ptr(image),
+                                                          image.stride(0), _stream()), "dfusion_render_image_points")
+    else:
+        capi.check(capi.lib().dfusion_render_image_depth(_ptr(src), cols * 2, _ptr(normals), cols * 16, cols, rows, intr.as_proj(), light,
+                                                         _ptr(image), image.stride(0), _stream()), "dfusion_render_image_depth")
+    return image
+
+
+def renderTangentColors(normals, image=None):
+    """kfusion::cuda::renderTangentColors (imgproc.cpp:193-201)."""
+    rows, cols = normals.shape[:2]
+    if image is None:
+        image = torch.empty((rows, cols, 4), dtype=torch.uint8, device=normals.device)
+    capi.check(capi.lib().dfusion_render_tangent_colors(_ptr(normals), cols * 16, cols, rows, _ptr(image), image.stride(0), _stream()),
+               "dfusion_render_tangent_colors")
+    return image
+
+
 def unpack_icp_sums(sums):
     """StreamHelper::get (projective_icp.cpp:43-61): 27 floats -> symmetric A (6x6) and b (6)."""
     A = np.zeros((6, 6), F32)

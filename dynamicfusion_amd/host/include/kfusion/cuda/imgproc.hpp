@@ -1,8 +1,7 @@
 // kfusion/cuda/imgproc.hpp -- the image operators KinFu::operator() calls, with the reference's names and argument order
 // (/root/reference/kfusion/include/kfusion/cuda/imgproc.hpp; host wrappers kfusion/src/imgproc.cpp).  Every function allocates its
 // outputs like the reference's wrapper does and enqueues one or two HIP kernels through the C-ABI (include/dfusion.h); nothing
-// synchronises except waitAllDefaultStream.  The viz helpers of that header (renderImage, renderTangentColors, cloudToDepth,
-// mergePointNormal) are out of scope.
+// synchronises except waitAllDefaultStream.  cloudToDepth / mergePointNormal (never called by KinFu or the demo) are out of scope.
 //
 //   image types   Depth / Dists : DeviceArray2D<unsigned short>   (millimetres / IEEE-half bits of the ray length in metres)
 //                 Cloud / Normals: DeviceArray2D<Point>            (float4, invalid pixels are NaN)
@@ -36,5 +35,12 @@ void computePointNormals(const Intr& intr, const Depth& depth, Cloud& points, No
 // ---- coarser levels of the ray-cast model (2x2 averages, NaN / 0 if any of the four is invalid)             imgproc.cpp:112-141
 void resizeDepthNormals(const Depth& depth, const Normals& normals, Depth& depth_out, Normals& normals_out);
 void resizePointsNormals(const Cloud& points, const Normals& normals, Cloud& points_out, Normals& normals_out);
+
+// ---- the views KinFu::renderImage returns (BGRA, `image` is created rows x cols)                              imgproc.cpp:152-201
+// Phong shading of a depth image / a points image with its normals, light at light_pose (metres, camera frame)
+void renderImage(const Depth& depth, const Normals& normals, const Intr& intr, const Vec3f& light_pose, Image& image);
+void renderImage(const Cloud& points, const Normals& normals, const Intr& intr, const Vec3f& light_pose, Image& image);
+// normals as colours
+void renderTangentColors(const Normals& normals, Image& image);
 
 } }

@@ -67,6 +67,8 @@ public:
     void compute_normals();
     const std::vector<Point>& get_cloud_host() const;
     const std::vector<Normal>& get_normal_host() const;
+    const std::vector<Point>* get_cloud_host_ptr() const { return &get_cloud_host(); }      // tsdf_volume.hpp:27-28 (cv::Mat* there)
+    const std::vector<Normal>* get_normal_host_ptr() const { return &get_normal_host(); }
     const DeviceArray<Point>& get_cloud_device() const { return cloud_; }
 
 private:

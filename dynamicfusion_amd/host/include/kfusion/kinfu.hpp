@@ -1,5 +1,5 @@
 // kfusion/kinfu.hpp -- kfusion::KinFuParams / kfusion::KinFu with the reference's interface
-// (/root/reference/kfusion/include/kfusion/kinfu.hpp:15-112) minus viz (renderImage) and the Opt/Ceres solver.
+// (/root/reference/kfusion/include/kfusion/kinfu.hpp:15-112) minus the Opt/Ceres solver (the data term is solved on the GPU instead).
 // Extensions: max_warp_nodes (node ids are 16-bit here; the seed cloud's stride-50 sampling, warp_field.cpp:49-60, widens if needed),
 // warped_fusion (call the per-voxel warped integrate instead of surface_fusion; default off = the reference's behaviour) and
 // device_resident (default on: same results as the reference's host staging, bit for bit, without the ~50 MB/frame of PCIe traffic;
@@ -39,7 +39,7 @@ namespace kfusion
         // tracker
         float icp_dist_thres, icp_angle_thres;
         std::vector<int> icp_iter_num;       // per pyramid level, finest first
-        Vec3f light_pose;                    // rendering only (out of scope here)
+        Vec3f light_pose;                    // metres, camera frame: renderImage's light
 
         // ---- extensions (defaults reproduce the reference's observable behaviour unless noted)
         int max_warp_nodes = 65535;          // node ids are 16-bit: the stride-50 sampling of the seed cloud widens if it must
@@ -68,7 +68,12 @@ namespace kfusion
 
         void reset();
         bool operator()(const cuda::Depth& depth, const cuda::Image& image = cuda::Image());
+        /// kinfu.cpp:312-343: the model as the tracker last saw it (prev_ pyramid level 0).  flags 1 (and anything outside 1..3): Phong
+        /// shading, 2: normals as colours, 3: both side by side (image is then 2 * cols wide)
+        void renderImage(cuda::Image& image, int flags = 0);
         void dynamicfusion(cuda::Depth& depth, cuda::Cloud live_frame, cuda::Normals current_normals);
+        /// kinfu.cpp:408-436: the same views of a fresh ray-cast from `pose`
+        void renderImage(cuda::Image& image, const Affine3f& pose, int flags = 0);
         Affine3f getCameraPose(int time = -1) const;
 
     protected:
@@ -82,6 +87,7 @@ namespace kfusion
         std::vector<Affine3f> poses_;
         cuda::Dists dists_;
         cuda::Frame curr_, prev_, first_;
+        cuda::Cloud points_; cuda::Normals normals_; cuda::Depth depths_;   // renderImage(image, pose, flags)
         std::unique_ptr<cuda::TsdfVolume> volume_;
         std::unique_ptr<cuda::ProjectiveICP> icp_;
         std::unique_ptr<WarpField> warp_;

@@ -1,7 +1,7 @@
 // kfusion/warp_field.hpp -- WarpField with the reference's hot-path interface
 // (/root/reference/kfusion/include/kfusion/warp_field.hpp:41-88): host node store + GPU k-NN / DQB / warp through the
-// C-ABI.  energy_data is the GPU data-term solve; energy_reg / getNodesAsMat are out of scope (no regularisation term is ever
-// added to the reference's problem either).
+// C-ABI.  energy_data is the GPU data-term solve; energy_reg is out of scope (no regularisation term is ever added to the
+// reference's problem either).
 #pragma once
 #include <vector>
 #include <kfusion/types.hpp>
@@ -66,6 +66,10 @@ namespace kfusion
         void setWarpToLive(const Affine3f& pose) { warp_to_live_ = pose; }
         const Affine3f& getWarpToLive() const { return warp_to_live_; }
         void buildKDTree() { commit(true); }                 // warp_field.cpp:275-282
+        /// warp_field.cpp:284-293: every node's position moved by its own translation, one Vec3f per node -- what the demo shows as
+        /// the "warp_field" cloud (apps/demo.cpp:67).  The reference returns a 1 x N CV_32FC3 cv::Mat: the same N x 3 floats.
+        typedef std::vector<Vec3f> NodesMat;
+        const NodesMat getNodesAsMat() const;
 
         int k() const { return k_; }
         DfWarpField* handle() const { return handle_; }
@@ -86,6 +90,7 @@ namespace kfusion
         mutable bool index_ok_;
         mutable const void* index_volume_;
         mutable bool index_tables_ = false;
+        mutable float index_key_[18] = {0};                  // dims, voxel size, pose of the geometry the index was built for
         int solver_iters_ = 100;
         float solver_lambda_ = 0.f;
         float last_energy_[2] = {0.f, 0.f};

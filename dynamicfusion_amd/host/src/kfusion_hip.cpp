@@ -390,10 +390,29 @@ void WarpField::energy_data(const std::vector<Vec3f>& canonical_vertices, const 
     energy_data(c, l, (int)n);
 }
 
+const WarpField::NodesMat WarpField::getNodesAsMat() const              // warp_field.cpp:284-293
+{
+    pullNodes();
+    NodesMat m(nodes_.size());
+    for (size_t i = 0; i < nodes_.size(); ++i) {
+        float x, y, z;
+        nodes_[i].transform.getTranslation(x, y, z);
+        m[i] = Vec3f(x, y, z) + nodes_[i].vertex;                         // matrix.at(i) += vertex
+    }
+    return m;
+}
+
 void WarpField::ensureIndex(const cuda::TsdfVolume& volume, bool tables) const
 {
-    if (index_ok_ && index_volume_ == &volume && (index_tables_ || !tables)) return;
+    // the index belongs to one volume GEOMETRY (dims, voxel size, pose), not to an object address: setPose / setSize / applyAffine
+    // on the same TsdfVolume must rebuild it (dfusion_integrate_warped would refuse the stale one with DF_E_NO_INDEX)
     float v2w[12]; affine_to_aff12(volume.getPose(), v2w);
+    const Vec3i d = volume.getDims(); const Vec3f vs = volume.getVoxelSize();
+    float key[18] = {(float)d[0], (float)d[1], (float)d[2], vs[0], vs[1], vs[2]};
+    std::memcpy(key + 6, v2w, sizeof(v2w));
+    const bool same = index_ok_ && index_volume_ == &volume && std::memcmp(key, index_key_, sizeof(key)) == 0;
+    if (same && (index_tables_ || !tables)) return;
+    std::memcpy(index_key_, key, sizeof(key));
     KF_DF(dfusion_warp_build_index(handle_, c_volume(volume), nullptr, v2w, k_, tables ? (DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE) : 0u, nullptr));
     index_ok_ = true; index_volume_ = &volume; index_tables_ = tables;
 }
@@ -416,6 +435,7 @@ void WarpField::warp(cuda::DeviceArray<float>& points, cuda::DeviceArray<float>&
 void WarpField::warp(std::vector<Vec3f>& points, std::vector<Vec3f>& normals) const
 {
     static_assert(sizeof(Vec3f) == 12, "Vec3f must be 3 packed floats");
+    if (points.empty()) return;
     DeviceArray<float> p, n;
     p.upload(points[0].val, points.size() * 3);
     if (!normals.empty()) n.upload(normals[0].val, normals.size() * 3);
@@ -468,6 +488,27 @@ void kfusion::cuda::resizePointsNormals(const Cloud& points, const Normals& norm
     KF_DF(dfusion_resize_points_normals((const float*)points.ptr(), points.step(), (const float*)normals.ptr(), normals.step(), points.cols(),
                                         points.rows(), (float*)points_out.ptr(), points_out.step(), (float*)normals_out.ptr(),
                                         normals_out.step(), nullptr));
+}
+
+// ------------------------------------------------------------------------------------------ views (imgproc.cpp:152-201)
+void kfusion::cuda::renderImage(const Depth& depth, const Normals& normals, const Intr& intr, const Vec3f& light_pose, Image& image)
+{
+    image.create(depth.rows(), depth.cols());
+    const float in[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
+    KF_DF(dfusion_render_image_depth(depth.ptr(), depth.step(), (const float*)normals.ptr(), normals.step(), depth.cols(), depth.rows(), in,
+                                     light_pose.val, (unsigned char*)image.ptr(), image.step(), nullptr));
+}
+void kfusion::cuda::renderImage(const Cloud& points, const Normals& normals, const Intr& /*intr*/, const Vec3f& light_pose, Image& image)
+{
+    image.create(points.rows(), points.cols());
+    KF_DF(dfusion_render_image_points((const float*)points.ptr(), points.step(), (const float*)normals.ptr(), normals.step(), points.cols(),
+                                      points.rows(), light_pose.val, (unsigned char*)image.ptr(), image.step(), nullptr));
+}
+void kfusion::cuda::renderTangentColors(const Normals& normals, Image& image)
+{
+    image.create(normals.rows(), normals.cols());
+    KF_DF(dfusion_render_tangent_colors((const float*)normals.ptr(), normals.step(), normals.cols(), normals.rows(), (unsigned char*)image.ptr(),
+                                        image.step(), nullptr));
 }
 
 // ------------------------------------------------------------------------------------------ ProjectiveICP (projective_icp.cpp:64-213)
@@ -679,6 +720,46 @@ void KinFu::optimiseWarp(std::vector<Vec3f>& canonical, std::vector<Vec3f>& cano
     if (params_.warp_solver_iterations <= 0) return;
     warp_->setSolverIterations(params_.warp_solver_iterations);
     warp_->energy_data(canonical, canonical_normals, live, canonical_normals);
+}
+
+// kinfu.cpp:312-343 / :408-436.  `image.create` of the render wrappers is a no-op on the user-pointer halves of the side-by-side view.
+static void render_views(const KinFuParams& p, const cuda::Depth* depth, const cuda::Cloud* points, const cuda::Normals& normals,
+                         cuda::Image& image, int flag)
+{
+    image.create(p.rows, flag != 3 ? p.cols : p.cols * 2);
+    auto phong = [&](cuda::Image& dst) {
+        if (depth) cuda::renderImage(*depth, normals, p.intr, p.light_pose, dst);
+        else cuda::renderImage(*points, normals, p.intr, p.light_pose, dst);
+    };
+    if (flag < 1 || flag > 3) phong(image);
+    else if (flag == 2) cuda::renderTangentColors(normals, image);
+    else if (flag == 1) phong(image);       // (the reference's `flag < 1 || flag > 3` test sends 1 to the last branch; with flag == 1 the
+                                            // image is only p.cols wide and its i2 half would be written out of bounds -- shaded view only)
+    else {
+        cuda::Image i1(p.rows, p.cols, image.ptr(), image.step());
+        cuda::Image i2(p.rows, p.cols, image.ptr() + p.cols, image.step());
+        phong(i1);
+        cuda::renderTangentColors(normals, i2);
+    }
+}
+void KinFu::renderImage(cuda::Image& image, int flag)
+{
+    if (params_.use_depth_pyramids) render_views(params_, &prev_.depth_pyr[0], nullptr, prev_.normals_pyr[0], image, flag);
+    else render_views(params_, nullptr, &prev_.points_pyr[0], prev_.normals_pyr[0], image, flag);
+}
+void KinFu::renderImage(cuda::Image& image, const Affine3f& pose, int flag)
+{
+    const KinFuParams& p = params_;
+    normals_.create(p.rows, p.cols);
+    if (p.use_depth_pyramids) {
+        depths_.create(p.rows, p.cols);
+        volume_->raycast(pose, p.intr, depths_, normals_);
+        render_views(p, &depths_, nullptr, normals_, image, flag);
+    } else {
+        points_.create(p.rows, p.cols);
+        volume_->raycast(pose, p.intr, points_, normals_);
+        render_views(p, nullptr, &points_, normals_, image, flag);
+    }
 }
 
 Affine3f KinFu::getCameraPose(int time) const                          // kinfu.cpp:213-218

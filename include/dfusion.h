@@ -274,6 +274,17 @@ int dfusion_resize_points_normals(const float *points_dev, size_t points_pitch, 
                                   int src_cols, int src_rows, float *points_out_dev, size_t points_out_pitch, float *normals_out_dev,
                                   size_t normals_out_pitch, dfStream stream);
 
+/* device::renderImage (Points and Depth variants) and renderTangentColors (internal.hpp:134-136; kernels imgproc.cu:420-583): the
+ * Phong view KinFu::renderImage produces (kinfu.cpp:312-343,408-436).  image: cols x rows BGRA bytes (device), light_pose in metres
+ * (KinFuParams::light_pose), intr = (fx, fy, cx, cy) of the depth image (the Points variant shades the points as given).             */
+int dfusion_render_image_points(const float *points_dev, size_t points_pitch, const float *normals_dev, size_t normals_pitch, int cols,
+                                int rows, const float light_pose[3], unsigned char *image_dev, size_t image_pitch, dfStream stream);
+int dfusion_render_image_depth(const uint16_t *depth_dev, size_t depth_pitch, const float *normals_dev, size_t normals_pitch, int cols,
+                               int rows, const float intr[4], const float light_pose[3], unsigned char *image_dev, size_t image_pitch,
+                               dfStream stream);
+int dfusion_render_tangent_colors(const float *normals_dev, size_t normals_pitch, int cols, int rows, unsigned char *image_dev,
+                                  size_t image_pitch, dfStream stream);
+
 /* The host loops of KinFu::dynamicfusion (kinfu.cpp:353-383) on the device: out(y,x) = aff * in(y,x) for a rows x cols grid of
  * 3-vectors (aff nullable = plain re-striding), with cv::Affine3f * Vec3f float arithmetic (products summed left to right,
  * then + t).  Element strides in floats (input >= 3, output 3 or 4; a 4th output component is set to 0), row pitches in

@@ -11,6 +11,7 @@
  *   points + normals        kfusion/src/cuda/imgproc.cu:210-252      (default build)
  *   resize depth+normals    kfusion/src/cuda/imgproc.cu:309-361
  *   resize points+normals   kfusion/src/cuda/imgproc.cu:368-414
+ *   renderImage (x2), renderTangentColors   kfusion/src/cuda/imgproc.cu:420-583
  *   ICP correspondence      kfusion/src/cuda/proj_icp.cu:30-110 (both variants), row build :350-371
  *   ICP block reduction     kfusion/src/cuda/proj_icp.cu:112-348 + Block::reduce temp_utils.hpp:503-523
  *   ICP final reduction     kfusion/src/cuda/proj_icp.cu:373-397
@@ -194,6 +195,67 @@ ORC_API void orc_resize_depth_normals(const uint16_t *dsrc, size_t dspitch, cons
             }
             PIX16(ddst, ddpitch, y, x) = d;
             memcpy(PIX4(ndst, ndpitch, y, x), n, 16);
+        }
+}
+
+/* ---------------------------------------------------------------- renderImage / renderTangentColors (imgproc.cu:420-583)
+ * The Phong shading KinFu::renderImage shows (kinfu.cpp:312-343,408-436).  __powf(x, 20) is a hardware approximation on the
+ * reference's side; (float)pow((double)x, 20.0) stands in (as (float)exp((double)x) does for __expf), __saturatef clamps to [0, 1]
+ * with NaN -> 0, the unsigned char casts truncate.  Pinned against the reference's own kernels in tests/test_oracle_refcu.py. */
+static inline float saturatef(float a) { return a != a ? 0.f : (a < 0.f ? 0.f : (a > 1.f ? 1.f : a)); }
+static inline void shade_pixel(int have, f3 P, f3 N, f3 light, int y, int rows, uint8_t out[4])
+{
+    f3 color;
+    if (!have) {
+        const f3 bgr1 = mk3(4.f / 255.f, 2.f / 255.f, 2.f / 255.f), bgr2 = mk3(236.f / 255.f, 120.f / 255.f, 120.f / 255.f);
+        const float w = (float)y / rows;
+        color = add3(scale3(bgr1, 1 - w), scale3(bgr2, w));                                          /* :439-444 */
+    } else {
+        const float Ka = 0.3f, Kd = 0.5f, Ks = 0.2f, n = 20.f, Ax = 1.f, Dx = 1.f, Sx = 1.f, Lx = 1.f;
+        const f3 L = normalized3(sub3(light, P));
+        const f3 V = normalized3(sub3(mk3(0.f, 0.f, 0.f), P));
+        const f3 R = normalized3(sub3(scale3(scale3(N, 2.f), dot3(N, L)), L));                       /* 2 * N * dot(N, L) - L */
+        const float Ix = Ax * Ka * Dx + Lx * Kd * Dx * fmaxf(0.f, dot3(N, L)) + Lx * Ks * Sx * (float)pow((double)fmaxf(0.f, dot3(R, V)), (double)n);
+        color = mk3(Ix, Ix, Ix);
+    }
+    out[0] = (uint8_t)(saturatef(color.x) * 255.f); out[1] = (uint8_t)(saturatef(color.y) * 255.f);
+    out[2] = (uint8_t)(saturatef(color.z) * 255.f); out[3] = 0;
+}
+ORC_API void orc_render_points(const float *points, size_t ppitch, const float *normals, size_t npitch, int cols, int rows,
+                               const float light[3], uint8_t *image, size_t ipitch)
+{
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const float *p = (const float *)((const char *)points + (size_t)y * ppitch) + 4 * x;
+            const float *n = (const float *)((const char *)normals + (size_t)y * npitch) + 4 * x;
+            shade_pixel(!isnan(p[0]), mk3(p[0], p[1], p[2]), mk3(n[0], n[1], n[2]), mk3(light[0], light[1], light[2]), y, rows,
+                        image + (size_t)y * ipitch + 4 * x);                                        /* :474-523 */
+        }
+}
+ORC_API void orc_render_depth(const uint16_t *depth, size_t dpitch, const float *normals, size_t npitch, int cols, int rows,
+                              const float intr[4], const float light[3], uint8_t *image, size_t ipitch)
+{
+    const float finvx = 1.f / intr[0], finvy = 1.f / intr[1];
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const int d = *(const uint16_t *)((const char *)depth + (size_t)y * dpitch + 2 * (size_t)x);
+            const float *n = (const float *)((const char *)normals + (size_t)y * npitch) + 4 * x;
+            const float z = d * 0.001f;
+            const f3 P = mk3(z * (x - intr[2]) * finvx, z * (y - intr[3]) * finvy, z);              /* Reprojector, device.hpp:42-48 */
+            shade_pixel(d != 0, P, mk3(n[0], n[1], n[2]), mk3(light[0], light[1], light[2]), y, rows,
+                        image + (size_t)y * ipitch + 4 * x);                                        /* :420-471 */
+        }
+}
+ORC_API void orc_render_tangent_colors(const float *normals, size_t npitch, int cols, int rows, uint8_t *image, size_t ipitch)
+{
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const float *n = (const float *)((const char *)normals + (size_t)y * npitch) + 4 * x;
+            uint8_t *o = image + (size_t)y * ipitch + 4 * x;
+            /* (unsigned char)(float): out-of-range and NaN values are undefined in C; the GPU conversion saturates (NaN -> 0) */
+            const float r = (5.f - n[0] * 3.5f) * 25.5f, g = (5.f - n[1] * 2.5f) * 25.5f, b = (5.f - n[2] * 3.5f) * 25.5f;
+            o[0] = (uint8_t)(b != b ? 0.f : fminf(fmaxf(b, 0.f), 255.f)); o[1] = (uint8_t)(g != g ? 0.f : fminf(fmaxf(g, 0.f), 255.f));
+            o[2] = (uint8_t)(r != r ? 0.f : fminf(fmaxf(r, 0.f), 255.f)); o[3] = 0;                  /* :552-573: (b, g, r, 0) */
         }
 }
 

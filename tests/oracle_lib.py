@@ -112,6 +112,13 @@ def lib():
         L.orc_resize_depth_normals.argtypes = [u16p, sz, f32p, sz, C.c_int, C.c_int, u16p, sz, f32p, sz]
         L.orc_resize_points_normals.restype = None
         L.orc_resize_points_normals.argtypes = [f32p, sz, f32p, sz, C.c_int, C.c_int, f32p, sz, f32p, sz]
+        u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+        L.orc_render_points.restype = None
+        L.orc_render_points.argtypes = [f32p, sz, f32p, sz, C.c_int, C.c_int, f32p, u8p, sz]
+        L.orc_render_depth.restype = None
+        L.orc_render_depth.argtypes = [u16p, sz, f32p, sz, C.c_int, C.c_int, f32p, f32p, u8p, sz]
+        L.orc_render_tangent_colors.restype = None
+        L.orc_render_tangent_colors.argtypes = [f32p, sz, C.c_int, C.c_int, u8p, sz]
         L.orc_icp_sums_points.restype = None
         L.orc_icp_sums_points.argtypes = [f32p, sz, f32p, sz, f32p, sz, f32p, sz, C.c_int, C.c_int, f32p, f32p, C.c_float, C.c_float,
                                           f32p, C.POINTER(C.c_int)]
@@ -477,6 +484,27 @@ def resize_points_normals(points, normals):
     lib().orc_resize_points_normals(p.reshape(-1), cols * 16, nrm.reshape(-1), cols * 16, cols, rows, po.reshape(-1), (cols // 2) * 16,
                                     no.reshape(-1), (cols // 2) * 16)
     return po, no
+
+
+def render_points(points, normals, light):
+    p, n = f32(points), f32(normals); rows, cols = p.shape[:2]
+    img = np.zeros((rows, cols, 4), np.uint8)
+    lib().orc_render_points(p.reshape(-1), cols * 16, n.reshape(-1), cols * 16, cols, rows, f32(light), img.reshape(-1), cols * 4)
+    return img
+
+
+def render_depth(depth, normals, intr, light):
+    d, n = _u16(depth), f32(normals); rows, cols = d.shape
+    img = np.zeros((rows, cols, 4), np.uint8)
+    lib().orc_render_depth(d, cols * 2, n.reshape(-1), cols * 16, cols, rows, f32(intr), f32(light), img.reshape(-1), cols * 4)
+    return img
+
+
+def render_tangent_colors(normals):
+    n = f32(normals); rows, cols = n.shape[:2]
+    img = np.zeros((rows, cols, 4), np.uint8)
+    lib().orc_render_tangent_colors(n.reshape(-1), cols * 16, cols, rows, img.reshape(-1), cols * 4)
+    return img
 
 
 def icp_sums(curr, ncurr, prev, nprev, aff, intr, dist2_thres, min_cosine, depth_variant=False):

@@ -115,3 +115,33 @@ def test_icp_depth_variant_and_degenerate_input():
     # argument validation
     assert capi.lib().dfusion_bilateral_filter(z.data_ptr(), 2 * cfg.cols, z.data_ptr(), 2 * cfg.cols, cfg.cols, cfg.rows, 7, 4.5, 0.04, None) == 100001
     assert capi.lib().dfusion_icp_workspace_floats(640, 480) == 27 * 1200
+
+
+def test_render_kernels_match_oracle_and_reference():
+    """dfusion_render_image_points / _depth / _tangent_colors (imgproc.cu:420-583) on a ray-cast of a fused volume: BGRA bytes equal
+    the oracle's, and -- where the prebuilt library travelled -- the reference's own kernels run on the host (oracle/cuda_shim)."""
+    from test_gpu_parity import make_gpu_volume
+    from scene import Scene
+    cfg = synth.Config(64, 1.0, cols=320, rows=240, nodes=0, k=8)
+    sc = Scene(cfg, n_frames=2, with_nodes=False)
+    intr = Intr(*cfg.intr)
+    vol = make_gpu_volume(sc)
+    for f in range(2):
+        vol.integrate(upload_u16(sc.dists[f]), sc.cam_poses[f], intr)
+    pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
+    vol.raycast(sc.cam_poses[1], intr, pts, nrm)
+    dep = torch.empty((cfg.rows, cfg.cols), dtype=torch.int16, device="cuda"); dnrm = torch.empty_like(pts)
+    vol.raycast(sc.cam_poses[1], intr, dep, dnrm)
+    torch.cuda.synchronize()
+    hp, hn, hd, hdn = pts.cpu().numpy(), nrm.cpu().numpy(), dep.cpu().numpy().view(np.uint16), dnrm.cpu().numpy()
+    for light in ((0.0, 0.0, 0.0), (0.4, -0.3, 0.2)):
+        a = frontend.renderImage(pts, nrm, intr, light).cpu().numpy()
+        b = frontend.renderImage(dep, dnrm, intr, light).cpu().numpy()
+        assert np.array_equal(a, O.render_points(hp, hn, light)) and np.array_equal(b, O.render_depth(hd, hdn, sc.intr, light))
+        assert len(np.unique(a[..., 0])) > 30
+        if O.have_refcu():
+            img = np.zeros((cfg.rows, cfg.cols, 4), np.uint8)
+            O.refcu().refcu_render_points(hp.reshape(-1), hn.reshape(-1), cfg.rows, cfg.cols, sc.intr, np.array(light, F32), img.reshape(-1))
+            assert np.array_equal(a, img)
+    t = frontend.renderTangentColors(nrm).cpu().numpy()
+    assert np.array_equal(t, O.render_tangent_colors(hn))

@@ -158,3 +158,21 @@ def test_live_tie_order_against_reference_nanoflann(M, n):
         i1, d1 = O.knn(pos, q, k)
         i2, d2 = O.knn(pos, q, k, use_ref=True)
         assert np.array_equal(i1, i2) and np.array_equal(bits(d1), bits(d2))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/kfusion/src/utils"), reason="reference checkout absent")
+def test_live_warped_integrate_through_reference_classes():
+    """The north-star composition (per-voxel DQB o TSDF update) driven by the reference's own nanoflann / DQB / transform classes
+    (ref_integrate_warped, what bench.py times as cpu_baseline kind "reference") gives the oracle's volume bit for bit."""
+    from dynamicfusion_amd import synth
+    from scene import Scene
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=100, k=8)
+    sc = Scene(cfg, n_frames=2)
+    a, b = sc.new_volume(), sc.new_volume()
+    for f in range(2):
+        n1 = O.integrate_warped(sc.dists[f], a, sc.ovol(a), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)), sc.intr, sc.pos,
+                                sc.dqs[f], sc.sigma, cfg.k)
+        n2, used = O.ref_integrate_warped(sc.dists[f], b, cfg.dims, sc.vs, sc.trunc, cfg.max_weight, synth.aff12(sc.pose),
+                                          synth.aff12(sc.world2cam(f)), sc.intr, sc.pos, sc.dqs[f], sc.sigma, cfg.k, 0, 0, cfg.dims[2])
+        assert n1 == n2 and used >= 1
+    assert np.array_equal(a, b) and (a >> 16).max() == 2

@@ -155,6 +155,29 @@ def test_frontend_kernels_equal_reference():
     assert np.array_equal(bits(po), bits(opo)) and np.array_equal(bits(no2), bits(ono2))
 
 
+@live
+def test_render_kernels_equal_reference():
+    """render_image_kernel (both variants) and tangent_colors_kernel, imgproc.cu:420-583, on a ray-cast of the fused volume."""
+    cfg, sc = make_scene(64, rotated=True)
+    a, _ = fuse_both(sc, 3)
+    args = (sc.ovol(a), synth.aff12(sc.cam2vol(1)), sc.rinv(1))
+    tail = (cfg.cols, cfg.rows, cfg.raycast_step_factor, cfg.gradient_delta_factor)
+    p, n, _, _ = O.raycast_points(*args, sc.reproj, *tail)
+    d, dn = O.raycast_depth(*args, sc.reproj, *tail)
+    R = O.refcu()
+    for light in ((0.0, 0.0, 0.0), (0.3, -0.2, 0.1)):
+        light = np.array(light, F32)
+        img = np.zeros((cfg.rows, cfg.cols, 4), np.uint8)
+        R.refcu_render_points(p.reshape(-1), n.reshape(-1), cfg.rows, cfg.cols, sc.intr, light, img.reshape(-1))
+        assert np.array_equal(img, O.render_points(p, n, light))
+        assert len(np.unique(img[..., 0])) > 20                            # shaded surface + background gradient
+        R.refcu_render_depth(d, dn.reshape(-1), cfg.rows, cfg.cols, sc.intr, light, img.reshape(-1))
+        assert np.array_equal(img, O.render_depth(d, dn, sc.intr, light))
+    img = np.zeros((cfg.rows, cfg.cols, 4), np.uint8)
+    R.refcu_render_tangent_colors(n.reshape(-1), cfg.rows, cfg.cols, img.reshape(-1))
+    assert np.array_equal(img, O.render_tangent_colors(n))
+
+
 # ------------------------------------------------------------------------------------------------ proj_icp.cu
 @live
 @pytest.mark.parametrize("cols,rows", [(160, 120), (64, 48)])
