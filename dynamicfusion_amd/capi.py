@@ -120,6 +120,10 @@ def lib():
     L.dfusion_icp_workspace_floats.argtypes = [C.c_int, C.c_int]
     L.dfusion_icp_sums_points.argtypes = [vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, vp, vp, vp, vp]
     L.dfusion_icp_sums_depth.argtypes = [vp, sz, vp, sz, vp, sz, vp, sz, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, vp, vp, vp, vp]
+    L.dfusion_render_image_points.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, fp, vp, sz, vp]
+    L.dfusion_render_image_depth.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, fp, fp, vp, sz, vp]
+    L.dfusion_render_tangent_colors.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp]
+    L.dfusion_debug_rigid.argtypes = [C.c_int]
     L.dfusion_copy_bandwidth_probe.argtypes = [vp, vp, C.c_size_t, vp]
     L.dfusion_read_bandwidth_probe.argtypes = [vp, C.c_size_t, vp, vp]
     for s in SYMBOLS:
