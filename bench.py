@@ -221,6 +221,7 @@ def main():
     trunc_eff = max(cfg.trunc_dist, 2.1 * vs_z)
     halo = sharded.halo_planes(trunc_eff, cfg.raycast_step_factor, cfg.gradient_delta_factor, vs_z)
     if world > 1:
+        sharded.validate_slabs(Z, world, halo)             # same verdict on every rank, before the first collective
         z_own0, z_own_n = sharded.slab_range(Z, rank, world)
         vol = TsdfVolume(cfg.dims, device=dev, slab=(z_own0, z_own_n, halo))
     else:

@@ -36,6 +36,20 @@ def slab_range(Z, rank, world):
     return lo, hi - lo
 
 
+def validate_slabs(Z, world, halo):
+    """Raise -- identically on every rank, BEFORE any collective is entered -- if the partition cannot work: a rank without planes,
+    or a slab thinner than the halo its neighbour needs from it (exchange_halos would otherwise die inside a collective while the
+    other ranks block in it)."""
+    if world < 1 or world > 255:
+        raise ValueError("world size %d: the merge key carries the rank in 8 bits (1..255 ranks)" % world)
+    for r in range(world):
+        lo, n = slab_range(Z, r, world)
+        if n <= 0:
+            raise ValueError("Z-slab partition of %d planes over %d ranks leaves rank %d without planes" % (Z, world, r))
+        if world > 1 and n < halo:
+            raise ValueError("rank %d owns %d planes, fewer than the %d halo planes its neighbours need" % (r, n, halo))
+
+
 def halo_planes(trunc_dist, step_factor, delta_factor, voxel_z):
     """Planes of the neighbour a slab must hold: the march's `next` sample can be one time_step beyond
     `curr` (tsdf_volume.cu:378-380), trilinear taps read g+1 (:236-243), gradient probes reach

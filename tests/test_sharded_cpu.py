@@ -107,3 +107,17 @@ def test_single_rank_is_a_no_op_path():
     out = sharded.raycast_sharded(lambda: (None, None), None, lambda k, v: (p, p), 0, 1)
     assert out[0] is p
     sharded.exchange_halos(None, 0, 0, 4, 4, 2, 0, 1)
+
+
+def test_validate_slabs_rejects_unworkable_partitions():
+    """A partition that leaves a rank empty or thinner than the halo must raise before any collective."""
+    import pytest
+    from dynamicfusion_amd import sharded
+    sharded.validate_slabs(512, 8, 8)
+    sharded.validate_slabs(64, 2, 8)
+    with pytest.raises(ValueError):
+        sharded.validate_slabs(16, 3, 2)           # slab_range gives rank 2 zero planes
+    with pytest.raises(ValueError):
+        sharded.validate_slabs(64, 8, 13)          # 8 planes per rank < 13 halo planes
+    with pytest.raises(ValueError):
+        sharded.validate_slabs(4096, 256, 1)       # rank does not fit the 8-bit tag
