@@ -55,6 +55,8 @@ HOST_APP = os.path.join(HOST_DIR, "headless_frame")
 HOST_KINFU_APP = os.path.join(HOST_DIR, "kinfu_headless")
 HOST_WARP_TESTS = os.path.join(HOST_DIR, "warp_tests")
 HOST_DEMO_CALLS = os.path.join(HOST_DIR, "demo_calls")
+HOST_ZSLAB_LIB = os.path.join(HOST_DIR, "libkfusion_zslab.so")       # kfusion::cuda::ZSlabComm: the RCCL side of the Z-slab sharding
+HOST_ZSLAB_APP = os.path.join(HOST_DIR, "zslab_frame")
 
 
 def build_host(force=False, verbose=False):
@@ -65,8 +67,10 @@ def build_host(force=False, verbose=False):
     app2 = os.path.join(HOST_DIR, "apps", "kinfu_headless.cpp")
     app3 = os.path.join(HOST_DIR, "apps", "warp_tests.cpp")
     app4 = os.path.join(HOST_DIR, "apps", "demo_calls.cpp")
-    deps = [src, app, app2, app3, app4, LIB_PATH] + [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(HOST_DIR, "include")) for f in fs]
-    outs = (HOST_LIB, HOST_APP, HOST_KINFU_APP, HOST_WARP_TESTS, HOST_DEMO_CALLS)
+    zsrc = os.path.join(HOST_DIR, "src", "zslab_rccl.cpp")
+    app5 = os.path.join(HOST_DIR, "apps", "zslab_frame.cpp")
+    deps = [src, app, app2, app3, app4, zsrc, app5, LIB_PATH] + [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(HOST_DIR, "include")) for f in fs]
+    outs = (HOST_LIB, HOST_APP, HOST_KINFU_APP, HOST_WARP_TESTS, HOST_DEMO_CALLS, HOST_ZSLAB_LIB, HOST_ZSLAB_APP)
     if not force and all(os.path.exists(f) for f in outs) and min(os.path.getmtime(f) for f in outs) >= max(os.path.getmtime(d) for d in deps):
         return HOST_LIB, HOST_APP
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
@@ -77,7 +81,9 @@ def build_host(force=False, verbose=False):
             common + [app, "-o", HOST_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
             common + [app2, "-o", HOST_KINFU_APP, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
             common + [app3, "-o", HOST_WARP_TESTS, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
-            common + [app4, "-o", HOST_DEMO_CALLS, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
+            common + [app4, "-o", HOST_DEMO_CALLS, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
+            common + ["-fPIC", "-shared", zsrc, "-o", HOST_ZSLAB_LIB, "-L", HOST_DIR, "-lkfusion_hip"] + link + ["-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."],
+            common + [app5, "-o", HOST_ZSLAB_APP, "-L", HOST_DIR, "-lkfusion_zslab", "-lkfusion_hip"] + link + ["-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
     for c in cmds:
         if verbose:
             print(" ".join(c))

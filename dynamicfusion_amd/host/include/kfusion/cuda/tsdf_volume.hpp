@@ -9,7 +9,10 @@
 //   * integrate(dists, pose, intr, warp) is an extra overload: the per-voxel warped fusion the reference's surface_fusion is
 //     meant to become;
 //   * surface_fusion has an extra overload taking the warped points on the device;
-//   * getGridOrigin / setGridOrigin are declared but never defined in the reference (:49-50) and are omitted.
+//   * getGridOrigin / setGridOrigin are declared but never defined in the reference (:49-50) and are omitted;
+//   * setSlab(): the volume becomes ONE Z-SLAB SHARD of the dims it was created with (one process per GPU; kfusion/cuda/zslab.hpp
+//     holds the RCCL side).  Every method then works on the owned planes (+ halo planes for the ray-cast), with results identical,
+//     bit for bit, to the corresponding planes / pixels of the unsharded volume.
 #pragma once
 #include <kfusion/types.hpp>
 
@@ -40,6 +43,22 @@ public:
     CudaData data();
     void swap(CudaData& data);
     virtual void clear();
+
+    // ---- Z-slab shard (extension): own planes [z_own0, z_own0 + z_own_n) of the full dims, stored with `halo` more planes on each
+    // side (clipped to the volume).  Reallocates and clears.  setSlab(0, dims.z, 0) is the unsharded volume.
+    void setSlab(int z_own0, int z_own_n, int halo);
+    bool isSlab() const { return has_slab_; }
+    int slabStore0() const { return z_store0_; }
+    int slabStoreN() const { return z_store_n_; }
+    int slabOwn0() const { return z_own0_; }
+    int slabOwnN() const { return z_own_n_; }
+    // the two-stage sharded ray-cast (include/dfusion.h dfusion_raycast_march / _select / _shade): see kfusion/cuda/zslab.hpp
+    // (keys64 / vertex: dense cols x rows arrays; points / normals of the shade: any pitch)
+    void raycastMarch(const Affine3f& camera_pose, const Intr& intr, int cols, int rows, unsigned rank, DeviceArray<unsigned long long>& keys64,
+                      DeviceArray<Point>& vertex) const;
+    static void raycastSelect(const DeviceArray<unsigned long long>& merged_keys64, unsigned rank, DeviceArray<Point>& vertex, int cols, int rows);
+    void raycastShade(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<Point>& vertex,
+                      const DeviceArray<unsigned long long>& merged_keys64, Cloud& points, Normals& normals) const;
 
     // ---- fusion
     virtual void integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr);                        // rigid, tsdf_volume.cpp:110-122
@@ -86,6 +105,8 @@ private:
     mutable std::vector<Normal> normal_host_;
     mutable bool cloud_host_stale_ = false, normal_host_stale_ = false;
     Dists fusion_dists_;                                                   // scratch of surface_fusion
+    bool has_slab_ = false;
+    int z_store0_ = 0, z_store_n_ = 0, z_own0_ = 0, z_own_n_ = 0;
 };
 
 } }

@@ -90,7 +90,7 @@ namespace kfusion
         mutable bool index_ok_;
         mutable const void* index_volume_;
         mutable bool index_tables_ = false;
-        mutable float index_key_[18] = {0};                  // dims, voxel size, pose of the geometry the index was built for
+        mutable float index_key_[20] = {0};                  // dims, voxel size, pose, slab of the geometry the index was built for
         int solver_iters_ = 100;
         float solver_lambda_ = 0.f;
         float last_energy_[2] = {0.f, 0.f};

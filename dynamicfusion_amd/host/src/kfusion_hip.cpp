@@ -102,6 +102,16 @@ static DfVolume c_volume(const TsdfVolume& v)
     return d;
 }
 
+static void raycast_args(const Affine3f& pose, const Affine3f& camera_pose, const Intr& intr, float aff[12], float Rinv[9], float reproj[4]);
+// the slab descriptor of a sharded volume for the C-ABI (null = the whole volume)
+struct SlabArg { DfSlab s; bool on; const DfSlab* ptr() const { return on ? &s : nullptr; } };
+static SlabArg c_slab(const TsdfVolume& v)
+{
+    SlabArg a; a.on = v.isSlab();
+    a.s.z_store0 = v.slabStore0(); a.s.z_store_n = v.slabStoreN(); a.s.z_own0 = v.slabOwn0(); a.s.z_own_n = v.slabOwnN();
+    return a;
+}
+
 TsdfVolume::TsdfVolume(const Vec3i& dims)               // tsdf_volume.cpp:7-17
     : data_(), trunc_dist_(0.03f), max_weight_(128), dims_(dims), size_(Vec3f::all(3.f)), pose_(Affine3f::Identity()),
       gradient_delta_factor_(0.75f), raycast_step_factor_(0.75f)
@@ -113,6 +123,7 @@ TsdfVolume::~TsdfVolume() {}
 void TsdfVolume::create(const Vec3i& dims)              // tsdf_volume.cpp:32-39 (size_t, not int: no overflow at 2048^3)
 {
     dims_ = dims;
+    has_slab_ = false; z_store0_ = 0; z_store_n_ = dims[2]; z_own0_ = 0; z_own_n_ = dims[2];
     const size_t voxels_number = (size_t)dims_[0] * dims_[1] * dims_[2];
     data_.create(voxels_number * sizeof(int));
     setTruncDist(trunc_dist_);
@@ -144,7 +155,42 @@ void TsdfVolume::applyAffine(const Affine3f& affine) { pose_ = affine * pose_; }
 
 void TsdfVolume::clear()                                // :89-102 (without the five leaked heap objects)
 {
-    KF_DF(dfusion_clear(c_volume(*this), nullptr, nullptr));
+    KF_DF(dfusion_clear(c_volume(*this), c_slab(*this).ptr(), nullptr));
+}
+
+void TsdfVolume::setSlab(int z_own0, int z_own_n, int halo)
+{
+    const int Z = dims_[2];
+    if (z_own0 < 0 || z_own_n < 0 || z_own0 + z_own_n > Z || halo < 0) kfusion::cuda::error("setSlab: planes outside the volume", __FILE__, __LINE__, "setSlab");
+    z_own0_ = z_own0; z_own_n_ = z_own_n;
+    z_store0_ = std::max(0, z_own0 - halo);
+    z_store_n_ = std::min(Z, z_own0 + z_own_n + halo) - z_store0_;
+    has_slab_ = true;
+    data_.create((size_t)dims_[0] * dims_[1] * (size_t)std::max(z_store_n_, 1) * sizeof(int));
+    clear();
+}
+
+void TsdfVolume::raycastMarch(const Affine3f& camera_pose, const Intr& intr, int cols, int rows, unsigned rank,
+                              DeviceArray<unsigned long long>& keys64, DeviceArray<Point>& vertex) const
+{
+    float aff[12], Rinv[9], reproj[4];
+    raycast_args(pose_, camera_pose, intr, aff, Rinv, reproj);
+    keys64.create((size_t)cols * rows); vertex.create((size_t)cols * rows);
+    KF_DF(dfusion_raycast_march(c_volume(*this), c_slab(*this).ptr(), aff, reproj, cols, rows, raycast_step_factor_, rank, keys64.ptr(),
+                                (float*)vertex.ptr(), nullptr));
+}
+void TsdfVolume::raycastSelect(const DeviceArray<unsigned long long>& merged_keys64, unsigned rank, DeviceArray<Point>& vertex, int cols, int rows)
+{
+    KF_DF(dfusion_raycast_select(merged_keys64.ptr(), rank, (float*)vertex.ptr(), cols, rows, nullptr));
+}
+void TsdfVolume::raycastShade(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<Point>& vertex,
+                              const DeviceArray<unsigned long long>& merged_keys64, Cloud& points, Normals& normals) const
+{
+    float aff[12], Rinv[9], reproj[4];
+    raycast_args(pose_, camera_pose, intr, aff, Rinv, reproj);
+    KF_DF(dfusion_raycast_shade(c_volume(*this), c_slab(*this).ptr(), aff, Rinv, reproj, (const float*)vertex.ptr(), merged_keys64.ptr(),
+                                (float*)points.ptr(), points.step(), (float*)normals.ptr(), normals.step(), points.cols(), points.rows(),
+                                gradient_delta_factor_, nullptr));
 }
 
 void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr)   // :110-122
@@ -152,7 +198,7 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, cons
     const Affine3f vol2cam = camera_pose.inv() * pose_;
     float aff[12]; affine_to_aff12(vol2cam, aff);
     const float proj[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
-    KF_DF(dfusion_integrate(dists.ptr(), dists.step(), dists.cols(), dists.rows(), c_volume(*this), nullptr, aff, proj, nullptr, nullptr));
+    KF_DF(dfusion_integrate(dists.ptr(), dists.step(), dists.cols(), dists.rows(), c_volume(*this), c_slab(*this).ptr(), aff, proj, nullptr, nullptr));
     KF_HIP(hipDeviceSynchronize());                     // device::integrate ends with cudaDeviceSynchronize (tsdf_volume.cu:160)
 }
 
@@ -163,7 +209,7 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, cons
     affine_to_aff12(pose_, v2w);
     affine_to_aff12(camera_pose.inv() * warp.getWarpToLive(), w2c);
     const float proj[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
-    KF_DF(dfusion_integrate_warped(dists.ptr(), dists.step(), dists.cols(), dists.rows(), c_volume(*this), nullptr, v2w, w2c, proj,
+    KF_DF(dfusion_integrate_warped(dists.ptr(), dists.step(), dists.cols(), dists.rows(), c_volume(*this), c_slab(*this).ptr(), v2w, w2c, proj,
                                    warp.handle(), warp.k(), 0u, nullptr, nullptr));
     KF_HIP(hipDeviceSynchronize());
 }
@@ -181,7 +227,7 @@ void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Depth& d
 {
     float aff[12], Rinv[9], reproj[4];
     raycast_args(pose_, camera_pose, intr, aff, Rinv, reproj);
-    KF_DF(dfusion_raycast_depth(c_volume(*this), nullptr, aff, Rinv, reproj, depth.ptr(), depth.step(), (float*)normals.ptr(),
+    KF_DF(dfusion_raycast_depth(c_volume(*this), c_slab(*this).ptr(), aff, Rinv, reproj, depth.ptr(), depth.step(), (float*)normals.ptr(),
                                 normals.step(), depth.cols(), depth.rows(), raycast_step_factor_, gradient_delta_factor_, nullptr));
 }
 
@@ -189,7 +235,7 @@ void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Cloud& p
 {
     float aff[12], Rinv[9], reproj[4];
     raycast_args(pose_, camera_pose, intr, aff, Rinv, reproj);
-    KF_DF(dfusion_raycast_points(c_volume(*this), nullptr, aff, Rinv, reproj, (float*)points.ptr(), points.step(), (float*)normals.ptr(),
+    KF_DF(dfusion_raycast_points(c_volume(*this), c_slab(*this).ptr(), aff, Rinv, reproj, (float*)points.ptr(), points.step(), (float*)normals.ptr(),
                                  normals.step(), points.cols(), points.rows(), raycast_step_factor_, gradient_delta_factor_, nullptr,
                                  nullptr));
 }
@@ -203,7 +249,7 @@ DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>& cloud_buffer) cons
     if (extract_count_.empty()) extract_count_.create(1);                   // (a hipMalloc + hipFree per frame otherwise: ~0.1 ms)
     DeviceArray<unsigned long long>& count = extract_count_;
     KF_HIP(hipMemset(count.ptr(), 0, sizeof(unsigned long long)));
-    KF_DF(dfusion_extract_cloud(c_volume(*this), nullptr, aff, (float*)cloud_buffer.ptr(), cloud_buffer.size(), count.ptr(), nullptr));
+    KF_DF(dfusion_extract_cloud(c_volume(*this), c_slab(*this).ptr(), aff, (float*)cloud_buffer.ptr(), cloud_buffer.size(), count.ptr(), nullptr));
     unsigned long long n = 0;
     count.download(&n);                                                     // cudaMemcpyFromSymbol(output_count), tsdf_volume.cu:815
     if (n > cloud_buffer.size()) n = cloud_buffer.size();
@@ -216,7 +262,7 @@ void TsdfVolume::fetchNormals(const DeviceArray<Point>& cloud, DeviceArray<Norma
     if (!cloud.size()) return;
     float aff[12]; affine_to_aff12(pose_, aff);
     const Mat3f ri = pose_.rotation().inv();                                // :214 inv(DECOMP_SVD)
-    KF_DF(dfusion_extract_normals(c_volume(*this), nullptr, aff, ri.val, (const float*)cloud.ptr(), cloud.size(), gradient_delta_factor_,
+    KF_DF(dfusion_extract_normals(c_volume(*this), c_slab(*this).ptr(), aff, ri.val, (const float*)cloud.ptr(), cloud.size(), gradient_delta_factor_,
                                   (float*)normals.ptr(), nullptr));
 }
 
@@ -234,7 +280,7 @@ void TsdfVolume::compute_normals()
     if (cloud_.size()) {
         float aff[12]; affine_to_aff12(pose_, aff);
         const Mat3f ri = pose_.rotation().inv();                            // :214 inv(DECOMP_SVD)
-        KF_DF(dfusion_extract_normals(c_volume(*this), nullptr, aff, ri.val, (const float*)cloud_.ptr(), cloud_.size(), gradient_delta_factor_,
+        KF_DF(dfusion_extract_normals(c_volume(*this), c_slab(*this).ptr(), aff, ri.val, (const float*)cloud_.ptr(), cloud_.size(), gradient_delta_factor_,
                                       (float*)normal_buffer_.ptr(), nullptr));
     }
     normal_host_stale_ = true;
@@ -408,12 +454,13 @@ void WarpField::ensureIndex(const cuda::TsdfVolume& volume, bool tables) const
     // on the same TsdfVolume must rebuild it (dfusion_integrate_warped would refuse the stale one with DF_E_NO_INDEX)
     float v2w[12]; affine_to_aff12(volume.getPose(), v2w);
     const Vec3i d = volume.getDims(); const Vec3f vs = volume.getVoxelSize();
-    float key[18] = {(float)d[0], (float)d[1], (float)d[2], vs[0], vs[1], vs[2]};
+    float key[20] = {(float)d[0], (float)d[1], (float)d[2], vs[0], vs[1], vs[2]};
     std::memcpy(key + 6, v2w, sizeof(v2w));
+    key[18] = (float)volume.slabOwn0(); key[19] = volume.isSlab() ? (float)volume.slabOwnN() : -1.f;
     const bool same = index_ok_ && index_volume_ == &volume && std::memcmp(key, index_key_, sizeof(key)) == 0;
     if (same && (index_tables_ || !tables)) return;
     std::memcpy(index_key_, key, sizeof(key));
-    KF_DF(dfusion_warp_build_index(handle_, c_volume(volume), nullptr, v2w, k_, tables ? (DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE) : 0u, nullptr));
+    KF_DF(dfusion_warp_build_index(handle_, c_volume(volume), c_slab(volume).ptr(), v2w, k_, tables ? (DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE) : 0u, nullptr));
     index_ok_ = true; index_volume_ = &volume; index_tables_ = tables;
 }
 

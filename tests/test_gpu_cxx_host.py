@@ -257,6 +257,41 @@ def test_cxx_demo_calls_render_and_warp_cloud(tmp_path):
     assert os.path.getsize(prefix + ".ppm") > cfg.rows * 2 * cfg.cols * 3
 
 
+@pytest.mark.parametrize("with_nodes", [False, True], ids=["rigid", "warped"])
+def test_cxx_zslab_rccl_path(tmp_path, with_nodes):
+    """kfusion::cuda::ZSlabComm + TsdfVolume::setSlab (host/src/zslab_rccl.cpp, host/apps/zslab_frame.cpp): the C++ side of the Z-slab
+    sharding.  One GPU here, so (i) the whole frame with a real RCCL communicator of ONE rank (broadcast, the two-stage ray-cast's
+    all-reduces and reduce with nranks = 1) must give the unsharded harness's bytes, and (ii) every shard of a 4-way partition,
+    integrated alone through the C++ slab path, must give its planes of the unsharded volume.  (N > 1 needs N GPUs: RCCL refuses two
+    ranks on one device; the collective sequence is the one of dynamicfusion_amd/sharded.py, which the gloo tests run at N = 2, 3.)"""
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=100, k=8)
+    frames = 2
+    sc = Scene(cfg, n_frames=frames)
+    vol, pts, nrm, _, _ = run_harness(tmp_path, cfg, sc, frames, with_nodes)
+    build.build_host()
+    fin = str(tmp_path / "in.bin")                                         # written by run_harness
+    M = cfg.nodes if with_nodes else 0
+    base = [build.HOST_ZSLAB_APP, str(cfg.dims[0]), str(cfg.size), str(cfg.cols), str(cfg.rows), str(frames), str(M), str(cfg.k), fin]
+    nv, npx = int(np.prod(cfg.dims)), cfg.rows * cfg.cols
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    for mode in ("exchange", "recompute"):
+        fout, idf = str(tmp_path / ("z_%s.bin" % mode)), str(tmp_path / ("id_%s" % mode))
+        r = subprocess.run(base + [fout, idf, mode], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "zslab_frame ok" in r.stdout, r.stdout + r.stderr
+        raw = np.fromfile(fout, np.uint8)
+        img = raw[:2 * npx * 16].view(np.float32).reshape(2, cfg.rows, cfg.cols, 4)
+        zvol = raw[2 * npx * 16:].view(np.uint32).reshape(cfg.dims[2], cfg.dims[1], cfg.dims[0])
+        assert np.array_equal(zvol, vol)
+        assert np.array_equal(img[0].view(np.uint32), pts.view(np.uint32)) and np.array_equal(img[1].view(np.uint32), nrm.view(np.uint32))
+    for r_ in range(4):
+        fout = str(tmp_path / ("slab%d.bin" % r_))
+        r = subprocess.run(base + [fout, str(tmp_path / "unused_id"), "exchange", "slab=%d/4" % r_], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        planes = np.fromfile(fout, np.uint8)[2 * npx * 16:].view(np.uint32).reshape(-1, cfg.dims[1], cfg.dims[0])
+        z0 = r_ * cfg.dims[2] // 4
+        assert planes.shape[0] == cfg.dims[2] // 4 and np.array_equal(planes, vol[z0:z0 + cfg.dims[2] // 4])
+
+
 def test_cxx_reference_warp_test_suites():
     """The reference's own solver tests (tests/ceres_warp_test.cpp, tests/warp_test.cpp) compiled against the C++ mirror: same
     WarpField calls and inputs, same 1e-3 bound (WarpAndReverseTest: the data term's least-squares optimum, see the source)."""
