@@ -456,6 +456,12 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "n_updated_per_launch": n_upd_launch,
                          "n_updated_all_ranks": n_upd_total, "measured_copy_GBps": copy_gbps,
                          "knn_cache_bytes": table_bytes,
+                         # the same achieved rate against the copy rate measured on this box, what the kernel really moves per
+                         # launch (PMC) against the algorithmic bytes, and the rate of that real traffic -- the sweep's actual HBM load
+                         "frac_of_measured_copy": (achieved / copy_gbps) if copy_gbps else None,
+                         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                         "traffic_GBps": (traffic / (ms_int * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac_of_measured_copy": (traffic / (ms_int * 1e-3) / 1e9 / copy_gbps) if (traffic and copy_gbps) else None,
                          "note": "achieved = SURVEY 8(d) algorithmic bytes (8*N_upd + 2*W*H + 48*M) / HIP-event time; the sweep "
                                  "also streams its per-voxel k-NN + weight cache (48 B/voxel at k=8), see DESIGN.md"},
         }
