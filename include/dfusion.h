@@ -19,9 +19,12 @@
  *     filled by device_cast, kfusion/src/precomp.hpp:19-28).
  *   - kernels are enqueued on `stream` and NOT synchronised (the reference's integrate ends in
  *     cudaDeviceSynchronize, tsdf_volume.cu:160; the C++ wrapper restores that behaviour).
- *   - no global state: any number of volumes / warp fields / streams may be used concurrently
+ *   - no global state: any number of volumes and warp fields may be used concurrently, each from its own stream
  *     (the reference is not re-entrant: global texture ref tsdf_volume.cu:50, host globals
- *     warp_field.cpp:11-15).
+ *     warp_field.cpp:11-15).  ONE warp-field handle, though, is single-stream: its calls rewrite
+ *     scratch it owns (the point queries' fallback list, the solver workspace, the cull's device
+ *     scalars), so calls on the same DfWarpField must be issued on one stream or serialised by the
+ *     caller.  (dfusion_debug_rigid is a process-wide validation switch, off the product path.)
  */
 #ifndef DFUSION_H
 #define DFUSION_H
