@@ -1,0 +1,67 @@
+// Max-pyramid of a frame's dists image: what the integrate kernels' behind-the-surface tests query.  Built by
+// df_build_dists_pyramid (dfusion_volume.hip) on the caller's stream; queried on the device with df_pyramid_max.
+#pragma once
+#include "dfusion_internal.h"
+
+// Per frame, for the sweeps' behind-the-surface tests: level l holds, per 2^l x 2^l pixel block, the maximum of the
+// dists HALF BITS taken as unsigned integers.  For non-negative finite halves that is the maximum ray length; negative values,
+// infinities and NaNs order ABOVE every finite length (sign / exponent bits), so a block containing one can never be culled --
+// the conservative direction.  Level 0 is the image itself.
+#define DF_PYR_MAX_LEVELS 14
+struct DfDistsPyramid {
+    const uint16_t* dists; size_t pitch; int cols, rows;
+    const uint16_t* mem;                     // levels 1..top, dense, level l at off[l] with width w[l]
+    int off[DF_PYR_MAX_LEVELS], w[DF_PYR_MAX_LEVELS], h[DF_PYR_MAX_LEVELS];
+    int top;                                 // coarsest level (1 x 1); 0 = no pyramid (test disabled)
+};
+
+
+// Builds levels 1..top into `mem` (df_pyramid_elems(cols, rows) uint16 entries) on `st`; out->top == 0 when the image is too small
+// (< 32 px) or too large for a pyramid: the callers then run without the test.
+int df_build_dists_pyramid(const uint16_t* dists, size_t pitch, int cols, int rows, uint16_t* mem, size_t mem_elems,
+                           DfDistsPyramid* out, hipStream_t st);
+size_t df_pyramid_elems(int cols, int rows);
+
+// max of the dists half bits over the pixel rectangle [u0, u1] x [v0, v1] (inclusive, inside the image) or a superset of it:
+// the coarsest level at which the rectangle spans at most 2 x 2 texels
+__device__ __forceinline__ uint32_t df_pyramid_max(const DfDistsPyramid& P, int u0, int v0, int u1, int v1)
+{
+    const int ext = max(u1 - u0, v1 - v0);
+    int L = ext == 0 ? 0 : 32 - __clz(ext);
+    L = min(L, P.top);
+    const int a0 = u0 >> L, a1 = u1 >> L, b0 = v0 >> L, b1 = v1 >> L;
+    if (L == 0) {
+        const uint16_t* r0 = (const uint16_t*)((const char*)P.dists + (size_t)b0 * P.pitch);
+        const uint16_t* r1 = (const uint16_t*)((const char*)P.dists + (size_t)b1 * P.pitch);
+        return max(max((uint32_t)r0[a0], (uint32_t)r0[a1]), max((uint32_t)r1[a0], (uint32_t)r1[a1]));
+    }
+    const uint16_t* lv = P.mem + P.off[L];
+    const int w = P.w[L];
+    uint32_t m = 0;
+    for (int b = b0; b <= b1; ++b)                       // (at the top level the rectangle may still span more than 2 x 2)
+        for (int a = a0; a <= a1; ++a) m = max(m, (uint32_t)lv[b * w + a]);
+    return m;
+}
+
+// The same over a finer cover: `shift` levels below the 2 x 2 one, at most (2^(shift+1) + 1)^2 texels -- for wide rectangles, where
+// the 2 x 2 cover takes in up to three times the rectangle's extent on each axis
+__device__ __forceinline__ uint32_t df_pyramid_max_fine(const DfDistsPyramid& P, int u0, int v0, int u1, int v1, int shift)
+{
+    const int ext = max(u1 - u0, v1 - v0);
+    int L = ext == 0 ? 0 : 32 - __clz(ext);
+    L = min(max(L - shift, 0), P.top);
+    const int a0 = u0 >> L, a1 = u1 >> L, b0 = v0 >> L, b1 = v1 >> L;
+    uint32_t m = 0;
+    if (L == 0) {
+        for (int b = b0; b <= b1; ++b) {
+            const uint16_t* r = (const uint16_t*)((const char*)P.dists + (size_t)b * P.pitch);
+            for (int a = a0; a <= a1; ++a) m = max(m, (uint32_t)r[a]);
+        }
+        return m;
+    }
+    const uint16_t* lv = P.mem + P.off[L];
+    const int w = P.w[L];
+    for (int b = b0; b <= b1; ++b)
+        for (int a = a0; a <= a1; ++a) m = max(m, (uint32_t)lv[b * w + a]);
+    return m;
+}

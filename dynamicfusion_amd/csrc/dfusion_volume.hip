@@ -14,6 +14,7 @@
 //   * Voxels are read/written only when their update branch is taken (tsdf_volume.cu:91), exactly
 //     the traffic the algorithmic-bytes figure 8*N_upd counts.
 #include "dfusion_internal.h"
+#include "dfusion_pyramid.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -161,19 +162,7 @@ extern "C" int dfusion_project_and_remove(const uint16_t* dists_in, size_t in_pi
     return DF_OK;
 }
 
-// ------------------------------------------------------------------------------------------ max-pyramid of the dists image
-// Per frame, for the rigid sweep's behind-the-surface test: level l holds, per 2^l x 2^l pixel block, the maximum of the
-// dists HALF BITS taken as unsigned integers.  For non-negative finite halves that is the maximum ray length; negative values,
-// infinities and NaNs order ABOVE every finite length (sign / exponent bits), so a block containing one can never be culled --
-// the conservative direction.  Level 0 is the image itself.
-#define DF_PYR_MAX_LEVELS 14
-struct DfDistsPyramid {
-    const uint16_t* dists; size_t pitch; int cols, rows;
-    const uint16_t* mem;                     // levels 1..top, dense, level l at off[l] with width w[l]
-    int off[DF_PYR_MAX_LEVELS], w[DF_PYR_MAX_LEVELS], h[DF_PYR_MAX_LEVELS];
-    int top;                                 // coarsest level (1 x 1); 0 = no pyramid (test disabled)
-};
-
+// ------------------------------------------------------------------------------------------ max-pyramid of the dists image (dfusion_pyramid.h)
 // levels 1..5 of one 32 x 32 pixel tile per workgroup
 __global__ __launch_bounds__(256) void df_pyramid_tiles_kernel(const DfDistsPyramid P, uint16_t* __restrict__ out)
 {
@@ -240,27 +229,6 @@ __global__ __launch_bounds__(256) void df_pyramid_top_kernel(const DfDistsPyrami
         pw = w; ph = h;
     }
 }
-// max of the dists half bits over the pixel rectangle [u0, u1] x [v0, v1] (inclusive, inside the image) or a superset of it:
-// the coarsest level at which the rectangle spans at most 2 x 2 texels
-__device__ __forceinline__ uint32_t df_pyramid_max(const DfDistsPyramid& P, int u0, int v0, int u1, int v1)
-{
-    const int ext = max(u1 - u0, v1 - v0);
-    int L = ext == 0 ? 0 : 32 - __clz(ext);
-    L = min(L, P.top);
-    const int a0 = u0 >> L, a1 = u1 >> L, b0 = v0 >> L, b1 = v1 >> L;
-    if (L == 0) {
-        const uint16_t* r0 = (const uint16_t*)((const char*)P.dists + (size_t)b0 * P.pitch);
-        const uint16_t* r1 = (const uint16_t*)((const char*)P.dists + (size_t)b1 * P.pitch);
-        return max(max((uint32_t)r0[a0], (uint32_t)r0[a1]), max((uint32_t)r1[a0], (uint32_t)r1[a1]));
-    }
-    const uint16_t* lv = P.mem + P.off[L];
-    const int w = P.w[L];
-    uint32_t m = 0;
-    for (int b = b0; b <= b1; ++b)                       // (at the top level the rectangle may still span more than 2 x 2)
-        for (int a = a0; a <= a1; ++a) m = max(m, (uint32_t)lv[b * w + a]);
-    return m;
-}
-
 // ------------------------------------------------------------------------------------------ integrate (rigid)
 static bool g_df_rigid_no_depth_cull = false, g_df_rigid_no_fast_forms = false;
 // bit 0: behind-the-surface test, bit 1: short arithmetic forms (default 3 = both on; validation switches, results must not change)
@@ -414,7 +382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 // the dists max-pyramid of one frame into `mem` (levels 1..top); returns the descriptor
-static int df_build_dists_pyramid(const uint16_t* dists, size_t pitch, int cols, int rows, uint16_t* mem, size_t mem_elems,
+int df_build_dists_pyramid(const uint16_t* dists, size_t pitch, int cols, int rows, uint16_t* mem, size_t mem_elems,
                                   DfDistsPyramid* out, hipStream_t st)
 {
     DfDistsPyramid P;
@@ -439,7 +407,7 @@ static int df_build_dists_pyramid(const uint16_t* dists, size_t pitch, int cols,
     *out = P;
     return DF_OK;
 }
-static size_t df_pyramid_elems(int cols, int rows)
+size_t df_pyramid_elems(int cols, int rows)
 {
     size_t n = 0;
     for (int l = 1; l < DF_PYR_MAX_LEVELS; ++l) {

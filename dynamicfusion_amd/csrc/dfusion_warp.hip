@@ -17,6 +17,7 @@
 //     staged in LDS once per brick and read back with broadcast ds_read_b128; each lane keeps the
 //     running top-k of its voxel in registers.
 #include "dfusion_internal.h"
+#include "dfusion_pyramid.h"
 #include <stdlib.h>
 #include <math.h>
 
@@ -86,7 +87,7 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
     (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids); (void)hipFree(wf->tile_wmax);
-    (void)hipFree(wf->nf_nodes); (void)hipFree(wf->nf_vpos);
+    (void)hipFree(wf->nf_nodes); (void)hipFree(wf->nf_vpos); (void)hipFree(wf->pyr_mem);
     free(wf);
     return DF_OK;
 }
@@ -809,6 +810,8 @@ struct DfWarpedArgs {
     float kf;                      // (float)k
     float tile_r;                  // half diagonal of a work tile's voxel-centre lattice (world metres), inflated
     float cam_scale;               // >= operator norm of world2cam.R (1 for a rigid pose), inflated
+    float origin_cam;              // |world2cam.t| = distance of the WORLD ORIGIN from the camera centre when world2cam is rigid, else < 0
+    DfDistsPyramid py;             // max-pyramid of this frame's dists (py.top == 0: only the image-wide maximum cull[2] is available)
     // per-voxel tables over planes [tab_z0, tab_z0 + tab_zn), TILE-MAJOR (private layout, see df_tab_index): the
     // 32x16x8 voxels a sweep workgroup owns are contiguous, so it streams 8 KiB (k-NN) + 2 x 8 KiB (weights) runs per plane:
     //   knn_tab  K uint16 node indices per voxel, ascending distance (16 B/voxel at K = 8: one dwordx4 per lane)
@@ -906,20 +909,31 @@ __device__ __forceinline__ void w_tab_load(const float* tab, size_t nvox, size_t
 // of its canonical one: the blend of unit quaternions with w >= 0 and weights >= 0 rotates (about the origin) by at
 // most theta_max, and |T| = |sum w_i t_i| <= k max|t_i| because w_i = exp(-..) <= 1.  So its camera-frame position
 // lies within rho = cam_scale*(tile_r + delta) of cc = world2cam * c.  No voxel of the tile can update if that ball
-// is entirely behind the camera, entirely outside one image-frustum side plane, or entirely farther than
-// max_dist + trunc from the camera centre.
+// is entirely behind the camera, entirely outside one image-frustum side plane, or entirely farther from the camera centre than
+// (the largest dists value it can meet) + trunc.
+// The DISTANCE from the camera centre moves much less than the position: the blend rotates about the world origin, which is
+// origin_cam from the camera centre, so |R x - o| = |x - R^T o| differs from |x - o| by at most 2 sin(theta_max/2) |o| -- not
+// (|c| + tile_r) -- and the distance of every warped voxel is at least |cc| - rho_r,
+//   rho_r = tile_r + 2 sin(theta_max/2) * origin_cam + k * max|t_i|        (rigid world2cam; rho otherwise).
+// "The largest dists value it can meet" is the maximum over the pixel rectangle the ball projects into (max-pyramid of the frame's
+// dists, dfusion_pyramid.h), or over the whole image where there is no pyramid or the ball reaches the camera plane.
 // wk >= sum_i w_i of every voxel of the tile: (float)k always (w_i <= 1), the table build's per-tile bound where there is one
 __device__ __forceinline__ bool df_tile_culled(const DfWarpedArgs& a, f3 c, float wk)
 {
-    const float max_t = a.cull[0], sin_half = a.cull[1], max_dist = a.cull[2];
+    const float max_t = a.cull[0], sin_half = a.cull[1];
     if (!(sin_half <= 1.0f && max_t < 1.0e30f)) return false;
+    float max_dist;                                                              // image-wide: the pyramid's top texel, or df_dists_max_kernel's result
+    if (a.py.top != 0) { const uint32_t tb = a.py.mem[a.py.off[a.py.top]]; max_dist = tb < 0x7c00u ? h2f_bits((uint16_t)tb) : 3.0e38f; }
+    else max_dist = a.cull[2];
     const float cn = sqrtf(dot3(c, c));
     const float delta = 2.f * sin_half * (cn + a.tile_r) + wk * max_t;
     const float rho = a.cam_scale * (a.tile_r + delta) * 1.002f + 1e-3f;
+    const float rho_r = a.origin_cam >= 0.f ? fminf(rho, (a.tile_r + 2.f * sin_half * a.origin_cam + wk * max_t) * 1.002f + 1e-3f) : rho;   // (both bounds hold)
     const f3 cc = aff_mul(a.world2cam, c);
+    const float rmin = sqrtf(dot3(cc, cc)) - rho_r;                              // no warped voxel of the tile is nearer to the camera centre
     bool out = false;
     if (cc.z + rho <= 0.f) out = true;                                           // behind the camera
-    if (sqrtf(dot3(cc, cc)) - rho > max_dist * 1.002f + a.P.trunc) out = true;   // sdf < -trunc everywhere
+    if (rmin > max_dist * 1.002f + a.P.trunc) out = true;                        // sdf < -trunc everywhere
     // side planes through the camera centre: u >= 0 <=> fx*x + cx*z >= 0 ; u < cols <=> -fx*x + (cols-cx)*z > 0
     const float nl = sqrtf(a.P.fx * a.P.fx + a.P.cx * a.P.cx);
     if ((a.P.fx * cc.x + a.P.cx * cc.z) / nl < -rho) out = true;
@@ -931,6 +945,25 @@ __device__ __forceinline__ bool df_tile_culled(const DfWarpedArgs& a, f3 c, floa
     const float cb = (float)a.P.rows - a.P.cy;
     const float nbt = sqrtf(a.P.fy * a.P.fy + cb * cb);
     if ((-a.P.fy * cc.y + cb * cc.z) / nbt < -rho) out = true;
+    // the pixels the ball can project to: the box [cc - rho, cc + rho] over the depths [zl, zh], two pixels of margin for the
+    // rounding of the projection and of the pixel pick (device.hpp:35-37)
+    const float zl = cc.z - rho, zh = cc.z + rho;
+    if (!out && a.py.top != 0 && zl > 0.05f) {
+        const float il = 1.f / zl, ih = 1.f / zh;
+        const float xl = cc.x - rho, xh = cc.x + rho, yl = cc.y - rho, yh = cc.y + rho;
+        const float ulo = a.P.fx * fminf(xl * il, xl * ih) + a.P.cx - 2.f, uhi = a.P.fx * fmaxf(xh * il, xh * ih) + a.P.cx + 2.f;
+        const float vlo = a.P.fy * fminf(yl * il, yl * ih) + a.P.cy - 2.f, vhi = a.P.fy * fmaxf(yh * il, yh * ih) + a.P.cy + 2.f;
+        if (ulo == ulo && uhi == uhi && vlo == vlo && vhi == vhi) {
+            if (uhi < 0.f || vhi < 0.f || ulo > (float)(a.P.cols - 1) || vlo > (float)(a.P.rows - 1)) out = true;   // projects outside the image
+            else {
+                const int iu0 = (int)fmaxf(ulo, 0.f), iv0 = (int)fmaxf(vlo, 0.f);
+                const int iu1 = (int)fminf(uhi, (float)(a.P.cols - 1)), iv1 = (int)fminf(vhi, (float)(a.P.rows - 1));
+                const uint32_t dbits = df_pyramid_max_fine(a.py, iu0, iv0, iu1, iv1, 2);        // <= 5 x 5 texels
+                if (dbits == 0u) out = true;                                     // no valid depth anywhere it can project to (Dp == 0, :86)
+                else if (dbits < 0x7c00u && rmin > h2f_bits((uint16_t)dbits) * 1.002f + a.P.trunc) out = true;   // finite non-negative lengths only
+            }
+        }
+    }
     return out;
 }
 
@@ -1125,16 +1158,25 @@ __global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArg
     const size_t plane = (size_t)a.X * a.Y;
     const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
     unsigned int my_upd = 0;
-    for (int l = 0; l < DF_LDS_ZT; ++l) {
-        const int zt = a.bz0 + blockIdx.y * DF_LDS_ZT + l;                // tile layer (DF_ROW_TZ planes)
-        const int zb = max(zt * DF_ROW_TZ, a.z_own0), ze = min(min((zt + 1) * DF_ROW_TZ, a.z_own0 + a.z_own_n), a.Z);
-        if (zb >= ze) continue;
-        if (a.cull) {
+    // the verdicts of the workgroup's layers first (lane l judges layer l, a ballot collects them): what the test needs is then
+    // dead before the sweep starts
+    unsigned alive;
+    {
+        const int l = threadIdx.x & 7;
+        const int zt = a.bz0 + blockIdx.y * DF_LDS_ZT + l;
+        bool keep = max(zt * DF_ROW_TZ, a.z_own0) < min(min((zt + 1) * DF_ROW_TZ, a.z_own0 + a.z_own_n), a.Z);
+        if (keep && a.cull) {
             const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX) + 0.5f * (DF_ROW_TX - 1)) * a.vsx,
                                                   ((float)(ty * DF_LDS_TY) + 0.5f * (DF_LDS_TY - 1)) * a.vsy,
                                                   ((float)(zt * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
-            if (df_tile_culled(a, c, a.kf)) continue;                           // block-uniform
+            keep = !df_tile_culled(a, c, a.kf);
         }
+        alive = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)__builtin_amdgcn_ballot_w64(keep) & 0xffu));   // block-uniform
+    }
+    for (int l = 0; l < DF_LDS_ZT; ++l) {
+        if (!((alive >> l) & 1u)) continue;
+        const int zt = a.bz0 + blockIdx.y * DF_LDS_ZT + l;                // tile layer (DF_ROW_TZ planes)
+        const int zb = max(zt * DF_ROW_TZ, a.z_own0), ze = min(min((zt + 1) * DF_ROW_TZ, a.z_own0 + a.z_own_n), a.Z);
         if (!in_xy) continue;
         // NB planes per batch: all table loads of the batch are issued back to back (NB * 3 KiB in flight per wave),
         // then the NB voxels are blended one after the other -- memory-level parallelism without more waves.
@@ -1550,7 +1592,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     a.P.fx = proj[0]; a.P.fy = proj[1]; a.P.cx = proj[2]; a.P.cy = proj[3];
     a.P.trunc = v.trunc_dist; a.P.trunc_inv = 1.f / v.trunc_dist; a.P.max_weight = v.max_weight;
     a.n_upd = n_updated;
-    a.kf = (float)k; a.cam_scale = 1.f;
+    a.kf = (float)k; a.cam_scale = 1.f; a.origin_cam = -1.f;
     const bool use_tab = wf->tab_valid && wf->tab_k == k && !(flags & DF_WARP_NO_TABLE) && s.z_own0 >= wf->tab_z0 &&
                          s.z_own0 + s.z_own_n <= wf->tab_z0 + wf->tab_zn;
     const bool use_w = use_tab && wf->w_tab_valid && !(flags & DF_WARP_NO_WEIGHT_TABLE);
@@ -1562,9 +1604,32 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     if (use_w) a.w_tab = wf->w_tab;
 
     if (!(flags & DF_WARP_NO_CULL) && proj[0] > 0.f && proj[1] > 0.f) {
-        DF_HIP(hipMemsetAsync(wf->bounds_dev + 2, 0, sizeof(float), st));
-        hipLaunchKernelGGL(df_dists_max_kernel, dim3(64), dim3(256), 0, st, dists, pitch, cols, rows, wf->bounds_dev + 2);
-        DF_LAUNCH_CHECK();
+        if (!(flags & DF_WARP_NO_DEPTH_PYRAMID)) {
+            const size_t elems = df_pyramid_elems(cols, rows);
+            if (elems > wf->pyr_cap) {
+                (void)hipFree(wf->pyr_mem); wf->pyr_mem = nullptr; wf->pyr_cap = 0;
+                DF_HIP(hipMalloc((void**)&wf->pyr_mem, elems * sizeof(uint16_t)));
+                wf->pyr_cap = elems;
+            }
+            int rc = df_build_dists_pyramid(dists, pitch, cols, rows, wf->pyr_mem, wf->pyr_cap, &a.py, st);
+            if (rc) return rc;
+        }
+        if (a.py.top == 0) {                                      // no pyramid (switched off, or an image under 32 px): the image-wide maximum alone
+            DF_HIP(hipMemsetAsync(wf->bounds_dev + 2, 0, sizeof(float), st));
+            hipLaunchKernelGGL(df_dists_max_kernel, dim3(64), dim3(256), 0, st, dists, pitch, cols, rows, wf->bounds_dev + 2);
+            DF_LAUNCH_CHECK();
+        }
+        {   // world2cam rigid (R^T R = I to 1e-5)?  Then the distance bound of df_tile_culled holds with |world2cam.t|.
+            bool rigid = true;
+            for (int i = 0; i < 3 && rigid; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double d = 0.0;
+                    for (int r = 0; r < 3; ++r) d += (double)world2cam[3 * r + i] * world2cam[3 * r + j];
+                    if (!(fabs(d - (i == j ? 1.0 : 0.0)) < 1e-5)) { rigid = false; break; }
+                }
+            a.origin_cam = rigid ? (float)(sqrt((double)world2cam[9] * world2cam[9] + (double)world2cam[10] * world2cam[10] +
+                                                (double)world2cam[11] * world2cam[11]) * 1.0001 + 1e-6) : -1.f;
+        }
         const double r = use_tab ? df_tile_radius(vol2world, DF_ROW_TX, DF_ROW_TY, DF_ROW_TZ, v)
                                  : df_tile_radius(vol2world, DF_BRICK, DF_BRICK, DF_BRICK, v);
         double fro = 0.0;    // Frobenius norm of world2cam.R bounds its operator norm; == sqrt(3) for a rotation

@@ -80,6 +80,8 @@ enum {
 #define DF_WARP_NO_PIPELINE 16u /* batched instead of software-pipelined table loads; validation switch */
 #define DF_WARP_NO_ZERO_SKIP 32u /* also sweep tiles whose blend weights are all so small that the reference's
                                  normalisation divides by zero (they cannot update); validation switch  */
+#define DF_WARP_NO_DEPTH_PYRAMID 64u /* cull against the image-wide maximum of dists only, not against the maximum
+                                 over the pixels a tile can project to; validation switch                  */
 /* flags for dfusion_warp_build_index */
 #define DF_INDEX_VOXEL_TABLE 1u /* also cache the exact k-NN of EVERY voxel of the slab in HBM:
                                    k * 2 bytes per voxel (2 GiB at 512^3, k = 8) -- the per-frame

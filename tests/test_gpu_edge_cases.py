@@ -203,3 +203,43 @@ def test_rotated_volume_pose_matches_oracle(k):
     assert stats[1] > 0 and np.array_equal(np.isnan(gp), np.isnan(rp))
     m = np.isfinite(rp)
     assert np.abs(gp[m] - rp[m]).max() <= 1e-4 and np.abs(gn[m] - rn[m]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("k,lean", [(8, False), (4, False), (8, True)])
+def test_depth_footprint_cull_with_near_occluders_matches_oracle(k, lean):
+    """The warped sweep skips a wave's 8x8x8 voxels when nothing in them can update; one of the tests compares the least distance
+    from the camera centre any warped voxel of the tile can have with the LARGEST dists value over the pixels the tile can project to
+    (max-pyramid of the frame's dists).  Depth images with near occluders, invalid (zero) regions and a far rim make that test fire in
+    every combination: the whole volume against the oracle, and against the sweep without the pyramid / without any cull, update
+    counts included.  Large node rotations, so that the lateral bound (rotation about the far world origin) is loose while the
+    distance bound stays tight."""
+    cfg = synth.Config(64, 1.0, cols=96, rows=72, nodes=60, k=k)
+    sc = Scene(cfg, n_frames=3)
+    sc.dqs = [synth.node_transforms(cfg, f, rot_amp=0.12, trans_amp=0.02) for f in range(3)]
+    rng = np.random.default_rng(5)
+    for f in range(3):
+        d = sc.depths[f].copy()
+        d[10:40, 20:60] = 620 + 40 * f                      # a near slab in front of the scene (0.62 m: just inside the volume)
+        d[50:72, 0:30] = 0                                  # no measurement
+        d[0:8, :] = 1450                                    # far rim
+        d[rng.random(d.shape) < 0.01] = 0
+        sc.depths[f] = d
+        sc.dists[f] = O.compute_dists(d, sc.intr)
+    intr = Intr(*cfg.intr)
+    wf = WarpField(k=k, voxel_table=not lean)
+    wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
+    ref = sc.new_volume()
+    kws = [dict(), dict(depth_pyramid=False), dict(cull=False), dict(pipelined=False)]
+    vols = [make_gpu_volume(sc) for _ in kws]
+    n = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in kws]
+    n_ref = 0
+    for f in range(3):
+        wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+        n_ref += O.integrate_warped(sc.dists[f], ref, sc.ovol(ref), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)), sc.intr, sc.pos, sc.dqs[f],
+                                    sc.sigma, k)
+        for v, kw, c in zip(vols, kws, n):
+            v.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, wf, n_updated=c, **kw)
+    assert int((ref >> 16).max()) == 3 and 0 < n_ref
+    for v, kw, c in zip(vols, kws, n):
+        assert compare_volumes(v.download(), ref)["bits_mismatch"] == 0, kw
+        assert int(c.item()) == n_ref, kw

@@ -63,7 +63,7 @@ def test_full_size_properties_and_sampled_oracle(name):
     for f in range(2):
         wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
         a.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, n_updated=n_upd, cull=True)
-        b.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, cull=False)
+        b.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, cull=(f == 1), depth_pyramid=False)     # no cull, then the image-wide depth test only
     assert torch.equal(a.data(), b.data())
     weights = (a.data() >> 16) & 0xFFFF
     assert int(weights.sum()) == int(n_upd.item()) and int(weights.max()) == 2

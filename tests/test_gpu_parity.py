@@ -229,7 +229,7 @@ def test_voxel_knn_table_equals_on_the_fly_search(cfg):
     # every sweep kernel the dispatcher can pick (include/dfusion.h DF_WARP_* validation switches): pipelined (default),
     # batched LDS, global-gather with / without the weight table
     variants = [dict(pipelined=False), dict(use_lds=False), dict(use_lds=False, use_weights=False), dict(zero_skip=False),
-                dict(zero_skip=False, cull=False)]
+                dict(zero_skip=False, cull=False), dict(depth_pyramid=False)]
     others = [make_gpu_volume(sc) for _ in variants]
     for f in range(2):
         d = upload_u16(sc.dists[f])

@@ -10,7 +10,7 @@ depth = upload_u16(synth.depth_frame(cfg, 0)); dists = compute_dists(depth, intr
 vol = TsdfVolume(cfg.dims); vol.setSize([cfg.size] * 3); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setPose(cfg.volume_pose)
 pos, sigma = synth.make_nodes(cfg); dq = synth.node_transforms(cfg, 1)
 wf = WarpField(k=cfg.k); wf.init(pos, sigma=sigma, transforms=dq); wf.ensure_index(vol, cfg.k)
-variants = {"pipelined": {}, "no-zero-skip": dict(zero_skip=False), "batched": dict(pipelined=False), "global-gather": dict(use_lds=False)}
+variants = {"pipelined": {}, "no-depth-pyramid": dict(depth_pyramid=False), "no-zero-skip": dict(zero_skip=False), "batched": dict(pipelined=False), "global-gather": dict(use_lds=False)}
 res = {k: [] for k in variants}
 for rnd in range(6):
     for k, kw in variants.items():
