@@ -70,4 +70,6 @@ struct DfWarpField {
     int pt_image_cols;                                 // dfusion_warp_set_point_tiling: 0 = point queries in linear order
     // replica of the reference's nanoflann tree over the node positions (rebuilt by dfusion_warp_set_nodes)
     DfNfNode* nf_nodes; uint16_t* nf_vpos; size_t nf_nodes_cap, nf_vpos_cap; bool nf_ok; int nf_depth;
+    // pipelined warped sweep: the launch plan (verdict masks of the strip items, the alive ones sorted by work), dfusion_warp.hip
+    unsigned long long* plan_mask; unsigned int* plan_list; unsigned int* plan_hist; size_t plan_cap; int plan_phase;
 };

@@ -19,6 +19,7 @@
 #include "dfusion_internal.h"
 #include "dfusion_pyramid.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <math.h>
 
 // ====================================================================================== nodes
@@ -88,6 +89,7 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
     (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids); (void)hipFree(wf->tile_wmax);
     (void)hipFree(wf->nf_nodes); (void)hipFree(wf->nf_vpos); (void)hipFree(wf->pyr_mem);
+    (void)hipFree(wf->plan_mask); (void)hipFree(wf->plan_list); (void)hipFree(wf->plan_hist);
     free(wf);
     return DF_OK;
 }
@@ -820,6 +822,15 @@ struct DfWarpedArgs {
     uint16_t* knn_tab; float* w_tab; int tab_z0; size_t tab_nvox; int tab_ntx, tab_nty;
     int zt;                        // pipelined sweep: tile layers per workgroup (1..16)
     int v2w_identity;              // vol2world.R is exactly the identity (set by the launcher)
+    // pipelined sweep: the launch plan.  A STRIP item is half a 32 x 16 tile column (4 patches of 8 x 8 columns side by side: the
+    // waves that share the 128-byte lines of the voxel rows) over one block of zt tile layers; item = ((zb * tiles_y + ty) * tiles_x
+    // + tx) * 2 + half.  plan_mask[item] holds its 4 x 16 verdict bits (bit 16 p + l: patch p, layer l alive); the items with w > 0
+    // bits set are listed in bin w (plan_bins[w * plan_items ...], plan_cnt[w] of them) -- all made on the stream by
+    // df_sweep_plan_kernel, so the sweep's workgroups are full of work from the first to the last, whatever the frustum cuts out.
+    const unsigned long long* plan_mask; const unsigned int* plan_bins; const unsigned int* plan_cnt; unsigned int plan_items; int plan_tiles_y;
+#ifdef DF_TRACE_WG
+    unsigned long long* trace;     // [waves][4]: start, end (s_memrealtime), hw id, alive layers
+#endif
     // max over the voxels of each table tile of sum_i w_i (written by the table build, frame-invariant); null = no zero-weight test
     float* tile_wmax;
 };
@@ -1344,47 +1355,35 @@ __device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<4>& r)
     return S;
 }
 
-// WGT = 512: one 32 x 16 tile column per workgroup, two workgroups per CU while the node table is <= 80 KiB (2560 nodes).
-// WGT = 1024: two x-adjacent tile columns share one node table, for the larger tables that leave room for only one workgroup per CU:
-// 16 waves (4 per SIMD) instead of 8.
-template <int K, int U, int WGT, bool V2W_IDENTITY>
-__global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
+// The launch plan of the pipelined sweep.  One wave per strip item: lane = (patch p = lane / 16, layer l = lane % 16) judges the
+// 8 x 8 x 8 voxels of its patch and layer (the verdict costs ~200 instructions; in the sweep itself it held a workgroup's LDS while
+// it ran); the ballot is the item's mask, its population count w the item's work.  Alive items go into bin w (bins[w * n_items ...],
+// cnt[w] entries; the order inside a bin is whatever the atomics make it -- items are independent, the result does not depend on
+// it): the sweep takes the bins from w = 64 down, i.e. the items most work first, without a sorting pass.  `cnt_next` is the counter
+// set of the NEXT launch (the two sets alternate), zeroed here: nothing reads it any more once this kernel runs.
+#define DF_PLAN_BINS 65
+#define DF_PLAN_WG 1024          // 16 items per workgroup: neighbours in the volume, mostly of equal work, so their bin slots are taken with one atomic
+__global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpedArgs a, int tiles_x, int tiles_y, unsigned n_items,
+                                                                   unsigned long long* __restrict__ mask_out, unsigned int* __restrict__ cnt,
+                                                                   unsigned int* __restrict__ bins, unsigned int* __restrict__ cnt_next)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
-    for (int j = threadIdx.x; j < W.M; j += WGT) { s_nodes[2 * j] = W.rot[j]; s_nodes[2 * j + 1] = W.node_t[j]; }
-    if ((unsigned)(size_t)(df_lds_cf4*)s_nodes != 0u) __builtin_trap();  // the blend addresses the table from LDS address 0
+    __shared__ unsigned int s_cnt[DF_PLAN_BINS], s_base[DF_PLAN_BINS];
+    if (threadIdx.x < DF_PLAN_BINS) { s_cnt[threadIdx.x] = 0u; if (blockIdx.x == 0) cnt_next[threadIdx.x] = 0u; }
     __syncthreads();
-
-    constexpr int TPW = WGT / 512;                                         // tile columns per workgroup
-    const int groups_x = (tiles_x + TPW - 1) / TPW;
-    const int tx = (blockIdx.x % groups_x) * TPW + (int)(threadIdx.x >> 9), ty = blockIdx.x / groups_x;   // wave-uniform
-    if (tx >= tiles_x) return;                                             // odd tile count: the second half of the last group is idle
-    // lane -> column of the 32 x 16 footprint: a wave owns an 8 x 8 patch (4 patches across, 2 down), not a 32 x 2 strip -- the
-    // same 8 cache lines per table load, but a compact footprint, so that the voxels of a wave fall on the same side of the frustum
-    // and of the observed surface more often
-    const int wv = (threadIdx.x >> 6) & 7, ln = threadIdx.x & 63;
-    const int x = tx * DF_ROW_TX + (wv & 3) * 8 + (ln & 7);
-    const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (ln >> 3);
-    const bool in_xy = x < a.X && y < a.Y;
-    const int xc = min(x, a.X - 1), yc = min(y, a.Y - 1);                 // clamped: out-of-volume lanes read valid entries, write nothing
-    const size_t plane = (size_t)a.X * a.Y;
-    const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
-    const int lt0 = a.bz0 + blockIdx.y * a.zt;                        // first tile layer of this workgroup
-    const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
-    auto layer_zb = [&](int l) { return max((lt0 + l) * DF_ROW_TZ, a.z_own0); };
-    auto layer_ze = [&](int l) { return min((lt0 + l + 1) * DF_ROW_TZ, own1); };
-
-    // wave-uniform: layers that are in range and whose 8 x 8 x 8 voxels of this wave are not culled (the waves of a workgroup walk
-    // their own batch sequences; nothing in the sweep synchronises them).  Lane l judges layer l (the verdict costs ~150
-    // instructions -- eight of them one after the other in all lanes was 7 % of the kernel's VALU work), a ballot collects them.
-    unsigned alive;
-    {
-        const int l = ln & 15;
-        bool keep = l < a.zt && layer_zb(l) < layer_ze(l);
+    const unsigned item = blockIdx.x * (DF_PLAN_WG / 64) + (threadIdx.x >> 6);
+    const int ln = threadIdx.x & 63, p = ln >> 4, l = ln & 15;
+    unsigned long long m = 0;
+    if (item < n_items) {                                                  // wave-uniform
+        const unsigned half = item & 1u, tcol = item >> 1;
+        const int tx = (int)(tcol % (unsigned)tiles_x), ty = (int)((tcol / (unsigned)tiles_x) % (unsigned)tiles_y);
+        const int zb = (int)(tcol / ((unsigned)tiles_x * (unsigned)tiles_y));
+        const int lt0 = a.bz0 + zb * a.zt;
+        const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
+        const int x0 = tx * DF_ROW_TX + p * 8, y0 = ty * DF_LDS_TY + (int)half * 8;                  // first column of the patch
+        bool keep = l < a.zt && max((lt0 + l) * DF_ROW_TZ, a.z_own0) < min((lt0 + l + 1) * DF_ROW_TZ, own1) && x0 < a.X && y0 < a.Y;
         if (keep && a.cull) {
-            // the wave's own 8 x 8 x 8 voxels of the layer, not the workgroup's 32 x 16 x 8: a third of the radius
-            const f3 c = aff_mul(a.vol2world, mk3(((float)(tx * DF_ROW_TX + (wv & 3) * 8) + 3.5f) * a.vsx,
-                                                  ((float)(ty * DF_LDS_TY + (wv >> 2) * 8) + 3.5f) * a.vsy,
+            // the patch's own 8 x 8 x 8 voxels of the layer, not the 32 x 16 x 8 tile: a third of the radius
+            const f3 c = aff_mul(a.vol2world, mk3(((float)x0 + 3.5f) * a.vsx, ((float)y0 + 3.5f) * a.vsy,
                                                   ((float)((lt0 + l) * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
             float wk = a.kf;
             if (a.tile_wmax) {
@@ -1394,10 +1393,73 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
             }
             keep = keep && !df_tile_culled(a, c, wk);
         }
-        alive = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)__builtin_amdgcn_ballot_w64(keep) & 0xffffu));
+        m = __builtin_amdgcn_ballot_w64(keep);
     }
-    unsigned int my_upd = 0;
+    const unsigned w = (unsigned)__popcll(m);
+    unsigned slot = 0;
+    if (ln == 0 && m) slot = atomicAdd(&s_cnt[w], 1u);
+    __syncthreads();
+    if (threadIdx.x < DF_PLAN_BINS && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cnt[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (ln == 0 && m) {
+        mask_out[item] = m;
+        bins[(size_t)w * n_items + s_base[w] + slot] = item;
+    }
+}
+
+// One workgroup = WGT / 256 strip items of the plan (2 at WGT = 512: two workgroups per CU while the node table is <= 80 KiB, 2560
+// nodes; 4 at WGT = 1024, for the larger tables that leave room for only one workgroup per CU: 16 waves, 4 per SIMD, either way).
+template <int K, int U, int WGT, bool V2W_IDENTITY>
+__global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
+    constexpr unsigned SPW = WGT / 256;                                    // strip items per workgroup
+    // entry e of the plan = the e-th item counting the bins from the fullest down: lane j holds the count of bin 64 - j and the
+    // running total up to and including it
+    const unsigned bin_cnt = a.plan_cnt[DF_PLAN_BINS - 1 - (threadIdx.x & 63)];
+    unsigned bin_end = bin_cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(bin_end, o, 64); if ((int)(threadIdx.x & 63) >= o) bin_end += t; }
+    const unsigned n_alive = (unsigned)__builtin_amdgcn_readlane((int)bin_end, 63);
+    if (blockIdx.x * SPW >= n_alive) return;                               // past the end of the plan (the grid is sized for every strip)
+#ifdef DF_TRACE_WG
+    const unsigned long long t_start = wall_clock64();
+#endif
+    for (int j = threadIdx.x; j < W.M; j += WGT) { s_nodes[2 * j] = W.rot[j]; s_nodes[2 * j + 1] = W.node_t[j]; }
+    if ((unsigned)(size_t)(df_lds_cf4*)s_nodes != 0u) __builtin_trap();  // the blend addresses the table from LDS address 0
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), ln = threadIdx.x & 63;    // in an SGPR: what follows from it stays scalar
+    const size_t plane = (size_t)a.X * a.Y;
+    const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
     const unsigned pitch24 = (unsigned)a.P.pitch;                          // rows, pitch < 2^24 (checked by the launcher): 24-bit multiply
+    unsigned int my_upd = 0;
+#ifdef DF_TRACE_WG
+    unsigned n_layers = 0;
+#endif
+    const unsigned sidx = blockIdx.x * SPW + (unsigned)(wave >> 2);           // this wave's plan entry: 4 waves per strip item
+    unsigned alive = 0, item = 0;
+    if (sidx < n_alive) {
+        const int j = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(sidx < bin_end)) - 1;      // its bin: the first running total above sidx
+        const unsigned r = sidx - ((unsigned)__builtin_amdgcn_readlane((int)bin_end, j) - (unsigned)__builtin_amdgcn_readlane((int)bin_cnt, j));
+        item = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_PLAN_BINS - 1 - j) * a.plan_items + r]);
+        const unsigned long long m = a.plan_mask[item];
+        const unsigned mp = (wave & 2) ? (unsigned)(m >> 32) : (unsigned)m;
+        alive = (unsigned)__builtin_amdgcn_readfirstlane((int)((wave & 1) ? mp >> 16 : mp & 0xffffu));
+    }
+    // item -> tile column, half, layer block; the wave's 8 x 8 patch is number wv of the 32 x 16 footprint (4 across, 2 down): a compact
+    // footprint, so that the voxels of a wave fall on the same side of the frustum and of the observed surface more often
+    const unsigned tcol = item >> 1;
+    const int tx = (int)(tcol % (unsigned)tiles_x), ty = (int)((tcol / (unsigned)tiles_x) % (unsigned)a.plan_tiles_y);
+    const int wv = (int)(item & 1u) * 4 + (wave & 3);
+    const int x = tx * DF_ROW_TX + (wv & 3) * 8 + (ln & 7);
+    const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (ln >> 3);
+    const bool in_xy = x < a.X && y < a.Y;
+    const int xc = min(x, a.X - 1), yc = min(y, a.Y - 1);                 // clamped: out-of-volume lanes read valid entries, write nothing
+    const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
+    const int lt0 = a.bz0 + (int)(tcol / ((unsigned)tiles_x * (unsigned)a.plan_tiles_y)) * a.zt;     // first tile layer of the item
+    auto layer_zb = [&](int l) { return max((lt0 + l) * DF_ROW_TZ, a.z_own0); };
+    auto layer_ze = [&](int l) { return min((lt0 + l + 1) * DF_ROW_TZ, own1); };
     if (alive) {
         // batch sequence: U planes per batch inside a layer, then the first batch of the next alive layer; l < 0 = none
         auto advance = [&](int l, int z0, int* nl, int* nz0) {
@@ -1530,6 +1592,17 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
         }
         finish_pending();                                                   // the last batch
     }
+#ifdef DF_TRACE_WG
+    n_layers += __popc(alive);
+    {
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (ln == 0) {
+            unsigned long long* t = a.trace + ((size_t)blockIdx.x * (WGT / 64) + (threadIdx.x >> 6)) * 4;
+            t[0] = t_start; t[1] = wall_clock64(); t[2] = ((unsigned long long)xcc << 32) | hw; t[3] = (unsigned long long)n_layers;
+        }
+    }
+#endif
     df_count_updates(a, my_upd);
 }
 
@@ -1663,7 +1736,6 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         a.zt = !pipe ? DF_LDS_ZT : cols_layers <= 8192 ? 4 : cols_layers <= 65536 ? 8 : 16;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + a.zt - 1) / a.zt));
         const bool wide = pipe_ok && (k == 8 || k == 4) && lds > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads
-        if (wide) grid.x = (unsigned)(((tiles_x + 1) / 2) * tiles_y);
         const bool vi = a.v2w_identity != 0;
         if (pipe_ok && k == 8)
             kern = wide ? (vi ? df_warp_rows_pipe_kernel<8, 2, 1024, true> : df_warp_rows_pipe_kernel<8, 2, 1024, false>)
@@ -1674,6 +1746,50 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
         else { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, false, 1>)); }
         DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (pipe) {
+            // the launch plan: verdict masks of all strip items (one wave each), the alive ones sorted by work; then one workgroup per
+            // 2 (4) plan entries.  The grid is sized for every strip -- nothing is read back -- and the workgroups past the plan's end
+            // return at once.
+            const unsigned n_zb = grid.y, n_items = (unsigned)tiles_x * (unsigned)tiles_y * 2u * n_zb;
+            if (n_items > wf->plan_cap) {
+                (void)hipFree(wf->plan_mask); (void)hipFree(wf->plan_list); wf->plan_mask = nullptr; wf->plan_list = nullptr; wf->plan_cap = 0;
+                DF_HIP(hipMalloc((void**)&wf->plan_mask, (size_t)n_items * sizeof(unsigned long long)));
+                DF_HIP(hipMalloc((void**)&wf->plan_list, (size_t)n_items * DF_PLAN_BINS * sizeof(unsigned int)));      // the bins
+                wf->plan_cap = n_items;
+            }
+            if (!wf->plan_hist) {                                          // two counter sets, used alternately; each plan launch zeroes the other one
+                DF_HIP(hipMalloc((void**)&wf->plan_hist, 2 * 128 * sizeof(unsigned int)));
+                DF_HIP(hipMemsetAsync(wf->plan_hist, 0, 2 * 128 * sizeof(unsigned int), st));
+                wf->plan_phase = 0;
+            }
+            unsigned int* cnt = wf->plan_hist + 128 * wf->plan_phase;
+            unsigned int* cnt_next = wf->plan_hist + 128 * (wf->plan_phase ^ 1);
+            hipLaunchKernelGGL(df_sweep_plan_kernel, dim3((n_items + DF_PLAN_WG / 64 - 1) / (DF_PLAN_WG / 64)), dim3(DF_PLAN_WG), 0, st, a, tiles_x, tiles_y, n_items, wf->plan_mask, cnt,
+                               wf->plan_list, cnt_next);
+            DF_LAUNCH_CHECK();
+            wf->plan_phase ^= 1;                                           // (only once the kernel that zeroes the other set is in the stream)
+            a.plan_mask = wf->plan_mask; a.plan_bins = wf->plan_list; a.plan_cnt = cnt; a.plan_items = n_items; a.plan_tiles_y = tiles_y;
+            const unsigned spw = wide ? 4u : 2u;
+            grid = dim3((n_items + spw - 1) / spw, 1);
+#ifdef DF_TRACE_WG
+            static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;
+            const size_t trace_n = (size_t)grid.x * (wide ? 16 : 8) * 4;
+            if (trace_n > trace_cap) { (void)hipFree(trace_dev); DF_HIP(hipMalloc((void**)&trace_dev, trace_n * 8)); trace_cap = trace_n; }
+            DF_HIP(hipMemsetAsync(trace_dev, 0, trace_n * 8, st));
+            a.trace = trace_dev;
+            kern<<<grid, dim3(wide ? 1024 : 512), lds, st>>>(a, W, tiles_x);
+            if (getenv("DF_TRACE_FILE")) {
+                DF_HIP(hipStreamSynchronize(st));
+                unsigned long long* h = (unsigned long long*)malloc(trace_n * 8);
+                DF_HIP(hipMemcpy(h, trace_dev, trace_n * 8, hipMemcpyDeviceToHost));
+                FILE* f = fopen(getenv("DF_TRACE_FILE"), "wb");
+                if (f) { unsigned long long hdr[4] = {grid.x, 1, (unsigned long long)(wide ? 16 : 8), 0}; fwrite(hdr, 8, 4, f); fwrite(h, 8, trace_n, f); fclose(f); }
+                free(h);
+            }
+            DF_LAUNCH_CHECK();
+            return DF_OK;
+#endif
+        }
         kern<<<grid, dim3(wide ? 1024 : 512), lds, st>>>(a, W, tiles_x);
     } else if (use_tab) {
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_ROW_TY - 1) / DF_ROW_TY;
