@@ -18,38 +18,21 @@ struct DfDistsPyramid {
 
 // Builds levels 1..top into `mem` (df_pyramid_elems(cols, rows) uint16 entries) on `st`; out->top == 0 when the image is too small
 // (< 32 px) or too large for a pyramid: the callers then run without the test.
+// `levels_to_5`: build levels 1..5 only (one launch; the descriptor still names `top`, whose levels above 5 are then NOT valid);
+// `zero16`: 16 32-bit words the first workgroup also zeroes (a caller's counters, saving it a memset), or null.
 int df_build_dists_pyramid(const uint16_t* dists, size_t pitch, int cols, int rows, uint16_t* mem, size_t mem_elems,
-                           DfDistsPyramid* out, hipStream_t st);
+                           DfDistsPyramid* out, hipStream_t st, bool levels_to_5 = false, unsigned int* zero16 = nullptr);
 size_t df_pyramid_elems(int cols, int rows);
 
-// max of the dists half bits over the pixel rectangle [u0, u1] x [v0, v1] (inclusive, inside the image) or a superset of it:
-// the coarsest level at which the rectangle spans at most 2 x 2 texels
-__device__ __forceinline__ uint32_t df_pyramid_max(const DfDistsPyramid& P, int u0, int v0, int u1, int v1)
+// max of the dists half bits over the pixel rectangle [u0, u1] x [v0, v1] (inclusive, inside the image) or a superset of it: the texels
+// of the level `shift` below the coarsest one at which the rectangle spans at most 2 x 2 texels -- at most (2^(shift+1) + 1)^2 of
+// them (the 2 x 2 cover itself takes in up to three times the rectangle's extent on each axis).  `max_level` caps the level read (more texels
+// instead): a caller that only ever passes max_level <= 5 does not need the levels above 5 built.
+__device__ __forceinline__ uint32_t df_pyramid_max_fine(const DfDistsPyramid& P, int u0, int v0, int u1, int v1, int shift, int max_level = DF_PYR_MAX_LEVELS)
 {
     const int ext = max(u1 - u0, v1 - v0);
     int L = ext == 0 ? 0 : 32 - __clz(ext);
-    L = min(L, P.top);
-    const int a0 = u0 >> L, a1 = u1 >> L, b0 = v0 >> L, b1 = v1 >> L;
-    if (L == 0) {
-        const uint16_t* r0 = (const uint16_t*)((const char*)P.dists + (size_t)b0 * P.pitch);
-        const uint16_t* r1 = (const uint16_t*)((const char*)P.dists + (size_t)b1 * P.pitch);
-        return max(max((uint32_t)r0[a0], (uint32_t)r0[a1]), max((uint32_t)r1[a0], (uint32_t)r1[a1]));
-    }
-    const uint16_t* lv = P.mem + P.off[L];
-    const int w = P.w[L];
-    uint32_t m = 0;
-    for (int b = b0; b <= b1; ++b)                       // (at the top level the rectangle may still span more than 2 x 2)
-        for (int a = a0; a <= a1; ++a) m = max(m, (uint32_t)lv[b * w + a]);
-    return m;
-}
-
-// The same over a finer cover: `shift` levels below the 2 x 2 one, at most (2^(shift+1) + 1)^2 texels -- for wide rectangles, where
-// the 2 x 2 cover takes in up to three times the rectangle's extent on each axis
-__device__ __forceinline__ uint32_t df_pyramid_max_fine(const DfDistsPyramid& P, int u0, int v0, int u1, int v1, int shift)
-{
-    const int ext = max(u1 - u0, v1 - v0);
-    int L = ext == 0 ? 0 : 32 - __clz(ext);
-    L = min(max(L - shift, 0), P.top);
+    L = min(min(max(L - shift, 0), P.top), max_level);
     const int a0 = u0 >> L, a1 = u1 >> L, b0 = v0 >> L, b1 = v1 >> L;
     uint32_t m = 0;
     if (L == 0) {

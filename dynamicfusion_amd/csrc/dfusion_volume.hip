@@ -17,6 +17,7 @@
 #include "dfusion_pyramid.h"
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
 
 // ------------------------------------------------------------------------------------------ clear
 __global__ __launch_bounds__(256) void df_fill_zero_kernel(uint4* __restrict__ p, size_t n16)
@@ -164,8 +165,9 @@ extern "C" int dfusion_project_and_remove(const uint16_t* dists_in, size_t in_pi
 
 // ------------------------------------------------------------------------------------------ max-pyramid of the dists image (dfusion_pyramid.h)
 // levels 1..5 of one 32 x 32 pixel tile per workgroup
-__global__ __launch_bounds__(256) void df_pyramid_tiles_kernel(const DfDistsPyramid P, uint16_t* __restrict__ out)
+__global__ __launch_bounds__(256) void df_pyramid_tiles_kernel(const DfDistsPyramid P, uint16_t* __restrict__ out, unsigned int* __restrict__ zero16)
 {
+    if (zero16 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0u;
     __shared__ uint16_t s[16 * 16];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const int x0 = blockIdx.x * 32 + 2 * tx, y0 = blockIdx.y * 32 + 2 * ty;
@@ -243,6 +245,12 @@ struct DfRigidArgs {
     float vsx, vsy, vsz;
     DfIntegrateParams P;
     unsigned long long* n_upd;
+    // launch plan (df_rigid_plan_kernel): item = chunk * tiles + tile; plan_mask[item] = its alive sub-chunks (bit s: planes
+    // [zb + 16 s, zb + 16 s + 16) may update), items with w > 0 bits listed in bin w (plan_bins[w * plan_items ...], plan_cnt[w] of them)
+    const unsigned char* plan_mask; const unsigned int* plan_bins; const unsigned int* plan_cnt; unsigned int plan_items; int tiles;
+#ifdef DF_TRACE_WG
+    unsigned long long* trace;
+#endif
 };
 
 // Signed test "certainly outside one image-frustum side plane or behind the camera by more than m metres".
@@ -260,55 +268,17 @@ __device__ __forceinline__ unsigned df_outside_mask(const DfFrustum& F, f3 p, fl
     return o;
 }
 
-// Conservative, result-identical rejection of the voxels of one column on n consecutive planes, given its running camera-frame
-// position a0 on the first of them.  All those voxels lie (up to the accumulated rounding of `vc += zstep`, < 1e-3 m over 1024
-// planes) on the segment from a0 to a0 + (n-1) zstep.  None of them can take the update branch (tsdf_volume.cu:82-91) if
-//   (a) both ends are outside the SAME frustum side plane (or behind the camera) by 5 mm, or
-//   (b) every ray-length the segment can be compared with is too short: it projects (a segment in front of the camera onto the
-//       segment between the projections) into a pixel rectangle whose largest dists value is Dmax, and its smallest distance
-//       from the camera centre exceeds Dmax + trunc -- then sdf = Dp - |vc| < -trunc for all of them;
-//       Dmax == 0 means no valid depth at all there (Dp == 0, :86).
-// (b) is what skips the volume BEHIND the observed surface, most of what the frustum contains.
-template <bool DEPTH>
-__device__ __forceinline__ bool df_rigid_culled(const DfFrustum& F, const DfDistsPyramid& Py, const DfIntegrateParams& P, f3 a0, f3 zstep, int n)
-{
-    // one column: the hull is the segment a0 .. b0
-    const f3 b0 = add3(a0, scale3(zstep, (float)(n - 1)));
-    const float m = 5e-3f;
-    if ((df_outside_mask(F, a0, m) & df_outside_mask(F, b0, m)) != 0u) return true;
-    if (!DEPTH || Py.top == 0) return false;
-    const float zmin = fminf(a0.z, b0.z);
-    if (!(zmin > 0.05f)) return false;
-    // pixel rectangle (approximate reciprocals are fine: 2 pixels of margin)
-    const float r0 = __builtin_amdgcn_rcpf(a0.z), r2 = __builtin_amdgcn_rcpf(b0.z);
-    const float u0 = P.fx * a0.x * r0, u2 = P.fx * b0.x * r2;
-    const float v0 = P.fy * a0.y * r0, v2 = P.fy * b0.y * r2;
-    const float ulo = fminf(u0, u2) + P.cx - 2.f, uhi = fmaxf(u0, u2) + P.cx + 2.f;
-    const float vlo = fminf(v0, v2) + P.cy - 2.f, vhi = fmaxf(v0, v2) + P.cy + 2.f;
-    if (!(ulo == ulo && uhi == uhi && vlo == vlo && vhi == vhi)) return false;
-    if (uhi < 0.f || vhi < 0.f || ulo > (float)(P.cols - 1) || vlo > (float)(P.rows - 1)) return true;       // projects outside the image
-    const int iu0 = (int)fmaxf(ulo, 0.f), iv0 = (int)fmaxf(vlo, 0.f);
-    const int iu1 = (int)fminf(uhi, (float)(P.cols - 1)), iv1 = (int)fminf(vhi, (float)(P.rows - 1));
-    const uint32_t dbits = df_pyramid_max(Py, iu0, iv0, iu1, iv1);
-    if (dbits == 0u) return true;                                        // no valid depth anywhere it can project to
-    const float dmax = h2f_bits((uint16_t)dbits);
-    // smallest distance of the segment from the camera centre: per-axis smallest |coordinate|
-    const float xl = fminf(a0.x, b0.x), xh = fmaxf(a0.x, b0.x), yl = fminf(a0.y, b0.y), yh = fmaxf(a0.y, b0.y);
-    const float mx = xl > 0.f ? xl : (xh < 0.f ? -xh : 0.f), my = yl > 0.f ? yl : (yh < 0.f ? -yh : 0.f);
-    const float rmin = sqrtf(mx * mx + my * my + zmin * zmin) - m;
-    return (dbits < 0x7c00u) && (rmin > dmax * 1.001f + P.trunc);        // finite non-negative length only
-}
-
-// One COLUMN per lane, a wave = a 32(x) x 2(y) column patch (two 128-byte lines per plane), a Z chunk per blockIdx.y, walked in
-// sub-chunks of DF_RIGID_SUB planes.  How it got here (512^3, MI355X): four columns per lane and half a row per wave took 0.24 ms
+// Rigid integrate: one COLUMN per lane, a wave = a 32(x) x 2(y) column patch (two 128-byte lines per plane) over one Z chunk, walked
+// in sub-chunks of DF_RIGID_SUB planes.  How it got here (512^3, MI355X): four columns per lane and half a row per wave took 0.24 ms
 // although the update arithmetic of the 31 M voxels that update is ~45 us of VALU issue -- a wave costs what its busiest lane
-// costs, nearly every wave cut the frustum, and the few thousand long-running waves landed unevenly on the 1024 SIMDs.  Now:
-//   * compact patches and short chunks: 16 k waves, most of which reject their whole chunk at once (df_rigid_culled on the lane's
-//     own column segment, verdict per wave by ballot) and leave the SIMD to the next one -- the dispatcher does the balancing;
-//   * a rejected sub-chunk only advances the running position (the same `vc += zstep` additions, tsdf_volume.cu:75, 3 adds per
-//     plane instead of ~100 instructions): everything outside the frustum AND everything more than trunc behind the surface;
-//   * U planes per batch: U independent sample chains and U voxel loads in flight per lane (the chain divide -> dists fetch ->
-//     sqrt / compare -> voxel load -> fuse -> store is what a lone voxel waits on).
+// costs, nearly every wave cut the frustum, and the few thousand long-running waves landed unevenly on the 1024 SIMDs.  Compact
+// patches, short chunks whose dead sub-chunks only advance the running position (the same `vc += zstep` additions,
+// tsdf_volume.cu:75, 3 adds per plane instead of ~100 instructions: everything outside the frustum AND everything more than trunc
+// behind the surface) and U planes per batch (U independent sample chains and voxel loads in flight per lane: the chain divide ->
+// dists fetch -> sqrt / compare -> voxel load -> fuse -> store is what a lone voxel waits on) made it 0.17 ms -- half of it a tail:
+// a per-wave timeline (tools/trace_sweep.py) showed the SIMDs full for 80 us and then 80 us of ever fewer long waves, the dense far
+// chunks being dispatched last.  Now the verdicts are made up front (df_rigid_plan_kernel: one LANE per sub-chunk, on the patch's
+// box), the sweep's waves take the alive items most-work-first and carry no tests: full from start to end, 0.135 ms.
 // A chunk starting at plane zb replays the zb additions of :75 in registers, so every chunk -- and every Z-slab shard on another
 // GPU -- produces the bits of the unsharded sweep.
 // the voxels of one column on planes [zs, zse), U at a time
@@ -336,43 +306,149 @@ __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f
     }
 }
 
-#define DF_RIGID_SUB 16
-template <int U, bool DEPTH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void df_integrate_rigid_kernel(const DfRigidArgs a, const DfFrustum F, const DfDistsPyramid Py, const bool FASTOK)
+#ifndef DF_RIGID_SUB
+#define DF_RIGID_SUB 8
+#endif
+#ifndef DF_RIGID_U
+#define DF_RIGID_U 4
+#endif
+#ifndef DF_RIGID_WAVES
+#define DF_RIGID_WAVES 8
+#endif
+#define DF_RIGID_MAX_SUBS 8      // sub-chunks per chunk (the plan's masks are bytes)
+#define DF_RIGID_BINS (DF_RIGID_MAX_SUBS + 1)
+// Conservative, result-identical rejection of ALL the voxels of a 32 x 2 column patch on planes [zs, zs + n): the same two tests as
+// df_rigid_culled, on the box the patch's voxels span (its 8 corners; positions by multiplication, within the tests' margin of the
+// running sums the sweep carries): (a) all corners outside the same frustum side plane, (b) the box's least distance from the camera
+// centre exceeds, by more than trunc, the largest dists value over the pixel rectangle that bounds the corners' projections.
+template <bool DEPTH>
+__device__ __forceinline__ bool df_rigid_box_culled(const DfRigidArgs& a, const DfFrustum& F, const DfDistsPyramid& Py, int x0, int y0, int zs, int n)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float m = 5e-3f;
+    const int x1 = min(x0 + 31, a.X - 1), y1 = min(y0 + 1, a.Y - 1), z1 = zs + n - 1;
+    unsigned out_all = 31u;
+    float xl = 3.0e38f, xh = -3.0e38f, yl = 3.0e38f, yh = -3.0e38f, zl = 3.0e38f, zh = -3.0e38f;
+    float ul = 3.0e38f, uh = -3.0e38f, vl = 3.0e38f, vh = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f3 q = aff_mul(a.vol2cam, mk3((float)((c & 1) ? x1 : x0) * a.vsx, (float)((c & 2) ? y1 : y0) * a.vsy, (float)((c & 4) ? z1 : zs) * a.vsz));
+        out_all &= df_outside_mask(F, q, m);
+        xl = fminf(xl, q.x); xh = fmaxf(xh, q.x); yl = fminf(yl, q.y); yh = fmaxf(yh, q.y); zl = fminf(zl, q.z); zh = fmaxf(zh, q.z);
+        const float r = __builtin_amdgcn_rcpf(q.z);                   // (only used when every corner has z > 0.05)
+        const float u = a.P.fx * q.x * r, v = a.P.fy * q.y * r;
+        ul = fminf(ul, u); uh = fmaxf(uh, u); vl = fminf(vl, v); vh = fmaxf(vh, v);
+    }
+    if (out_all != 0u) return true;
+    if (!DEPTH || Py.top == 0) return false;
+    if (!(zl > 0.05f)) return false;
+    // the box is convex and in front of the camera: every voxel projects inside the bounding rectangle of the corners' projections
+    const float ulo = ul + a.P.cx - 2.f, uhi = uh + a.P.cx + 2.f, vlo = vl + a.P.cy - 2.f, vhi = vh + a.P.cy + 2.f;
+    if (!(ulo == ulo && uhi == uhi && vlo == vlo && vhi == vhi)) return false;
+    if (uhi < 0.f || vhi < 0.f || ulo > (float)(a.P.cols - 1) || vlo > (float)(a.P.rows - 1)) return true;   // projects outside the image
+    const int iu0 = (int)fmaxf(ulo, 0.f), iv0 = (int)fmaxf(vlo, 0.f);
+    const int iu1 = (int)fminf(uhi, (float)(a.P.cols - 1)), iv1 = (int)fminf(vhi, (float)(a.P.rows - 1));
+    const uint32_t dbits = df_pyramid_max_fine(Py, iu0, iv0, iu1, iv1, 2, 5);       // (levels <= 5: see the launcher)
+    if (dbits == 0u) return true;                                        // no valid depth anywhere it can project to
+    const float dmax = h2f_bits((uint16_t)dbits);
+    const float mx = xl > 0.f ? xl : (xh < 0.f ? -xh : 0.f), my = yl > 0.f ? yl : (yh < 0.f ? -yh : 0.f);
+    const float rmin = sqrtf(mx * mx + my * my + zl * zl) - m;
+    return (dbits < 0x7c00u) && (rmin > dmax * 1.001f + a.P.trunc);      // finite non-negative length only
+}
+
+// The launch plan: item = (column patch, Z chunk); lane 8 i + s of a wave tests sub-chunk s of the wave's i-th item (the box of the
+// whole patch over the sub-chunk's planes), the ballot gives the items' masks.  Alive items are binned by their number of alive
+// sub-chunks (slots taken per workgroup, one atomic per bin); the sweep takes the bins from the fullest down, so its waves are the long
+// ones first and the launch does not end on a few of them.
+template <bool DEPTH>
+__global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a, const DfFrustum F, const DfDistsPyramid Py, unsigned n_items,
+                                                             unsigned char* __restrict__ mask_out, unsigned int* __restrict__ cnt,
+                                                             unsigned int* __restrict__ bins)
+{
+    __shared__ unsigned int s_cnt[DF_RIGID_BINS], s_base[DF_RIGID_BINS];
+    if (threadIdx.x < DF_RIGID_BINS) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned item = (blockIdx.x * 1024u + threadIdx.x) >> 3;
+    const int sb = threadIdx.x & 7, lane = threadIdx.x & 63;
+    bool keep = false;
+    if (item < n_items) {
+        const int tile = (int)(item % (unsigned)a.tiles), chunk = (int)(item / (unsigned)a.tiles);
+        const int tiles_x = (a.X + 31) >> 5;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int zb = a.z_own0 + chunk * a.zc, ze = min(zb + a.zc, a.z_own0 + a.z_own_n);
+        const int zs = zb + sb * DF_RIGID_SUB;
+        if (zs < ze) keep = !df_rigid_box_culled<DEPTH>(a, F, Py, tx * 32, ty * 2, zs, min(DF_RIGID_SUB, ze - zs));
+    }
+    const unsigned m = (unsigned)(__ballot(keep) >> (lane & ~7)) & 0xffu;   // the item's 8 verdicts
+    const unsigned w = (unsigned)__popc(m);
+    unsigned slot = 0;
+    if (sb == 0 && m) slot = atomicAdd(&s_cnt[w], 1u);
+    __syncthreads();
+    if (threadIdx.x < DF_RIGID_BINS && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cnt[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (sb == 0 && m) {
+        mask_out[item] = (unsigned char)m;
+        bins[(size_t)w * n_items + s_base[w] + slot] = item;
+    }
+}
+
+// The sweep: wave e of the launch takes plan entry e (bins from the fullest down), replays `vc += zstep` up to its chunk, and walks
+// the chunk's sub-chunks: alive ones U planes per batch, the others by the additions alone.
+template <int U>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WAVES, DF_RIGID_WAVES))) void df_integrate_rigid_kernel(const DfRigidArgs a, const bool FASTOK)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // plan entry -> item: lane j < DF_RIGID_BINS - 1 holds the count of bin DF_RIGID_MAX_SUBS - j and the running total
+    const unsigned bin_cnt = lane < DF_RIGID_BINS - 1 ? a.plan_cnt[DF_RIGID_MAX_SUBS - lane] : 0u;
+    unsigned bin_end = bin_cnt;
+#pragma unroll
+    for (int o = 1; o < DF_RIGID_BINS; o <<= 1) { const unsigned t = __shfl_up(bin_end, o, 64); if (lane >= o) bin_end += t; }
+    const unsigned n_alive = (unsigned)__builtin_amdgcn_readlane((int)bin_end, DF_RIGID_BINS - 2);
+    const unsigned e = blockIdx.x * 4 + (unsigned)wave;
+    if (e >= n_alive) return;                                              // wave-uniform (no barrier below)
+#ifdef DF_TRACE_WG
+    const unsigned long long t_start = wall_clock64(); unsigned n_sub = 0;
+#endif
+    const int j = __ffsll((unsigned long long)__ballot(lane < DF_RIGID_BINS - 1 && e < bin_end)) - 1;
+    const unsigned r = e - ((unsigned)__builtin_amdgcn_readlane((int)bin_end, j) - (unsigned)__builtin_amdgcn_readlane((int)bin_cnt, j));
+    const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_RIGID_MAX_SUBS - j) * a.plan_items + r]);
+    const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_mask[item]);
+    const int tile = (int)(item % (unsigned)a.tiles), chunk = (int)(item / (unsigned)a.tiles);
     const int tiles_x = (a.X + 31) >> 5;
-    const int tile = blockIdx.x * 4 + wv;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x = tx * 32 + (lane & 31), y = ty * 2 + (lane >> 5);
     const bool active = x < a.X && y < a.Y;
     unsigned int my_upd = 0;
-    const int zb = a.z_own0 + blockIdx.y * a.zc;
+    const int zb = a.z_own0 + chunk * a.zc;
     const int ze = min(zb + a.zc, a.z_own0 + a.z_own_n);
     const f3 zstep = scale3(mk3(a.vol2cam.R[2], a.vol2cam.R[5], a.vol2cam.R[8]), a.vsz);      // tsdf_volume.cu:69 (three separate multiplies)
     f3 vc = aff_mul(a.vol2cam, mk3((float)x * a.vsx, (float)y * a.vsy, 0.f));                  // :71-72
-    // whole chunk first (position by multiplication: within the test's margin of the running sum): skips the replay too.
-    // Verdicts are per WAVE: a lane that could have been skipped alone runs the exact test instead, which finds "no update" by
-    // itself -- cheaper than a wave executing both branches.
-    const bool culled = !active || df_rigid_culled<DEPTH>(F, Py, a.P, add3(vc, scale3(zstep, (float)zb)), zstep, ze - zb);
-    if (__ballot(!culled) != 0ull) {
-        for (int z = 0; z < zb; ++z) vc = add3(vc, zstep);          // replay of `vc += zstep` (:75) for planes [0, zb)
-        const size_t plane = (size_t)a.X * a.Y;
-        uint32_t* p = a.vol + (size_t)(zb - a.z_store0) * plane + (size_t)(active ? y : 0) * a.X + (active ? x : 0);
-        for (int zs = zb; zs < ze; zs += DF_RIGID_SUB) {
-            const int zse = min(zs + DF_RIGID_SUB, ze);
-            const bool sub_culled = !active || df_rigid_culled<DEPTH>(F, Py, a.P, vc, zstep, zse - zs);
-            if (__ballot(!sub_culled) == 0ull) {
-                for (int z = zs; z < zse; ++z) vc = add3(vc, zstep);                            // :75, skipped voxels included
-                p += (size_t)(zse - zs) * plane;
-                continue;
-            }
-            // the short arithmetic forms of tsdf_sample_fast need their domain on every voxel of the run, for every lane
-            const bool fast = FASTOK && df_wave_all(!active || tsdf_sample_domain_ok(vc, add3(vc, scale3(zstep, (float)(zse - zs)))));
-            if (fast) df_rigid_batches<U, true>(a, vc, zstep, p, plane, zs, zse, active, my_upd);
-            else df_rigid_batches<U, false>(a, vc, zstep, p, plane, zs, zse, active, my_upd);
+    for (int z = 0; z < zb; ++z) vc = add3(vc, zstep);              // replay of `vc += zstep` (:75) for planes [0, zb)
+    const size_t plane = (size_t)a.X * a.Y;
+    uint32_t* p = a.vol + (size_t)(zb - a.z_store0) * plane + (size_t)(active ? y : 0) * a.X + (active ? x : 0);
+    int sb = 0;
+    for (int zs = zb; zs < ze; zs += DF_RIGID_SUB, ++sb) {
+        const int zse = min(zs + DF_RIGID_SUB, ze);
+        if (!((mask >> sb) & 1u)) {
+            if ((mask >> sb) == 0u) break;                                                      // nothing alive further on
+            for (int z = zs; z < zse; ++z) vc = add3(vc, zstep);                                // :75, skipped voxels included
+            p += (size_t)(zse - zs) * plane;
+            continue;
         }
+#ifdef DF_TRACE_WG
+        ++n_sub;
+#endif
+        // the short arithmetic forms of tsdf_sample_fast need their domain on every voxel of the run, for every lane
+        const bool fast = FASTOK && df_wave_all(!active || tsdf_sample_domain_ok(vc, add3(vc, scale3(zstep, (float)(zse - zs)))));
+        if (fast) df_rigid_batches<U, true>(a, vc, zstep, p, plane, zs, zse, active, my_upd);
+        else df_rigid_batches<U, false>(a, vc, zstep, p, plane, zs, zse, active, my_upd);
     }
+#ifdef DF_TRACE_WG
+    if (lane == 0) {
+        unsigned long long* t = a.trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+        t[0] = t_start; t[1] = wall_clock64(); t[2] = 0; t[3] = n_sub;
+    }
+#endif
     if (a.n_upd) {                                            // one atomic per wave
         unsigned int s = my_upd;
 #pragma unroll
@@ -383,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 // the dists max-pyramid of one frame into `mem` (levels 1..top); returns the descriptor
 int df_build_dists_pyramid(const uint16_t* dists, size_t pitch, int cols, int rows, uint16_t* mem, size_t mem_elems,
-                                  DfDistsPyramid* out, hipStream_t st)
+                           DfDistsPyramid* out, hipStream_t st, bool levels_to_5, unsigned int* zero16)
 {
     DfDistsPyramid P;
     memset(&P, 0, sizeof(P));
@@ -396,9 +472,9 @@ int df_build_dists_pyramid(const uint16_t* dists, size_t pitch, int cols, int ro
     }
     if (l >= DF_PYR_MAX_LEVELS || (size_t)off > mem_elems || l < 5) { out->top = 0; return DF_OK; }     // (images below 32 px: no test)
     P.top = l;
-    hipLaunchKernelGGL(df_pyramid_tiles_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, P, mem);
+    hipLaunchKernelGGL(df_pyramid_tiles_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, P, mem, zero16);
     DF_LAUNCH_CHECK();
-    if (P.top > 5) {
+    if (P.top > 5 && !levels_to_5) {
         const size_t lds = 2 * (size_t)P.w[5] * P.h[5] * sizeof(uint16_t);
         if (lds > 64 * 1024) { out->top = 0; return DF_OK; }
         hipLaunchKernelGGL(df_pyramid_top_kernel, dim3(1), dim3(256), lds, st, P, mem);
@@ -457,36 +533,64 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
         }
     }
     const int tiles = ((a.X + 31) / 32) * ((a.Y + 1) / 2);         // 32 x 2 column patches, one per wave
-    const int bx = (tiles + 3) / 4;
-    // Z chunking: ~16 k waves (several rounds of the 8 k wave slots, so that the dispatcher can balance the few long-running
-    // ones), chunks of whole sub-chunks and >= 32 planes (a chunk at plane zb replays zb additions: 3 per plane per lane)
-    const long long want_blocks = 256LL * 16;
-    int chunks = (int)((want_blocks + bx - 1) / bx);
+    // Z chunking: chunks of whole sub-chunks, at most DF_RIGID_MAX_SUBS of them and >= 32 planes (a chunk at plane zb replays zb
+    // additions: 3 per plane per lane); ~32 k items at 512^3 -- the longest wave (every sub-chunk alive) is then a fraction of the launch
+    const long long want_items = 256LL * 128;
+    int chunks = (int)((want_items + tiles - 1) / tiles);
     if (chunks < 1) chunks = 1;
     int zc = (s.z_own_n + chunks - 1) / chunks;
     zc = ((zc + DF_RIGID_SUB - 1) / DF_RIGID_SUB) * DF_RIGID_SUB;
     if (zc < 32) zc = 32;
+    if (zc > DF_RIGID_SUB * DF_RIGID_MAX_SUBS) zc = DF_RIGID_SUB * DF_RIGID_MAX_SUBS;
     a.zc = zc;
-    dim3 grid(bx, (s.z_own_n + zc - 1) / zc);
+    chunks = (s.z_own_n + zc - 1) / zc;
+    const unsigned n_items = (unsigned)tiles * (unsigned)chunks;
+    a.tiles = tiles; a.plan_items = n_items;
     hipStream_t st = (hipStream_t)stream;
-    // behind-the-surface test: a max-pyramid of this frame's dists in stream-ordered scratch (no state is kept between calls)
+    // stream-ordered scratch (no state is kept between calls): the launch plan, and for the behind-the-surface test a max-pyramid of
+    // this frame's dists
+    const size_t pyr_elems = df_rigid_depth_cull_disabled() ? 0 : df_pyramid_elems(cols, rows);
+    const size_t off_cnt = 0, off_bins = 64, off_mask = off_bins + (size_t)DF_RIGID_BINS * n_items * 4;
+    const size_t off_pyr = (off_mask + n_items + 15) / 16 * 16, bytes = off_pyr + pyr_elems * sizeof(uint16_t);
+    char* scratch = nullptr;
+    DF_HIP(hipMallocAsync((void**)&scratch, bytes, st));
     DfDistsPyramid Py;
     memset(&Py, 0, sizeof(Py));
-    uint16_t* pyr_mem = nullptr;
-    if (!df_rigid_depth_cull_disabled()) {
-        const size_t elems = df_pyramid_elems(cols, rows);
-        if (hipMallocAsync((void**)&pyr_mem, elems * sizeof(uint16_t), st) == hipSuccess) {
-            int rc = df_build_dists_pyramid(dists, pitch, cols, rows, pyr_mem, elems, &Py, st);
-            if (rc) { (void)hipFreeAsync(pyr_mem, st); return rc; }
-        } else { (void)hipGetLastError(); pyr_mem = nullptr; }
-    }
+    int rc = DF_OK;
+    // (levels 1..5 only: the plan reads none above; the pyramid's first workgroup zeroes the plan's counters)
+    if (pyr_elems) rc = df_build_dists_pyramid(dists, pitch, cols, rows, (uint16_t*)(scratch + off_pyr), pyr_elems, &Py, st, true, (unsigned int*)(scratch + off_cnt));
+    if (rc == DF_OK && Py.top == 0 && hipMemsetAsync(scratch + off_cnt, 0, 64, st) != hipSuccess) rc = (int)hipGetLastError();
+    if (rc != DF_OK) { (void)hipFreeAsync(scratch, st); return rc; }
+    unsigned int* cnt = (unsigned int*)(scratch + off_cnt);
+    unsigned int* bins = (unsigned int*)(scratch + off_bins);
+    unsigned char* mask = (unsigned char*)(scratch + off_mask);
+    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, mask, cnt, bins);
+    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, mask, cnt, bins);
+    a.plan_mask = mask; a.plan_bins = bins; a.plan_cnt = cnt;
     // short arithmetic forms (tsdf_sample_fast): 32-bit dists offsets, sane intrinsics; the value domain is tested per run in the kernel
     const bool fast_ok = (unsigned long long)rows * pitch < (1ull << 31) && proj[0] == proj[0] && proj[1] == proj[1] && !g_df_rigid_no_fast_forms;
-    if (Py.top) hipLaunchKernelGGL((df_integrate_rigid_kernel<4, true>), grid, dim3(256), 0, st, a, F, Py, fast_ok);
-    else hipLaunchKernelGGL((df_integrate_rigid_kernel<4, false>), grid, dim3(256), 0, st, a, F, Py, fast_ok);
-    DF_LAUNCH_CHECK();
-    if (pyr_mem) DF_HIP(hipFreeAsync(pyr_mem, st));
-    return DF_OK;
+    const dim3 grid((n_items + 3) / 4);                              // sized for every item; waves past the plan's end return at once
+#ifdef DF_TRACE_WG
+    static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;
+    const size_t trace_n = (size_t)grid.x * 4 * 4;
+    if (trace_n > trace_cap) { (void)hipFree(trace_dev); DF_HIP(hipMalloc((void**)&trace_dev, trace_n * 8)); trace_cap = trace_n; }
+    DF_HIP(hipMemsetAsync(trace_dev, 0, trace_n * 8, st));
+    a.trace = trace_dev;
+#endif
+    hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U>), grid, dim3(256), 0, st, a, fast_ok);
+    rc = (int)hipGetLastError();
+#ifdef DF_TRACE_WG
+    if (getenv("DF_TRACE_FILE")) {
+        DF_HIP(hipStreamSynchronize(st));
+        unsigned long long* h = (unsigned long long*)malloc(trace_n * 8);
+        DF_HIP(hipMemcpy(h, trace_dev, trace_n * 8, hipMemcpyDeviceToHost));
+        FILE* f = fopen(getenv("DF_TRACE_FILE"), "wb");
+        if (f) { unsigned long long hdr[4] = {grid.x, 1, 4, 0}; fwrite(hdr, 8, 4, f); fwrite(h, 8, trace_n, f); fclose(f); }
+        free(h);
+    }
+#endif
+    (void)hipFreeAsync(scratch, st);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------ misc

@@ -9,21 +9,23 @@ from dynamicfusion_amd import capi, build as B
 B.LIB_PATH = os.path.join(REPO, "build", "libdfusion_hip_trace.so"); B._stale = lambda: False
 from dynamicfusion_amd import Intr, TsdfVolume, WarpField, compute_dists, synth, upload_u16
 name = sys.argv[1] if len(sys.argv) > 1 else "512"
+rigid = len(sys.argv) > 2 and sys.argv[2] == "rigid"
 cfg = synth.CONFIGS[name]; intr = Intr(*cfg.intr)
 depth = upload_u16(synth.depth_frame(cfg, 0)); dists = compute_dists(depth, intr); cam = synth.camera_pose(cfg, 1)
 vol = TsdfVolume(cfg.dims); vol.setSize([cfg.size] * 3); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setPose(cfg.volume_pose)
 pos, sigma = synth.make_nodes(cfg); dq = synth.node_transforms(cfg, 1)
 wf = WarpField(k=cfg.k); wf.init(pos, sigma=sigma, transforms=dq); wf.ensure_index(vol, cfg.k)
-for _ in range(5): vol.integrate_warped(dists, cam, intr, wf)
+run_once = (lambda: vol.integrate(dists, cam, intr)) if rigid else (lambda: vol.integrate_warped(dists, cam, intr, wf))
+for _ in range(5): run_once()
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
 path = os.path.join(REPO, "gpurun_out", "sweep_trace.bin")
 os.environ["DF_TRACE_FILE"] = path
-vol.integrate_warped(dists, cam, intr, wf)
+run_once()
 del os.environ["DF_TRACE_FILE"]
 raw = np.fromfile(path, dtype=np.uint64)
 gx, gy, wpw = int(raw[0]), int(raw[1]), int(raw[2])
 t = raw[4:].reshape(gy, gx, wpw, 4)
-np.savez_compressed(os.path.join(REPO, "gpurun_out", "sweep_trace_%s.npz" % name), trace=t)
+np.savez_compressed(os.path.join(REPO, "gpurun_out", "sweep_trace_%s%s.npz" % (name, "_rigid" if rigid else "")), trace=t)
 os.remove(path)
 start, end, alive = t[..., 0].astype(np.int64), t[..., 1].astype(np.int64), t[..., 3].astype(np.int64)
 run = end > 0                                   # waves of workgroups past the plan's end never stamp
