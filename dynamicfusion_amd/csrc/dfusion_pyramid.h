@@ -44,6 +44,16 @@ __device__ __forceinline__ uint32_t df_pyramid_max_fine(const DfDistsPyramid& P,
     }
     const uint16_t* lv = P.mem + P.off[L];
     const int w = P.w[L];
+    if (a1 - a0 < 5 && b1 - b0 < 5) {
+        // the usual case (shift <= 1 always, shift = 2 unless max_level cut in): 25 clamped, unconditional loads, all in flight together
+        // (the loops below wait for each texel in turn -- 25 dependent round trips in a kernel that does little else)
+        uint32_t t[25];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) t[i] = (uint32_t)lv[min(b0 + i / 5, b1) * w + min(a0 + i % 5, a1)];
+#pragma unroll
+        for (int i = 0; i < 25; ++i) m = max(m, t[i]);
+        return m;
+    }
     for (int b = b0; b <= b1; ++b)
         for (int a = a0; a <= a1; ++a) m = max(m, (uint32_t)lv[b * w + a]);
     return m;
