@@ -245,9 +245,10 @@ struct DfRigidArgs {
     float vsx, vsy, vsz;
     DfIntegrateParams P;
     unsigned long long* n_upd;
-    // launch plan (df_rigid_plan_kernel): item = chunk * tiles + tile; plan_mask[item] = its alive sub-chunks (bit s: planes
-    // [zb + 16 s, zb + 16 s + 16) may update), items with w > 0 bits listed in bin w (plan_bins[w * plan_items ...], plan_cnt[w] of them)
-    const unsigned char* plan_mask; const unsigned int* plan_bins; const unsigned int* plan_cnt; unsigned int plan_items; int tiles;
+    // launch plan (df_rigid_plan_kernel): item = chunk * tiles + tile, its mask = its alive sub-chunks (bit s: planes [zb + SUB s,
+    // zb + SUB s + SUB) may update); items with w > 0 bits are listed in bin w (plan_bins[w * plan_items ...], plan_cnt[w] entries
+    // item | mask << 24)
+    const unsigned int* plan_bins; const unsigned int* plan_cnt; unsigned int plan_items; int tiles;
 #ifdef DF_TRACE_WG
     unsigned long long* trace;
 #endif
@@ -361,8 +362,7 @@ __device__ __forceinline__ bool df_rigid_box_culled(const DfRigidArgs& a, const 
 // ones first and the launch does not end on a few of them.
 template <bool DEPTH>
 __global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a, const DfFrustum F, const DfDistsPyramid Py, unsigned n_items,
-                                                             unsigned char* __restrict__ mask_out, unsigned int* __restrict__ cnt,
-                                                             unsigned int* __restrict__ bins)
+                                                             unsigned int* __restrict__ cnt, unsigned int* __restrict__ bins)
 {
     __shared__ unsigned int s_cnt[DF_RIGID_BINS], s_base[DF_RIGID_BINS];
     if (threadIdx.x < DF_RIGID_BINS) s_cnt[threadIdx.x] = 0u;
@@ -385,10 +385,7 @@ __global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a
     __syncthreads();
     if (threadIdx.x < DF_RIGID_BINS && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cnt[threadIdx.x], s_cnt[threadIdx.x]);
     __syncthreads();
-    if (sb == 0 && m) {
-        mask_out[item] = (unsigned char)m;
-        bins[(size_t)w * n_items + s_base[w] + slot] = item;
-    }
+    if (sb == 0 && m) bins[(size_t)w * n_items + s_base[w] + slot] = item | (m << 24);      // (n_items < 2^24, checked by the launcher)
 }
 
 // The sweep: wave e of the launch takes plan entry e (bins from the fullest down), replays `vc += zstep` up to its chunk, and walks
@@ -411,8 +408,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
 #endif
     const int j = __ffsll((unsigned long long)__ballot(lane < DF_RIGID_BINS - 1 && e < bin_end)) - 1;
     const unsigned r = e - ((unsigned)__builtin_amdgcn_readlane((int)bin_end, j) - (unsigned)__builtin_amdgcn_readlane((int)bin_cnt, j));
-    const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_RIGID_MAX_SUBS - j) * a.plan_items + r]);
-    const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_mask[item]);
+    const unsigned ent = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_RIGID_MAX_SUBS - j) * a.plan_items + r]);
+    const unsigned item = ent & 0xffffffu, mask = ent >> 24;            // one dependent load instead of two before a wave can start
     const int tile = (int)(item % (unsigned)a.tiles), chunk = (int)(item / (unsigned)a.tiles);
     const int tiles_x = (a.X + 31) >> 5;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -550,8 +547,9 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     // stream-ordered scratch (no state is kept between calls): the launch plan, and for the behind-the-surface test a max-pyramid of
     // this frame's dists
     const size_t pyr_elems = df_rigid_depth_cull_disabled() ? 0 : df_pyramid_elems(cols, rows);
-    const size_t off_cnt = 0, off_bins = 64, off_mask = off_bins + (size_t)DF_RIGID_BINS * n_items * 4;
-    const size_t off_pyr = (off_mask + n_items + 15) / 16 * 16, bytes = off_pyr + pyr_elems * sizeof(uint16_t);
+    if (n_items >= (1u << 24)) return DF_E_INVALID;                  // (a plan entry carries the item in 24 bits: 500 M columns x chunks)
+    const size_t off_cnt = 0, off_bins = 64, off_pyr = (off_bins + (size_t)DF_RIGID_BINS * n_items * 4 + 15) / 16 * 16;
+    const size_t bytes = off_pyr + pyr_elems * sizeof(uint16_t);
     char* scratch = nullptr;
     DF_HIP(hipMallocAsync((void**)&scratch, bytes, st));
     DfDistsPyramid Py;
@@ -563,10 +561,9 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     if (rc != DF_OK) { (void)hipFreeAsync(scratch, st); return rc; }
     unsigned int* cnt = (unsigned int*)(scratch + off_cnt);
     unsigned int* bins = (unsigned int*)(scratch + off_bins);
-    unsigned char* mask = (unsigned char*)(scratch + off_mask);
-    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, mask, cnt, bins);
-    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, mask, cnt, bins);
-    a.plan_mask = mask; a.plan_bins = bins; a.plan_cnt = cnt;
+    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, cnt, bins);
+    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, cnt, bins);
+    a.plan_bins = bins; a.plan_cnt = cnt;
     // short arithmetic forms (tsdf_sample_fast): 32-bit dists offsets, sane intrinsics; the value domain is tested per run in the kernel
     const bool fast_ok = (unsigned long long)rows * pitch < (1ull << 31) && proj[0] == proj[0] && proj[1] == proj[1] && !g_df_rigid_no_fast_forms;
     const dim3 grid((n_items + 3) / 4);                              // sized for every item; waves past the plan's end return at once
