@@ -23,8 +23,11 @@
  *     (the reference is not re-entrant: global texture ref tsdf_volume.cu:50, host globals
  *     warp_field.cpp:11-15).  ONE warp-field handle, though, is single-stream: its calls rewrite
  *     scratch it owns (the point queries' fallback list, the solver workspace, the cull's device
- *     scalars), so calls on the same DfWarpField must be issued on one stream or serialised by the
- *     caller.  (dfusion_debug_rigid is a process-wide validation switch, off the product path.)
+ *     scalars, the dists max-pyramid and the launch plan of the warped sweep), so calls on the same
+ *     DfWarpField must be issued on one stream or serialised by the caller.  dfusion_integrate keeps
+ *     nothing between calls: its pyramid and launch plan live in stream-ordered scratch
+ *     (hipMallocAsync / hipFreeAsync on `stream`).  (dfusion_debug_rigid is a process-wide validation
+ *     switch, off the product path.)
  */
 #ifndef DFUSION_H
 #define DFUSION_H
