@@ -232,9 +232,14 @@ __global__ __launch_bounds__(256) void df_pyramid_top_kernel(const DfDistsPyrami
     }
 }
 // ------------------------------------------------------------------------------------------ integrate (rigid)
-static bool g_df_rigid_no_depth_cull = false, g_df_rigid_no_fast_forms = false;
-// bit 0: behind-the-surface test, bit 1: short arithmetic forms (default 3 = both on; validation switches, results must not change)
-extern "C" int dfusion_debug_rigid(int flags) { g_df_rigid_no_depth_cull = !(flags & 1); g_df_rigid_no_fast_forms = !(flags & 2); return DF_OK; }
+static bool g_df_rigid_no_depth_cull = false, g_df_rigid_no_fast_forms = false, g_df_rigid_keep_all = false;
+// bit 0: behind-the-surface test, bit 1: short arithmetic forms, bit 2 SET: the plan keeps every sub-chunk (no frustum test either);
+// default 3 (validation switches, results must not change)
+extern "C" int dfusion_debug_rigid(int flags)
+{
+    g_df_rigid_no_depth_cull = !(flags & 1); g_df_rigid_no_fast_forms = !(flags & 2); g_df_rigid_keep_all = (flags & 4) != 0;
+    return DF_OK;
+}
 
 struct DfRigidArgs {
     uint32_t* vol;            // first stored plane
@@ -361,7 +366,7 @@ __device__ __forceinline__ bool df_rigid_box_culled(const DfRigidArgs& a, const 
 // sub-chunks (slots taken per workgroup, one atomic per bin); the sweep takes the bins from the fullest down, so its waves are the long
 // ones first and the launch does not end on a few of them.
 template <bool DEPTH>
-__global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a, const DfFrustum F, const DfDistsPyramid Py, unsigned n_items,
+__global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a, const DfFrustum F, const DfDistsPyramid Py, unsigned n_items, bool keep_all,
                                                              unsigned int* __restrict__ cnt, unsigned int* __restrict__ bins)
 {
     __shared__ unsigned int s_cnt[DF_RIGID_BINS], s_base[DF_RIGID_BINS];
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int zb = a.z_own0 + chunk * a.zc, ze = min(zb + a.zc, a.z_own0 + a.z_own_n);
         const int zs = zb + sb * DF_RIGID_SUB;
-        if (zs < ze) keep = !df_rigid_box_culled<DEPTH>(a, F, Py, tx * 32, ty * 2, zs, min(DF_RIGID_SUB, ze - zs));
+        if (zs < ze) keep = keep_all || !df_rigid_box_culled<DEPTH>(a, F, Py, tx * 32, ty * 2, zs, min(DF_RIGID_SUB, ze - zs));
     }
     const unsigned m = (unsigned)(__ballot(keep) >> (lane & ~7)) & 0xffu;   // the item's 8 verdicts
     const unsigned w = (unsigned)__popc(m);
@@ -561,8 +566,8 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     if (rc != DF_OK) { (void)hipFreeAsync(scratch, st); return rc; }
     unsigned int* cnt = (unsigned int*)(scratch + off_cnt);
     unsigned int* bins = (unsigned int*)(scratch + off_bins);
-    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, cnt, bins);
-    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, cnt, bins);
+    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, g_df_rigid_keep_all, cnt, bins);
+    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, g_df_rigid_keep_all, cnt, bins);
     a.plan_bins = bins; a.plan_cnt = cnt;
     // short arithmetic forms (tsdf_sample_fast): 32-bit dists offsets, sane intrinsics; the value domain is tested per run in the kernel
     const bool fast_ok = (unsigned long long)rows * pitch < (1ull << 31) && proj[0] == proj[0] && proj[1] == proj[1] && !g_df_rigid_no_fast_forms;

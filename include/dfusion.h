@@ -218,7 +218,8 @@ int dfusion_selftest_exact_forms(unsigned long long n_random, unsigned long long
 /* Validation switches of dfusion_integrate, so that tests can assert the volumes are identical with and without them (process-wide,
  * default 3; no reference counterpart).  bit 0: the behind-the-surface test (a conservative, result-identical skip of voxels that
  * lie more than trunc_dist behind every depth value they can be compared with; per-frame max-pyramid of dists); bit 1: the short
- * forms of the correctly rounded divisions / square root on runs of voxels whose coordinates are inside their domain.              */
+ * forms of the correctly rounded divisions / square root on runs of voxels whose coordinates are inside their domain; bit 2 SET:
+ * the launch plan keeps every sub-chunk (no frustum test either: every voxel goes through the reference's own tests).              */
 int dfusion_debug_rigid(int flags);
 
 /* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k], ascending distance; exactly

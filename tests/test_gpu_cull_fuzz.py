@@ -1,0 +1,112 @@
+"""Randomised stress of the two result-identical culls: the sweeps' launch plans (df_sweep_plan_kernel: ball around the tile centre,
+frustum side planes, distance bound against the max-pyramid of dists; df_rigid_plan_kernel: the patch's box against the same) must
+never drop a voxel that updates.  Random camera poses (inside / outside / beside the volume, tilted), random volume poses, depth
+images made of random blocks of near / far / invalid values, strong node motions: the volume with the cull must equal the volume
+without it, bit for bit, update counts included.  (The no-cull sweeps are themselves compared with the oracle elsewhere.)"""
+import numpy as np
+import pytest
+import torch
+
+from dynamicfusion_amd import Intr, TsdfVolume, WarpField, capi, compute_dists, synth, upload_u16
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def rot(axis, ang):
+    a = np.asarray(axis, np.float64); a /= np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+
+
+def random_pose(rng, centre, dist_lo, dist_hi, tilt):
+    """camera somewhere around `centre`, looking roughly at it (z forward), rolled and tilted by up to `tilt` rad"""
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    eye = centre + d * rng.uniform(dist_lo, dist_hi)
+    z = centre - eye; z /= np.linalg.norm(z)
+    up = rng.normal(size=3); x = np.cross(up, z); x /= np.linalg.norm(x); y = np.cross(z, x)
+    R = np.stack([x, y, z], 1) @ rot(rng.normal(size=3), rng.uniform(-tilt, tilt))
+    m = np.eye(4, dtype=F32); m[:3, :3] = R.astype(F32); m[:3, 3] = eye.astype(F32)
+    return m
+
+
+def random_depth(rng, cols, rows, lo_mm, hi_mm):
+    d = np.zeros((rows, cols), np.uint16)
+    d[:] = rng.integers(lo_mm, hi_mm)
+    for _ in range(rng.integers(3, 12)):
+        x0, y0 = rng.integers(0, cols), rng.integers(0, rows)
+        w, h = rng.integers(1, cols // 2 + 1), rng.integers(1, rows // 2 + 1)
+        d[y0:y0 + h, x0:x0 + w] = 0 if rng.random() < 0.25 else rng.integers(lo_mm, hi_mm)
+    d[rng.random(d.shape) < 0.02] = 0
+    return d
+
+
+def make_volume(dims, size, pose, trunc=0.04):
+    v = TsdfVolume(dims); v.setSize([size] * 3); v.setTruncDist(trunc); v.setMaxWeight(64); v.setPose(pose)
+    return v
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_rigid_plan_never_drops_an_update(seed):
+    rng = np.random.default_rng(100 + seed)
+    dims = [(64, 64, 64), (40, 72, 56), (96, 32, 64)][seed % 3]
+    size = float(rng.uniform(0.8, 2.0))
+    cols, rows = [(96, 72), (160, 120), (67, 45)][(seed // 3) % 3]
+    intr = Intr(*(F32(rng.uniform(0.7, 1.4) * cols), F32(rng.uniform(0.7, 1.4) * cols), F32(cols / 2 + rng.uniform(-8, 8)), F32(rows / 2 + rng.uniform(-8, 8))))
+    vol_pose = np.eye(4, dtype=F32); vol_pose[:3, :3] = rot(rng.normal(size=3), rng.uniform(0, 0.6) * (seed % 2)).astype(F32)
+    vol_pose[:3, 3] = rng.uniform(-0.5, 0.5, 3).astype(F32)
+    centre = (vol_pose[:3, :3].astype(np.float64) @ (np.array([size, size, size]) / 2)) + vol_pose[:3, 3]
+    L = capi.lib()
+    res = []
+    frames = [(random_pose(rng, centre, 0.0 if seed % 4 == 0 else 0.3 * size, 2.2 * size, 0.5), random_depth(rng, cols, rows, 300, int(3500 * size)))
+              for _ in range(3)]
+    try:
+        for flags in (3, 2, 6):                               # the plan's tests: both, frustum only, none (every sub-chunk swept)
+            capi.check(L.dfusion_debug_rigid(flags))
+            v = make_volume(dims, size, vol_pose)
+            n = torch.zeros(1, dtype=torch.int64, device="cuda")
+            for cam, depth in frames:
+                v.integrate(compute_dists(upload_u16(depth), intr), cam, intr, n_updated=n)
+            res.append((v.download(), int(n.item())))
+    finally:
+        capi.check(L.dfusion_debug_rigid(3))
+    print("rigid fuzz seed", seed, "updates", res[0][1])
+    for r in res[1:]:
+        assert np.array_equal(res[0][0], r[0]) and res[0][1] == r[1]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_warped_plan_never_drops_an_update(seed):
+    rng = np.random.default_rng(500 + seed)
+    dims = [(64, 64, 64), (32, 48, 64), (96, 32, 40)][seed % 3]
+    size = float(rng.uniform(0.8, 2.0))
+    cols, rows = [(96, 72), (160, 120), (67, 45)][(seed // 3) % 3]
+    k = [8, 4][seed % 2]
+    intr = Intr(*(F32(rng.uniform(0.7, 1.4) * cols), F32(rng.uniform(0.7, 1.4) * cols), F32(cols / 2 + rng.uniform(-8, 8)), F32(rows / 2 + rng.uniform(-8, 8))))
+    vol_pose = np.eye(4, dtype=F32)                           # (rotated volume poses take the general kernel: see test_gpu_edge_cases)
+    if seed % 4 == 3: vol_pose[:3, :3] = rot(rng.normal(size=3), rng.uniform(0, 0.5)).astype(F32)
+    vol_pose[:3, 3] = rng.uniform(-0.5, 0.5, 3).astype(F32)
+    ext = np.array(dims, np.float64) / max(dims) * size
+    centre = (vol_pose[:3, :3].astype(np.float64) @ (ext / 2)) + vol_pose[:3, 3]
+    M = int(rng.integers(30, 120))
+    pos = (vol_pose[:3, :3].astype(np.float64) @ (rng.uniform(0.1, 0.9, (M, 3)) * ext).T).T + vol_pose[:3, 3]
+    sigma = np.full(M, rng.uniform(0.03, 0.15) * size, F32)
+    amp_r, amp_t = [(0.02, 0.005), (0.15, 0.03), (0.5, 0.1)][seed % 3]
+    frames = []
+    for _ in range(3):
+        dq = synth.dq_from_twist(rng.uniform(-amp_r, amp_r, (M, 3)).astype(F32), rng.uniform(-amp_t, amp_t, (M, 3)).astype(F32))
+        frames.append((random_pose(rng, centre, 0.0 if seed % 5 == 0 else 0.3 * size, 2.2 * size, 0.5),
+                       random_depth(rng, cols, rows, 300, int(3500 * size)), dq))
+    wf = WarpField(k=k, voxel_table=(seed % 6 != 5))
+    wf.init(pos.astype(F32), sigma=sigma, transforms=frames[0][2])
+    res = []
+    for kw in (dict(), dict(depth_pyramid=False), dict(cull=False)):
+        v = TsdfVolume(dims); v.setSize(list(ext)); v.setTruncDist(0.04); v.setMaxWeight(64); v.setPose(vol_pose)
+        n = torch.zeros(1, dtype=torch.int64, device="cuda")
+        for cam, depth, dq in frames:
+            wf.set_transforms(torch.from_numpy(dq).cuda())
+            v.integrate_warped(compute_dists(upload_u16(depth), intr), cam, intr, wf, n_updated=n, **kw)
+        res.append((v.download(), int(n.item())))
+    print("warped fuzz seed", seed, "updates", res[0][1])
+    for r in res[1:]:
+        assert np.array_equal(res[0][0], r[0]) and res[0][1] == r[1]

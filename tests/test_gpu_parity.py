@@ -105,7 +105,7 @@ def test_integrate_rigid_depth_cull_is_result_identical(cfg):
     L = capi.lib()
     vols = []
     try:
-        for flags in (3, 0, 1, 2):                       # bit 0: depth cull, bit 1: short arithmetic forms
+        for flags in (3, 0, 1, 2, 6, 4):                 # bit 0: depth cull, bit 1: short arithmetic forms, bit 2 set: the plan keeps everything
             capi.check(L.dfusion_debug_rigid(flags))
             vol = make_gpu_volume(sc)
             n_upd = torch.zeros(1, dtype=torch.int64, device="cuda")
