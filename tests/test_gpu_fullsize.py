@@ -128,12 +128,12 @@ def test_full_size_properties_and_sampled_oracle(name):
     gp, gn = fp.cpu().numpy(), fn.cpu().numpy()
     assert np.array_equal(bits(gp), bits(rp)) and np.array_equal(bits(gn), bits(rn))
 
-    # ---- rigid: slab-sharded == unsharded at full size (replayed vc accumulation); behind-the-surface skip on == off
+    # ---- rigid: slab-sharded == unsharded at full size (replayed vc accumulation); launch plan's tests and short forms on == all off
     r_full = setup(cfg)
     r_full.integrate(dists[0], sc.cam_poses[0], intr)
     from dynamicfusion_amd import capi
     try:
-        capi.check(capi.lib().dfusion_debug_rigid(0))
+        capi.check(capi.lib().dfusion_debug_rigid(4))           # every sub-chunk swept, generic arithmetic
         r_nocull = setup(cfg)
         r_nocull.integrate(dists[0], sc.cam_poses[0], intr)
     finally:
