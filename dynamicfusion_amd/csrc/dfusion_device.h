@@ -294,7 +294,10 @@ __device__ __forceinline__ bool tsdf_sample_fast(const DfIntegrateParams& P, f3 
     const float r = df_rcp_refined(vc.z);
     const float u = fmaf(P.fx, df_div_shared(vc.x, vc.z, r), P.cx);        // device.hpp:35
     const float v = fmaf(P.fy, df_div_shared(vc.y, vc.z, r), P.cy);        // device.hpp:36
-    bool ok = (u >= 0.f) & (v >= 0.f) & (u < (float)P.cols) & (v < (float)P.rows);   // :82 (:86's vc.z > 0 holds on the domain)
+    // :82 (:86's vc.z > 0 holds on the domain).  0 <= u < cols as ONE unsigned compare of the float bits: non-negative floats order
+    // like their bits, negative ones and NaNs have bits above every positive finite float's.  (-0.f would differ -- it is >= 0 --
+    // but u = fma(fx, q, cx) with cx > 0, which the callers of this form require, is never -0.)
+    bool ok = (__float_as_uint(u) < __float_as_uint((float)P.cols)) & (__float_as_uint(v) < __float_as_uint((float)P.rows));
     const uint32_t ui = (uint32_t)(int)__builtin_amdgcn_fmed3f(u, 0.f, (float)(P.cols - 1));
     const uint32_t vi = (uint32_t)(int)__builtin_amdgcn_fmed3f(v, 0.f, (float)(P.rows - 1));
     const uint32_t off = vi * (uint32_t)P.pitch + 2u * ui;
@@ -311,6 +314,22 @@ __device__ __forceinline__ uint32_t tsdf_fuse(uint32_t vox, float tsdf, int max_
     float tsdf_prev = h2f_bits(vox);
     float tsdf_new = fmaf(tsdf_prev, (float)weight_prev, tsdf) / (float)(weight_prev + 1);
     int weight_new = min(weight_prev + 1, max_weight);
+    return f2h_bits(tsdf_new) | (((uint32_t)weight_new & 0xffffu) << 16);
+}
+
+// The same with the division in its short form (df_div_shared: hipcc's own sequence minus v_div_scale / v_div_fixup).  The
+// denominator is an integer in [1, 65536]; the numerator fma(prev, w, tsdf) is 0 or at least ~2^-50 in magnitude (prev is a half,
+// w an integer, |tsdf| a difference of a half-derived and an f32 length times 1 / trunc): no operand, quotient or residual comes near
+// the denormal range, where v_div_scale would have acted.  Valid for FINITE prev (tsdf_fuse_short_ok); the generic form otherwise.
+// dfusion_selftest_exact_forms compares the two on every half x every weight x a spread of tsdf values.
+__device__ __forceinline__ bool tsdf_fuse_short_ok(uint32_t vox) { return (vox & 0x7c00u) != 0x7c00u; }
+__device__ __forceinline__ uint32_t tsdf_fuse_short(uint32_t vox, float tsdf, int max_weight)
+{
+    const int weight_prev = (int)(vox >> 16);
+    const float tsdf_prev = h2f_bits(vox);
+    const float d = (float)(weight_prev + 1);
+    const float tsdf_new = df_div_shared(fmaf(tsdf_prev, (float)weight_prev, tsdf), d, df_rcp_refined(d));
+    const int weight_new = min(weight_prev + 1, max_weight);
     return f2h_bits(tsdf_new) | (((uint32_t)weight_new & 0xffffu) << 16);
 }
 

@@ -78,14 +78,47 @@ __global__ __launch_bounds__(256) void df_selftest_quat_kernel(unsigned long lon
     }
 }
 
+// [5] tsdf_fuse_short vs tsdf_fuse on EVERY finite stored half x weights 0..64 and a spread up to 65535 x `per` tsdf values each
+//     (the values a sample can produce: min(1, sdf / trunc) -- random in [-2, 1], tiny ones of both signs, zeros, 1)
+__global__ __launch_bounds__(256) void df_selftest_fuse_kernel(unsigned per, unsigned long long* __restrict__ counts)
+{
+    unsigned long long bad = 0;
+    unsigned long long seed = 0xd1b54a32d192ed03ull * (blockIdx.x * 256ull + threadIdx.x + 1ull);
+    const unsigned n_w = 65 + 32;
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < 65536ull * n_w; i += (unsigned long long)gridDim.x * 256ull) {
+        const unsigned h = (unsigned)(i & 0xffffu), wi = (unsigned)(i >> 16);
+        const unsigned w = wi < 65 ? wi : 65u + (st_rng(seed) % 65471u);
+        const uint32_t vox = h | (w << 16);
+        if (!tsdf_fuse_short_ok(vox)) continue;
+        for (unsigned j = 0; j < per; ++j) {
+            const unsigned r = st_rng(seed), m = st_rng(seed);
+            float t;
+            switch (r & 7u) {
+                case 0: t = 0.f; break;
+                case 1: t = 1.f; break;
+                case 2: t = __uint_as_float((m & 0x807fffffu) | ((90u + (r >> 8) % 37u) << 23)); break;      // 2^-37 .. 2^-1, both signs
+                case 3: t = -h2f_bits((uint16_t)h) * (float)w; break;                                      // cancels the stored sum exactly
+                case 4: t = -h2f_bits((uint16_t)h) * (float)w * (1.f + (float)((int)(m & 15u) - 8) * 0x1p-23f); break;   // ... nearly
+                default: t = fminf(1.f, (float)(int)(m >> 8) * 0x1p-23f * 1.5f - 2.f + (float)(m & 255u) * 0x1p-31f); break;   // [-2, 1]
+            }
+            bad += tsdf_fuse_short(vox, t, 64) != tsdf_fuse(vox, t, 64);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bad += __shfl_xor(bad, o, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&counts[5], bad);
+}
+
 extern "C" int dfusion_selftest_exact_forms(unsigned long long n_random, unsigned long long* counts_dev, dfStream stream)
 {
     if (!counts_dev) return DF_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    DF_HIP(hipMemsetAsync(counts_dev, 0, 5 * sizeof(unsigned long long), st));
+    DF_HIP(hipMemsetAsync(counts_dev, 0, 6 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(df_selftest_scan_kernel, dim3(4096), dim3(256), 0, st, counts_dev);
     DF_LAUNCH_CHECK();
     hipLaunchKernelGGL(df_selftest_quat_kernel, dim3(2048), dim3(256), 0, st, n_random, counts_dev);
+    DF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(df_selftest_fuse_kernel, dim3(2048), dim3(256), 0, st, (unsigned)(n_random >> 21 ? n_random >> 21 : 1), counts_dev);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }

@@ -305,9 +305,15 @@ __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f
 #pragma unroll
         for (int u = 0; u < U; ++u)                     // stage 2: the voxel loads of the batch in flight together
             if (up[u]) v[u] = p[(size_t)u * plane];
+        bool fin = FAST;                                // the fuse division's short form: finite stored values (a wave decides together)
+        if (FAST) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) fin = fin & (!up[u] | tsdf_fuse_short_ok(v[u]));
+            fin = df_wave_all(fin);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u)                     // stage 3: fuse (:97-103) and store
-            if (up[u]) { p[(size_t)u * plane] = tsdf_fuse(v[u], ts[u], a.P.max_weight); ++my_upd; }
+            if (up[u]) { p[(size_t)u * plane] = fin ? tsdf_fuse_short(v[u], ts[u], a.P.max_weight) : tsdf_fuse(v[u], ts[u], a.P.max_weight); ++my_upd; }
         p += (size_t)min(U, zse - z) * plane;
     }
 }
@@ -570,7 +576,8 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, g_df_rigid_keep_all, cnt, bins);
     a.plan_bins = bins; a.plan_cnt = cnt;
     // short arithmetic forms (tsdf_sample_fast): 32-bit dists offsets, sane intrinsics; the value domain is tested per run in the kernel
-    const bool fast_ok = (unsigned long long)rows * pitch < (1ull << 31) && proj[0] == proj[0] && proj[1] == proj[1] && !g_df_rigid_no_fast_forms;
+    const bool fast_ok = (unsigned long long)rows * pitch < (1ull << 31) && proj[0] == proj[0] && proj[1] == proj[1] && proj[2] > 0.f && proj[3] > 0.f &&
+                         !g_df_rigid_no_fast_forms;          // (cx, cy > 0: the one-compare pixel range test of tsdf_sample_fast)
     const dim3 grid((n_items + 3) / 4);                              // sized for every item; waves past the plan's end return at once
 #ifdef DF_TRACE_WG
     static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;

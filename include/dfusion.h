@@ -212,7 +212,8 @@ int dfusion_warp_set_point_tiling(DfWarpField *wf, int image_cols);
 /* Device self-test of the sweep's short arithmetic forms (dfusion_device.h) against the generic ones they replace; no reference
  * counterpart, used by the parity tests.  counts_dev[5] (device) receives mismatch counts: [0] short sqrtf over every f32 of its
  * domain, [1] short f64 reciprocal over every positive normal f32, [2] packed quaternion products on n_random random pairs
- * (specials included), [3] near-unit normalisation on the normalised quaternions among them, [4] how many of those there were.   */
+ * (specials included), [3] near-unit normalisation on the normalised quaternions among them, [4] how many of those there were,
+ * [5] the short fuse division on every finite stored half x 97 weights x (n_random >> 21) tsdf values.  counts_dev: 6 entries.      */
 int dfusion_selftest_exact_forms(unsigned long long n_random, unsigned long long *counts_dev, dfStream stream);
 
 /* Validation switches of dfusion_integrate, so that tests can assert the volumes are identical with and without them (process-wide,
