@@ -398,8 +398,9 @@ __global__ __launch_bounds__(64) void df_points_index_kernel(DfWarpView W, DfPoi
     // query points (pixels) mostly share a brick: the wave visits its DISTINCT bricks one after the other, stages each brick's
     // candidate positions through LDS with coalesced loads (a per-lane walk of the list is a chain of dependent global loads --
     // measured no faster than scanning all nodes), and the lanes of that brick rank them from LDS.
-    __shared__ float4 s_pos[64];
-    __shared__ int s_id[64];
+    constexpr int CAP = 384, NBMAX = 8;                    // LDS stage (7.5 KiB: 20 one-wave workgroups per CU), bricks per pass
+    __shared__ float4 s_pos[CAP];
+    __shared__ int s_id[CAP];
     const int lane = threadIdx.x;
     // image_cols > 0 (dfusion_warp_set_point_tiling): the points are the pixels of an image that wide and a wave takes an 8 x 8 pixel
     // tile instead of 64 consecutive pixels of a row -- 3 distinct bricks per wave instead of 8 on a 640 x 480 ray-cast cloud, and every
@@ -433,28 +434,60 @@ __global__ __launch_bounds__(64) void df_points_index_kernel(DfWarpView W, DfPoi
             dq = sqrtf(dot3(dc, dc));
         }
     }
+    // A pass stages the candidate lists of up to NBMAX of the wave's distinct bricks in LDS TOGETHER (their entries dealt out over the
+    // lanes: two dependent load rounds -- ids, then positions -- for all of them, not two per brick and 64 candidates) and every lane
+    // then ranks ITS brick's candidates from there, all bricks at once: the pass costs the longest list, not the sum of the lists.
+    // Each lane still sees its brick's candidates in list order, so the results (ties included) are those of the one-brick-at-a-time walk.
     unsigned long long todo = __ballot(brick != -1);
     while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int b = __shfl(brick, leader, 64);
-        const bool mine = brick == b;
-        todo &= ~__ballot(mine);
-        const uint32_t beg = W.brick_off[b], end = W.brick_off[b + 1];
-        for (uint32_t c0 = beg; c0 < end; c0 += 64) {
-            const int n = (int)min(64u, end - c0);
+        int nb = 0, myslot = -1, slot_brick = 0;
+        for (unsigned long long rem = todo; rem && nb < NBMAX; ++nb) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const int b = __shfl(brick, leader, 64);
+            const bool mine = brick == b;
+            if (mine) myslot = nb;
+            if (lane == nb) slot_brick = b;
+            rem &= ~__ballot(mine);
+        }
+        uint32_t lo = 0, len = 0;                          // lane s < nb: list range of brick s of this pass
+        if (lane < nb) { lo = W.brick_off[slot_brick]; len = W.brick_off[slot_brick + 1] - lo; }
+        uint32_t end = len;                                // running total over the slots
+#pragma unroll
+        for (int o = 1; o < NBMAX; o <<= 1) { const uint32_t t = __shfl_up(end, o, 64); if (lane >= o) end += t; }
+        const uint32_t base = end - len;
+        // the slots whose lists fit the stage together (a prefix of them); none = the first list alone is longer: walked in pieces
+        const int nfit = __popcll(__ballot(lane < nb && end <= (uint32_t)CAP));
+        const int ntake = max(nfit, 1);
+        const int ms = min(max(myslot, 0), ntake - 1);
+        const bool mine = myslot >= 0 && myslot < ntake;
+        const uint32_t my_base = __shfl(base, ms, 64), my_len = __shfl(len, ms, 64);
+        const uint32_t total = nfit ? (uint32_t)__shfl(end, nfit - 1, 64) : (uint32_t)__shfl(len, 0, 64);
+        for (uint32_t c0 = 0; c0 < total; c0 += CAP) {     // (one round unless a single list exceeds the stage)
+            const uint32_t n = min((uint32_t)CAP, total - c0);
             __syncthreads();
-            if (lane < n) {
-                const int j = (int)W.brick_list[c0 + lane];
-                s_id[lane] = j;
-                s_pos[lane] = W.pos_sigma[j];
+            for (uint32_t e = lane; e < n; e += 64) {
+                // list position of staged entry c0 + e: it belongs to the last slot that starts at or before it (the per-slot values
+                // are read with readlane -- scalar, whatever lanes this loop has left active)
+                uint32_t adj = (uint32_t)__builtin_amdgcn_readlane((int)lo, 0) - (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+#pragma unroll
+                for (int i = 1; i < NBMAX; ++i)
+                    if (i < ntake && c0 + e >= (uint32_t)__builtin_amdgcn_readlane((int)base, i))
+                        adj = (uint32_t)__builtin_amdgcn_readlane((int)lo, i) - (uint32_t)__builtin_amdgcn_readlane((int)base, i);
+                const uint32_t src = c0 + e + adj;
+                const int j = (int)W.brick_list[src];
+                s_id[e] = j;
+                s_pos[e] = W.pos_sigma[j];
             }
             __syncthreads();
-            if (mine)
-                for (int c = 0; c < n; ++c) {
-                    const float4 p = s_pos[c];
-                    topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), s_id[c], W.nf, q);
+            if (mine) {
+                const uint32_t b0 = max(my_base, c0), b1 = min(my_base + my_len, c0 + n);
+                for (uint32_t c = b0; c < b1; ++c) {
+                    const float4 p = s_pos[c - c0];
+                    topk_insert<K>(bd, bi, knn_dist2(q, p.x, p.y, p.z), s_id[c - c0], W.nf, q);
                 }
+            }
         }
+        todo &= ~__ballot(mine);
     }
     // Exactness check: a node outside the brick's list is farther than thr from the brick centre, hence farther than thr - dq from
     // the query; if the k-th distance found is within that, nothing outside the list can belong to the k nearest.  (Always true for
