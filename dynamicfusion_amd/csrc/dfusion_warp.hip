@@ -688,29 +688,33 @@ __global__ __launch_bounds__(256) void df_brick_index_kernel(const float4* __res
     // centre of the brick's voxel-centre lattice (voxel (i,j,k) sits at (i*vsx, j*vsy, k*vsz), tsdf_volume.cu:71)
     const f3 c = aff_mul(g.vol2world, mk3(((float)(bxx * DF_BRICK) + 3.5f) * g.vsx, ((float)(byy * DF_BRICK) + 3.5f) * g.vsy,
                                           ((float)(bzz * DF_BRICK) + 3.5f) * g.vsz));
-    // pass 1: D_k(c)^2 -- per-lane top-K over a strided share of the nodes, then K wave-min pops
-    float bd[K]; int bi[K];
-    topk_init<K>(bd, bi);
-    for (int j = lane; j < M; j += 64) {
-        const float4 p = pos_sigma[j];
-        topk_insert<K>(bd, bi, knn_dist2(c, p.x, p.y, p.z), j);
-    }
-    float dk2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < K; ++r) {
-        const float m = wave_min_f32(bd[0]);
-        dk2 = m;
-        const unsigned long long who = __ballot(bd[0] == m);
-        const int first = __ffsll((long long)who) - 1;
-        if (lane == first) {                               // pop this lane's head
-#pragma unroll
-            for (int i = 0; i < K - 1; ++i) bd[i] = bd[i + 1];
-            bd[K - 1] = __uint_as_float(0x7f800000u);
+    // pass 1 (counting launch only; the filling launch reads its result back): D_k(c)^2 -- per-lane top-K over a strided share of the
+    // nodes, then K wave-min pops
+    float thr;
+    if (!FILL) {
+        float bd[K]; int bi[K];
+        topk_init<K>(bd, bi);
+        for (int j = lane; j < M; j += 64) {
+            const float4 p = pos_sigma[j];
+            topk_insert<K>(bd, bi, knn_dist2(c, p.x, p.y, p.z), j);
         }
-    }
-    // inclusion radius (squared), inflated for rounding: any node that can be in the k-NN of ANY voxel of
-    // the brick satisfies |n - c| <= D_k(c) + 2 r_B.
-    const float thr = (sqrtf(dk2) + g.r2x) * 1.0001f + 1e-6f;
+        float dk2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const float m = wave_min_f32(bd[0]);
+            dk2 = m;
+            const unsigned long long who = __ballot(bd[0] == m);
+            const int first = __ffsll((long long)who) - 1;
+            if (lane == first) {                               // pop this lane's head
+#pragma unroll
+                for (int i = 0; i < K - 1; ++i) bd[i] = bd[i + 1];
+                bd[K - 1] = __uint_as_float(0x7f800000u);
+            }
+        }
+        // inclusion radius (squared), inflated for rounding: any node that can be in the k-NN of ANY voxel of
+        // the brick satisfies |n - c| <= D_k(c) + 2 r_B.
+        thr = (sqrtf(dk2) + g.r2x) * 1.0001f + 1e-6f;
+    } else thr = brick_thr[b];
     const float thr2 = thr * thr;
     // pass 2: ballot / popcount-prefix compaction in node-index order
     uint32_t total = 0;
@@ -723,8 +727,7 @@ __global__ __launch_bounds__(256) void df_brick_index_kernel(const float4* __res
         if (FILL && in) list[o + total + (uint32_t)__popcll(m & lane_mask_lt())] = (uint16_t)j;
         total += (uint32_t)__popcll(m);
     }
-    if (!FILL && lane == 0) cnt[b] = total;
-    if (FILL && lane == 0 && brick_thr) brick_thr[b] = thr;   // every node NOT in the list is farther than this from the brick centre
+    if (!FILL && lane == 0) { cnt[b] = total; brick_thr[b] = thr; }   // every node NOT in the list is farther than thr from the brick centre
 }
 
 // Exclusive scan of n counts into off[0..n] with ONE 1024-thread block (n <= a few million).
@@ -789,7 +792,7 @@ extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const DfSla
     }
     const dim3 grid((unsigned)((nb + 3) / 4));
     DF_DISPATCH_K(k, df_brick_index_kernel<K, false><<<grid, dim3(256), 0, st>>>(wf->pos_sigma, wf->M, g, wf->brick_cnt,
-                                                                                 (const uint32_t*)nullptr, (uint16_t*)nullptr, (float*)nullptr));
+                                                                                 (const uint32_t*)nullptr, (uint16_t*)nullptr, wf->brick_thr));
     DF_LAUNCH_CHECK();
     hipLaunchKernelGGL(df_scan_kernel, dim3(1), dim3(1024), 0, st, wf->brick_cnt, wf->brick_off, (int)nb);
     DF_LAUNCH_CHECK();
