@@ -47,7 +47,7 @@ SYMBOLS = [
     "dfusion_bilateral_filter", "dfusion_truncate_depth", "dfusion_depth_pyramid", "dfusion_compute_normals_mask_depth",
     "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
     "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate",
-    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_debug_rigid",
+    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_debug_rigid", "dfusion_debug_rigid_counters",
     "dfusion_render_image_points", "dfusion_render_image_depth", "dfusion_render_tangent_colors",
 ]
 
@@ -75,7 +75,20 @@ def lib():
     except Exception as e:
         if not os.path.exists(path):
             raise DfusionError("libdfusion_hip.so is missing and could not be built: %s" % e)
+    _lib = load(path)
+    return _lib
+
+
+def load(path, strict=True):
+    """dlopen a build of the library and declare its entry points.  strict=False (tools comparing against OLDER builds only)
+    tolerates entry points the build does not have yet."""
     L = C.CDLL(path)
+    if not strict:
+        class _Missing:
+            missing = True
+        for s in SYMBOLS:
+            if not hasattr(L, s):
+                setattr(L, s, _Missing())
     fp = C.POINTER(C.c_float)
     vp = C.c_void_p
     L.dfusion_abi_version.restype = C.c_int
@@ -125,12 +138,12 @@ def lib():
     L.dfusion_render_image_depth.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, fp, fp, vp, sz, vp]
     L.dfusion_render_tangent_colors.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp]
     L.dfusion_debug_rigid.argtypes = [C.c_int]
+    L.dfusion_debug_rigid_counters.argtypes = [vp]
     L.dfusion_copy_bandwidth_probe.argtypes = [vp, vp, C.c_size_t, vp]
     L.dfusion_read_bandwidth_probe.argtypes = [vp, C.c_size_t, vp, vp]
     for s in SYMBOLS:
         if s not in ("dfusion_error_string",):
             getattr(L, s).restype = C.c_int
-    _lib = L
     return L
 
 

@@ -307,6 +307,65 @@ __device__ __forceinline__ bool tsdf_sample_fast(const DfIntegrateParams& P, f3 
     *tsdf_out = fminf(1.f, sdf * P.trunc_inv);             // :93
     return ok;
 }
+// ---- the sample in two stages, for sweeps that decide wave-wide whether the exact square root is needed at all.
+// Most voxels that update lie in observed free space, far in front of the surface: their tsdf saturates at exactly 1.f
+// (:93), whatever the last bits of |vc| are.  tsdf_sample_pre does everything of tsdf_sample_fast up to the hardware
+// approximation s ~ sqrt(|vc|^2) (v_sqrt_f32, 1 ulp); with sdf_a = Dp - s, the EXACT sdf = Dp - sqrtf(|vc|^2) differs from
+// sdf_a by at most 1.5 ulp(s) + two roundings of the difference, < 2^-17 + 2^-23 |sdf_a| for |vc| < 64 m.  With
+//     T = trunc * (1 + 2^-10) + 2^-16            (df_sat_threshold; 2^-10 <= trunc <= 2^10)
+//   sdf_a >=  T  =>  sdf >= trunc (1 + 2^-20)  =>  fl(sdf * fl(1 / trunc)) >= 1  =>  tsdf = fminf(1, .) = 1.f exactly;
+//   sdf_a <= -T  =>  sdf < -trunc: the update branch (:91) is not taken;
+//   |sdf_a| < T  =>  undecided: tsdf_sample_finish corrects s to the correctly rounded root (df_sqrt_short's tail) and
+//                    evaluates :89-93 as written.  NaN / inf dists values fall out right: NaN compares false everywhere
+//                    (no update, as in `sdf >= -trunc`), +inf saturates, -inf is below -T.
+// A wave takes the finish only when one of its voxels is undecided (a few planes either side of the surface).
+struct DfSamplePre { float Dp, d2, s; bool ok; };
+__device__ __forceinline__ DfSamplePre tsdf_sample_pre(const DfIntegrateParams& P, f3 vc)
+{
+    DfSamplePre r;
+    const float rc = df_rcp_refined(vc.z);
+    const float u = fmaf(P.fx, df_div_shared(vc.x, vc.z, rc), P.cx);       // device.hpp:35
+    const float v = fmaf(P.fy, df_div_shared(vc.y, vc.z, rc), P.cy);       // device.hpp:36
+    r.ok = (__float_as_uint(u) < __float_as_uint((float)P.cols)) & (__float_as_uint(v) < __float_as_uint((float)P.rows));   // :82 (see tsdf_sample_fast)
+    const uint32_t ui = (uint32_t)(int)__builtin_amdgcn_fmed3f(u, 0.f, (float)(P.cols - 1));
+    const uint32_t vi = (uint32_t)(int)__builtin_amdgcn_fmed3f(v, 0.f, (float)(P.rows - 1));
+    const uint32_t off = vi * (uint32_t)P.pitch + 2u * ui;
+#ifdef DF_EXP_NODISTS    // (timing experiments only)
+    r.Dp = __uint_as_float(0x40a00000u | (off & 1u));
+#else
+    r.Dp = h2f_bits(*(const uint16_t*)((const char*)P.dists + off));      // :85
+#endif
+    r.ok = r.ok & (r.Dp != 0.f);                                           // :86
+    r.d2 = dot3(vc, vc);
+    r.s = __builtin_amdgcn_sqrtf(r.d2);
+    return r;
+}
+__device__ __forceinline__ float df_sat_threshold(float trunc) { return trunc * (1.f + 0x1p-10f) + 0x1p-16f; }
+__host__ __device__ __forceinline__ bool df_sat_trunc_ok(float trunc) { return (trunc >= 0x1p-10f) & (trunc <= 0x1p10f); }
+// both ends of a run: every coordinate within 32 m (|vc| < 64: the error budget above)
+__device__ __forceinline__ bool tsdf_sat_domain_ok(f3 a, f3 b)
+{
+    return fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(b.x)), fmaxf(fabsf(a.y), fabsf(b.y))), fmaxf(fabsf(a.z), fabsf(b.z))) <= 32.f;
+}
+__device__ __forceinline__ bool tsdf_sample_finish(const DfIntegrateParams& P, const DfSamplePre& r, float* tsdf_out)
+{
+    const float s = r.s, x = r.d2;                                          // df_sqrt_short from its second line on
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+    float n = (rd <= 0.f) ? sd : s;
+    n = (ru > 0.f) ? su : n;
+    const float sdf = r.Dp - n;                                             // :89
+    *tsdf_out = fminf(1.f, sdf * P.trunc_inv);                              // :93
+    return r.ok & (sdf >= -P.trunc);                                        // :91
+}
+// :97-103 for a saturated sample (tsdf = 1.f) on a voxel whose stored value is 1.0 or that is still cleared: fma(1, w, 1) = w + 1
+// exactly (w <= 65535), (w + 1) / (w + 1) = 1; fma(0, 0, 1) / 1 = 1 -- the new value is 1.0 (0x3c00) without any arithmetic.
+__device__ __forceinline__ bool tsdf_fuse_one_ok(uint32_t vox) { return (vox == 0u) | ((vox & 0xffffu) == 0x3c00u); }
+__device__ __forceinline__ uint32_t tsdf_fuse_one(uint32_t vox, int max_weight)
+{
+    const int weight_new = min((int)(vox >> 16) + 1, max_weight);
+    return 0x3c00u | (((uint32_t)weight_new & 0xffffu) << 16);
+}
 // :97-103
 __device__ __forceinline__ uint32_t tsdf_fuse(uint32_t vox, float tsdf, int max_weight)
 {

@@ -232,12 +232,22 @@ __global__ __launch_bounds__(256) void df_pyramid_top_kernel(const DfDistsPyrami
     }
 }
 // ------------------------------------------------------------------------------------------ integrate (rigid)
-static bool g_df_rigid_no_depth_cull = false, g_df_rigid_no_fast_forms = false, g_df_rigid_keep_all = false;
-// bit 0: behind-the-surface test, bit 1: short arithmetic forms, bit 2 SET: the plan keeps every sub-chunk (no frustum test either);
+static bool g_df_rigid_no_depth_cull = false, g_df_rigid_no_fast_forms = false, g_df_rigid_keep_all = false, g_df_rigid_no_sat = false;
+static unsigned long long* g_df_rigid_swept = nullptr;
+// bit 0: behind-the-surface test, bit 1: short arithmetic forms, bit 2 SET: the plan keeps every sub-chunk (no frustum test either),
+// bit 3 SET: no saturated-sample shortcuts (every sample takes the exact square root and the fuse division);
 // default 3 (validation switches, results must not change)
 extern "C" int dfusion_debug_rigid(int flags)
 {
     g_df_rigid_no_depth_cull = !(flags & 1); g_df_rigid_no_fast_forms = !(flags & 2); g_df_rigid_keep_all = (flags & 4) != 0;
+    g_df_rigid_no_sat = (flags & 8) != 0;
+    return DF_OK;
+}
+// measurement hook: while set (device pointer, nullable), every dfusion_integrate launch adds the number of voxels its sweep put
+// through the sample chain to *swept_dev -- the denominator of "swept / updated" next to n_updated_dev
+extern "C" int dfusion_debug_rigid_counters(unsigned long long* swept_dev)
+{
+    g_df_rigid_swept = swept_dev;
     return DF_OK;
 }
 
@@ -250,6 +260,7 @@ struct DfRigidArgs {
     float vsx, vsy, vsz;
     DfIntegrateParams P;
     unsigned long long* n_upd;
+    unsigned long long* n_swept;   // nullable: += voxels that went through the sample chain (alive sub-chunks x columns inside the volume)
     // launch plan (df_rigid_plan_kernel): item = chunk * tiles + tile, its mask = its alive sub-chunks (bit s: planes [zb + SUB s,
     // zb + SUB s + SUB) may update); items with w > 0 bits are listed in bin w (plan_bins[w * plan_items ...], plan_cnt[w] entries
     // item | mask << 24)
@@ -288,41 +299,101 @@ __device__ __forceinline__ unsigned df_outside_mask(const DfFrustum& F, f3 p, fl
 // A chunk starting at plane zb replays the zb additions of :75 in registers, so every chunk -- and every Z-slab shard on another
 // GPU -- produces the bits of the unsharded sweep.
 // the voxels of one column on planes [zs, zse), U at a time
-template <int U, bool FAST>
+#ifdef DF_EXP_NOSTORE        // (timing experiments only: the store is kept alive by an impossible condition)
+#define DF_EXP_STORE(dst, val) do { const uint32_t v__ = (val); if (v__ == 0xdeadbeefu) (dst) = v__; } while (0)
+#else
+#define DF_EXP_STORE(dst, val) (dst) = (val)
+#endif
+template <int U, bool FAST, bool SAT>
 __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f3 zstep, uint32_t*& p, size_t plane, int zs, int zse,
                                                  bool active, unsigned int& my_upd)
 {
+    const float sat_t = df_sat_threshold(a.P.trunc);
     for (int z = zs; z < zse; z += U) {
         float ts[U];
         bool up[U];
+        bool sat = false;                               // every sample of the batch is decided without the exact square root
+        if constexpr (FAST && SAT) {
+            // stage 1 in two halves (dfusion_device.h, tsdf_sample_pre): the approximate |vc| decides wherever the voxel is not
+            // within trunc of the surface -- the tsdf is then exactly 1.f or the voxel does not update
+            const f3 vc0 = vc;
+            bool undecided = false;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {                   // stage 1: U branch-free sample chains
-            const bool inr = z + u < zse;
-            up[u] = (FAST ? tsdf_sample_fast(a.P, vc, &ts[u]) : tsdf_sample_nb(a.P, vc, &ts[u])) && inr && active;
-            if (inr) vc = add3(vc, zstep);              // :75
+            for (int u = 0; u < U; ++u) {
+                const bool inr = z + u < zse;
+                const DfSamplePre pre = tsdf_sample_pre(a.P, vc);
+                ts[u] = pre.Dp - pre.s;                 // approximate sdf
+                up[u] = pre.ok && inr && active;
+                undecided = undecided | (up[u] & (fabsf(ts[u]) < sat_t));
+                if (inr) vc = add3(vc, zstep);          // :75
+            }
+            sat = __builtin_amdgcn_ballot_w64(undecided) == 0ull;
+            if (sat) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { up[u] = up[u] & (ts[u] >= sat_t); ts[u] = 1.f; }
+            } else {                                    // within trunc of the surface: the batch again, as written (same additions, same bits)
+                f3 w = vc0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool inr = z + u < zse;
+                    up[u] = tsdf_sample_fast(a.P, w, &ts[u]) && inr && active;
+                    if (inr) w = add3(w, zstep);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {               // stage 1: U branch-free sample chains
+                const bool inr = z + u < zse;
+                up[u] = (FAST ? tsdf_sample_fast(a.P, vc, &ts[u]) : tsdf_sample_nb(a.P, vc, &ts[u])) && inr && active;
+                if (inr) vc = add3(vc, zstep);          // :75
+            }
         }
         uint32_t v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)                     // stage 2: the voxel loads of the batch in flight together
+#ifdef DF_EXP_NOLOAD
+            v[u] = 0x00013c00u;
+#else
             if (up[u]) v[u] = p[(size_t)u * plane];
-        bool fin = FAST;                                // the fuse division's short form: finite stored values (a wave decides together)
-        if (FAST) {
+#endif
+        bool one = false;                               // saturated samples onto stored 1.0 / cleared voxels: the fuse is a weight increment
+        if (FAST && SAT && sat) {
+            one = true;
 #pragma unroll
-            for (int u = 0; u < U; ++u) fin = fin & (!up[u] | tsdf_fuse_short_ok(v[u]));
-            fin = df_wave_all(fin);
+            for (int u = 0; u < U; ++u) one = one & (!up[u] | tsdf_fuse_one_ok(v[u]));
+            one = df_wave_all(one);
         }
+        if (one) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)                     // stage 3: fuse (:97-103) and store
-            if (up[u]) { p[(size_t)u * plane] = fin ? tsdf_fuse_short(v[u], ts[u], a.P.max_weight) : tsdf_fuse(v[u], ts[u], a.P.max_weight); ++my_upd; }
+            for (int u = 0; u < U; ++u)
+                if (up[u]) { DF_EXP_STORE(p[(size_t)u * plane], tsdf_fuse_one(v[u], a.P.max_weight)); ++my_upd; }
+        } else {
+            bool fin = FAST;                            // the fuse division's short form: finite stored values (a wave decides together)
+            if (FAST) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) fin = fin & (!up[u] | tsdf_fuse_short_ok(v[u]));
+                fin = df_wave_all(fin);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)                 // stage 3: fuse (:97-103) and store
+                if (up[u]) { DF_EXP_STORE(p[(size_t)u * plane], fin ? tsdf_fuse_short(v[u], ts[u], a.P.max_weight) : tsdf_fuse(v[u], ts[u], a.P.max_weight)); ++my_upd; }
+        }
         p += (size_t)min(U, zse - z) * plane;
     }
 }
 
+#ifndef DF_RIGID_PX
+#define DF_RIGID_PX 32           // columns of a wave's patch along x (a power of two <= 64); 64 / DF_RIGID_PX rows
+#endif
+#define DF_RIGID_PY (64 / DF_RIGID_PX)
 #ifndef DF_RIGID_SUB
 #define DF_RIGID_SUB 8
 #endif
 #ifndef DF_RIGID_U
-#define DF_RIGID_U 4
+#define DF_RIGID_U 2
+#endif
+#ifndef DF_RIGID_U_GENERIC
+#define DF_RIGID_U_GENERIC 2
 #endif
 #ifndef DF_RIGID_WAVES
 #define DF_RIGID_WAVES 8
@@ -337,7 +408,7 @@ template <bool DEPTH>
 __device__ __forceinline__ bool df_rigid_box_culled(const DfRigidArgs& a, const DfFrustum& F, const DfDistsPyramid& Py, int x0, int y0, int zs, int n)
 {
     const float m = 5e-3f;
-    const int x1 = min(x0 + 31, a.X - 1), y1 = min(y0 + 1, a.Y - 1), z1 = zs + n - 1;
+    const int x1 = min(x0 + DF_RIGID_PX - 1, a.X - 1), y1 = min(y0 + DF_RIGID_PY - 1, a.Y - 1), z1 = zs + n - 1;
     unsigned out_all = 31u;
     float xl = 3.0e38f, xh = -3.0e38f, yl = 3.0e38f, yh = -3.0e38f, zl = 3.0e38f, zh = -3.0e38f;
     float ul = 3.0e38f, uh = -3.0e38f, vl = 3.0e38f, vh = -3.0e38f;
@@ -383,11 +454,11 @@ __global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a
     bool keep = false;
     if (item < n_items) {
         const int tile = (int)(item % (unsigned)a.tiles), chunk = (int)(item / (unsigned)a.tiles);
-        const int tiles_x = (a.X + 31) >> 5;
+        const int tiles_x = (a.X + DF_RIGID_PX - 1) / DF_RIGID_PX;
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int zb = a.z_own0 + chunk * a.zc, ze = min(zb + a.zc, a.z_own0 + a.z_own_n);
         const int zs = zb + sb * DF_RIGID_SUB;
-        if (zs < ze) keep = keep_all || !df_rigid_box_culled<DEPTH>(a, F, Py, tx * 32, ty * 2, zs, min(DF_RIGID_SUB, ze - zs));
+        if (zs < ze) keep = keep_all || !df_rigid_box_culled<DEPTH>(a, F, Py, tx * DF_RIGID_PX, ty * DF_RIGID_PY, zs, min(DF_RIGID_SUB, ze - zs));
     }
     const unsigned m = (unsigned)(__ballot(keep) >> (lane & ~7)) & 0xffu;   // the item's 8 verdicts
     const unsigned w = (unsigned)__popc(m);
@@ -401,7 +472,7 @@ __global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a
 
 // The sweep: wave e of the launch takes plan entry e (bins from the fullest down), replays `vc += zstep` up to its chunk, and walks
 // the chunk's sub-chunks: alive ones U planes per batch, the others by the additions alone.
-template <int U>
+template <int U, bool SAT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WAVES, DF_RIGID_WAVES))) void df_integrate_rigid_kernel(const DfRigidArgs a, const bool FASTOK)
 {
     const int lane = threadIdx.x & 63;
@@ -422,11 +493,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
     const unsigned ent = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_RIGID_MAX_SUBS - j) * a.plan_items + r]);
     const unsigned item = ent & 0xffffffu, mask = ent >> 24;            // one dependent load instead of two before a wave can start
     const int tile = (int)(item % (unsigned)a.tiles), chunk = (int)(item / (unsigned)a.tiles);
-    const int tiles_x = (a.X + 31) >> 5;
+    const int tiles_x = (a.X + DF_RIGID_PX - 1) / DF_RIGID_PX;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int x = tx * 32 + (lane & 31), y = ty * 2 + (lane >> 5);
+    const int x = tx * DF_RIGID_PX + (lane & (DF_RIGID_PX - 1)), y = ty * DF_RIGID_PY + (lane / DF_RIGID_PX);
     const bool active = x < a.X && y < a.Y;
-    unsigned int my_upd = 0;
+    unsigned int my_upd = 0, my_swept = 0;
     const int zb = a.z_own0 + chunk * a.zc;
     const int ze = min(zb + a.zc, a.z_own0 + a.z_own_n);
     const f3 zstep = scale3(mk3(a.vol2cam.R[2], a.vol2cam.R[5], a.vol2cam.R[8]), a.vsz);      // tsdf_volume.cu:69 (three separate multiplies)
@@ -447,9 +518,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
         ++n_sub;
 #endif
         // the short arithmetic forms of tsdf_sample_fast need their domain on every voxel of the run, for every lane
-        const bool fast = FASTOK && df_wave_all(!active || tsdf_sample_domain_ok(vc, add3(vc, scale3(zstep, (float)(zse - zs)))));
-        if (fast) df_rigid_batches<U, true>(a, vc, zstep, p, plane, zs, zse, active, my_upd);
-        else df_rigid_batches<U, false>(a, vc, zstep, p, plane, zs, zse, active, my_upd);
+        const f3 vc_end = add3(vc, scale3(zstep, (float)(zse - zs)));
+        // (SAT: the saturated-sample shortcuts also want every coordinate within 32 m; the generic forms otherwise)
+        const bool fast = FASTOK && df_wave_all(!active || (tsdf_sample_domain_ok(vc, vc_end) && (!SAT || tsdf_sat_domain_ok(vc, vc_end))));
+        my_swept += (unsigned)(zse - zs);               // (wave-uniform; times the wave's columns inside the volume at the end)
+        if (fast) df_rigid_batches<U, true, SAT>(a, vc, zstep, p, plane, zs, zse, active, my_upd);
+        else df_rigid_batches<DF_RIGID_U_GENERIC, false, false>(a, vc, zstep, p, plane, zs, zse, active, my_upd);   // (rare: fewer chains in flight, fewer registers)
     }
 #ifdef DF_TRACE_WG
     if (lane == 0) {
@@ -462,6 +536,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.n_upd, (unsigned long long)s);
+    }
+    if (a.n_swept) {                                          // (validation / measurement hook: dfusion_debug_rigid_counters)
+        const unsigned long long s = (unsigned long long)my_swept * (unsigned)__popcll(__builtin_amdgcn_ballot_w64(active));
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.n_swept, s);
     }
 }
 
@@ -528,6 +606,7 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     a.P.trunc = v.trunc_dist; a.P.trunc_inv = 1.f / v.trunc_dist;       // tsdf_volume.cu:147
     a.P.max_weight = v.max_weight;
     a.n_upd = n_updated;
+    a.n_swept = g_df_rigid_swept;
 
     DfFrustum F;
     {
@@ -540,7 +619,7 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
             F.nlx = F.nrx = F.nty = F.nby = 0.f; F.nlz = F.nrz = F.ntz = F.nbz = 0.f;
         }
     }
-    const int tiles = ((a.X + 31) / 32) * ((a.Y + 1) / 2);         // 32 x 2 column patches, one per wave
+    const int tiles = ((a.X + DF_RIGID_PX - 1) / DF_RIGID_PX) * ((a.Y + DF_RIGID_PY - 1) / DF_RIGID_PY);         // 32 x 2 column patches, one per wave
     // Z chunking: chunks of whole sub-chunks, at most DF_RIGID_MAX_SUBS of them and >= 32 planes (a chunk at plane zb replays zb
     // additions: 3 per plane per lane); ~32 k items at 512^3 -- the longest wave (every sub-chunk alive) is then a fraction of the launch
     const long long want_items = 256LL * 128;
@@ -586,7 +665,9 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     DF_HIP(hipMemsetAsync(trace_dev, 0, trace_n * 8, st));
     a.trace = trace_dev;
 #endif
-    hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U>), grid, dim3(256), 0, st, a, fast_ok);
+    const bool sat_ok = fast_ok && !g_df_rigid_no_sat && df_sat_trunc_ok(v.trunc_dist);
+    if (sat_ok) hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U, true>), grid, dim3(256), 0, st, a, fast_ok);
+    else hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U, false>), grid, dim3(256), 0, st, a, fast_ok);
     rc = (int)hipGetLastError();
 #ifdef DF_TRACE_WG
     if (getenv("DF_TRACE_FILE")) {

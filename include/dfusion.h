@@ -220,8 +220,14 @@ int dfusion_selftest_exact_forms(unsigned long long n_random, unsigned long long
  * default 3; no reference counterpart).  bit 0: the behind-the-surface test (a conservative, result-identical skip of voxels that
  * lie more than trunc_dist behind every depth value they can be compared with; per-frame max-pyramid of dists); bit 1: the short
  * forms of the correctly rounded divisions / square root on runs of voxels whose coordinates are inside their domain; bit 2 SET:
- * the launch plan keeps every sub-chunk (no frustum test either: every voxel goes through the reference's own tests).              */
+ * the launch plan keeps every sub-chunk (no frustum test either: every voxel goes through the reference's own tests); bit 3 SET:
+ * no saturated-sample shortcuts (batches of voxels all farther than trunc_dist from the surface skip the exact square root -- their
+ * tsdf is exactly 1 or they do not update -- and, onto stored 1.0 / cleared voxels, the fuse division).                            */
 int dfusion_debug_rigid(int flags);
+/* Measurement hook of dfusion_integrate (process-wide, like the switches above; NULL switches it off): while set, every launch ADDS
+ * to *swept_dev (device, 8 bytes) the number of voxels its sweep put through the projective sample (tsdf_volume.cu:77-93) -- the
+ * voxels of the launch plan's alive sub-chunks.  Beside n_updated_dev this gives swept / updated, the sweep's over-work.          */
+int dfusion_debug_rigid_counters(unsigned long long *swept_dev);
 
 /* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k], ascending distance; exactly
  * equidistant nodes in the order the reference's nanoflann walk meets them (nanoflann.hpp:110-131,1200-1254).                    */

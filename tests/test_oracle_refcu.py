@@ -215,3 +215,69 @@ def test_oracle_matches_committed_reference_golden():
     rd, _ = O.raycast_depth(sc.ovol(a), synth.aff12(sc.cam2vol(2)), sc.rinv(2), sc.reproj, cfg.cols, cfg.rows,
                             cfg.raycast_step_factor, cfg.gradient_delta_factor)
     assert np.array_equal(rd, g["depth"])
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE sizes, full volume
+@live
+@pytest.mark.parametrize("name", ["256", "512"])
+def test_integrate_and_raycast_equal_reference_kernels_at_baseline_size(name):
+    """The link the small cases leave to transitivity (VERDICT r2 #1 i): at BASELINE.json's own sizes -- 640x480 into 256^3 / 1 m and
+    512^3 / 3 m -- the restatement and the reference's integrate_kernel (tsdf_volume.cu:51-108) produce the same volume, every voxel,
+    over two frames, and its raycast_kernel (:340-405) the same points and normals, every pixel."""
+    cfg = synth.CONFIGS[name]
+    sc = Scene(cfg, n_frames=2, with_nodes=False)
+    a, b = fuse_both(sc, 2)
+    assert (a >> 16).max() == 2 and ((a >> 16) != 0).sum() > 0.15 * a.size
+    assert np.array_equal(a, b)
+    del b
+    args = (sc.ovol(a), synth.aff12(sc.cam2vol(1)), sc.rinv(1))
+    tail = (cfg.cols, cfg.rows, cfg.raycast_step_factor, cfg.gradient_delta_factor)
+    rp, rn, _, st = O.raycast_points(*args, sc.reproj, *tail)
+    qp, qn = O.refcu_raycast_points(*args, sc.intr, *tail)
+    assert int(st[1]) > 0.5 * cfg.cols * cfg.rows
+    assert np.array_equal(bits(rp), bits(qp)) and np.array_equal(bits(rn), bits(qn))
+
+
+@live
+def test_project_and_remove_equals_reference_kernel_up_to_its_race():
+    """project_kernel (tsdf_volume.cu:113-139) reads dists(coo) and zeroes it in the same launch: a second point landing on a pixel
+    sees 0 or the old value depending on thread timing.  Compiled for the host its threads run in order, so a later point on an
+    already-removed pixel reads 0 -- the restatement (and the HIP kernel) sample a snapshot instead.  Hence:
+    the removed-pixel set is identical, and every point is bit-identical except exactly those the reference gave Dp = 0 because an
+    EARLIER point had zeroed their pixel; for those the restatement holds the pixel's original value."""
+    cfg, sc = make_scene(64, frames=2, rotated=True)
+    a, _ = fuse_both(sc, 2)
+    pts, _, _, _ = O.raycast_points(sc.ovol(a), synth.aff12(sc.cam2vol(1)), sc.rinv(1), sc.reproj, cfg.cols, cfg.rows,
+                                    cfg.raycast_step_factor, cfg.gradient_delta_factor)
+    pts = pts.copy()
+    pts[..., :1] *= F32(1.6)                        # stretch in x: some points leave the image ...
+    pts[..., 1:2] *= F32(0.7)                       # ... squeeze in y: many share a pixel
+    proj = sc.intr
+    op, odists, _, n_in = O.project_and_remove(sc.dists[0], pts.reshape(-1, 4), proj)
+    rdists = sc.dists[0].copy()
+    rp = pts.copy()
+    O.refcu().refcu_project_and_remove(rdists, cfg.rows, cfg.cols, rp.reshape(-1), cfg.rows, cfg.cols, f32c(proj))
+    rp = rp.reshape(-1, 4)
+    assert n_in > 0.3 * len(op)
+    assert np.array_equal(odists, rdists)                                                      # same pixels removed (:132)
+    diff = (bits(op) != bits(rp)).any(axis=1)
+    # every differing point: the reference read Dp = 0 (z = 0 and x = y = 0 * coo), the restatement a non-zero original value
+    assert (rp[diff, 2] == 0).all() and (op[diff, 2] != 0).all()
+    assert 0 < diff.sum() < 0.2 * len(op)
+    # and it is a later point on a pixel an earlier point removed: recompute the pixel of every point in order
+    inside = np.isfinite(op[:, 2]) & (op[:, 2] != 0)
+    z = np.where(inside, op[:, 2], 1).astype(np.float64)
+    u = np.floor(np.where(inside, op[:, 0], 0) / z).astype(np.int64)       # (coo.x * Dp) / Dp: the pixel the point landed on
+    v = np.floor(np.where(inside, op[:, 1], 0) / z).astype(np.int64)
+    seen, n_late = set(), 0
+    for i in np.nonzero(inside)[0]:
+        key = (int(v[i]), int(u[i]))
+        if diff[i]:
+            assert key in seen                      # a differing point's pixel was taken by an earlier point
+            n_late += 1
+        seen.add(key)
+    assert n_late == diff.sum()
+
+
+def f32c(a):
+    return np.ascontiguousarray(a, np.float32)
