@@ -64,12 +64,14 @@ def measured_copy_gbps(nbytes=1 << 30, iters=10):
     return 2.0 * nbytes / (ms * 1e-3) / 1e9        # read + write bytes
 
 
-def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=10.0):
+def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=10.0, gpu_after=None):
     """The reference-style CPU path timed on the host cores on a BOUNDED sample of the same frame: per-voxel warped
     integrate through the reference's OWN nanoflann k-NN + DQB + transform classes (oracle/_ref, one tree / result set per OpenMP
     thread -- the reference's WarpField is single-threaded and not re-entrant) on a band of Z planes in the middle of the volume,
     scaled to all planes, + the full ray-cast (oracle restatement, pinned to the reference's kernel).  kind = "reference".
-    Also reported: the same band on ONE thread (how the reference itself would run it) and the oracle port (restated nanoflann)."""
+    Also reported: the same band on ONE thread (how the reference itself would run it) and the oracle port (restated nanoflann).
+    gpu_after: the GPU's volume after integrating THE SAME frame from the same start volume -- the band the reference classes just
+    computed is compared with it voxel for voxel (`integrate_bit_identical`: reference vs HIP at the headline size, no oracle between)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_lib as O
     depth, _, pose, cam_pose, pos, sigma, dq = sc_inputs
@@ -81,6 +83,8 @@ def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=10.0):
     world2cam = synth.affine_inv(cam_pose)
     have_ref = O.have_ref()
 
+    last_ref = {}
+
     def timed_band(n_planes, mode, threads=0):
         z0 = (Z - n_planes) // 2
         sample = np.ascontiguousarray(vol_u32[z0:z0 + n_planes]).copy()
@@ -88,6 +92,8 @@ def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=10.0):
         if mode == "reference":
             _, used = O.ref_integrate_warped(dists, sample, cfg.dims, vs, trunc, cfg.max_weight, synth.aff12(pose), synth.aff12(world2cam), intr,
                                              pos, dq, sigma, cfg.k, z0, z0, n_planes, threads=threads)
+            if threads == 0:
+                last_ref["z0"], last_ref["band"] = z0, sample
         else:
             ov = O.make_volume(sample, cfg.dims, vs, trunc, cfg.max_weight)
             O.integrate_warped(dists, sample, ov, synth.aff12(pose), synth.aff12(world2cam), intr, pos, dq, sigma, cfg.k,
@@ -123,6 +129,15 @@ def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=10.0):
            "sample": "per-voxel warped integrate through the reference's own nanoflann + DQB classes (oracle/_ref, OpenMP, one tree per thread) on "
                      "%d of %d Z planes in %.1f s on %d threads, scaled x%.1f (est %.2f s/frame) + full %dx%d ray-cast (%.2f s)"
                      % (planes, Z, t_band, cores, Z / planes, t_int, cfg.cols, cfg.rows, t_ray)}
+    if gpu_after is not None and "band" in last_ref:
+        z0, band = last_ref["z0"], last_ref["band"]
+        diff = band != gpu_after[z0:z0 + band.shape[0]]
+        out["integrate_bit_identical"] = bool(not diff.any())
+        out["integrate_compare"] = {"what": "volume planes [%d, %d) after this frame: the reference's WarpField::DQB + DualQuaternion::transform classes "
+                                            "composed with TsdfIntegrator (oracle/_ref, unmodified headers) vs dfusion_integrate_warped, same start volume"
+                                            % (z0, z0 + band.shape[0]),
+                                    "voxels_compared": int(band.size), "voxels_differing": int(diff.sum()),
+                                    "voxels_updated_in_band": int((band != vol_u32[z0:z0 + band.shape[0]]).sum())}
     if have_ref:
         # one thread, as the reference's own (non-re-entrant) WarpField would run it: one plane is ~0.2-0.5 s
         t1, _ = timed_band(2, "reference", threads=1)
@@ -196,9 +211,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # DFUSION_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL process group, slab volume, broadcast, the merge collectives) with
+    # whatever WORLD_SIZE is -- with one rank it is an RCCL dry run of every collective, dtype and op of the sharded frame
+    # (tests/test_gpu_sharded.py runs it), since an 8-GPU node is only ever seen by the driver
+    dist_on = world > 1 or os.environ.get("DFUSION_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
@@ -220,7 +243,7 @@ def main():
     vs_z = cfg.size / Z
     trunc_eff = max(cfg.trunc_dist, 2.1 * vs_z)
     halo = sharded.halo_planes(trunc_eff, cfg.raycast_step_factor, cfg.gradient_delta_factor, vs_z)
-    if world > 1:
+    if dist_on:
         sharded.validate_slabs(Z, world, halo)             # same verdict on every rank, before the first collective
         z_own0, z_own_n = sharded.slab_range(Z, rank, world)
         vol = TsdfVolume(cfg.dims, device=dev, slab=(z_own0, z_own_n, halo))
@@ -233,7 +256,7 @@ def main():
 
     # N > 1: every rank also integrates its halo planes (a pure function of the broadcast inputs: bit-identical with the neighbour's
     # planes), so the frame has NO halo collective; `vol_int` is the same blob seen as owner of all its stored planes.
-    vol_int = vol.owning_stored_planes() if (world > 1 and args.halo == "recompute") else vol
+    vol_int = vol.owning_stored_planes() if (dist_on and args.halo == "recompute") else vol
     wf = WarpField(k=cfg.k, device=dev)
     wf.init(pos, sigma=sigma, transforms=dqs_np[0])
     t0 = time.time()
@@ -242,8 +265,7 @@ def main():
     t_index = time.time() - t0
 
     dists = torch.empty_like(depths[0])
-    keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device=dev) if world > 1 else None
-    vertex = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev) if world > 1 else None
+    keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device=dev) if dist_on else None
     out2 = torch.empty((2, cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev)
     pts, nrm = out2[0], out2[1]
     # frame inputs travel as ONE byte bundle (depth image + node transforms): one ncclBroadcast per frame
@@ -257,7 +279,7 @@ def main():
 
     def step(i, timed_idx=None):
         f = i % F
-        if world > 1:                                  # rank 0 owns the sensor frame and the solver output
+        if dist_on:                                    # rank 0 owns the sensor frame and the solver output
             if rank == 0:
                 depth_in.copy_(depths[f]); dq_in.copy_(dqs[f])
             dist.broadcast(bundle, 0)
@@ -269,13 +291,12 @@ def main():
         if timed_idx is not None: ev[timed_idx][0].record()
         vol_int.integrate_warped(dists, cam_poses[f], intr, wf, sync=False)
         if timed_idx is not None: ev[timed_idx][1].record()
-        if world > 1 and args.halo == "exchange":
+        if dist_on and args.halo == "exchange":
             sharded.exchange_halos(vol.data(), vol.z_store0, vol.z_own0, vol.z_own_n, Z, halo, rank, world)
-        if world > 1:
-            out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, vertex, rank),
-                                          lambda mk, vx: vol.raycast_select(mk, vx, rank),
-                                          lambda mk, vx: (vol.raycast_shade(cam_poses[f], intr, vx, mk, pts, nrm), out2)[1],
-                                          rank, world)
+        if dist_on:
+            out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, rank),
+                                          lambda mk: (vol.raycast_shade(cam_poses[f], intr, mk, pts, nrm), out2)[1],
+                                          rank, world, collectives=True)
         else:
             vol.raycast(cam_poses[f], intr, pts, nrm)
             out = (pts, nrm)
@@ -283,7 +304,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -295,7 +316,7 @@ def main():
         step(args.warmup + i, timed_idx=i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -311,12 +332,15 @@ def main():
 
     # ---- algorithmic bytes of one integrate launch: 8*N_upd + 2*W*H + 48*M.
     # N_upd counted by the kernel itself (parity-checked against the oracle's count in tests/), untimed pass.
-    n_upd = torch.zeros(1, dtype=torch.int64, device=dev)
+    n_upd = torch.zeros(2, dtype=torch.int64, device=dev)          # [0] updated, [1] swept (the plan's alive cells, dfusion_debug_warp_counters)
+    capi.check(capi.lib().dfusion_debug_warp_counters(n_upd[1:].data_ptr()))
     for f in range(F):
-        vol.integrate_warped(compute_dists(depths[f], intr, dists), cam_poses[f], intr, wf, n_updated=n_upd, sync=False)
+        vol.integrate_warped(compute_dists(depths[f], intr, dists), cam_poses[f], intr, wf, n_updated=n_upd[:1], sync=False)
     torch.cuda.synchronize()
-    n_upd_launch = float(n_upd.item()) / F
-    if world > 1:
+    capi.check(capi.lib().dfusion_debug_warp_counters(None))
+    n_upd_launch = float(n_upd[0].item()) / F
+    n_swept_launch = float(n_upd[1].item()) / F
+    if dist_on:
         t = torch.tensor([n_upd_launch], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         n_upd_total = float(t.item())
@@ -326,10 +350,10 @@ def main():
     achieved = alg_bytes / (ms_int * 1e-3) / 1e9
 
     extra = {}
-    if not args.no_extras and world == 1:
+    if not args.no_extras and not dist_on:
         vol2 = TsdfVolume(cfg.dims, device=dev)
         vol2.setSize([cfg.size] * 3); vol2.setTruncDist(cfg.trunc_dist); vol2.setMaxWeight(cfg.max_weight); vol2.setPose(cfg.volume_pose)
-        nr = torch.zeros(1, dtype=torch.int64, device=dev)
+        nr = torch.zeros(2, dtype=torch.int64, device=dev)       # [0] updated, [1] swept (dfusion_debug_rigid_counters)
         for f in range(2):
             vol2.integrate(dists, cam_poses[f], intr, sync=False)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -338,13 +362,18 @@ def main():
             vol2.integrate(dists, cam_poses[i % F], intr, sync=False)
         e1.record()
         torch.cuda.synchronize()
+        capi.check(capi.lib().dfusion_debug_rigid_counters(nr[1:].data_ptr()))
         for f in range(F):
-            vol2.integrate(dists, cam_poses[f], intr, n_updated=nr, sync=False)
+            vol2.integrate(dists, cam_poses[f], intr, n_updated=nr[:1], sync=False)
         torch.cuda.synchronize()
+        capi.check(capi.lib().dfusion_debug_rigid_counters(None))
         ms_r = e0.elapsed_time(e1) / 20
-        b_r = 8.0 * float(nr.item()) / F + 2.0 * cfg.cols * cfg.rows
-        extra["rigid_integrate"] = {"ms": ms_r, "achieved_GBps": b_r / (ms_r * 1e-3) / 1e9, "frac_of_peak": b_r / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                    "n_updated": float(nr.item()) / F}
+        b_r = 8.0 * float(nr[0].item()) / F + 2.0 * cfg.cols * cfg.rows
+        extra["rigid_integrate"] = {"kernel": "df_integrate_rigid_kernel<2, true, false> (+ df_rigid_plan_kernel, df_pyramid_tiles_kernel)",
+                                    "ms": ms_r, "achieved_GBps": b_r / (ms_r * 1e-3) / 1e9, "frac_of_peak": b_r / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                    "n_updated": float(nr[0].item()) / F, "n_swept": float(nr[1].item()) / F,
+                                    "swept_over_updated": float(nr[1].item()) / max(float(nr[0].item()), 1.0),
+                                    "algorithmic_bytes_per_launch": b_r}
         del vol2
         # surface extraction (kinfu.cpp:398-399) on the fused volume: a pure HBM scan, 4 B/voxel
         st = torch.cuda.current_stream().cuda_stream
@@ -421,16 +450,22 @@ def main():
     table_bytes = int(X) * Y * vol.z_own_n * cfg.k * 6
     traffic, traffic_src = None, None
     pmc_file = os.path.join(REPO, "profiles", "pmc_latest.json")
-    if world == 1 and os.path.exists(pmc_file):
+    if not dist_on and os.path.exists(pmc_file):
         try:
             pm = json.load(open(pmc_file))
             ent = pm.get(args.config, {}).get(kernel_name.split("<")[0])
-            if ent:
+            # the counters belong to ONE build of the kernel: the file carries the sha256 of the source it was taken from, and a
+            # figure from another build is not reported
+            import hashlib
+            src_sha = hashlib.sha256(open(os.path.join(REPO, "dynamicfusion_amd", "csrc", "dfusion_warp.hip"), "rb").read()).hexdigest()
+            if ent and ent.get("source_sha256") == src_sha:
                 traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/pmc_latest.json (%s)" % ent.get("how", "rocprofv3 --pmc")
+            elif ent:
+                traffic_src = "profiles/pmc_latest.json is from another build of dfusion_warp.hip (sha256 %s...): traffic dropped" % str(ent.get("source_sha256"))[:12]
         except Exception:
             pass
     if rank == 0:
-        copy_gbps = measured_copy_gbps() if world == 1 else None
+        copy_gbps = measured_copy_gbps() if not dist_on else None
         out = {
             "metric": "frames/sec integrate+raycast, %dx%d->%d^3 TSDF" % (cfg.cols, cfg.rows, cfg.dims[0]),
             "value": args.steps / elapsed,
@@ -444,9 +479,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg.name, "volume_dims": list(cfg.dims), "volume_size_m": cfg.size,
                        "depth": [cfg.cols, cfg.rows], "warp_nodes": cfg.nodes, "k": cfg.k,
-                       "parallelism": "zslab%d" % world if world > 1 else "single", "halo_planes": halo if world > 1 else 0,
+                       "parallelism": "zslab%d" % world if dist_on else "single", "halo_planes": halo if dist_on else 0,
                        "halo": (("integrated redundantly by every rank, no halo collective" if args.halo == "recompute" else
-                                 "exchanged after the integrate (paired isend/irecv of %d planes per side)" % halo) if world > 1 else None),
+                                 "exchanged after the integrate (paired isend/irecv of %d planes per side)" % halo) if dist_on else None),
                        "frame": "set_transforms + compute_dists + integrate_warped + raycast_points"},
             "kernel_ms": {"integrate_warped": ms_int, "raycast(+merge)": ms_ray, "index_build_once_s": t_index},
             "frame_stats": frame_stats,
@@ -454,6 +489,7 @@ def main():
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "n_updated_per_launch": n_upd_launch,
+                         "n_swept_per_launch": n_swept_launch, "swept_over_updated": (n_swept_launch / n_upd_launch) if n_upd_launch else None,
                          "n_updated_all_ranks": n_upd_total, "measured_copy_GBps": copy_gbps,
                          "knn_cache_bytes": table_bytes,
                          # the same achieved rate against the copy rate measured on this box, what the kernel really moves per
@@ -466,9 +502,15 @@ def main():
                                  "also streams its per-voxel k-NN + weight cache (48 B/voxel at k=8), see DESIGN.md"},
         }
         out.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
+        if not dist_on and not args.no_cpu_baseline:
             vol_host = vol.download()
-            out["cpu_baseline"] = cpu_baseline(cfg, (depths_np[0], None, cfg.volume_pose, cam_poses[0], pos, sigma, dqs_np[0]), vol_host)
+            # the same frame on the GPU from the same start volume (for cpu_baseline.integrate_bit_identical)
+            wf.set_transforms(dqs[0])
+            vol.integrate_warped(compute_dists(depths[0], intr, dists), cam_poses[0], intr, wf)
+            vol_after = vol.download()
+            out["cpu_baseline"] = cpu_baseline(cfg, (depths_np[0], None, cfg.volume_pose, cam_poses[0], pos, sigma, dqs_np[0]), vol_host,
+                                               gpu_after=vol_after)
+            del vol_after
             rcb = out["cpu_baseline"].pop("raycast_algorithmic_bytes")
             out["raycast"] = {"kernel": "df_raycast_kernel<0>", "ms": ms_ray, "algorithmic_bytes": rcb,
                               "steps": out["cpu_baseline"].pop("raycast_steps"), "hits": out["cpu_baseline"].pop("raycast_hits"),
@@ -481,9 +523,18 @@ def main():
                     out["cpu_baseline"]["reference_warp"] = rw
             except Exception as e:                      # the reference build is optional; never lose the bench line over it
                 out["cpu_baseline"]["reference_warp"] = {"error": repr(e)[:200]}
-        print(json.dumps(out))
-    if world > 1:
+        line = json.dumps(out)
+    if dist_on:
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line is the last thing on stdout: RCCL writes its version banner through C stdio, which a pipe buffers until
+        # exit -- flush that first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -40,14 +40,14 @@ DF_INDEX_WEIGHT_TABLE = 2
 # every symbol include/dfusion.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "dfusion_abi_version", "dfusion_error_string", "dfusion_clear", "dfusion_compute_dists", "dfusion_project_and_remove", "dfusion_integrate",
-    "dfusion_raycast_points", "dfusion_raycast_depth", "dfusion_raycast_march", "dfusion_raycast_select", "dfusion_raycast_shade", "dfusion_extract_cloud",
+    "dfusion_raycast_points", "dfusion_raycast_depth", "dfusion_raycast_march", "dfusion_raycast_shade", "dfusion_extract_cloud",
     "dfusion_extract_normals", "dfusion_warp_create", "dfusion_warp_destroy",
     "dfusion_warp_set_nodes", "dfusion_warp_set_transforms", "dfusion_warp_build_index", "dfusion_knn",
     "dfusion_warp_points", "dfusion_integrate_warped", "dfusion_copy_bandwidth_probe", "dfusion_read_bandwidth_probe",
     "dfusion_bilateral_filter", "dfusion_truncate_depth", "dfusion_depth_pyramid", "dfusion_compute_normals_mask_depth",
     "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
     "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate",
-    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_debug_rigid", "dfusion_debug_rigid_counters",
+    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_debug_rigid", "dfusion_debug_rigid_counters", "dfusion_debug_warp_counters",
     "dfusion_render_image_points", "dfusion_render_image_depth", "dfusion_render_tangent_colors",
 ]
 
@@ -102,9 +102,8 @@ def load(path, strict=True):
                                          C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]
     L.dfusion_raycast_depth.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, C.c_size_t, vp, C.c_size_t,
                                         C.c_int, C.c_int, C.c_float, C.c_float, vp]
-    L.dfusion_raycast_march.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, C.c_int, C.c_int, C.c_float, C.c_uint, vp, vp, vp]
-    L.dfusion_raycast_select.argtypes = [vp, C.c_uint, vp, C.c_int, C.c_int, vp]
-    L.dfusion_raycast_shade.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, vp, vp, C.c_size_t, vp, C.c_size_t,
+    L.dfusion_raycast_march.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, C.c_int, C.c_int, C.c_float, C.c_uint, vp, vp]
+    L.dfusion_raycast_shade.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, vp, C.c_size_t, vp, C.c_size_t,
                                         C.c_int, C.c_int, C.c_float, vp]
     L.dfusion_extract_cloud.argtypes = [DfVolume, C.POINTER(DfSlab), fp, vp, C.c_ulonglong, vp, vp]
     L.dfusion_extract_normals.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, vp, C.c_ulonglong, C.c_float, vp, vp]
@@ -139,6 +138,7 @@ def load(path, strict=True):
     L.dfusion_render_tangent_colors.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp]
     L.dfusion_debug_rigid.argtypes = [C.c_int]
     L.dfusion_debug_rigid_counters.argtypes = [vp]
+    L.dfusion_debug_warp_counters.argtypes = [vp]
     L.dfusion_copy_bandwidth_probe.argtypes = [vp, vp, C.c_size_t, vp]
     L.dfusion_read_bandwidth_probe.argtypes = [vp, C.c_size_t, vp, vp]
     for s in SYMBOLS:

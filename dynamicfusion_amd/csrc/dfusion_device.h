@@ -330,11 +330,7 @@ __device__ __forceinline__ DfSamplePre tsdf_sample_pre(const DfIntegrateParams& 
     const uint32_t ui = (uint32_t)(int)__builtin_amdgcn_fmed3f(u, 0.f, (float)(P.cols - 1));
     const uint32_t vi = (uint32_t)(int)__builtin_amdgcn_fmed3f(v, 0.f, (float)(P.rows - 1));
     const uint32_t off = vi * (uint32_t)P.pitch + 2u * ui;
-#ifdef DF_EXP_NODISTS    // (timing experiments only)
-    r.Dp = __uint_as_float(0x40a00000u | (off & 1u));
-#else
     r.Dp = h2f_bits(*(const uint16_t*)((const char*)P.dists + off));      // :85
-#endif
     r.ok = r.ok & (r.Dp != 0.f);                                           // :86
     r.d2 = dot3(vc, vc);
     r.s = __builtin_amdgcn_sqrtf(r.d2);

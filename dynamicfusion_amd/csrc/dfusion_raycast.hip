@@ -168,14 +168,23 @@ __device__ __forceinline__ DfRayHit rc_march(const DfRayArgs& a, int x, int y)
     return h;
 }
 
-// :386-391 : vertex (volume frame) of a hit.  Reads only the trilinear neighbourhoods of curr and next.
-__device__ __forceinline__ f3 rc_locate(const DfRayArgs& a, const DfRayHit& h)
+// :386-391 : the refined ray parameter Ts of a hit and its vertex org + dir * Ts (volume frame).  Reads only the trilinear
+// neighbourhoods of curr and next.
+__device__ __forceinline__ float rc_locate_ts(const DfRayArgs& a, const DfRayHit& h)
 {
     const f3 vsi = mk3(a.vsix, a.vsiy, a.vsiz);
     const float Ft = rc_interpolate(a, mul3(h.p_curr, vsi));                          // :386
     const float Ftdt = rc_interpolate(a, mul3(h.p_next, vsi));                        // :387
-    const float Ts = h.t_hit - (a.time_step * Ft) / (Ftdt - Ft);                      // :389  (may extrapolate far!)
-    return add3(h.org, scale3(h.dir, Ts));
+    return h.t_hit - (a.time_step * Ft) / (Ftdt - Ft);                                // :389  (may extrapolate far!)
+}
+__device__ __forceinline__ f3 rc_vertex(f3 org, f3 dir, float Ts) { return add3(org, scale3(dir, Ts)); }          // :390
+__device__ __forceinline__ f3 rc_locate(const DfRayArgs& a, const DfRayHit& h) { return rc_vertex(h.org, h.dir, rc_locate_ts(a, h)); }
+// the ray of pixel (x, y), :353-354 (what rc_march starts from)
+__device__ __forceinline__ void rc_ray_of_pixel(const DfRayArgs& a, int x, int y, f3* org, f3* dir)
+{
+    *org = mk3(a.aff.t[0], a.aff.t[1], a.aff.t[2]);
+    const f3 rp = mk3(1.f * ((float)x - a.cx) * a.finvx, 1.f * ((float)y - a.cy) * a.finvy, 1.f);   // device.hpp:43-48 with z = 1.f
+    *dir = normalized3(mat3_mul(a.aff.R, rp));
 }
 
 // :392-401 : normal at the vertex, validity test, camera-frame outputs.
@@ -225,43 +234,38 @@ __global__ __launch_bounds__(256) void df_raycast_kernel(const DfRayArgs a)
     if (a.keys) a.keys[(size_t)y * a.cols + x] = h.key;
 }
 
-// ---- sharded cast, stage 1: first event on owned steps + located vertex (volume frame) of hits.
-__global__ __launch_bounds__(256) void df_raycast_march_kernel(const DfRayArgs a, float4* __restrict__ vertex,
-                                                               unsigned long long* __restrict__ keys64, unsigned int rank_tag)
+// ---- sharded cast, stage 1: first event on owned steps, and for a hit its refined ray parameter Ts (:389).
+// The merge key (DF_RC_KEY_* in dfusion.h): [ 0 | step k : 23 | hit : 1 | rank : 7 | Ts bits : 32 ].  A per-pixel MIN over ranks
+// (ncclMin on int64; the top bit stays 0) picks the first event along the ray, names its owner AND delivers Ts -- the vertex is
+// org + dir * Ts, which every rank recomputes from the pixel exactly as the unsharded cast does (:390), so no vertex image has to
+// cross GPUs.  No event at all: 0x7fffffffffffffff, larger than every event.
+__global__ __launch_bounds__(256) void df_raycast_march_kernel(const DfRayArgs a, unsigned long long* __restrict__ keys64, unsigned int rank_tag)
 {
     int x, y;
     if (!rc_pixel(a, &x, &y)) return;
     const DfRayHit h = rc_march(a, x, y);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (h.hit) { const f3 p = rc_locate(a, h); v = make_float4(p.x, p.y, p.z, 0.f); }
-    vertex[(size_t)y * a.cols + x] = v;
-    // (event key << 8) | rank: a per-pixel MIN over ranks (ncclMin on int64) picks the first event and names its owner
-    keys64[(size_t)y * a.cols + x] = ((unsigned long long)h.key << 8) | rank_tag;
+    unsigned long long k64 = 0x7fffffffffffffffull;
+    if (h.key != 0xffffffffu) {
+        const float ts = h.hit ? rc_locate_ts(a, h) : 0.f;
+        k64 = ((unsigned long long)((h.key << 7) | rank_tag) << 32) | (unsigned long long)__float_as_uint(ts);
+    }
+    keys64[(size_t)y * a.cols + x] = k64;
 }
 
-// ---- between the stages: keep the located vertex only where this rank won the MIN, zero bits elsewhere, so that an
-// integer SUM across ranks hands every rank the winner's vertex.
-__global__ __launch_bounds__(256) void df_raycast_select_kernel(const unsigned long long* __restrict__ merged, unsigned int rank_tag,
-                                                                uint4* __restrict__ vertex, int n)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && (unsigned int)(merged[i] & 0xffull) != rank_tag) vertex[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-// ---- sharded cast, stage 2: after the per-pixel MIN merge of keys and the broadcast of the winners' vertices,
-// the slab that owns the vertex' plane computes the normal.  Pixels this slab does not resolve get all-zero
-// bits (the host sums integer views across ranks); resolved misses get the reference's NaN fill.
-__global__ __launch_bounds__(256) void df_raycast_shade_kernel(const DfRayArgs a, const float4* __restrict__ vertex,
-                                                               const unsigned long long* __restrict__ merged_keys)
+// ---- sharded cast, stage 2: after the per-pixel MIN merge of the keys, the slab that owns the vertex' plane computes the
+// normal.  Pixels this slab does not resolve get all-zero bits (the host sums integer views across ranks); resolved misses get
+// the reference's NaN fill.
+__global__ __launch_bounds__(256) void df_raycast_shade_kernel(const DfRayArgs a, const unsigned long long* __restrict__ merged_keys)
 {
     int x, y;
     if (!rc_pixel(a, &x, &y)) return;
-    const uint32_t key = (uint32_t)(merged_keys[(size_t)y * a.cols + x] >> 8);
+    const unsigned long long k64 = merged_keys[(size_t)y * a.cols + x];
     const float qn = qnanf_();
     float4 out_p = make_float4(0.f, 0.f, 0.f, 0.f), out_n = out_p;
-    if (key != 0xffffffffu && (key & 1u)) {
-        const float4 v4 = vertex[(size_t)y * a.cols + x];
-        const f3 v = mk3(v4.x, v4.y, v4.z);
+    if (k64 != 0x7fffffffffffffffull && ((k64 >> 39) & 1ull)) {
+        f3 org, dir;
+        rc_ray_of_pixel(a, x, y, &org, &dir);
+        const f3 v = rc_vertex(org, dir, __uint_as_float((unsigned int)k64));
         // owner of the vertex: the slab holding its nearest plane (clamped into the volume; NaN -> plane 0)
         float zf = rintf(v.z * a.vsiz);
         int pz = (zf == zf) ? (int)fminf(fmaxf(zf, 0.f), (float)(a.Z - 1)) : 0;
@@ -329,43 +333,29 @@ extern "C" int dfusion_raycast_depth(DfVolume v, const DfSlab* slab, const float
 
 // ---- sharded (Z-slab) cast in two stages; no reference counterpart (the reference is single-GPU).
 extern "C" int dfusion_raycast_march(DfVolume v, const DfSlab* slab, const float cam2vol[12], const float reproj[4], int cols,
-                                     int rows, float step_factor, unsigned int rank_tag, unsigned long long* keys, float* vertex,
-                                     dfStream stream)
+                                     int rows, float step_factor, unsigned int rank_tag, unsigned long long* keys, dfStream stream)
 {
-    if (!keys || !vertex || rank_tag > 255u) return DF_E_INVALID;
+    if (!keys || rank_tag > DF_RC_KEY_MAX_RANK) return DF_E_INVALID;
     DfRayArgs a;
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     int rc = df_raycast_setup(a, v, slab, cam2vol, ident, reproj, cols, rows, step_factor, 0.5f);
     if (rc) return rc;
-    hipLaunchKernelGGL(df_raycast_march_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, (float4*)vertex, keys,
-                       rank_tag);
-    DF_LAUNCH_CHECK();
-    return DF_OK;
-}
-
-extern "C" int dfusion_raycast_select(const unsigned long long* merged_keys, unsigned int rank_tag, float* vertex, int cols, int rows,
-                                      dfStream stream)
-{
-    if (!merged_keys || !vertex || cols <= 0 || rows <= 0) return DF_E_INVALID;
-    const int n = cols * rows;
-    hipLaunchKernelGGL(df_raycast_select_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, merged_keys, rank_tag,
-                       (uint4*)vertex, n);
+    hipLaunchKernelGGL(df_raycast_march_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, keys, rank_tag);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }
 
 extern "C" int dfusion_raycast_shade(DfVolume v, const DfSlab* slab, const float cam2vol[12], const float Rinv[9],
-                                     const float reproj[4], const float* vertex, const unsigned long long* merged_keys, float* points,
+                                     const float reproj[4], const unsigned long long* merged_keys, float* points,
                                      size_t ppitch, float* normals, size_t npitch, int cols, int rows, float delta_factor,
                                      dfStream stream)
 {
-    if (!vertex || !merged_keys || !points || !normals) return DF_E_INVALID;
+    if (!merged_keys || !points || !normals) return DF_E_INVALID;
     DfRayArgs a;
     int rc = df_raycast_setup(a, v, slab, cam2vol, Rinv, reproj, cols, rows, 0.75f, delta_factor);
     if (rc) return rc;
     a.pts = points; a.ppitch = ppitch; a.nrm = normals; a.npitch = npitch;
-    hipLaunchKernelGGL(df_raycast_shade_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a,
-                       (const float4*)vertex, merged_keys);
+    hipLaunchKernelGGL(df_raycast_shade_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, merged_keys);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }

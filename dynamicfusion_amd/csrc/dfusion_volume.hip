@@ -41,31 +41,52 @@ extern "C" int dfusion_clear(DfVolume v, const DfSlab* slab, dfStream stream)
 }
 
 // ------------------------------------------------------------------------------------------ copy probe
-__global__ __launch_bounds__(256) void df_copy_kernel(uint4* __restrict__ d, const uint4* __restrict__ s, size_t n16)
+// The MEASURED roofline denominator.  Which plain copy is fastest on this part was measured (tools/copy_probe.hip, round 3): a
+// grid-stride loop of single 16-byte accesses -- the usual form, and round 2's probe -- reaches 4.4-4.9 TB/s, because the lines a
+// workgroup touches at one time are scattered over the whole buffer; a workgroup that copies ONE CONTIGUOUS 16 KiB run, four
+// non-temporal 16-byte loads in flight per lane and non-temporal stores, reaches 5.7-6.3 TB/s (the guide's 6.29 TB/s float4 copy).
+typedef unsigned int df_probe_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void df_copy_kernel(df_probe_u4* __restrict__ d, const df_probe_u4* __restrict__ s, size_t n16)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
-        d[i] = s[i];
+    const size_t b = (size_t)blockIdx.x * 1024, e = b + 1024 < n16 ? b + 1024 : n16;
+    size_t i = b + threadIdx.x;
+    if (i + 768 < e) {
+        df_probe_u4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(s + i + u * 256);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], d + i + u * 256);
+    } else {
+        for (; i < e; i += 256) d[i] = s[i];
+    }
 }
 
 extern "C" int dfusion_copy_bandwidth_probe(void* dst, const void* src, size_t bytes, dfStream stream)
 {
     if (!dst || !src || (bytes % 16)) return DF_E_INVALID;
-    size_t n16 = bytes / 16;
-    size_t blocks = (n16 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(df_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint4*)dst, (const uint4*)src, n16);
+    const size_t n16 = bytes / 16;
+    const size_t blocks = (n16 + 1023) / 1024;
+    if (blocks == 0) return DF_OK;
+    if (blocks > 0x7fffffffull) return DF_E_INVALID;
+    hipLaunchKernelGGL(df_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (df_probe_u4*)dst, (const df_probe_u4*)src, n16);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }
 
-// read-only stream probe: the measured roofline denominator for scan kernels (extract)
-__global__ __launch_bounds__(256) void df_read_kernel(const uint4* __restrict__ s, size_t n16, unsigned int* __restrict__ sink)
+// read-only stream probe: the measured roofline denominator for scan kernels (extract); four non-temporal loads in flight per lane
+__global__ __launch_bounds__(256) void df_read_kernel(const df_probe_u4* __restrict__ s, size_t n16, unsigned int* __restrict__ sink)
 {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     unsigned int acc = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
-        const uint4 v = s[i];
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        df_probe_u4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(s + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
     }
+    for (; i < n16; i += stride) { const df_probe_u4 v = s[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
     if (acc == 0x9e3779b9u) *sink = acc;              // practically never true: keeps the loads alive without a store stream
 }
 
@@ -74,8 +95,9 @@ extern "C" int dfusion_read_bandwidth_probe(const void* src, size_t bytes, void*
     if (!src || !sink4 || (bytes % 16)) return DF_E_INVALID;
     size_t n16 = bytes / 16;
     size_t blocks = (n16 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(df_read_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, n16, (unsigned int*)sink4);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (blocks == 0) return DF_OK;
+    hipLaunchKernelGGL(df_read_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const df_probe_u4*)src, n16, (unsigned int*)sink4);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }
@@ -167,7 +189,7 @@ extern "C" int dfusion_project_and_remove(const uint16_t* dists_in, size_t in_pi
 // levels 1..5 of one 32 x 32 pixel tile per workgroup
 __global__ __launch_bounds__(256) void df_pyramid_tiles_kernel(const DfDistsPyramid P, uint16_t* __restrict__ out, unsigned int* __restrict__ zero16)
 {
-    if (zero16 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0u;
+    if (zero16 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) zero16[threadIdx.x] = 0u;     // (the rigid plan's 64 counters)
     __shared__ uint16_t s[16 * 16];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const int x0 = blockIdx.x * 32 + 2 * tx, y0 = blockIdx.y * 32 + 2 * ty;
@@ -261,10 +283,13 @@ struct DfRigidArgs {
     DfIntegrateParams P;
     unsigned long long* n_upd;
     unsigned long long* n_swept;   // nullable: += voxels that went through the sample chain (alive sub-chunks x columns inside the volume)
-    // launch plan (df_rigid_plan_kernel): item = chunk * tiles + tile, its mask = its alive sub-chunks (bit s: planes [zb + SUB s,
-    // zb + SUB s + SUB) may update); items with w > 0 bits are listed in bin w (plan_bins[w * plan_items ...], plan_cnt[w] entries
-    // item | mask << 24)
-    const unsigned int* plan_bins; const unsigned int* plan_cnt; unsigned int plan_items; int tiles;
+    // launch plan (df_rigid_plan_kernel).  A patch = DF_RIGID_PX x DF_RIGID_PY columns (one wave), tile = ty * tiles_x + tx with
+    // tiles_x a multiple of 4; a STRIP = 4 patches side by side in x (one workgroup: the four waves touch 4 * PX * 4 contiguous bytes
+    // of every voxel row together); item = chunk * strips + strip, its mask = 4 x 8 bits (bit 8 k + s: sub-chunk s of patch k may
+    // update, planes [zb + SUB s, zb + SUB s + SUB)); items with w > 0 bits are listed in bin w (plan_bins[w * plan_items ...],
+    // plan_cnt[w] entries), their masks in plan_mask[item]
+    const unsigned int* plan_bins; const unsigned int* plan_cnt; const unsigned int* plan_mask; unsigned int plan_items; int tiles, tiles_x;
+    const float4* plan_starts;     // [item][lane]: the running position of lane's column at the item's first plane
 #ifdef DF_TRACE_WG
     unsigned long long* trace;
 #endif
@@ -299,15 +324,11 @@ __device__ __forceinline__ unsigned df_outside_mask(const DfFrustum& F, f3 p, fl
 // A chunk starting at plane zb replays the zb additions of :75 in registers, so every chunk -- and every Z-slab shard on another
 // GPU -- produces the bits of the unsharded sweep.
 // the voxels of one column on planes [zs, zse), U at a time
-#ifdef DF_EXP_NOSTORE        // (timing experiments only: the store is kept alive by an impossible condition)
-#define DF_EXP_STORE(dst, val) do { const uint32_t v__ = (val); if (v__ == 0xdeadbeefu) (dst) = v__; } while (0)
-#else
-#define DF_EXP_STORE(dst, val) (dst) = (val)
-#endif
-template <int U, bool FAST, bool SAT>
+template <int U, bool FAST, bool SAT, bool FULL, bool COUNT>
 __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f3 zstep, uint32_t*& p, size_t plane, int zs, int zse,
                                                  bool active, unsigned int& my_upd)
 {
+    // FULL: the run is a whole number of batches (every sub-chunk but a slab's last): no per-plane range tests
     const float sat_t = df_sat_threshold(a.P.trunc);
     for (int z = zs; z < zse; z += U) {
         float ts[U];
@@ -316,14 +337,14 @@ __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f
         if constexpr (FAST && SAT) {
             // stage 1 in two halves (dfusion_device.h, tsdf_sample_pre): the approximate |vc| decides wherever the voxel is not
             // within trunc of the surface -- the tsdf is then exactly 1.f or the voxel does not update
-            const f3 vc0 = vc;
+            DfSamplePre pre[U];
             bool undecided = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool inr = z + u < zse;
-                const DfSamplePre pre = tsdf_sample_pre(a.P, vc);
-                ts[u] = pre.Dp - pre.s;                 // approximate sdf
-                up[u] = pre.ok && inr && active;
+                const bool inr = FULL || z + u < zse;
+                pre[u] = tsdf_sample_pre(a.P, vc);
+                ts[u] = pre[u].Dp - pre[u].s;           // approximate sdf
+                up[u] = pre[u].ok && inr && active;
                 undecided = undecided | (up[u] & (fabsf(ts[u]) < sat_t));
                 if (inr) vc = add3(vc, zstep);          // :75
             }
@@ -331,19 +352,14 @@ __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f
             if (sat) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) { up[u] = up[u] & (ts[u] >= sat_t); ts[u] = 1.f; }
-            } else {                                    // within trunc of the surface: the batch again, as written (same additions, same bits)
-                f3 w = vc0;
+            } else {                                    // within trunc of the surface: the exact root and :89-93 as written
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const bool inr = z + u < zse;
-                    up[u] = tsdf_sample_fast(a.P, w, &ts[u]) && inr && active;
-                    if (inr) w = add3(w, zstep);
-                }
+                for (int u = 0; u < U; ++u) up[u] = tsdf_sample_finish(a.P, pre[u], &ts[u]) & up[u];
             }
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) {               // stage 1: U branch-free sample chains
-                const bool inr = z + u < zse;
+                const bool inr = FULL || z + u < zse;
                 up[u] = (FAST ? tsdf_sample_fast(a.P, vc, &ts[u]) : tsdf_sample_nb(a.P, vc, &ts[u])) && inr && active;
                 if (inr) vc = add3(vc, zstep);          // :75
             }
@@ -351,11 +367,7 @@ __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f
         uint32_t v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)                     // stage 2: the voxel loads of the batch in flight together
-#ifdef DF_EXP_NOLOAD
-            v[u] = 0x00013c00u;
-#else
             if (up[u]) v[u] = p[(size_t)u * plane];
-#endif
         bool one = false;                               // saturated samples onto stored 1.0 / cleared voxels: the fuse is a weight increment
         if (FAST && SAT && sat) {
             one = true;
@@ -366,7 +378,7 @@ __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f
         if (one) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (up[u]) { DF_EXP_STORE(p[(size_t)u * plane], tsdf_fuse_one(v[u], a.P.max_weight)); ++my_upd; }
+                if (up[u]) { p[(size_t)u * plane] = tsdf_fuse_one(v[u], a.P.max_weight); if (COUNT) ++my_upd; }
         } else {
             bool fin = FAST;                            // the fuse division's short form: finite stored values (a wave decides together)
             if (FAST) {
@@ -376,10 +388,106 @@ __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)                 // stage 3: fuse (:97-103) and store
-                if (up[u]) { DF_EXP_STORE(p[(size_t)u * plane], fin ? tsdf_fuse_short(v[u], ts[u], a.P.max_weight) : tsdf_fuse(v[u], ts[u], a.P.max_weight)); ++my_upd; }
+                if (up[u]) { p[(size_t)u * plane] = fin ? tsdf_fuse_short(v[u], ts[u], a.P.max_weight) : tsdf_fuse(v[u], ts[u], a.P.max_weight); if (COUNT) ++my_upd; }
         }
-        p += (size_t)min(U, zse - z) * plane;
+        p += (size_t)(FULL ? U : min(U, zse - z)) * plane;
     }
+}
+
+// The same run of voxels, software-pipelined (FAST + SAT, whole batches): the sweep is bound by what a voxel WAITS for -- the dists
+// gather, then the voxel word, each a trip to L2 / HBM -- not by its instructions (PMC, round 3: a third fewer VALU instructions
+// changed nothing while 2 x 8 voxels per SIMD were in flight).  So (a) the voxel word is requested together with the dists gather,
+// for every column of the patch inside the volume, whatever the verdict will be (the sweep reads 1.26 x the words it writes), and
+// (b) batch b + 1 is projected and its four requests issued BEFORE batch b is decided, fused and stored: 2 U voxels in flight per
+// wave instead of U, and one wait per batch instead of two dependent ones.
+#ifndef DF_RIGID_STARTS
+#define DF_RIGID_STARTS 1       // chunk starts made once per column by the plan kernel (0: every chunk replays the additions from plane 0)
+#endif
+#ifndef DF_RIGID_LOOKAHEAD
+#define DF_RIGID_LOOKAHEAD 1
+#endif
+template <int U> struct DfRigidPend { float Dp[U], d2[U], s[U]; uint32_t v[U]; bool ok[U]; };
+template <int U>
+__device__ __forceinline__ void df_rigid_issue(const DfRigidArgs& a, f3& vc, f3 zstep, const uint32_t* p, size_t plane, bool active, DfRigidPend<U>& P)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const DfSamplePre pre = tsdf_sample_pre(a.P, vc);                   // (issues the dists gather)
+        P.Dp[u] = pre.Dp; P.d2[u] = pre.d2; P.s[u] = pre.s; P.ok[u] = pre.ok && active;
+        P.v[u] = 0u;
+        if (active) P.v[u] = p[(size_t)u * plane];                          // the voxel word, unconditionally
+        vc = add3(vc, zstep);                                               // :75
+    }
+}
+template <int U, bool COUNT>
+__device__ __forceinline__ void df_rigid_finish(const DfRigidArgs& a, uint32_t* p, size_t plane, const DfRigidPend<U>& P, float sat_t, unsigned int& my_upd)
+{
+    float ts[U]; bool up[U];
+    bool undecided = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        ts[u] = P.Dp[u] - P.s[u];                                           // approximate sdf (see tsdf_sample_pre)
+        undecided = undecided | (P.ok[u] & (fabsf(ts[u]) < sat_t));
+    }
+    const bool sat = __builtin_amdgcn_ballot_w64(undecided) == 0ull;
+    if (sat) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { up[u] = P.ok[u] & (ts[u] >= sat_t); ts[u] = 1.f; }
+    } else {                                                                // within trunc of the surface: the exact root, :89-93 as written
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            DfSamplePre pre; pre.Dp = P.Dp[u]; pre.d2 = P.d2[u]; pre.s = P.s[u]; pre.ok = P.ok[u];
+            up[u] = tsdf_sample_finish(a.P, pre, &ts[u]);
+        }
+    }
+    bool one = sat;                                                         // saturated samples onto stored 1.0 / cleared voxels: a weight increment
+    if (sat) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) one = one & (!up[u] | tsdf_fuse_one_ok(P.v[u]));
+        one = df_wave_all(one);
+    }
+    if (one) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (up[u]) { p[(size_t)u * plane] = tsdf_fuse_one(P.v[u], a.P.max_weight); if (COUNT) ++my_upd; }
+    } else {
+        bool fin = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) fin = fin & (!up[u] | tsdf_fuse_short_ok(P.v[u]));
+        fin = df_wave_all(fin);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (up[u]) { p[(size_t)u * plane] = fin ? tsdf_fuse_short(P.v[u], ts[u], a.P.max_weight) : tsdf_fuse(P.v[u], ts[u], a.P.max_weight); if (COUNT) ++my_upd; }
+    }
+}
+// planes [zs, zs + n), n a multiple of U
+template <int U, bool COUNT>
+__device__ __forceinline__ void df_rigid_run_pipe(const DfRigidArgs& a, f3& vc, f3 zstep, uint32_t*& p, size_t plane, int n, bool active, unsigned int& my_upd)
+{
+    const float sat_t = df_sat_threshold(a.P.trunc);
+#if DF_RIGID_LOOKAHEAD
+    DfRigidPend<U> A, B;
+    df_rigid_issue<U>(a, vc, zstep, p, plane, active, A);
+    for (int z = U; z < n; z += 2 * U) {
+        df_rigid_issue<U>(a, vc, zstep, p + (size_t)U * plane, plane, active, B);
+        df_rigid_finish<U, COUNT>(a, p, plane, A, sat_t, my_upd);
+        p += (size_t)U * plane;
+        if (z + U < n) {
+            df_rigid_issue<U>(a, vc, zstep, p + (size_t)U * plane, plane, active, A);
+            df_rigid_finish<U, COUNT>(a, p, plane, B, sat_t, my_upd);
+            p += (size_t)U * plane;
+        } else { A = B; }
+    }
+    df_rigid_finish<U, COUNT>(a, p, plane, A, sat_t, my_upd);
+    p += (size_t)U * plane;
+#else
+    for (int z = 0; z < n; z += U) {
+        DfRigidPend<U> A;
+        df_rigid_issue<U>(a, vc, zstep, p, plane, active, A);
+        df_rigid_finish<U, COUNT>(a, p, plane, A, sat_t, my_upd);
+        p += (size_t)U * plane;
+    }
+#endif
 }
 
 #ifndef DF_RIGID_PX
@@ -399,7 +507,13 @@ __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f
 #define DF_RIGID_WAVES 8
 #endif
 #define DF_RIGID_MAX_SUBS 8      // sub-chunks per chunk (the plan's masks are bytes)
-#define DF_RIGID_BINS (DF_RIGID_MAX_SUBS + 1)
+#ifndef DF_RIGID_STRIP
+#define DF_RIGID_STRIP 1         // patches (waves) side by side in x per plan item: 1, 2 or 4 (a sweep workgroup = 4 waves = 4 / STRIP items)
+#endif
+#ifndef DF_RIGID_ZC
+#define DF_RIGID_ZC 32           // planes per chunk wanted (a multiple of DF_RIGID_SUB, <= DF_RIGID_SUB * DF_RIGID_MAX_SUBS)
+#endif
+#define DF_RIGID_BINS (DF_RIGID_STRIP * DF_RIGID_MAX_SUBS + 1)
 // Conservative, result-identical rejection of ALL the voxels of a 32 x 2 column patch on planes [zs, zs + n): the same two tests as
 // df_rigid_culled, on the box the patch's voxels span (its 8 corners; positions by multiplication, within the tests' margin of the
 // running sums the sweep carries): (a) all corners outside the same frustum side plane, (b) the box's least distance from the camera
@@ -438,71 +552,124 @@ __device__ __forceinline__ bool df_rigid_box_culled(const DfRigidArgs& a, const 
     return (dbits < 0x7c00u) && (rmin > dmax * 1.001f + a.P.trunc);      // finite non-negative length only
 }
 
-// The launch plan: item = (column patch, Z chunk); lane 8 i + s of a wave tests sub-chunk s of the wave's i-th item (the box of the
-// whole patch over the sub-chunk's planes), the ballot gives the items' masks.  Alive items are binned by their number of alive
-// sub-chunks (slots taken per workgroup, one atomic per bin); the sweep takes the bins from the fullest down, so its waves are the long
-// ones first and the launch does not end on a few of them.
+// The launch plan.  One wave per patch and group of 8 chunks: lane 8 c + s tests sub-chunk s of the group's c-th chunk (the box of
+// the whole patch over the sub-chunk's planes), the ballot gives the patch's masks.  Four neighbouring waves are the four patches of a
+// STRIP; their masks meet in LDS and make the strip items' 32-bit masks.  Alive items are binned by their number of alive
+// (patch, sub-chunk) cells (slots taken per workgroup, one atomic per bin); the sweep takes the bins from the fullest down, so its
+// workgroups are the long ones first and the launch does not end on a few of them.
+// Why strips (round 3): what bounded the sweep was neither its instructions nor the voxels it had in flight but the WAY it touched
+// HBM -- independent waves, each read-modify-writing 64 (16 x 4 patch) or 128 (32 x 2) contiguous bytes per voxel row at places
+// unrelated to what every other wave was touching: tools/rmw_probe.hip measures 2.6 / 4.4 TB/s for exactly that traffic, and
+// 6.3-6.6 TB/s as soon as >= 256 contiguous bytes of a row are touched together.
+// With DF_RIGID_STARTS the same wave then makes the CHUNK STARTS of its patch: a chunk at plane zb needs the running position after zb
+// additions `vc += zstep` (tsdf_volume.cu:75) -- the sequence cannot be shortcut, its roundings are the result.  Lane l walks column l
+// of the patch ONCE, up to the last alive chunk, and leaves the position at every alive chunk's first plane in `starts`.
 template <bool DEPTH>
-__global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a, const DfFrustum F, const DfDistsPyramid Py, unsigned n_items, bool keep_all,
-                                                             unsigned int* __restrict__ cnt, unsigned int* __restrict__ bins)
+__global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a, const DfFrustum F, const DfDistsPyramid Py, unsigned n_items, int chunks,
+                                                             bool keep_all, unsigned int* __restrict__ cnt, unsigned int* __restrict__ bins,
+                                                             unsigned int* __restrict__ mask_out, float4* __restrict__ starts)
 {
     __shared__ unsigned int s_cnt[DF_RIGID_BINS], s_base[DF_RIGID_BINS];
+    __shared__ unsigned long long s_alive[16];
     if (threadIdx.x < DF_RIGID_BINS) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
-    const unsigned item = (blockIdx.x * 1024u + threadIdx.x) >> 3;
-    const int sb = threadIdx.x & 7, lane = threadIdx.x & 63;
+    // a wave = one patch and a group of cpw = 64 / subs chunks (subs = sub-chunks per chunk, a power of two <= 8): lane = cl * subs + sb
+    const int subs = a.zc / DF_RIGID_SUB, sshift = __ffs(subs) - 1, cpw = 64 >> sshift;
+    const int groups = (chunks + cpw - 1) / cpw;
+    const unsigned wg = blockIdx.x * 16u + (threadIdx.x >> 6);            // (chunk group, tile): tile fastest, a.tiles a multiple of 4
+    const int cg = (int)(wg / (unsigned)a.tiles), tile = (int)(wg % (unsigned)a.tiles);
+    const int lane = threadIdx.x & 63, sb = lane & (subs - 1), chunk = cg * cpw + (lane >> sshift);
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     bool keep = false;
-    if (item < n_items) {
-        const int tile = (int)(item % (unsigned)a.tiles), chunk = (int)(item / (unsigned)a.tiles);
-        const int tiles_x = (a.X + DF_RIGID_PX - 1) / DF_RIGID_PX;
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    if (cg < groups && chunk < chunks && tx * DF_RIGID_PX < a.X && ty * DF_RIGID_PY < a.Y) {
         const int zb = a.z_own0 + chunk * a.zc, ze = min(zb + a.zc, a.z_own0 + a.z_own_n);
         const int zs = zb + sb * DF_RIGID_SUB;
         if (zs < ze) keep = keep_all || !df_rigid_box_culled<DEPTH>(a, F, Py, tx * DF_RIGID_PX, ty * DF_RIGID_PY, zs, min(DF_RIGID_SUB, ze - zs));
     }
-    const unsigned m = (unsigned)(__ballot(keep) >> (lane & ~7)) & 0xffu;   // the item's 8 verdicts
-    const unsigned w = (unsigned)__popc(m);
-    unsigned slot = 0;
-    if (sb == 0 && m) slot = atomicAdd(&s_cnt[w], 1u);
+    const unsigned long long alive = __ballot(keep);                      // bits [cl * subs, (cl + 1) * subs): the patch's mask in chunk cg * cpw + cl
+    if (lane == 0) s_alive[threadIdx.x >> 6] = alive;
+    __syncthreads();
+    // the workgroup's 16 waves are 16 / STRIP strips x cpw chunks of plan items: one thread per item
+    const unsigned smask = (1u << subs) - 1u;
+    unsigned m = 0, w = 0, slot = 0, item = 0;
+    const int n_local = (16 / DF_RIGID_STRIP) * cpw;
+    if ((int)threadIdx.x < n_local) {
+        const int q = threadIdx.x / cpw, c = threadIdx.x % cpw;
+#pragma unroll
+        for (int k = 0; k < DF_RIGID_STRIP; ++k) m |= ((unsigned)(s_alive[DF_RIGID_STRIP * q + k] >> (c * subs)) & smask) << (8 * k);
+        const unsigned wg0 = blockIdx.x * 16u + (unsigned)(DF_RIGID_STRIP * q);      // the strip's first wave
+        const int scg = (int)(wg0 / (unsigned)a.tiles), strip = (int)(wg0 % (unsigned)a.tiles) / DF_RIGID_STRIP;
+        item = (unsigned)(scg * cpw + c) * (unsigned)(a.tiles / DF_RIGID_STRIP) + (unsigned)strip;
+        w = (unsigned)__popc(m);
+        if (m) slot = atomicAdd(&s_cnt[w], 1u);
+    }
     __syncthreads();
     if (threadIdx.x < DF_RIGID_BINS && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cnt[threadIdx.x], s_cnt[threadIdx.x]);
     __syncthreads();
-    if (sb == 0 && m) bins[(size_t)w * n_items + s_base[w] + slot] = item | (m << 24);      // (n_items < 2^24, checked by the launcher)
+    if ((int)threadIdx.x < n_local && m) { bins[(size_t)w * n_items + s_base[w] + slot] = item; mask_out[item] = m; }
+#if DF_RIGID_STARTS
+    if (alive) {                                                           // wave-uniform: the chunk starts of the patch's columns
+        const int x = tx * DF_RIGID_PX + (lane & (DF_RIGID_PX - 1)), y = ty * DF_RIGID_PY + (lane / DF_RIGID_PX);
+        const f3 zstep = scale3(mk3(a.vol2cam.R[2], a.vol2cam.R[5], a.vol2cam.R[8]), a.vsz);  // tsdf_volume.cu:69 (three separate multiplies)
+        f3 vc = aff_mul(a.vol2cam, mk3((float)x * a.vsx, (float)y * a.vsy, 0.f));              // :71-72
+        const int last = (63 - __clzll((long long)alive)) >> sshift;       // last alive chunk of the group
+        int z = 0;
+        for (int c = 0; c <= last; ++c) {
+            const int zb = a.z_own0 + (cg * cpw + c) * a.zc;
+            for (; z + 8 <= zb; z += 8) {                                  // :75, planes [0, zb)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vc = add3(vc, zstep);
+            }
+            for (; z < zb; ++z) vc = add3(vc, zstep);
+            if ((alive >> (c * subs)) & (unsigned long long)smask)
+                starts[((size_t)(cg * cpw + c) * a.tiles + tile) * 64 + lane] = make_float4(vc.x, vc.y, vc.z, 0.f);
+        }
+    }
+#endif
 }
 
 // The sweep: wave e of the launch takes plan entry e (bins from the fullest down), replays `vc += zstep` up to its chunk, and walks
 // the chunk's sub-chunks: alive ones U planes per batch, the others by the additions alone.
-template <int U, bool SAT>
+template <int U, bool SAT, bool COUNT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WAVES, DF_RIGID_WAVES))) void df_integrate_rigid_kernel(const DfRigidArgs a, const bool FASTOK)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // plan entry -> item: lane j < DF_RIGID_BINS - 1 holds the count of bin DF_RIGID_MAX_SUBS - j and the running total
-    const unsigned bin_cnt = lane < DF_RIGID_BINS - 1 ? a.plan_cnt[DF_RIGID_MAX_SUBS - lane] : 0u;
+    // plan entry -> strip item: lane j < DF_RIGID_BINS - 1 holds the count of bin DF_RIGID_BINS - 1 - j and the running total
+    const unsigned bin_cnt = lane < DF_RIGID_BINS - 1 ? a.plan_cnt[DF_RIGID_BINS - 1 - lane] : 0u;
     unsigned bin_end = bin_cnt;
 #pragma unroll
     for (int o = 1; o < DF_RIGID_BINS; o <<= 1) { const unsigned t = __shfl_up(bin_end, o, 64); if (lane >= o) bin_end += t; }
     const unsigned n_alive = (unsigned)__builtin_amdgcn_readlane((int)bin_end, DF_RIGID_BINS - 2);
-    const unsigned e = blockIdx.x * 4 + (unsigned)wave;
+    const unsigned e = blockIdx.x * (4 / DF_RIGID_STRIP) + (unsigned)(wave / DF_RIGID_STRIP);      // plan entry: a strip of STRIP waves
     if (e >= n_alive) return;                                              // wave-uniform (no barrier below)
 #ifdef DF_TRACE_WG
     const unsigned long long t_start = wall_clock64(); unsigned n_sub = 0;
 #endif
     const int j = __ffsll((unsigned long long)__ballot(lane < DF_RIGID_BINS - 1 && e < bin_end)) - 1;
     const unsigned r = e - ((unsigned)__builtin_amdgcn_readlane((int)bin_end, j) - (unsigned)__builtin_amdgcn_readlane((int)bin_cnt, j));
-    const unsigned ent = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_RIGID_MAX_SUBS - j) * a.plan_items + r]);
-    const unsigned item = ent & 0xffffffu, mask = ent >> 24;            // one dependent load instead of two before a wave can start
-    const int tile = (int)(item % (unsigned)a.tiles), chunk = (int)(item / (unsigned)a.tiles);
-    const int tiles_x = (a.X + DF_RIGID_PX - 1) / DF_RIGID_PX;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const unsigned sitem = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_RIGID_BINS - 1 - j) * a.plan_items + r]);
+    const unsigned mask = ((unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_mask[sitem]) >> (8 * (wave % DF_RIGID_STRIP))) & 0xffu;
+    if (mask == 0u) return;                                                // nothing alive in this wave's patch
+    const int strips = a.tiles / DF_RIGID_STRIP;
+    const int chunk = (int)(sitem / (unsigned)strips), tile = (int)(sitem % (unsigned)strips) * DF_RIGID_STRIP + (wave % DF_RIGID_STRIP);
+    const unsigned item = (unsigned)chunk * (unsigned)a.tiles + (unsigned)tile;     // (patch item: indexes plan_starts)
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int x = tx * DF_RIGID_PX + (lane & (DF_RIGID_PX - 1)), y = ty * DF_RIGID_PY + (lane / DF_RIGID_PX);
     const bool active = x < a.X && y < a.Y;
     unsigned int my_upd = 0, my_swept = 0;
     const int zb = a.z_own0 + chunk * a.zc;
     const int ze = min(zb + a.zc, a.z_own0 + a.z_own_n);
     const f3 zstep = scale3(mk3(a.vol2cam.R[2], a.vol2cam.R[5], a.vol2cam.R[8]), a.vsz);      // tsdf_volume.cu:69 (three separate multiplies)
+    // the column's running position at plane zb: vol2cam * (x, y, 0) + zb additions of zstep (:71-75), made once per column by
+    // the plan kernel
+#if DF_RIGID_STARTS
+    const float4 st4 = a.plan_starts[(size_t)item * 64 + lane];
+    f3 vc = mk3(st4.x, st4.y, st4.z);
+#else
     f3 vc = aff_mul(a.vol2cam, mk3((float)x * a.vsx, (float)y * a.vsy, 0.f));                  // :71-72
     for (int z = 0; z < zb; ++z) vc = add3(vc, zstep);              // replay of `vc += zstep` (:75) for planes [0, zb)
+#endif
     const size_t plane = (size_t)a.X * a.Y;
     uint32_t* p = a.vol + (size_t)(zb - a.z_store0) * plane + (size_t)(active ? y : 0) * a.X + (active ? x : 0);
     int sb = 0;
@@ -522,8 +689,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
         // (SAT: the saturated-sample shortcuts also want every coordinate within 32 m; the generic forms otherwise)
         const bool fast = FASTOK && df_wave_all(!active || (tsdf_sample_domain_ok(vc, vc_end) && (!SAT || tsdf_sat_domain_ok(vc, vc_end))));
         my_swept += (unsigned)(zse - zs);               // (wave-uniform; times the wave's columns inside the volume at the end)
-        if (fast) df_rigid_batches<U, true, SAT>(a, vc, zstep, p, plane, zs, zse, active, my_upd);
-        else df_rigid_batches<DF_RIGID_U_GENERIC, false, false>(a, vc, zstep, p, plane, zs, zse, active, my_upd);   // (rare: fewer chains in flight, fewer registers)
+        if (fast && SAT && (zse - zs) % U == 0) df_rigid_run_pipe<U, COUNT>(a, vc, zstep, p, plane, zse - zs, active, my_upd);
+        else if (fast && zse - zs == DF_RIGID_SUB) df_rigid_batches<DF_RIGID_U_GENERIC, true, SAT, true, COUNT>(a, vc, zstep, p, plane, zs, zse, active, my_upd);
+        else if (fast) df_rigid_batches<DF_RIGID_U_GENERIC, true, SAT, false, COUNT>(a, vc, zstep, p, plane, zs, zse, active, my_upd);
+        else df_rigid_batches<DF_RIGID_U_GENERIC, false, false, false, COUNT>(a, vc, zstep, p, plane, zs, zse, active, my_upd);   // (rare: fewer chains in flight, fewer registers)
     }
 #ifdef DF_TRACE_WG
     if (lane == 0) {
@@ -531,13 +700,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
         t[0] = t_start; t[1] = wall_clock64(); t[2] = 0; t[3] = n_sub;
     }
 #endif
-    if (a.n_upd) {                                            // one atomic per wave
+    if (COUNT && a.n_upd) {                                   // one atomic per wave
         unsigned int s = my_upd;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.n_upd, (unsigned long long)s);
     }
-    if (a.n_swept) {                                          // (validation / measurement hook: dfusion_debug_rigid_counters)
+    if (COUNT && a.n_swept) {                                          // (validation / measurement hook: dfusion_debug_rigid_counters)
         const unsigned long long s = (unsigned long long)my_swept * (unsigned)__popcll(__builtin_amdgcn_ballot_w64(active));
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.n_swept, s);
     }
@@ -619,27 +788,29 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
             F.nlx = F.nrx = F.nty = F.nby = 0.f; F.nlz = F.nrz = F.ntz = F.nbz = 0.f;
         }
     }
-    const int tiles = ((a.X + DF_RIGID_PX - 1) / DF_RIGID_PX) * ((a.Y + DF_RIGID_PY - 1) / DF_RIGID_PY);         // 32 x 2 column patches, one per wave
-    // Z chunking: chunks of whole sub-chunks, at most DF_RIGID_MAX_SUBS of them and >= 32 planes (a chunk at plane zb replays zb
-    // additions: 3 per plane per lane); ~32 k items at 512^3 -- the longest wave (every sub-chunk alive) is then a fraction of the launch
-    const long long want_items = 256LL * 128;
-    int chunks = (int)((want_items + tiles - 1) / tiles);
-    if (chunks < 1) chunks = 1;
-    int zc = (s.z_own_n + chunks - 1) / chunks;
-    zc = ((zc + DF_RIGID_SUB - 1) / DF_RIGID_SUB) * DF_RIGID_SUB;
-    if (zc < 32) zc = 32;
-    if (zc > DF_RIGID_SUB * DF_RIGID_MAX_SUBS) zc = DF_RIGID_SUB * DF_RIGID_MAX_SUBS;
+    // column patches (one per wave), 4 side by side per strip (one per workgroup): the patch grid's x extent is padded to whole strips
+    const int tiles_x = ((a.X + DF_RIGID_PX - 1) / DF_RIGID_PX + DF_RIGID_STRIP - 1) / DF_RIGID_STRIP * DF_RIGID_STRIP;
+    const int tiles = tiles_x * ((a.Y + DF_RIGID_PY - 1) / DF_RIGID_PY);
+    // Z chunking: chunks of DF_RIGID_ZC planes -- 1, 2, 4 or 8 sub-chunks.  Short enough that the longest wave is a fraction of the
+    // launch: a per-wave timeline (tools/trace_sweep.py, round 3) showed 64-plane items taking up to 93 us of a 115 us launch whose
+    // waves summed to 71 us per slot -- the launch ended on a few long waves.  (Chunk starts come from the plan kernel: a short
+    // chunk does not pay a long replay.)
+    int zc = DF_RIGID_ZC;
+    while ((s.z_own_n + zc - 1) / zc > 4096 && zc < DF_RIGID_SUB * DF_RIGID_MAX_SUBS) zc *= 2;      // (very deep slabs)
     a.zc = zc;
-    chunks = (s.z_own_n + zc - 1) / zc;
-    const unsigned n_items = (unsigned)tiles * (unsigned)chunks;
-    a.tiles = tiles; a.plan_items = n_items;
+    const int chunks = (s.z_own_n + zc - 1) / zc;
+    const unsigned n_pitems = (unsigned)tiles * (unsigned)chunks;        // patch items (chunk starts)
+    const unsigned n_items = n_pitems / DF_RIGID_STRIP;                  // strip items (the plan's entries)
+    a.tiles = tiles; a.tiles_x = tiles_x; a.plan_items = n_items;
     hipStream_t st = (hipStream_t)stream;
     // stream-ordered scratch (no state is kept between calls): the launch plan, and for the behind-the-surface test a max-pyramid of
     // this frame's dists
     const size_t pyr_elems = df_rigid_depth_cull_disabled() ? 0 : df_pyramid_elems(cols, rows);
-    if (n_items >= (1u << 24)) return DF_E_INVALID;                  // (a plan entry carries the item in 24 bits: 500 M columns x chunks)
-    const size_t off_cnt = 0, off_bins = 64, off_pyr = (off_bins + (size_t)DF_RIGID_BINS * n_items * 4 + 15) / 16 * 16;
-    const size_t bytes = off_pyr + pyr_elems * sizeof(uint16_t);
+    if (n_pitems >= (1u << 30)) return DF_E_INVALID;
+    const size_t off_cnt = 0, off_bins = 256, off_mask = off_bins + (size_t)DF_RIGID_BINS * n_items * 4;
+    const size_t off_pyr = (off_mask + (size_t)n_items * 4 + 15) / 16 * 16;
+    const size_t off_starts = (off_pyr + pyr_elems * sizeof(uint16_t) + 255) / 256 * 256;
+    const size_t bytes = off_starts + (DF_RIGID_STARTS ? (size_t)n_pitems * 64 * sizeof(float4) : 0);
     char* scratch = nullptr;
     DF_HIP(hipMallocAsync((void**)&scratch, bytes, st));
     DfDistsPyramid Py;
@@ -647,17 +818,21 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     int rc = DF_OK;
     // (levels 1..5 only: the plan reads none above; the pyramid's first workgroup zeroes the plan's counters)
     if (pyr_elems) rc = df_build_dists_pyramid(dists, pitch, cols, rows, (uint16_t*)(scratch + off_pyr), pyr_elems, &Py, st, true, (unsigned int*)(scratch + off_cnt));
-    if (rc == DF_OK && Py.top == 0 && hipMemsetAsync(scratch + off_cnt, 0, 64, st) != hipSuccess) rc = (int)hipGetLastError();
+    if (rc == DF_OK && Py.top == 0 && hipMemsetAsync(scratch + off_cnt, 0, 256, st) != hipSuccess) rc = (int)hipGetLastError();
     if (rc != DF_OK) { (void)hipFreeAsync(scratch, st); return rc; }
     unsigned int* cnt = (unsigned int*)(scratch + off_cnt);
     unsigned int* bins = (unsigned int*)(scratch + off_bins);
-    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, g_df_rigid_keep_all, cnt, bins);
-    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((n_items + 127) / 128), dim3(1024), 0, st, a, F, Py, n_items, g_df_rigid_keep_all, cnt, bins);
-    a.plan_bins = bins; a.plan_cnt = cnt;
+    unsigned int* pmask = (unsigned int*)(scratch + off_mask);
+    float4* starts = (float4*)(scratch + off_starts);
+    const int cpw = 64 / (zc / DF_RIGID_SUB);
+    const unsigned plan_waves = (unsigned)tiles * (unsigned)((chunks + cpw - 1) / cpw);
+    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((plan_waves + 15) / 16), dim3(1024), 0, st, a, F, Py, n_items, chunks, g_df_rigid_keep_all, cnt, bins, pmask, starts);
+    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((plan_waves + 15) / 16), dim3(1024), 0, st, a, F, Py, n_items, chunks, g_df_rigid_keep_all, cnt, bins, pmask, starts);
+    a.plan_bins = bins; a.plan_cnt = cnt; a.plan_mask = pmask; a.plan_starts = starts;
     // short arithmetic forms (tsdf_sample_fast): 32-bit dists offsets, sane intrinsics; the value domain is tested per run in the kernel
     const bool fast_ok = (unsigned long long)rows * pitch < (1ull << 31) && proj[0] == proj[0] && proj[1] == proj[1] && proj[2] > 0.f && proj[3] > 0.f &&
                          !g_df_rigid_no_fast_forms;          // (cx, cy > 0: the one-compare pixel range test of tsdf_sample_fast)
-    const dim3 grid((n_items + 3) / 4);                              // sized for every item; waves past the plan's end return at once
+    const dim3 grid((n_items * DF_RIGID_STRIP + 3) / 4);             // 4 waves per workgroup; those past the plan's end return at once
 #ifdef DF_TRACE_WG
     static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;
     const size_t trace_n = (size_t)grid.x * 4 * 4;
@@ -666,8 +841,11 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     a.trace = trace_dev;
 #endif
     const bool sat_ok = fast_ok && !g_df_rigid_no_sat && df_sat_trunc_ok(v.trunc_dist);
-    if (sat_ok) hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U, true>), grid, dim3(256), 0, st, a, fast_ok);
-    else hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U, false>), grid, dim3(256), 0, st, a, fast_ok);
+    const bool count = a.n_upd || a.n_swept;
+    if (sat_ok && !count) hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U, true, false>), grid, dim3(256), 0, st, a, fast_ok);
+    else if (sat_ok) hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U, true, true>), grid, dim3(256), 0, st, a, fast_ok);
+    else if (!count) hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U, false, false>), grid, dim3(256), 0, st, a, fast_ok);
+    else hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U, false, true>), grid, dim3(256), 0, st, a, fast_ok);
     rc = (int)hipGetLastError();
 #ifdef DF_TRACE_WG
     if (getenv("DF_TRACE_FILE")) {

@@ -841,6 +841,7 @@ struct DfWarpedArgs {
     DfAff vol2world, world2cam;
     DfIntegrateParams P;
     unsigned long long* n_upd;
+    unsigned long long* n_swept;   // nullable (dfusion_debug_warp_counters): += voxels of the plan's alive (patch, layer) cells
     // conservative cull (disabled when cull == null).  cull[0] = max |t_i|, cull[1] = max sin(theta_i/2)
     // (> 1 => bound unavailable), cull[2] = max dists value of this frame; all produced on the stream, so the
     // frame needs no host round trip.
@@ -1430,6 +1431,12 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
             keep = keep && !df_tile_culled(a, c, wk);
         }
         m = __builtin_amdgcn_ballot_w64(keep);
+        if (a.n_swept) {                                                   // (measurement hook: what the sweep will put through the warp)
+            unsigned v = keep ? (unsigned)(64 * (min((lt0 + l + 1) * DF_ROW_TZ, own1) - max((lt0 + l) * DF_ROW_TZ, a.z_own0))) : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (ln == 0 && v) atomicAdd(a.n_swept, (unsigned long long)v);
+        }
     }
     const unsigned w = (unsigned)__popcll(m);
     unsigned slot = 0;
@@ -1673,6 +1680,14 @@ static double df_tile_radius(const float vol2world[12], double nx, double ny, do
     return r;
 }
 
+// measurement hook, the warped sweep's counterpart of dfusion_debug_rigid_counters (process-wide, off the product path)
+static unsigned long long* g_df_warp_swept = nullptr;
+extern "C" int dfusion_debug_warp_counters(unsigned long long* swept_dev)
+{
+    g_df_warp_swept = swept_dev;
+    return DF_OK;
+}
+
 extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
                                         const float vol2world[12], const float world2cam[12], const float proj[4],
                                         DfWarpField* wf, int k, unsigned flags, unsigned long long* n_updated, dfStream stream)
@@ -1701,6 +1716,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     a.P.fx = proj[0]; a.P.fy = proj[1]; a.P.cx = proj[2]; a.P.cy = proj[3];
     a.P.trunc = v.trunc_dist; a.P.trunc_inv = 1.f / v.trunc_dist; a.P.max_weight = v.max_weight;
     a.n_upd = n_updated;
+    a.n_swept = g_df_warp_swept;
     a.kf = (float)k; a.cam_scale = 1.f; a.origin_cam = -1.f;
     const bool use_tab = wf->tab_valid && wf->tab_k == k && !(flags & DF_WARP_NO_TABLE) && s.z_own0 >= wf->tab_z0 &&
                          s.z_own0 + s.z_own_n <= wf->tab_z0 + wf->tab_zn;

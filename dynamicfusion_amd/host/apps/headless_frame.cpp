@@ -22,10 +22,7 @@ static Affine3f read_affine(FILE* f)
 {
     float a[12];
     if (std::fread(a, 4, 12, f) != 12) { std::fprintf(stderr, "short read\n"); std::exit(2); }
-    Affine3f r;
-    for (int i = 0; i < 9; ++i) r.R.val[i] = a[i];
-    for (int i = 0; i < 3; ++i) r.t[i] = a[9 + i];
-    return r;
+    return aff12_to_affine(a);
 }
 
 int main(int argc, char** argv)

@@ -6,7 +6,8 @@
 // ray-cast is the two-stage sharded one.  out.bin (rank 0): points f32[rows*cols*4], normals f32[rows*cols*4] of the last frame, then
 // this rank's OWN planes u32[z_own_n * dims^2].
 // slab=<r>/<n> (single process, no communicator): integrate only slab r of n and write its own planes -- lets a one-GPU test compare
-// every shard of the C++ path with the unsharded volume.
+// every shard of the C++ path with the unsharded volume.  With `recompute` the shard is setSlab(z0, n, halo, integrate_halo = true)
+// and ALL its stored planes (own + the halo planes it integrated itself) are written.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,10 +23,7 @@ using namespace kfusion;
 static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
 static Affine3f to_affine(const float a[12])
 {
-    Affine3f r;
-    for (int i = 0; i < 9; ++i) r.R.val[i] = a[i];
-    for (int i = 0; i < 3; ++i) r.t[i] = a[9 + i];
-    return r;
+    return aff12_to_affine(a);
 }
 
 int main(int argc, char** argv)
@@ -75,13 +73,14 @@ int main(int argc, char** argv)
     volume.create(Vec3i(dims, dims, dims));
     volume.setSize(Vec3f::all(size)); volume.setTruncDist(0.04f); volume.setMaxWeight(64); volume.setPose(to_affine(pose12));
     volume.setRaycastStepFactor(0.75f); volume.setGradientDeltaFactor(0.5f);
-    // halo recompute: the rank OWNS (integrates) its halo planes too -- the integrate is a pure function of the broadcast inputs, so
-    // the planes come out exactly as the neighbour computes them and no exchange is needed
-    const int lo = std::max(0, z0 - halo), hi = std::min(dims, z0 + zn + halo);
-    if (only_n > 0 || !exchange) volume.setSlab(only_n > 0 ? z0 : lo, only_n > 0 ? zn : hi - lo, 0);
-    else volume.setSlab(z0, zn, halo);
+    // halo recompute: the rank also INTEGRATES its halo planes -- the integrate is a pure function of the broadcast inputs, so the
+    // planes come out exactly as the neighbour computes them and no exchange is needed.  The own range stays the non-overlapping one:
+    // it is what the ray-cast's march / shade and the merge partition the rays by.
+    if (only_n > 0 && exchange) volume.setSlab(z0, zn, 0);
+    else volume.setSlab(z0, zn, halo, !exchange);
 
     cuda::ZSlabComm* comm = only_n > 0 ? nullptr : new cuda::ZSlabComm(rank, world, argv[10]);
+    if (comm && !comm->ok()) { std::fprintf(stderr, "zslab_frame: %s\n", comm->lastError().c_str()); return 4; }
     WarpField warp(k);
     if (M > 0) {
         std::vector<Vec3f> pts(M);
@@ -104,6 +103,7 @@ int main(int argc, char** argv)
         if (comm) {
             comm->broadcast(depth_device.ptr(), depth_device.step() * (size_t)rows);        // the pitched image as it lies (same pitch on every rank)
             if (M > 0) comm->broadcast(dq_device.ptr(), (size_t)M * 8 * sizeof(float));
+            if (!comm->ok()) { std::fprintf(stderr, "zslab_frame: %s\n", comm->lastError().c_str()); return 4; }
         }
         cuda::computeDists(depth_device, dists, intr);
         if (M > 0) {
@@ -116,8 +116,9 @@ int main(int argc, char** argv)
         }
         if (comm && exchange) comm->exchangeHalos(volume, halo);
         if (comm) comm->raycast(volume, cam[f], intr, cols, rows, points, normals, 0);
+        if (comm && !comm->ok()) { std::fprintf(stderr, "zslab_frame: %s\n", comm->lastError().c_str()); return 4; }
     }
-    if (comm) comm->barrier(); else cuda::waitAllDefaultStream();
+    if (comm) { if (!comm->barrier()) { std::fprintf(stderr, "zslab_frame: %s\n", comm->lastError().c_str()); return 4; } } else cuda::waitAllDefaultStream();
 
     if (rank == 0 || !comm) {
         FILE* out = std::fopen(argv[9], "wb");
@@ -129,8 +130,12 @@ int main(int argc, char** argv)
         const size_t plane = (size_t)dims * dims;
         std::vector<unsigned int> vol(plane * (size_t)volume.slabStoreN());
         volume.data().download(vol.data());
-        const int own_first = (only_n > 0 ? z0 : z0) - volume.slabStore0();
-        std::fwrite(vol.data() + (size_t)own_first * plane, 4, plane * (size_t)zn, out);
+        if (only_n > 0 && !exchange) {                        // slab=r/n recompute: every STORED plane (own + recomputed halos)
+            std::fwrite(vol.data(), 4, plane * (size_t)volume.slabStoreN(), out);
+        } else {
+            const int own_first = z0 - volume.slabStore0();
+            std::fwrite(vol.data() + (size_t)own_first * plane, 4, plane * (size_t)zn, out);
+        }
         std::fclose(out);
     }
     std::printf("zslab_frame ok: rank %d of %d, planes [%d, %d), halo %d (%s), %d frames, %d nodes\n", rank, world, z0, z0 + zn, halo,

@@ -46,19 +46,23 @@ public:
 
     // ---- Z-slab shard (extension): own planes [z_own0, z_own0 + z_own_n) of the full dims, stored with `halo` more planes on each
     // side (clipped to the volume).  Reallocates and clears.  setSlab(0, dims.z, 0) is the unsharded volume.
-    void setSlab(int z_own0, int z_own_n, int halo);
+    // integrate_halo: the integrate methods also update the stored HALO planes (the integrate is a pure function of the frame's
+    // inputs, so the planes come out exactly as the neighbour computes them and no halo exchange is needed); ray-cast, extraction and
+    // the merge still see the non-overlapping own range.
+    void setSlab(int z_own0, int z_own_n, int halo, bool integrate_halo = false);
     bool isSlab() const { return has_slab_; }
+    bool integratesHalo() const { return integrate_halo_; }
+    int slabIntegrate0() const { return integrate_halo_ ? z_store0_ : z_own0_; }      // planes the integrate methods update
+    int slabIntegrateN() const { return integrate_halo_ ? z_store_n_ : z_own_n_; }
     int slabStore0() const { return z_store0_; }
     int slabStoreN() const { return z_store_n_; }
     int slabOwn0() const { return z_own0_; }
     int slabOwnN() const { return z_own_n_; }
-    // the two-stage sharded ray-cast (include/dfusion.h dfusion_raycast_march / _select / _shade): see kfusion/cuda/zslab.hpp
-    // (keys64 / vertex: dense cols x rows arrays; points / normals of the shade: any pitch)
-    void raycastMarch(const Affine3f& camera_pose, const Intr& intr, int cols, int rows, unsigned rank, DeviceArray<unsigned long long>& keys64,
-                      DeviceArray<Point>& vertex) const;
-    static void raycastSelect(const DeviceArray<unsigned long long>& merged_keys64, unsigned rank, DeviceArray<Point>& vertex, int cols, int rows);
-    void raycastShade(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<Point>& vertex,
-                      const DeviceArray<unsigned long long>& merged_keys64, Cloud& points, Normals& normals) const;
+    // the two-stage sharded ray-cast (include/dfusion.h dfusion_raycast_march / _shade): see kfusion/cuda/zslab.hpp
+    // (keys64: a dense cols x rows array of merge keys; points / normals of the shade: any pitch)
+    void raycastMarch(const Affine3f& camera_pose, const Intr& intr, int cols, int rows, unsigned rank, DeviceArray<unsigned long long>& keys64) const;
+    void raycastShade(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64, Cloud& points,
+                      Normals& normals) const;
 
     // ---- fusion
     virtual void integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr);                        // rigid, tsdf_volume.cpp:110-122
@@ -84,10 +88,19 @@ public:
     void fetchNormals(const DeviceArray<Point>& cloud, DeviceArray<Normal>& normals) const;
     void compute_points();
     void compute_normals();
-    const std::vector<Point>& get_cloud_host() const;
-    const std::vector<Normal>& get_normal_host() const;
+#ifdef KFUSION_USE_OPENCV
+    cv::Mat get_cloud_host() const;                                        // tsdf_volume.hpp:24-28: 1 x N CV_32FC4 (copies of the vectors below)
+    cv::Mat get_normal_host() const;
+    cv::Mat* get_cloud_host_ptr() const;
+    cv::Mat* get_normal_host_ptr() const;
+#else
+    const std::vector<Point>& get_cloud_host() const { return cloud_host_vector(); }
+    const std::vector<Normal>& get_normal_host() const { return normal_host_vector(); }
     const std::vector<Point>* get_cloud_host_ptr() const { return &get_cloud_host(); }      // tsdf_volume.hpp:27-28 (cv::Mat* there)
     const std::vector<Normal>* get_normal_host_ptr() const { return &get_normal_host(); }
+#endif
+    const std::vector<Point>& cloud_host_vector() const;                  // the host copies themselves, filled on first use after compute_*
+    const std::vector<Normal>& normal_host_vector() const;
     const DeviceArray<Point>& get_cloud_device() const { return cloud_; }
 
 private:
@@ -104,8 +117,11 @@ private:
     mutable std::vector<Point> cloud_host_;
     mutable std::vector<Normal> normal_host_;
     mutable bool cloud_host_stale_ = false, normal_host_stale_ = false;
+#ifdef KFUSION_USE_OPENCV
+    mutable cv::Mat cloud_host_mat_, normal_host_mat_;
+#endif
     Dists fusion_dists_;                                                   // scratch of surface_fusion
-    bool has_slab_ = false;
+    bool has_slab_ = false, integrate_halo_ = false;
     int z_store0_ = 0, z_store_n_ = 0, z_own0_ = 0, z_own_n_ = 0;
 };
 

@@ -5,13 +5,15 @@
 //   broadcast()      the frame inputs from rank 0 (depth image, node transforms) -- one ncclBroadcast of bytes each
 //   exchangeHalos()  after the integrate: the H boundary planes to / from both Z neighbours, paired ncclSend / ncclRecv in one
 //                    group (ring neighbours only: two of the seven xGMI links).  Not needed when every rank integrates its halo
-//                    planes itself (TsdfVolume::setSlab(z0 - H, n + 2H, 0) as the integrate view; the integrate is a pure function
-//                    of the broadcast inputs) -- the harness offers both
+//                    planes itself -- TsdfVolume::setSlab(z0, n, H, /*integrate_halo=*/true): the integrate is a pure function of
+//                    the broadcast inputs, the own range stays the non-overlapping one -- the harness offers both
 //   raycast()        two stages, because the zero-crossing refinement can move a vertex into ANOTHER rank's slab
 //                    (tsdf_volume.cu:389): march on the global step lattice (each rank evaluates only the steps whose sample lies
-//                    in a plane it owns) -> ncclAllReduce(MIN) of (event key << 8 | rank) as int64 -> winners' vertices by
-//                    ncclAllReduce(SUM) on their int32 view (every summand but one is integer zero) -> the owner of the vertex'
-//                    plane shades -> ncclReduce(SUM) of the int32 views to rank `dst`: bit-identical with the unsharded ray-cast.
+//                    in a plane it owns) -> ONE ncclAllReduce(MIN) of the int64 merge keys [step | hit | rank | Ts bits]
+//                    (include/dfusion.h): first event along every ray, its owner, and its refined ray parameter Ts, from which
+//                    every rank recomputes the vertex -> the owner of the vertex' plane shades -> ONE ncclReduce(SUM) of the int32
+//                    view of points + normals to rank `dst` (every summand but one is integer zero): bit-identical with the
+//                    unsharded ray-cast.  (Round 2 exchanged the winners' vertices with a second all-reduce, 4.9 MB per frame.)
 // The same sequence, collective for collective, as dynamicfusion_amd/sharded.py (torch.distributed), which the world-size-2/3 gloo
 // tests and the one-GPU 8-slab emulation exercise; this file is what a C++ host (KinFu) links instead.
 #pragma once
@@ -25,7 +27,9 @@ class ZSlabComm
 {
 public:
     /// Collective over all ranks of the node.  `id_path`: a file every rank can read (e.g. under /tmp): rank 0 publishes the RCCL
-    /// unique id there, the others wait for it.  The calling thread's current HIP device is the rank's GPU.
+    /// unique id there (removing a stale one first, and the file itself once every rank is in), the others wait for it; give every
+    /// rank of a run the same DFUSION_ZSLAB_NONCE (e.g. the launcher's pid) and a leftover file of another run is never accepted.
+    /// The calling thread's current HIP device is the rank's GPU.  Check ok() afterwards.
     ZSlabComm(int rank, int world, const std::string& id_path);
     ~ZSlabComm();
     ZSlabComm(const ZSlabComm&) = delete;
@@ -42,18 +46,25 @@ public:
     /// every rank, to be asked BEFORE the first collective
     static bool partitionOk(int Z, int world, int halo, std::string* why = nullptr);
 
-    void broadcast(void* device_ptr, size_t bytes, int root = 0);
-    void exchangeHalos(TsdfVolume& slab, int halo);
-    /// result on rank `dst`.  points / normals become dense cols x rows VIEWS of buffers this object owns (valid until the next
+    /// Every collective returns false on an RCCL / HIP error (lastError() says which) instead of ending the process; ok() is false
+    /// from then on -- and from the start if the communicator could not be made -- and further calls fail at once.
+    bool ok() const { return ok_; }
+    const std::string& lastError() const { return error_; }
+    bool broadcast(void* device_ptr, size_t bytes, int root = 0);
+    bool exchangeHalos(TsdfVolume& slab, int halo);
+    /// result on rank `dst`.  points / normals become dense cols x rows VIEWS of a buffer this object owns (valid until the next
     /// raycast); on the other ranks they hold that rank's partial image
-    void raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Intr& intr, int cols, int rows, Cloud& points, Normals& normals, int dst = 0);
-    void barrier();
+    bool raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Intr& intr, int cols, int rows, Cloud& points, Normals& normals, int dst = 0);
+    bool barrier();
 private:
+    bool fail(const std::string& what);
     int rank_, world_;
     void* comm_;                 // ncclComm_t
     void* stream_;               // hipStream_t: the null stream (the C++ mirror enqueues everything there)
+    bool ok_;
+    std::string error_;
     DeviceArray<unsigned long long> keys64_;
-    DeviceArray<Point> vertex_, points_, normals_;
+    DeviceArray<Point> out_;     // points, then normals
     DeviceArray<int> token_;
 };
 

@@ -53,7 +53,11 @@ namespace kfusion
     class KinFu
     {
     public:
+#ifdef KFUSION_USE_OPENCV
+        typedef cv::Ptr<KinFu> Ptr;                                         // kinfu.hpp:52
+#else
         typedef std::shared_ptr<KinFu> Ptr;
+#endif
         KinFu(const KinFuParams& params);
         virtual ~KinFu() {}
 

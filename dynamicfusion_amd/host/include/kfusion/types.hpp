@@ -1,8 +1,9 @@
 // kfusion/types.hpp -- value types named by the hot-path API of the reference
-// (/root/reference/kfusion/include/kfusion/types.hpp:11-63), for builds WITHOUT OpenCV.
-// With OpenCV present the reference's own typedefs (cv::Vec3f, cv::Affine3f, ...) are used instead, so that
-// apps/demo.cpp-style callers keep compiling against cv types; this image has no OpenCV, so the minimal
-// stand-ins below are what the headless harness and the tests exercise.
+// (/root/reference/kfusion/include/kfusion/types.hpp:11-63).
+// With -DKFUSION_USE_OPENCV (and the OpenCV headers on the include path) the reference's own typedefs are used -- cv::Vec3f,
+// cv::Affine3f, cv::Mat returns, cv::Ptr<KinFu> -- so that the reference's apps/demo.cpp compiles against these headers
+// UNMODIFIED (tests/test_demo_ref.py does that, against a test-side stand-in for OpenCV, which this image does not have).
+// Without it the minimal stand-ins below are used; they are what the headless harnesses and the GPU tests exercise.
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -143,5 +144,12 @@ namespace kfusion
         const Mat3f R = a.rotation(); const Vec3f t = a.translation();
         for (int i = 0; i < 9; ++i) out[i] = R.val[i];
         for (int i = 0; i < 3; ++i) out[9 + i] = t[i];
+    }
+    inline Affine3f aff12_to_affine(const float in[12])                 // (through the (R, t) constructor: what cv::Affine3f offers too)
+    {
+        Mat3f R; Vec3f t;
+        for (int i = 0; i < 9; ++i) R.val[i] = in[i];
+        for (int i = 0; i < 3; ++i) t[i] = in[9 + i];
+        return Affine3f(R, t);
     }
 }

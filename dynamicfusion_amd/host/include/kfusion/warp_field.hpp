@@ -68,8 +68,14 @@ namespace kfusion
         void buildKDTree() { commit(true); }                 // warp_field.cpp:275-282
         /// warp_field.cpp:284-293: every node's position moved by its own translation, one Vec3f per node -- what the demo shows as
         /// the "warp_field" cloud (apps/demo.cpp:67).  The reference returns a 1 x N CV_32FC3 cv::Mat: the same N x 3 floats.
+#ifdef KFUSION_USE_OPENCV
+        typedef cv::Mat NodesMat;                                          // 1 x N, CV_32FC3, as in the reference
+#else
         typedef std::vector<Vec3f> NodesMat;
+#endif
         const NodesMat getNodesAsMat() const;
+        /// the same N x 3 floats whatever the build
+        std::vector<Vec3f> getNodesAsVector() const;
 
         int k() const { return k_; }
         DfWarpField* handle() const { return handle_; }

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <hip/hip_runtime_api.h>
 #include <kfusion/cuda/tsdf_volume.hpp>
 #include <kfusion/cuda/imgproc.hpp>
@@ -111,6 +112,13 @@ static SlabArg c_slab(const TsdfVolume& v)
     a.s.z_store0 = v.slabStore0(); a.s.z_store_n = v.slabStoreN(); a.s.z_own0 = v.slabOwn0(); a.s.z_own_n = v.slabOwnN();
     return a;
 }
+// the same for the integrate methods (and the k-NN tables they stream): with setSlab(..., integrate_halo = true) they own every stored plane
+static SlabArg c_slab_integrate(const TsdfVolume& v)
+{
+    SlabArg a = c_slab(v);
+    a.s.z_own0 = v.slabIntegrate0(); a.s.z_own_n = v.slabIntegrateN();
+    return a;
+}
 
 TsdfVolume::TsdfVolume(const Vec3i& dims)               // tsdf_volume.cpp:7-17
     : data_(), trunc_dist_(0.03f), max_weight_(128), dims_(dims), size_(Vec3f::all(3.f)), pose_(Affine3f::Identity()),
@@ -158,37 +166,32 @@ void TsdfVolume::clear()                                // :89-102 (without the 
     KF_DF(dfusion_clear(c_volume(*this), c_slab(*this).ptr(), nullptr));
 }
 
-void TsdfVolume::setSlab(int z_own0, int z_own_n, int halo)
+void TsdfVolume::setSlab(int z_own0, int z_own_n, int halo, bool integrate_halo)
 {
     const int Z = dims_[2];
     if (z_own0 < 0 || z_own_n < 0 || z_own0 + z_own_n > Z || halo < 0) kfusion::cuda::error("setSlab: planes outside the volume", __FILE__, __LINE__, "setSlab");
     z_own0_ = z_own0; z_own_n_ = z_own_n;
     z_store0_ = std::max(0, z_own0 - halo);
     z_store_n_ = std::min(Z, z_own0 + z_own_n + halo) - z_store0_;
-    has_slab_ = true;
+    has_slab_ = true; integrate_halo_ = integrate_halo;
     data_.create((size_t)dims_[0] * dims_[1] * (size_t)std::max(z_store_n_, 1) * sizeof(int));
     clear();
 }
 
 void TsdfVolume::raycastMarch(const Affine3f& camera_pose, const Intr& intr, int cols, int rows, unsigned rank,
-                              DeviceArray<unsigned long long>& keys64, DeviceArray<Point>& vertex) const
+                              DeviceArray<unsigned long long>& keys64) const
 {
     float aff[12], Rinv[9], reproj[4];
     raycast_args(pose_, camera_pose, intr, aff, Rinv, reproj);
-    keys64.create((size_t)cols * rows); vertex.create((size_t)cols * rows);
-    KF_DF(dfusion_raycast_march(c_volume(*this), c_slab(*this).ptr(), aff, reproj, cols, rows, raycast_step_factor_, rank, keys64.ptr(),
-                                (float*)vertex.ptr(), nullptr));
+    keys64.create((size_t)cols * rows);
+    KF_DF(dfusion_raycast_march(c_volume(*this), c_slab(*this).ptr(), aff, reproj, cols, rows, raycast_step_factor_, rank, keys64.ptr(), nullptr));
 }
-void TsdfVolume::raycastSelect(const DeviceArray<unsigned long long>& merged_keys64, unsigned rank, DeviceArray<Point>& vertex, int cols, int rows)
-{
-    KF_DF(dfusion_raycast_select(merged_keys64.ptr(), rank, (float*)vertex.ptr(), cols, rows, nullptr));
-}
-void TsdfVolume::raycastShade(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<Point>& vertex,
-                              const DeviceArray<unsigned long long>& merged_keys64, Cloud& points, Normals& normals) const
+void TsdfVolume::raycastShade(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64, Cloud& points,
+                              Normals& normals) const
 {
     float aff[12], Rinv[9], reproj[4];
     raycast_args(pose_, camera_pose, intr, aff, Rinv, reproj);
-    KF_DF(dfusion_raycast_shade(c_volume(*this), c_slab(*this).ptr(), aff, Rinv, reproj, (const float*)vertex.ptr(), merged_keys64.ptr(),
+    KF_DF(dfusion_raycast_shade(c_volume(*this), c_slab(*this).ptr(), aff, Rinv, reproj, merged_keys64.ptr(),
                                 (float*)points.ptr(), points.step(), (float*)normals.ptr(), normals.step(), points.cols(), points.rows(),
                                 gradient_delta_factor_, nullptr));
 }
@@ -198,7 +201,7 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, cons
     const Affine3f vol2cam = camera_pose.inv() * pose_;
     float aff[12]; affine_to_aff12(vol2cam, aff);
     const float proj[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
-    KF_DF(dfusion_integrate(dists.ptr(), dists.step(), dists.cols(), dists.rows(), c_volume(*this), c_slab(*this).ptr(), aff, proj, nullptr, nullptr));
+    KF_DF(dfusion_integrate(dists.ptr(), dists.step(), dists.cols(), dists.rows(), c_volume(*this), c_slab_integrate(*this).ptr(), aff, proj, nullptr, nullptr));
     KF_HIP(hipDeviceSynchronize());                     // device::integrate ends with cudaDeviceSynchronize (tsdf_volume.cu:160)
 }
 
@@ -209,7 +212,7 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, cons
     affine_to_aff12(pose_, v2w);
     affine_to_aff12(camera_pose.inv() * warp.getWarpToLive(), w2c);
     const float proj[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
-    KF_DF(dfusion_integrate_warped(dists.ptr(), dists.step(), dists.cols(), dists.rows(), c_volume(*this), c_slab(*this).ptr(), v2w, w2c, proj,
+    KF_DF(dfusion_integrate_warped(dists.ptr(), dists.step(), dists.cols(), dists.rows(), c_volume(*this), c_slab_integrate(*this).ptr(), v2w, w2c, proj,
                                    warp.handle(), warp.k(), 0u, nullptr, nullptr));
     KF_HIP(hipDeviceSynchronize());
 }
@@ -286,7 +289,7 @@ void TsdfVolume::compute_normals()
     normal_host_stale_ = true;
 }
 
-const std::vector<Point>& TsdfVolume::get_cloud_host() const
+const std::vector<Point>& TsdfVolume::cloud_host_vector() const
 {
     if (cloud_host_stale_) {
         cloud_host_.resize(cloud_.size());
@@ -296,7 +299,7 @@ const std::vector<Point>& TsdfVolume::get_cloud_host() const
     return cloud_host_;
 }
 
-const std::vector<Normal>& TsdfVolume::get_normal_host() const
+const std::vector<Normal>& TsdfVolume::normal_host_vector() const
 {
     if (normal_host_stale_) {
         normal_host_.resize(cloud_.size());
@@ -305,6 +308,18 @@ const std::vector<Normal>& TsdfVolume::get_normal_host() const
     }
     return normal_host_;
 }
+#ifdef KFUSION_USE_OPENCV
+// tsdf_volume.cpp:74-77: the reference keeps the clouds as 1 x N CV_32FC4 matrices
+template <typename T> static void kf_vector_to_mat(const std::vector<T>& v, cv::Mat& m)
+{
+    m.create(1, (int)v.size(), CV_32FC4);
+    if (!v.empty()) std::memcpy(m.data, v.data(), v.size() * sizeof(T));
+}
+cv::Mat TsdfVolume::get_cloud_host() const { kf_vector_to_mat(cloud_host_vector(), cloud_host_mat_); return cloud_host_mat_; }
+cv::Mat TsdfVolume::get_normal_host() const { kf_vector_to_mat(normal_host_vector(), normal_host_mat_); return normal_host_mat_; }
+cv::Mat* TsdfVolume::get_cloud_host_ptr() const { kf_vector_to_mat(cloud_host_vector(), cloud_host_mat_); return &cloud_host_mat_; }
+cv::Mat* TsdfVolume::get_normal_host_ptr() const { kf_vector_to_mat(normal_host_vector(), normal_host_mat_); return &normal_host_mat_; }
+#endif
 
 // ------------------------------------------------------------------------------------------ psdf / surface_fusion (tsdf_volume.cpp:228-306)
 // project_and_remove + the K^-1 arithmetic run in one kernel; `removed` receives the zeros (dists itself when null).
@@ -436,16 +451,27 @@ void WarpField::energy_data(const std::vector<Vec3f>& canonical_vertices, const 
     energy_data(c, l, (int)n);
 }
 
-const WarpField::NodesMat WarpField::getNodesAsMat() const              // warp_field.cpp:284-293
+std::vector<Vec3f> WarpField::getNodesAsVector() const                 // warp_field.cpp:284-293
 {
     pullNodes();
-    NodesMat m(nodes_.size());
+    std::vector<Vec3f> m(nodes_.size());
     for (size_t i = 0; i < nodes_.size(); ++i) {
         float x, y, z;
         nodes_[i].transform.getTranslation(x, y, z);
         m[i] = Vec3f(x, y, z) + nodes_[i].vertex;                         // matrix.at(i) += vertex
     }
     return m;
+}
+const WarpField::NodesMat WarpField::getNodesAsMat() const
+{
+#ifdef KFUSION_USE_OPENCV
+    const std::vector<Vec3f> v = getNodesAsVector();
+    cv::Mat matrix(1, (int)v.size(), CV_32FC3);                            // warp_field.cpp:286
+    for (size_t i = 0; i < v.size(); ++i) matrix.at<cv::Vec3f>((int)i) = v[i];
+    return matrix;
+#else
+    return getNodesAsVector();
+#endif
 }
 
 void WarpField::ensureIndex(const cuda::TsdfVolume& volume, bool tables) const
@@ -456,11 +482,11 @@ void WarpField::ensureIndex(const cuda::TsdfVolume& volume, bool tables) const
     const Vec3i d = volume.getDims(); const Vec3f vs = volume.getVoxelSize();
     float key[20] = {(float)d[0], (float)d[1], (float)d[2], vs[0], vs[1], vs[2]};
     std::memcpy(key + 6, v2w, sizeof(v2w));
-    key[18] = (float)volume.slabOwn0(); key[19] = volume.isSlab() ? (float)volume.slabOwnN() : -1.f;
+    key[18] = (float)volume.slabIntegrate0(); key[19] = volume.isSlab() ? (float)volume.slabIntegrateN() : -1.f;
     const bool same = index_ok_ && index_volume_ == &volume && std::memcmp(key, index_key_, sizeof(key)) == 0;
     if (same && (index_tables_ || !tables)) return;
     std::memcpy(index_key_, key, sizeof(key));
-    KF_DF(dfusion_warp_build_index(handle_, c_volume(volume), c_slab(volume).ptr(), v2w, k_, tables ? (DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE) : 0u, nullptr));
+    KF_DF(dfusion_warp_build_index(handle_, c_volume(volume), c_slab_integrate(volume).ptr(), v2w, k_, tables ? (DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE) : 0u, nullptr));
     index_ok_ = true; index_volume_ = &volume; index_tables_ = tables;
 }
 
@@ -632,8 +658,7 @@ bool ProjectiveICP::iterate(Affine3f& affine, const Intr& intr, const void* cons
         KF_DF(dfusion_icp_estimate(lv, LEVELS, depth_variant ? 1 : 0, in, dist2_thres, min_cosine, buffer_.ptr(), state_dev, nullptr));
         float st[13];
         KF_HIP(hipMemcpy(st, state_dev, sizeof(st), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 9; ++i) affine.R.val[i] = st[i];
-        for (int i = 0; i < 3; ++i) affine.t[i] = st[9 + i];
+        affine = aff12_to_affine(st);
         return st[12] != 0.f;
     }
     for (int level_index = LEVELS - 1; level_index >= 0; --level_index) {
@@ -839,7 +864,7 @@ bool KinFu::operator()(const cuda::Depth& depth, const cuda::Image& /*image*/)  
         // the node array zero-initialised; here only the kept points become nodes, with a larger stride if they would not fit
         // The extraction order depends on atomics (here and in the reference); the seed set must not, or every run would deform
         // differently: the cloud is put in (z, y, x) order before sampling.
-        std::vector<Point> cloud = volume_->get_cloud_host();
+        std::vector<Point> cloud = volume_->cloud_host_vector();
         std::sort(cloud.begin(), cloud.end(), [](const Point& a, const Point& b) {
             return a.z != b.z ? a.z < b.z : (a.y != b.y ? a.y < b.y : a.x < b.x); });
         size_t step = 50;

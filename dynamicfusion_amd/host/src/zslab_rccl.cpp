@@ -4,7 +4,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <kfusion/cuda/zslab.hpp>
@@ -12,32 +14,52 @@
 using namespace kfusion;
 using namespace kfusion::cuda;
 
-#define ZS_NCCL(expr) do { ncclResult_t r__ = (expr); if (r__ != ncclSuccess) { std::fprintf(stderr, "RCCL: %s at %s:%d\n", ncclGetErrorString(r__), __FILE__, __LINE__); std::exit(1); } } while (0)
-#define ZS_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { std::fprintf(stderr, "HIP: %s at %s:%d\n", hipGetErrorString(e__), __FILE__, __LINE__); std::exit(1); } } while (0)
+// Errors do not end the process: the failing call records what failed (lastError()) and returns false; after a failed collective the
+// communicator is unusable (the other ranks may be blocked in it) and every later call fails at once.
+#define ZS_NCCL(expr) do { ncclResult_t r__ = (expr); if (r__ != ncclSuccess) return fail(std::string("RCCL: ") + ncclGetErrorString(r__) + " in " #expr); } while (0)
+#define ZS_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(std::string("HIP: ") + hipGetErrorString(e__) + " in " #expr); } while (0)
 
-ZSlabComm::ZSlabComm(int rank, int world, const std::string& id_path) : rank_(rank), world_(world), comm_(nullptr), stream_(nullptr)
+bool ZSlabComm::fail(const std::string& what)
 {
-    if (world < 1 || world > 255 || rank < 0 || rank >= world) { std::fprintf(stderr, "ZSlabComm: rank %d of %d (1..255 ranks: the merge key carries the rank in 8 bits)\n", rank, world); std::exit(1); }
-    ncclUniqueId id;
+    error_ = what; ok_ = false;
+    return false;
+}
+
+// The rendezvous file carries {magic, nonce, ncclUniqueId}.  Rank 0 removes whatever an earlier run left under the name BEFORE it
+// publishes (atomically, by rename) and again once every rank holds the communicator; a reader only accepts a file whose nonce is the
+// one the launcher gave every rank (DFUSION_ZSLAB_NONCE, default 0) -- so ranks of a new run cannot pick up the id of an old one.
+namespace { struct IdFile { unsigned long long magic, nonce; ncclUniqueId id; }; const unsigned long long ID_MAGIC = 0x44465a534c414231ull; }
+
+ZSlabComm::ZSlabComm(int rank, int world, const std::string& id_path) : rank_(rank), world_(world), comm_(nullptr), stream_(nullptr), ok_(true)
+{
+    if (world < 1 || world > 128 || rank < 0 || rank >= world) { fail("ZSlabComm: rank " + std::to_string(rank) + " of " + std::to_string(world) + " (1..128 ranks: the merge key carries the rank in 7 bits)"); return; }
+    const char* ne = std::getenv("DFUSION_ZSLAB_NONCE");
+    IdFile f; f.magic = ID_MAGIC; f.nonce = ne ? std::strtoull(ne, nullptr, 10) : 0ull;
     if (rank == 0) {
-        ZS_NCCL(ncclGetUniqueId(&id));
-        const std::string tmp = id_path + ".tmp";
-        FILE* f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) { std::perror("ZSlabComm id file"); std::exit(1); }
-        std::fclose(f);
-        if (std::rename(tmp.c_str(), id_path.c_str()) != 0) { std::perror("ZSlabComm id rename"); std::exit(1); }   // atomic publish
+        (void)std::remove(id_path.c_str());                                  // a stale id of an earlier run
+        if (ncclGetUniqueId(&f.id) != ncclSuccess) { fail("ncclGetUniqueId"); return; }
+        const std::string tmp = id_path + ".tmp." + std::to_string((long long)getpid());
+        FILE* fp = std::fopen(tmp.c_str(), "wb");
+        if (!fp || std::fwrite(&f, sizeof(f), 1, fp) != 1) { if (fp) std::fclose(fp); fail("ZSlabComm: cannot write " + tmp); return; }
+        std::fclose(fp);
+        if (std::rename(tmp.c_str(), id_path.c_str()) != 0) { fail("ZSlabComm: cannot publish " + id_path); return; }   // atomic publish
     } else {
         for (int tries = 0;; ++tries) {
-            FILE* f = std::fopen(id_path.c_str(), "rb");
-            if (f) { const size_t n = std::fread(&id, sizeof(id), 1, f); std::fclose(f); if (n == 1) break; }
-            if (tries > 6000) { std::fprintf(stderr, "ZSlabComm: no RCCL id at %s after 60 s\n", id_path.c_str()); std::exit(1); }
+            IdFile g;
+            FILE* fp = std::fopen(id_path.c_str(), "rb");
+            if (fp) {
+                const size_t n = std::fread(&g, sizeof(g), 1, fp); std::fclose(fp);
+                if (n == 1 && g.magic == ID_MAGIC && g.nonce == f.nonce) { f = g; break; }
+            }
+            if (tries > 6000) { fail("ZSlabComm: no RCCL id for this run at " + id_path + " after 60 s"); return; }
             std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
     }
     ncclComm_t c;
-    ZS_NCCL(ncclCommInitRank(&c, world, id, rank));
+    if (ncclCommInitRank(&c, world, f.id, rank) != ncclSuccess) { fail("ncclCommInitRank"); return; }
     comm_ = c;
     token_.create(1);
+    if (rank == 0) (void)std::remove(id_path.c_str());                       // every rank is in: the file has done its job
 }
 
 ZSlabComm::~ZSlabComm()
@@ -67,23 +89,26 @@ bool ZSlabComm::partitionOk(int Z, int world, int halo, std::string* why)
     return true;
 }
 
-void ZSlabComm::broadcast(void* device_ptr, size_t bytes, int root)
+bool ZSlabComm::broadcast(void* device_ptr, size_t bytes, int root)
 {
-    if (world_ == 1 || !bytes) return;
+    if (!ok_) return false;
+    if (world_ == 1 || !bytes) return true;
     ZS_NCCL(ncclBroadcast(device_ptr, device_ptr, bytes, ncclUint8, root, (ncclComm_t)comm_, (hipStream_t)stream_));
+    return true;
 }
 
-void ZSlabComm::exchangeHalos(TsdfVolume& slab, int halo)
+bool ZSlabComm::exchangeHalos(TsdfVolume& slab, int halo)
 {
-    if (world_ == 1) return;
+    if (!ok_) return false;
+    if (world_ == 1) return true;
     const Vec3i d = slab.getDims();
     const size_t plane = (size_t)d[0] * d[1];                      // voxels per plane (4 bytes each)
     int* base = slab.data().ptr<int>();
     const int lo_local = slab.slabOwn0() - slab.slabStore0(), hi_local = lo_local + slab.slabOwnN();
     const int n_lo = lo_local, n_hi = slab.slabStoreN() - hi_local;
-    if ((rank_ > 0 && (n_lo != halo || slab.slabOwnN() < halo)) || (rank_ < world_ - 1 && (n_hi != halo || slab.slabOwnN() < halo))) {
-        std::fprintf(stderr, "ZSlabComm::exchangeHalos: rank %d slab does not hold %d halo planes (ask partitionOk first)\n", rank_, halo); std::exit(1);
-    }
+    // (a local precondition, checked the same way on every rank by partitionOk: no collective has been entered yet)
+    if ((rank_ > 0 && (n_lo != halo || slab.slabOwnN() < halo)) || (rank_ < world_ - 1 && (n_hi != halo || slab.slabOwnN() < halo)))
+        return fail("ZSlabComm::exchangeHalos: the slab does not hold " + std::to_string(halo) + " halo planes (ask partitionOk first)");
     ncclComm_t c = (ncclComm_t)comm_; hipStream_t st = (hipStream_t)stream_;
     ZS_NCCL(ncclGroupStart());
     if (rank_ > 0) {                                                // lower neighbour: my first own planes out, its last ones in
@@ -95,30 +120,29 @@ void ZSlabComm::exchangeHalos(TsdfVolume& slab, int halo)
         ZS_NCCL(ncclRecv(base + (size_t)hi_local * plane, (size_t)n_hi * plane, ncclInt32, rank_ + 1, c, st));
     }
     ZS_NCCL(ncclGroupEnd());
+    return true;
 }
 
-void ZSlabComm::raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Intr& intr, int cols, int rows, Cloud& points, Normals& normals, int dst)
+bool ZSlabComm::raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Intr& intr, int cols, int rows, Cloud& points, Normals& normals, int dst)
 {
+    if (!ok_) return false;
     ncclComm_t c = (ncclComm_t)comm_; hipStream_t st = (hipStream_t)stream_;
     const size_t px = (size_t)cols * rows;
-    slab.raycastMarch(camera_pose, intr, cols, rows, (unsigned)rank_, keys64_, vertex_);
-    if (world_ > 1) {
-        ZS_NCCL(ncclAllReduce(keys64_.ptr(), keys64_.ptr(), px, ncclInt64, ncclMin, c, st));            // first event per pixel, over ranks
-        TsdfVolume::raycastSelect(keys64_, (unsigned)rank_, vertex_, cols, rows);
-        ZS_NCCL(ncclAllReduce(vertex_.ptr(), vertex_.ptr(), px * 4, ncclInt32, ncclSum, c, st));        // the winners' vertex bits
-    }
-    points_.create(px); normals_.create(px);
-    points = Cloud(rows, cols, points_.ptr(), (size_t)cols * sizeof(Point));
-    normals = Normals(rows, cols, normals_.ptr(), (size_t)cols * sizeof(Normal));
-    slab.raycastShade(camera_pose, intr, vertex_, keys64_, points, normals);
-    if (world_ > 1) {
-        ZS_NCCL(ncclReduce(points_.ptr(), points_.ptr(), px * 4, ncclInt32, ncclSum, dst, c, st));
-        ZS_NCCL(ncclReduce(normals_.ptr(), normals_.ptr(), px * 4, ncclInt32, ncclSum, dst, c, st));
-    }
+    slab.raycastMarch(camera_pose, intr, cols, rows, (unsigned)rank_, keys64_);
+    // ONE merge collective: the per-pixel MIN of the keys is the first event along every ray, its owner and its Ts (dfusion.h)
+    if (world_ > 1) ZS_NCCL(ncclAllReduce(keys64_.ptr(), keys64_.ptr(), px, ncclInt64, ncclMin, c, st));
+    out_.create(2 * px);                                            // points then normals: one buffer, one reduce
+    points = Cloud(rows, cols, out_.ptr(), (size_t)cols * sizeof(Point));
+    normals = Normals(rows, cols, out_.ptr() + px, (size_t)cols * sizeof(Normal));
+    slab.raycastShade(camera_pose, intr, keys64_, points, normals);
+    if (world_ > 1) ZS_NCCL(ncclReduce(out_.ptr(), out_.ptr(), 2 * px * 4, ncclInt32, ncclSum, dst, c, st));   // every summand but one is integer zero
+    return true;
 }
 
-void ZSlabComm::barrier()
+bool ZSlabComm::barrier()
 {
+    if (!ok_) return false;
     if (world_ > 1) ZS_NCCL(ncclAllReduce(token_.ptr(), token_.ptr(), 1, ncclInt32, ncclSum, (ncclComm_t)comm_, (hipStream_t)stream_));
     ZS_HIP(hipDeviceSynchronize());
+    return true;
 }

@@ -7,13 +7,15 @@ torch.distributed).  The reference is single-GPU; this is the only parallelism o
   halo        after integrate every rank sends its H boundary planes to each Z neighbour
               (paired isend/irecv = ncclSend/ncclRecv over one xGMI link per neighbour).
   raycast     every rank marches ALL rays on the same global step lattice but only evaluates steps
-              whose `curr` sample lies in a plane it owns, emitting per pixel its first event key
-              (step<<1 | hit) and, for hits, the located vertex.  Merge = per-pixel MIN over ranks
-              (all_reduce MIN on int64 key<<8 | rank) + broadcast of the winner's vertex bits; the
-              zero-crossing refinement can extrapolate the vertex into ANOTHER rank's slab
-              (tsdf_volume.cu:389), so the normal is computed by the rank that owns the vertex and the
-              final point/normal bits are summed to rank 0 (every other rank contributes integer zero:
-              bit-identical with the unsharded cast).
+              whose `curr` sample lies in a plane it owns, emitting per pixel ONE 64-bit key: first
+              event (step, hit / back-face break), rank, and -- for a hit -- the refined ray parameter
+              Ts as f32 bits (include/dfusion.h).  Merge = ONE per-pixel MIN over ranks (all_reduce MIN
+              on int64): it names the first event along every ray and hands every rank the winner's
+              Ts, from which the vertex origin + direction * Ts is recomputed locally, bit for bit as
+              the unsharded cast computes it.  The refinement can extrapolate the vertex into ANOTHER
+              rank's slab (tsdf_volume.cu:389), so the normal is computed by the rank that owns the
+              vertex and the final point/normal bits are summed to rank 0 (every other rank contributes
+              integer zero: bit-identical with the unsharded cast).
 
 The collectives go through `torch.distributed`, so the same code runs over RCCL on GPUs and over gloo
 in the world_size-2 CPU tests (tests/test_sharded_cpu.py), where a stand-in backend supplies the
@@ -25,7 +27,29 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-NO_EVENT = 0xFFFFFFFF
+NO_EVENT = 0xFFFFFFFF                 # per-slab event key (step << 1 | hit): none
+KEY_NONE = 0x7FFFFFFFFFFFFFFF         # merge key: no event (include/dfusion.h DF_RC_KEY_NONE)
+MAX_RANKS = 128                       # the merge key carries the rank in 7 bits
+
+
+def pack_merge_keys(event_keys, ts, rank):
+    """numpy: per-slab event keys (uint32, NO_EVENT = none) + Ts (float32) -> int64 merge keys, the layout dfusion_raycast_march
+    writes: [0 | step k : 23 | hit : 1 | rank : 7 | Ts bits : 32]."""
+    k = np.asarray(event_keys, np.uint32).astype(np.int64)
+    t = np.ascontiguousarray(ts, np.float32).view(np.uint32).astype(np.int64)
+    out = (((k << 7) | int(rank)) << 32) | t
+    out[np.asarray(event_keys, np.uint32) == NO_EVENT] = KEY_NONE
+    return out
+
+
+def unpack_merge_keys(keys64):
+    """-> (event keys uint32 with NO_EVENT for none, Ts float32, rank)"""
+    k64 = np.asarray(keys64, np.int64)
+    none = k64 == KEY_NONE
+    ev = ((k64 >> 39) & 0xFFFFFF).astype(np.uint32)
+    ev[none] = NO_EVENT
+    ts = (k64 & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+    return ev, np.where(none, np.float32(0), ts), ((k64 >> 32) & 0x7F).astype(np.int32)
 
 
 def slab_range(Z, rank, world):
@@ -40,8 +64,8 @@ def validate_slabs(Z, world, halo):
     """Raise -- identically on every rank, BEFORE any collective is entered -- if the partition cannot work: a rank without planes,
     or a slab thinner than the halo its neighbour needs from it (exchange_halos would otherwise die inside a collective while the
     other ranks block in it)."""
-    if world < 1 or world > 255:
-        raise ValueError("world size %d: the merge key carries the rank in 8 bits (1..255 ranks)" % world)
+    if world < 1 or world > MAX_RANKS:
+        raise ValueError("world size %d: the merge key carries the rank in 7 bits (1..%d ranks)" % (world, MAX_RANKS))
     for r in range(world):
         lo, n = slab_range(Z, r, world)
         if n <= 0:
@@ -85,25 +109,23 @@ def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, 
         r.wait()
 
 
-def raycast_sharded(march_fn, select_fn, shade_fn, rank, world, dst=0, group=None):
-    """Two-stage sharded ray-cast (include/dfusion.h: dfusion_raycast_march / _select / _shade).
+def raycast_sharded(march_fn, shade_fn, rank, world, dst=0, group=None, collectives=None):
+    """Two-stage sharded ray-cast (include/dfusion.h: dfusion_raycast_march / _shade).
 
-    march_fn()              -> (keys64 int64 [rows, cols] = (event key << 8) | rank, vertex float32 [rows, cols, 4])
-    select_fn(keys64, vtx)  -> zeroes `vtx` in place wherever this rank did not win the MIN
-    shade_fn(keys64, vtx)   -> out float32 [2, rows, cols, 4] (points, normals); all-zero bits for pixels this slab does
-                               not resolve
+    march_fn()        -> keys64 int64 [rows, cols]: the merge keys of this slab (first event | rank | Ts bits)
+    shade_fn(keys64)  -> out float32 [2, rows, cols, 4] (points, normals); all-zero bits for pixels this slab does not resolve
     Returns (points, normals) of the merged cast on rank `dst`, (None, None) elsewhere.
 
-    Three collectives per frame: all_reduce(MIN) of the int64 keys (2.4 MB at 640x480), all_reduce(SUM) of the winners'
-    vertex bits (4.9 MB), reduce(SUM) of the final point/normal bits (9.8 MB).  Every summand but one is integer zero,
-    so the result is bit-identical with the unsharded cast."""
-    keys64, vertex = march_fn()
-    if world > 1:
+    TWO collectives per frame: all_reduce(MIN) of the int64 keys (2.4 MB at 640x480) -- which also delivers the winners' Ts, so no
+    vertex image is exchanged (round 2 did, 4.9 MB more) -- and reduce(SUM) of the final point/normal bits (9.8 MB).  Every summand
+    but one is integer zero, so the result is bit-identical with the unsharded cast.  collectives: None = only when world > 1;
+    True = also with one rank (an RCCL dry run of the dtypes and ops)."""
+    on = world > 1 if collectives is None else collectives
+    keys64 = march_fn()
+    if on:
         dist.all_reduce(keys64, op=dist.ReduceOp.MIN, group=group)
-        select_fn(keys64, vertex)
-        dist.all_reduce(vertex.view(torch.int32), op=dist.ReduceOp.SUM, group=group)
-    out = shade_fn(keys64, vertex)
-    if world > 1:
+    out = shade_fn(keys64)
+    if on:
         dist.reduce(out.view(torch.int32), dst=dst, op=dist.ReduceOp.SUM, group=group)
         if rank != dst:
             return None, None

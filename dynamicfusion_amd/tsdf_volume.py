@@ -230,28 +230,22 @@ class TsdfVolume:
                                                self.raycast_step_factor_, self.gradient_delta_factor_, _stream()),
                        "dfusion_raycast_depth")
 
-    # ---- Z-slab two-stage cast (dfusion_raycast_march / _select / _shade; no reference counterpart)
-    def raycast_march(self, camera_pose, intr, keys64, vertex, rank=0):
-        """keys64: int64 [rows, cols] <- (event key << 8) | rank ; vertex: float32 [rows, cols, 4] (volume frame)."""
+    # ---- Z-slab two-stage cast (dfusion_raycast_march / _shade; no reference counterpart)
+    def raycast_march(self, camera_pose, intr, keys64, rank=0):
+        """keys64: int64 [rows, cols] <- merge key [step k : 23 | hit : 1 | rank : 7 | Ts bits : 32] (include/dfusion.h), DF_RC_KEY_NONE
+        where this slab saw no event: a MIN over ranks is the whole merge."""
         aff, _ = self._raycast_args(camera_pose)
         rows, cols = keys64.shape
         capi.check(capi.lib().dfusion_raycast_march(self.c_volume(), self.c_slab(), aff, intr.as_reproj(), cols, rows,
-                                                    self.raycast_step_factor_, int(rank), _ptr(keys64), _ptr(vertex), _stream()),
+                                                    self.raycast_step_factor_, int(rank), _ptr(keys64), _stream()),
                    "dfusion_raycast_march")
-        return keys64, vertex
+        return keys64
 
-    @staticmethod
-    def raycast_select(merged_keys64, vertex, rank=0):
-        rows, cols = merged_keys64.shape
-        capi.check(capi.lib().dfusion_raycast_select(_ptr(merged_keys64), int(rank), _ptr(vertex), cols, rows, _stream()),
-                   "dfusion_raycast_select")
-        return vertex
-
-    def raycast_shade(self, camera_pose, intr, vertex, merged_keys64, points, normals):
+    def raycast_shade(self, camera_pose, intr, merged_keys64, points, normals):
         aff, Rinv = self._raycast_args(camera_pose)
         rows, cols = merged_keys64.shape
         capi.check(capi.lib().dfusion_raycast_shade(self.c_volume(), self.c_slab(), aff, Rinv, intr.as_reproj(),
-                                                    _ptr(vertex), _ptr(merged_keys64), _ptr(points), cols * 16,
+                                                    _ptr(merged_keys64), _ptr(points), cols * 16,
                                                     _ptr(normals), cols * 16, cols, rows, self.gradient_delta_factor_,
                                                     _stream()), "dfusion_raycast_shade")
         return points, normals

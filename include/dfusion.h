@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 1
+#define DFUSION_ABI_VERSION 2   /* 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
@@ -143,22 +143,23 @@ int dfusion_raycast_depth(DfVolume v, const DfSlab *slab, const float cam2vol[12
 /* Z-slab (multi-GPU) cast in two stages; no reference counterpart.  The zero-crossing refinement
  * Ts = t - step*Ft/(Ftdt-Ft) (tsdf_volume.cu:389) may EXTRAPOLATE arbitrarily far along the ray, so the
  * vertex of a hit can lie in another GPU's slab: stage 1 finds, on the steps this slab owns, the first
- * event key and (for hits) the located vertex in the VOLUME frame (float4 per pixel, zeros otherwise);
- * the host MIN-merges the keys and broadcasts the winners' vertices; stage 2 lets the slab that owns the
+ * event and (for hits) Ts; the host MIN-merges the 64-bit keys over the ranks -- ONE collective, which
+ * delivers the first event along every ray, its owner and its Ts; stage 2 lets the slab that owns the
  * vertex' nearest plane compute the normal (needs a 2-plane halo) and write the final camera-frame
- * point/normal.  Pixels a slab does not resolve are written as all-zero BITS (the slab owning plane 0
- * writes the NaN fill of misses), so integer-summing the slabs' outputs equals the unsharded cast.      */
-/* stage 1: keys64_dev[pixel] = (event key << 8) | rank_tag (rank_tag <= 255), so a per-pixel MIN over ranks (ncclMin on
- * int64) selects the first event and names its owner.                                                       */
+ * point/normal, with vertex = origin + direction * Ts recomputed from the pixel exactly as the unsharded
+ * cast computes it (:390).  Pixels a slab does not resolve are written as all-zero BITS (the slab owning
+ * plane 0 writes the NaN fill of misses), so integer-summing the slabs' outputs equals the unsharded cast.
+ *
+ * key layout (a non-negative int64, so ncclMin on ncclInt64 orders it):
+ *   bit 63 = 0 | bits 62..40 step index k | bit 39 kind (1 = hit, 0 = back-face break) | bits 38..32 rank_tag | bits 31..0 Ts (f32 bits)
+ * DF_RC_KEY_NONE (no event on this slab's steps) is larger than every event key.                          */
+#define DF_RC_KEY_NONE 0x7fffffffffffffffull
+#define DF_RC_KEY_MAX_RANK 127u
 int dfusion_raycast_march(DfVolume v, const DfSlab *slab, const float cam2vol[12], const float reproj[4], int cols,
                           int rows, float step_factor, unsigned int rank_tag, unsigned long long *keys64_dev,
-                          float *vertex_dev, dfStream stream);
-/* between the stages: zero this rank's vertex image wherever it did not win the MIN, so that an integer SUM over
- * ranks (ncclSum on the int32 view) hands every rank the winners' vertices.                                   */
-int dfusion_raycast_select(const unsigned long long *merged_keys64_dev, unsigned int rank_tag, float *vertex_dev,
-                           int cols, int rows, dfStream stream);
+                          dfStream stream);
 int dfusion_raycast_shade(DfVolume v, const DfSlab *slab, const float cam2vol[12], const float Rinv[9],
-                          const float reproj[4], const float *vertex_dev, const unsigned long long *merged_keys64_dev,
+                          const float reproj[4], const unsigned long long *merged_keys64_dev,
                           float *points_dev, size_t points_pitch, float *normals_dev, size_t normals_pitch, int cols,
                           int rows, float delta_factor, dfStream stream);
 
@@ -210,7 +211,7 @@ int dfusion_warp_index_info(const DfWarpField *wf, unsigned long long *total_ent
 int dfusion_warp_set_point_tiling(DfWarpField *wf, int image_cols);
 
 /* Device self-test of the sweep's short arithmetic forms (dfusion_device.h) against the generic ones they replace; no reference
- * counterpart, used by the parity tests.  counts_dev[5] (device) receives mismatch counts: [0] short sqrtf over every f32 of its
+ * counterpart, used by the parity tests.  counts_dev[6] (device, SIX entries) receives mismatch counts: [0] short sqrtf over every f32 of its
  * domain, [1] short f64 reciprocal over every positive normal f32, [2] packed quaternion products on n_random random pairs
  * (specials included), [3] near-unit normalisation on the normalised quaternions among them, [4] how many of those there were,
  * [5] the short fuse division on every finite stored half x 97 weights x (n_random >> 21) tsdf values.  counts_dev: 6 entries.      */
@@ -228,6 +229,9 @@ int dfusion_debug_rigid(int flags);
  * to *swept_dev (device, 8 bytes) the number of voxels its sweep put through the projective sample (tsdf_volume.cu:77-93) -- the
  * voxels of the launch plan's alive sub-chunks.  Beside n_updated_dev this gives swept / updated, the sweep's over-work.          */
 int dfusion_debug_rigid_counters(unsigned long long *swept_dev);
+/* The same for dfusion_integrate_warped's cached sweep (the pipelined kernel): += the voxels of the (8 x 8 column patch, 8-plane
+ * layer) cells its launch plan keeps, i.e. the voxels that go through blend -> transform -> project.                              */
+int dfusion_debug_warp_counters(unsigned long long *swept_dev);
 
 /* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k], ascending distance; exactly
  * equidistant nodes in the order the reference's nanoflann walk meets them (nanoflann.hpp:110-131,1200-1254).                    */

@@ -751,13 +751,22 @@ static inline rc_hit ray_march(const rc_ctx *c, const float aff[12], const float
     }
     return h;
 }
-/* stage 2 (locate), :386-391 : vertex in the volume frame.  Ts may extrapolate far beyond [curr, next]. */
-static inline f3 ray_locate(const rc_ctx *c, const rc_hit *h)
+/* stage 2 (locate), :386-391 : the refined ray parameter Ts and the vertex org + dir * Ts in the volume frame.  Ts may
+ * extrapolate far beyond [curr, next]. */
+static inline float ray_locate_ts(const rc_ctx *c, const rc_hit *h)
 {
     float Ft = interpolate(c, mul3(h->p_curr, c->vsi));
     float Ftdt = interpolate(c, mul3(h->p_next, c->vsi));
-    float Ts = h->t_hit - (c->time_step * Ft) / (Ftdt - Ft);                   /* :389 */
-    return add3(h->org, scale3(h->dir, Ts));
+    return h->t_hit - (c->time_step * Ft) / (Ftdt - Ft);                       /* :389 */
+}
+static inline f3 ray_vertex(f3 org, f3 dir, float Ts) { return add3(org, scale3(dir, Ts)); }   /* :390 */
+static inline f3 ray_locate(const rc_ctx *c, const rc_hit *h) { return ray_vertex(h->org, h->dir, ray_locate_ts(c, h)); }
+/* the ray of pixel (x, y): :353-354 (the first lines of ray_march) */
+static inline void ray_of_pixel(const float aff[12], const float reproj[4], int x, int y, f3 *org, f3 *dir)
+{
+    *org = mk3(aff[9], aff[10], aff[11]);
+    f3 rp = mk3(1.f * ((float)x - reproj[2]) * reproj[0], 1.f * ((float)y - reproj[3]) * reproj[1], 1.f);
+    *dir = normalized3(mat3_mul(aff, rp));
 }
 /* stage 3 (shade), :392-401 : normal at the vertex; camera-frame outputs if the normal is finite. */
 static inline int ray_shade(const rc_ctx *c, const float aff[12], const float Rinv[9], f3 vertex, f3 *vertex_out, f3 *normal_out)
@@ -846,26 +855,26 @@ ORC_API void orc_raycast_depth(OrcVolume v, const OrcSlab *slab, const float cam
 }
 
 /* ---- Z-slab (multi-GPU) cast in two stages, mirroring dfusion_raycast_march / dfusion_raycast_shade.
- * march: keys[cols*rows] + located vertex (float4, volume frame; zeros unless this slab found a hit).      */
+ * march: keys[cols*rows] (event key, ORC_RC_NO_EVENT = none) + ts[cols*rows]: the refined ray parameter Ts of a hit (:389),
+ * 0 otherwise.  The vertex of a hit is org + dir * Ts -- recomputable by anyone who knows the pixel and Ts, which is what lets the
+ * sharded merge carry Ts inside the key instead of exchanging vertices.                                                        */
 ORC_API void orc_raycast_march(OrcVolume v, const OrcSlab *slab, const float cam2vol[12], const float reproj[4],
-                               int cols, int rows, float step_factor, uint32_t *keys, float *vertex)
+                               int cols, int rows, float step_factor, uint32_t *keys, float *ts)
 {
     rc_ctx c; rc_setup(&c, &v, slab, step_factor, 0.5f);
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < rows; ++y)
         for (int x = 0; x < cols; ++x) {
             rc_hit h = ray_march(&c, cam2vol, reproj, x, y);
-            float *o = vertex + 4 * ((size_t)y * cols + x);
-            o[0] = o[1] = o[2] = o[3] = 0.f;
-            if (h.hit) { f3 p = ray_locate(&c, &h); o[0] = p.x; o[1] = p.y; o[2] = p.z; }
+            ts[(size_t)y * cols + x] = h.hit ? ray_locate_ts(&c, &h) : 0.f;
             keys[(size_t)y * cols + x] = h.key;
         }
 }
-/* shade: given the MERGED keys and the winners' vertices, the slab owning the vertex' nearest plane writes the
+/* shade: given the MERGED keys and the winners' Ts, the slab owning the vertex' nearest plane writes the
  * final point/normal (NaN if the normal is not finite); the slab owning plane 0 writes the NaN fill of misses;
  * everything else is all-zero bits so that integer-summing the slabs' outputs reproduces the unsharded cast. */
-ORC_API void orc_raycast_shade(OrcVolume v, const OrcSlab *slab, const float cam2vol[12], const float Rinv[9],
-                               const float *vertex, const uint32_t *merged_keys, float *points, size_t ppitch,
+ORC_API void orc_raycast_shade(OrcVolume v, const OrcSlab *slab, const float cam2vol[12], const float Rinv[9], const float reproj[4],
+                               const float *ts, const uint32_t *merged_keys, float *points, size_t ppitch,
                                float *normals, size_t npitch, int cols, int rows, float delta_factor)
 {
     rc_ctx c; rc_setup(&c, &v, slab, 0.75f, delta_factor);
@@ -879,12 +888,13 @@ ORC_API void orc_raycast_shade(OrcVolume v, const OrcSlab *slab, const float cam
             float fill = 0.f;
             int resolved = 0; f3 vtx, nrm;
             if (key != ORC_RC_NO_EVENT && (key & 1u)) {
-                const float *vv = vertex + 4 * ((size_t)y * cols + x);
-                float zf = rintf(vv[2] * c.vsi.z);
+                f3 org, dir; ray_of_pixel(cam2vol, reproj, x, y, &org, &dir);
+                const f3 vv = ray_vertex(org, dir, ts[(size_t)y * cols + x]);
+                float zf = rintf(vv.z * c.vsi.z);
                 int pz = (zf == zf) ? (int)fminf(fmaxf(zf, 0.f), (float)(c.Z - 1)) : 0;
                 if (pz >= c.s.z_own0 && pz < c.s.z_own0 + c.s.z_own_n) {
                     fill = qn;
-                    resolved = ray_shade(&c, cam2vol, Rinv, mk3(vv[0], vv[1], vv[2]), &vtx, &nrm);
+                    resolved = ray_shade(&c, cam2vol, Rinv, vv, &vtx, &nrm);
                 }
             } else if (c.s.z_own0 == 0) fill = qn;
             for (int i = 0; i < 4; ++i) { prow[4 * x + i] = fill; nrow[4 * x + i] = fill; }

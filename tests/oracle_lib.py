@@ -91,7 +91,7 @@ def lib():
         L.orc_raycast_march.restype = None
         L.orc_raycast_march.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, C.c_int, C.c_int, C.c_float, u32p, f32p]
         L.orc_raycast_shade.restype = None
-        L.orc_raycast_shade.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, u32p, f32p, C.c_size_t, f32p, C.c_size_t,
+        L.orc_raycast_shade.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, f32p, u32p, f32p, C.c_size_t, f32p, C.c_size_t,
                                         C.c_int, C.c_int, C.c_float]
         L.orc_extract_cloud.restype = C.c_uint64
         L.orc_extract_cloud.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, C.c_uint64]
@@ -345,18 +345,19 @@ def raycast_points(volume, cam2vol, Rinv, reproj, cols, rows, step_factor, delta
 
 
 def raycast_march(volume, cam2vol, reproj, cols, rows, step_factor, slab=None):
+    """-> (event keys uint32 [rows, cols], Ts float32 [rows, cols]: the refined ray parameter of hits, 0 elsewhere)"""
     keys = np.empty((rows, cols), np.uint32)
-    vertex = np.empty((rows, cols, 4), np.float32)
+    ts = np.empty((rows, cols), np.float32)
     lib().orc_raycast_march(volume, C.byref(slab) if slab else None, f32(cam2vol).reshape(-1), f32(reproj), cols, rows,
-                            step_factor, keys.reshape(-1), vertex.reshape(-1))
-    return keys, vertex
+                            step_factor, keys.reshape(-1), ts.reshape(-1))
+    return keys, ts
 
 
-def raycast_shade(volume, cam2vol, Rinv, vertex, merged_keys, cols, rows, delta_factor, slab=None):
+def raycast_shade(volume, cam2vol, Rinv, reproj, ts, merged_keys, cols, rows, delta_factor, slab=None):
     pts = np.empty((rows, cols, 4), np.float32)
     nrm = np.empty((rows, cols, 4), np.float32)
-    lib().orc_raycast_shade(volume, C.byref(slab) if slab else None, f32(cam2vol).reshape(-1), f32(Rinv).reshape(-1),
-                            np.ascontiguousarray(vertex, np.float32).reshape(-1), np.ascontiguousarray(merged_keys, np.uint32).reshape(-1),
+    lib().orc_raycast_shade(volume, C.byref(slab) if slab else None, f32(cam2vol).reshape(-1), f32(Rinv).reshape(-1), f32(reproj),
+                            np.ascontiguousarray(ts, np.float32).reshape(-1), np.ascontiguousarray(merged_keys, np.uint32).reshape(-1),
                             pts.reshape(-1), cols * 16, nrm.reshape(-1), cols * 16, cols, rows, delta_factor)
     return pts, nrm
 

@@ -290,6 +290,18 @@ def test_cxx_zslab_rccl_path(tmp_path, with_nodes):
         planes = np.fromfile(fout, np.uint8)[2 * npx * 16:].view(np.uint32).reshape(-1, cfg.dims[1], cfg.dims[0])
         z0 = r_ * cfg.dims[2] // 4
         assert planes.shape[0] == cfg.dims[2] // 4 and np.array_equal(planes, vol[z0:z0 + cfg.dims[2] // 4])
+    # halo-recompute shards: setSlab(z0, n, halo, integrate_halo = true) integrates the halo planes too -- every STORED
+    # plane equals the unsharded volume -- while the own range the ray-cast partitions rays by stays [z0, z0 + n)
+    from dynamicfusion_amd import sharded
+    halo = sharded.halo_planes(sc.trunc, cfg.raycast_step_factor, cfg.gradient_delta_factor, float(sc.vs[2]))
+    for r_ in range(4):
+        fout = str(tmp_path / ("slabr%d.bin" % r_))
+        r = subprocess.run(base + [fout, str(tmp_path / "unused_id"), "recompute", "slab=%d/4" % r_], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "planes [%d, %d)" % (r_ * cfg.dims[2] // 4, (r_ + 1) * cfg.dims[2] // 4) in r.stdout, r.stdout + r.stderr
+        planes = np.fromfile(fout, np.uint8)[2 * npx * 16:].view(np.uint32).reshape(-1, cfg.dims[1], cfg.dims[0])
+        z0 = r_ * cfg.dims[2] // 4
+        lo, hi = max(0, z0 - halo), min(cfg.dims[2], z0 + cfg.dims[2] // 4 + halo)
+        assert planes.shape[0] == hi - lo and np.array_equal(planes, vol[lo:hi])
 
 
 def test_cxx_reference_warp_test_suites():

@@ -69,17 +69,22 @@ def test_full_size_properties_and_sampled_oracle(name):
     assert int(weights.sum()) == int(n_upd.item()) and int(weights.max()) == 2
     del b
 
-    # ---- oracle on a bounded sample: 2 planes in the middle of the volume, both frames
-    z0 = Z // 2 - 1
-    ref = np.zeros((2, Y, X), np.uint32)
-    slab = O.make_slab(z0, 2, z0, 2)
-    for f in range(2):
-        O.integrate_warped(sc.dists[f], ref, sc.ovol(ref), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)), sc.intr,
-                           sc.pos, sc.dqs[f], sc.sigma, cfg.k, slab=slab)
-    s = compare_volumes(a.data()[z0:z0 + 2].cpu().numpy().view(np.uint32), ref)
-    print(name, "sampled-plane parity:", s)
-    assert s["bits_mismatch"] == 0, s
-    assert (ref >> 16).max() == 2
+    # ---- oracle on a bounded sample of planes, both frames: 2 planes in the middle of the volume at 256^3 / 512^3 (40 planes of each
+    # are compared by test_warped_and_rigid_planes_bit_exact below), 16 planes -- 8 pairs spread over the depth of the volume, tile-layer
+    # boundaries included -- at 1024^3, the size no other test reaches
+    pairs = [Z // 2 - 1] if name != "1024" else [Z * (2 * i + 1) // 16 - 1 for i in range(8)]
+    n_checked = 0
+    for z0 in pairs:
+        ref = np.zeros((2, Y, X), np.uint32)
+        slab = O.make_slab(z0, 2, z0, 2)
+        for f in range(2):
+            O.integrate_warped(sc.dists[f], ref, sc.ovol(ref), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)), sc.intr,
+                               sc.pos, sc.dqs[f], sc.sigma, cfg.k, slab=slab)
+        s = compare_volumes(a.data()[z0:z0 + 2].cpu().numpy().view(np.uint32), ref)
+        print(name, "planes", z0, z0 + 1, "parity:", s)
+        assert s["bits_mismatch"] == 0, s
+        n_checked += int(((ref >> 16) != 0).sum())
+    assert n_checked > 0.05 * 2 * len(pairs) * X * Y                     # the sample lies in the fused part of the volume
 
     # ---- slab-sharded (world = 8) integrate + raycast == unsharded
     world = 8
@@ -88,7 +93,7 @@ def test_full_size_properties_and_sampled_oracle(name):
     fn = torch.empty_like(fp)
     fk = torch.empty((cfg.rows, cfg.cols), dtype=torch.int32, device="cuda")
     a.raycast(sc.cam_poses[1], intr, fp, fn, keys=fk)
-    slabs, k64s, vxs = [], [], []
+    slabs, k64s = [], []
     for r in range(world):
         zs, zn = sharded.slab_range(Z, r, world)
         v = setup(cfg, slab=(zs, zn, halo))
@@ -99,20 +104,15 @@ def test_full_size_properties_and_sampled_oracle(name):
         assert torch.equal(v.data()[own], a.data()[zs:zs + zn])
         v.data().copy_(a.data()[v.z_store0:v.z_store0 + v.z_store_n])      # halos as the exchange would deliver them
         k64 = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device="cuda")
-        vx = torch.empty_like(fp)
-        v.raycast_march(sc.cam_poses[1], intr, k64, vx, rank=r)
-        slabs.append(v); k64s.append(k64); vxs.append(vx)
-    merged = torch.stack(k64s).min(0).values.contiguous()
-    assert torch.equal(merged >> 8, fk.to(torch.int64) & 0xFFFFFFFF)
-    vsum = torch.zeros((cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
-    for r, v in enumerate(slabs):
-        v.raycast_select(merged, vxs[r], rank=r)
-        vsum += vxs[r].view(torch.int32)
-    vtx = vsum.view(torch.float32)
+        v.raycast_march(sc.cam_poses[1], intr, k64, rank=r)
+        slabs.append(v); k64s.append(k64)
+    merged = torch.stack(k64s).min(0).values.contiguous()          # what all_reduce(MIN) computes: the whole merge
+    best = torch.where(merged == sharded.KEY_NONE, torch.full_like(merged, 0xFFFFFFFF), (merged >> 39) & 0xFFFFFF)
+    assert torch.equal(best, fk.to(torch.int64) & 0xFFFFFFFF)
     acc = torch.zeros((2, cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
     for v in slabs:
         p, n = torch.empty_like(fp), torch.empty_like(fp)
-        v.raycast_shade(sc.cam_poses[1], intr, vtx, merged, p, n)
+        v.raycast_shade(sc.cam_poses[1], intr, merged, p, n)
         acc[0] += p.view(torch.int32)
         acc[1] += n.view(torch.int32)
     del slabs

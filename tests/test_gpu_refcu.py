@@ -80,3 +80,61 @@ def test_hip_equals_reference_kernels_live_128():
     rinv = np.linalg.inv(sc.pose[:3, :3].astype(np.float64)).astype(F32)
     rn = O.refcu_extract_normals(sc.ovol(ref), synth.aff12(sc.pose), rinv, c, cfg.gradient_delta_factor)
     assert np.array_equal(bits(normals.cpu().numpy())[:, :3], bits(rn)[:, :3])
+
+
+@pytest.mark.skipif(not O.have_refcu(), reason="oracle/_ref/libdfref_cu.so did not travel")
+def test_hip_equals_reference_kernels_live_512_full_volume():
+    """The headline size with nothing in between (VERDICT r2 #1 ii): 640x480 into 512^3 / 3 m, THREE frames of the reference's own
+    integrate_kernel (tsdf_volume.cu:51-108, compiled for the host) vs dfusion_integrate -- every one of the 134 M voxels --, then its
+    raycast_kernel (Points and Depth variants, :272-405) vs the HIP kernels on that volume."""
+    cfg = synth.CONFIGS["512"]
+    from scene import Scene
+    sc = Scene(cfg, n_frames=3, with_nodes=False)
+    vol, intr = gpu_frames(sc, cfg, 3)
+    ref = sc.new_volume()
+    for f in range(3):
+        O.refcu_integrate(sc.dists[f], sc.ovol(ref), synth.aff12(sc.vol2cam(f)), sc.intr)
+    assert (ref >> 16).max() == 3 and ((ref >> 16) != 0).sum() > 0.15 * ref.size
+    got = vol.download()
+    assert np.array_equal(got, ref), "%d of %d voxels differ" % (int((got != ref).sum()), ref.size)
+    del got
+    tail = (cfg.cols, cfg.rows, cfg.raycast_step_factor, cfg.gradient_delta_factor)
+    p, n, d, dn = gpu_raycast(vol, sc, cfg, intr, 2)
+    rp, rn = O.refcu_raycast_points(sc.ovol(ref), synth.aff12(sc.cam2vol(2)), sc.rinv(2), sc.intr, *tail)
+    rd, rdn = O.refcu_raycast_depth(sc.ovol(ref), synth.aff12(sc.cam2vol(2)), sc.rinv(2), sc.intr, *tail)
+    assert np.isfinite(rp[..., 0]).sum() > 0.5 * cfg.cols * cfg.rows
+    assert np.array_equal(bits(p), bits(rp)) and np.array_equal(bits(n), bits(rn))
+    assert np.array_equal(d, rd) and np.array_equal(bits(dn), bits(rdn))
+    # fetchCloud: the reference's FullScan6 runs as fibers on the host (warp-synchronous scan) -- 3 minutes at this size -- so the
+    # 512^3 cloud is compared with the restatement, which is pinned to FullScan6 at 64^3 (test_oracle_refcu.py) and live at 128^3 above
+    cloud = vol.fetchCloud()
+    torch.cuda.synchronize()
+    rc, count = O.extract_cloud(sc.ovol(ref), synth.aff12(sc.pose), 1 << 23)
+    assert count == cloud.shape[0] and count > 100000
+    key = lambda a: np.sort(np.ascontiguousarray(bits(a)[:, :3]).view([("x", "u4"), ("y", "u4"), ("z", "u4")]).reshape(-1), order=("x", "y", "z"))
+    assert np.array_equal(key(cloud.cpu().numpy()), key(rc[:count]))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref/libdfref.so did not travel")
+def test_warped_frame_equals_reference_classes_256_full_volume():
+    """BASELINE config 1 (256^3 / 1 m, ~500 nodes, k = 4), EVERY voxel: the per-voxel composition driven by the reference's own
+    classes -- nanoflann k-NN, WarpField::DQB weights and blend, DualQuaternion::transform, then TsdfIntegrator's arithmetic
+    (oracle/ref_glue.cpp ref_integrate_warped: the reference's headers, unmodified) -- vs dfusion_integrate_warped, two frames."""
+    from dynamicfusion_amd import WarpField
+    from scene import Scene
+    cfg = synth.CONFIGS["256"]
+    sc = Scene(cfg, n_frames=2)
+    intr = Intr(*cfg.intr)
+    vol = make_gpu_volume(sc)
+    wf = WarpField(k=cfg.k)
+    wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
+    ref = sc.new_volume()
+    Z = cfg.dims[2]
+    for f in range(2):
+        wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+        vol.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, wf)
+        O.ref_integrate_warped(sc.dists[f], ref, cfg.dims, sc.vs, sc.trunc, cfg.max_weight, synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)),
+                               sc.intr, sc.pos, sc.dqs[f], sc.sigma, cfg.k, 0, 0, Z)
+    got = vol.download()
+    assert (ref >> 16).max() == 2 and ((ref >> 16) != 0).sum() > 0.1 * ref.size
+    assert np.array_equal(got, ref), "%d of %d voxels differ" % (int((got != ref).sum()), ref.size)

@@ -36,26 +36,19 @@ def run_sharded(sc, world, frames, k=None, recompute_halo=False):
             n_hi = a.data().shape[0] - a_hi
             a.data()[a_hi:a_hi + n_hi].copy_(b.data()[b_lo:b_lo + n_hi])             # b's bottom own planes -> a's upper halo
     f = frames - 1
-    # stage 1 per slab, then what all_reduce(MIN) computes
-    k64s, vxs = [], []
+    # stage 1 per slab, then what all_reduce(MIN) computes: the whole merge (first event, owner, Ts)
+    k64s = []
     for r, v in enumerate(vols):
         k64 = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device="cuda")
-        vx = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
-        v.raycast_march(sc.cam_poses[f], intr, k64, vx, rank=r)
-        k64s.append(k64); vxs.append(vx)
+        v.raycast_march(sc.cam_poses[f], intr, k64, rank=r)
+        k64s.append(k64)
     merged = torch.stack(k64s).min(0).values.contiguous()
-    # select per slab, then what all_reduce(SUM) of the int32 views computes
-    vsum = torch.zeros((cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
-    for r, v in enumerate(vols):
-        v.raycast_select(merged, vxs[r], rank=r)
-        vsum += vxs[r].view(torch.int32)
-    vtx = vsum.view(torch.float32)
-    best = merged >> 8
+    best = torch.where(merged == sharded.KEY_NONE, torch.full_like(merged, 0xFFFFFFFF), (merged >> 39) & 0xFFFFFF)
     acc = torch.zeros((2, cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
     for v in vols:                                      # stage 2 + what reduce(SUM) of the bit patterns computes
         p = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
         n = torch.empty_like(p)
-        v.raycast_shade(sc.cam_poses[f], intr, vtx, merged, p, n)
+        v.raycast_shade(sc.cam_poses[f], intr, merged, p, n)
         acc[0] += p.view(torch.int32)
         acc[1] += n.view(torch.int32)
     torch.cuda.synchronize()
@@ -85,3 +78,31 @@ def test_slab_pipeline_equals_unsharded(cfg, world, recompute_halo):
     assert torch.equal(best, fk.to(torch.int64) & 0xFFFFFFFF)
     assert (~torch.isnan(fp)).float().mean() > 0.2
     assert torch.equal(mp, fp.view(torch.int32)) and torch.equal(mn, fn.view(torch.int32))     # bit-identical incl. NaN fill
+
+
+def test_bench_sharded_branch_runs_over_rccl_with_one_rank():
+    """bench.py's N > 1 code path -- slab volume, halo-recompute integrate view, the frame-input broadcast (uint8), the merge's
+    all_reduce(MIN) on int64 keys, the reduce(SUM) on int32 views, the float64 MAX / SUM of the timing, barrier -- through a REAL
+    RCCL process group of one rank (DFUSION_BENCH_FORCE_DIST=1).  RCCL refuses two ranks on one device, so N > 1 itself is only ever
+    run by the driver's 8-GPU node; this is the dry run that proves every dtype / op of the frame exists in RCCL before that, and that
+    the sharded frame's result is the unsharded one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for mode, env in (("single", {}), ("rccl1", {"DFUSION_BENCH_FORCE_DIST": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})):
+        for halo in (("recompute", "exchange") if mode == "rccl1" else ("recompute",)):
+            r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--config", "256", "--steps", "4", "--warmup", "1", "--no-extras",
+                                "--no-cpu-baseline", "--halo", halo], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            assert r.stdout.strip().splitlines()[-1].startswith('{"metric"'), r.stdout[-600:]      # the JSON line is the LAST line (driver contract)
+            lines[(mode, halo)] = json.loads(r.stdout.strip().splitlines()[-1])
+    one = lines[("single", "recompute")]
+    for halo in ("recompute", "exchange"):
+        d = lines[("rccl1", halo)]
+        assert d["config"]["parallelism"] == "zslab1" and d["n_gpus"] == 1
+        # same frames, same inputs: the sharded path updates exactly the voxels the unsharded one does
+        assert d["roofline"]["n_updated_all_ranks"] == one["roofline"]["n_updated_per_launch"]
+        assert d["value"] > 0

@@ -126,24 +126,22 @@ def test_raycast_hits_reproduce_depth():
 
 
 def _two_stage_cast(sc, vol, f, world, halo, cfg):
-    """march per slab -> MIN-merge keys + winner's vertex -> shade per slab -> integer-sum (what sharded.py does)."""
+    """march per slab -> MIN-merge of the 64-bit keys (event | rank | Ts) -> shade per slab -> integer-sum (what sharded.py does)."""
     Z = cfg.dims[2]
     slabs = []
     for r in range(world):
         z0, zn = sharded_mod().slab_range(Z, r, world)
         lo, hi = max(0, z0 - halo), min(Z, z0 + zn + halo)
         slabs.append((np.ascontiguousarray(vol[lo:hi]), O.make_slab(lo, hi - lo, z0, zn)))
-    best = np.full((cfg.rows, cfg.cols), 0xffffffff, np.uint32)
-    vtx = np.zeros((cfg.rows, cfg.cols, 4), np.float32)
-    for part, slab in slabs:
-        k, v = O.raycast_march(sc.ovol(part), synth.aff12(sc.cam2vol(f)), sc.reproj, cfg.cols, cfg.rows, cfg.raycast_step_factor, slab=slab)
-        better = k < best
-        best[better] = k[better]
-        vtx[better] = v[better]
+    merged = np.full((cfg.rows, cfg.cols), sharded_mod().KEY_NONE, np.int64)
+    for r, (part, slab) in enumerate(slabs):
+        k, t = O.raycast_march(sc.ovol(part), synth.aff12(sc.cam2vol(f)), sc.reproj, cfg.cols, cfg.rows, cfg.raycast_step_factor, slab=slab)
+        merged = np.minimum(merged, sharded_mod().pack_merge_keys(k, t, r))          # all_reduce(MIN)
+    best, ts, _ = sharded_mod().unpack_merge_keys(merged)
     acc_p = np.zeros((cfg.rows, cfg.cols, 4), np.uint32)
     acc_n = np.zeros_like(acc_p)
     for part, slab in slabs:
-        p, n = O.raycast_shade(sc.ovol(part), synth.aff12(sc.cam2vol(f)), sc.rinv(f), vtx, best, cfg.cols, cfg.rows,
+        p, n = O.raycast_shade(sc.ovol(part), synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.reproj, ts, best, cfg.cols, cfg.rows,
                                cfg.gradient_delta_factor, slab=slab)
         acc_p += p.view(np.uint32)
         acc_n += n.view(np.uint32)

@@ -66,20 +66,17 @@ def _worker(rank, world, port, recompute_halo):
                 sharded.exchange_halos(vol_t, lo, z0, zn, Z, halo, rank, world)
 
             def march():
-                k, vx = O.raycast_march(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.reproj, CFG.cols, CFG.rows,
+                k, ts = O.raycast_march(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.reproj, CFG.cols, CFG.rows,
                                         CFG.raycast_step_factor, slab=slab)
-                return (torch.from_numpy(k.astype(np.int64)) << 8) | rank, torch.from_numpy(vx)
+                return torch.from_numpy(sharded.pack_merge_keys(k, ts, rank))         # the layout dfusion_raycast_march writes
 
-            def select(k64, vx):
-                vx[(k64 & 0xFF) != rank] = 0
-
-            def shade(k64, vx):
-                merged = (k64 >> 8).numpy().astype(np.uint32)
-                p, n = O.raycast_shade(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.rinv(f), vx.numpy(), merged, CFG.cols, CFG.rows,
+            def shade(k64):
+                merged, ts, _ = sharded.unpack_merge_keys(k64.numpy())
+                p, n = O.raycast_shade(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.reproj, ts, merged, CFG.cols, CFG.rows,
                                        CFG.gradient_delta_factor, slab=slab)
                 return torch.from_numpy(np.stack([p, n]))
 
-            pts, nrm = sharded.raycast_sharded(march, select, shade, rank, world)
+            pts, nrm = sharded.raycast_sharded(march, shade, rank, world)
         # every rank checks its slab (own + halo planes) against the unsharded volume; rank 0 checks the merged cast
         full, fp, fn = _unsharded(sc)
         assert np.array_equal(vol, full[lo:hi]), "rank %d: slab (incl. halos) differs from the unsharded volume" % rank
@@ -104,7 +101,7 @@ def test_zslab_pipeline_over_gloo(world, recompute_halo):
 
 def test_single_rank_is_a_no_op_path():
     p = torch.zeros((4, 4, 4))
-    out = sharded.raycast_sharded(lambda: (None, None), None, lambda k, v: (p, p), 0, 1)
+    out = sharded.raycast_sharded(lambda: None, lambda k: (p, p), 0, 1)
     assert out[0] is p
     sharded.exchange_halos(None, 0, 0, 4, 4, 2, 0, 1)
 
@@ -120,4 +117,4 @@ def test_validate_slabs_rejects_unworkable_partitions():
     with pytest.raises(ValueError):
         sharded.validate_slabs(64, 8, 13)          # 8 planes per rank < 13 halo planes
     with pytest.raises(ValueError):
-        sharded.validate_slabs(4096, 256, 1)       # rank does not fit the 8-bit tag
+        sharded.validate_slabs(4096, 129, 1)       # rank does not fit the 7-bit tag

@@ -34,7 +34,7 @@ for t in libs:
     if has_cnt: libs[t].dfusion_debug_rigid_counters(n[1:].data_ptr())
     snaps = []
     for f in range(11):
-        v.integrate(dists[f % F], cams[f % F], intr, n_updated=n[:1])
+        v.integrate(dists[f % F], cams[f % F], intr, n_updated=n[:1] if f % 2 == 0 else None)     # (both the counting and the plain kernels)
         if f in (0, 2, 10): snaps.append(v.data().clone())
     if has_cnt: libs[t].dfusion_debug_rigid_counters(None)
     upd, swept = int(n[0]), int(n[1])

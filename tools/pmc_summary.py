@@ -7,7 +7,15 @@ HBM bytes per launch follow MI355X_MICROARCH.md's HBM section: FETCH_SIZE / WRIT
 FETCH_SIZE counts a 128-byte request as 64 bytes for wide coalesced reads, so fetch bytes = 2 * FETCH_SIZE * 1024
 (cross-checked against TCC_EA0_RDREQ * 128, collected in its own pass); write bytes = WRITE_SIZE * 1024.
 """
-import argparse, collections, csv, glob, json, os
+import argparse, collections, csv, glob, hashlib, json, os
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_sha(kernel):
+    """sha256 of the .hip the kernel lives in: bench.py only reports counters taken from the build it runs"""
+    f = "dfusion_warp.hip" if kernel.startswith(("df_warp", "df_sweep")) else ("dfusion_raycast.hip" if kernel.startswith(("df_raycast", "df_extract")) else "dfusion_volume.hip")
+    return hashlib.sha256(open(os.path.join(REPO, "dynamicfusion_amd", "csrc", f), "rb").read()).hexdigest()
 
 ap = argparse.ArgumentParser()
 ap.add_argument("root", nargs="?", default="gpurun_out/pmc")
@@ -36,7 +44,7 @@ for k in sorted(rows):
         print("    %-22s %.4g GB (fetch %.4g + write %.4g; RDREQ*128 = %.4g)" %
               ("hbm_bytes/launch", (fetch + write) / 1e9, fetch / 1e9, write / 1e9, rd / 1e9))
         out[k.split("<")[0]] = {"kernel": k, "hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
-                                "tcc_ea0_rdreq_x128": rd,
+                                "tcc_ea0_rdreq_x128": rd, "source_sha256": source_sha(k),
                                 "how": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, %s" % args.tag}
     if "SQ_BUSY_CYCLES" in mean and "SQ_ACTIVE_INST_VALU" in mean and "SQ_WAVES" in mean:
         print("    %-22s %.4g per wave" % ("VALU instr", mean.get("SQ_INSTS_VALU", 0) / max(mean["SQ_WAVES"], 1)))

@@ -12,7 +12,7 @@ for f in range(3):
     vol.integrate(compute_dists(upload_u16(synth.depth_frame(cfg, f)), intr), synth.camera_pose(cfg, f), intr)
 cam = synth.camera_pose(cfg, 2)
 pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
-keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device="cuda"); vtx = torch.empty_like(pts)
+keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device="cuda")
 def timeit(fn, n=30):
     for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,7 +21,7 @@ def timeit(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 print("fused  %.4f ms" % timeit(lambda: vol.raycast(cam, intr, pts, nrm)))
-print("march  %.4f ms" % timeit(lambda: vol.raycast_march(cam, intr, keys, vtx)))
-vol.raycast_march(cam, intr, keys, vtx)
-print("shade  %.4f ms" % timeit(lambda: vol.raycast_shade(cam, intr, vtx, keys, pts, nrm)))
-hit = int(((keys >> 8) & 1).sum()); print("hits", hit, "of", cfg.rows * cfg.cols)
+print("march  %.4f ms" % timeit(lambda: vol.raycast_march(cam, intr, keys)))
+vol.raycast_march(cam, intr, keys)
+print("shade  %.4f ms" % timeit(lambda: vol.raycast_shade(cam, intr, keys, pts, nrm)))
+hit = int((((keys >> 39) & 1) * (keys != 0x7FFFFFFFFFFFFFFF)).sum()); print("hits", hit, "of", cfg.rows * cfg.cols)

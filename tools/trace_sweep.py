@@ -6,7 +6,7 @@ import os, sys
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
 from dynamicfusion_amd import capi, build as B
-B.LIB_PATH = os.path.join(REPO, "build", "libdfusion_hip_trace.so"); B._stale = lambda: False
+B.LIB_PATH = os.path.join(REPO, "build", "libdfusion_hip_%s.so" % os.environ.get("DF_TRACE_LIB", "trace")); B._stale = lambda: False
 from dynamicfusion_amd import Intr, TsdfVolume, WarpField, compute_dists, synth, upload_u16
 name = sys.argv[1] if len(sys.argv) > 1 else "512"
 rigid = len(sys.argv) > 2 and sys.argv[2] == "rigid"
