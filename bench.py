@@ -41,6 +41,9 @@ def parse():
                     help="N>1: how a rank gets its neighbours' boundary planes for the ray-cast -- recompute them (default: every rank "
                          "integrates its halo planes too, no collective) or exchange them after the integrate (paired isend/irecv over RCCL, "
                          "the north star's wording; one more collective per frame, 2*H fewer planes to sweep)")
+    ap.add_argument("--slabs", choices=["balanced", "uniform"], default="balanced",
+                    help="N>1: Z-slab boundaries -- equal shares of the integrate's WORK (planes weighted by how much of them lies inside the frustum "
+                         "and in front of the first frame's surface; the far slabs are thin) or equal plane counts")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (rigid_integrate, extract_cloud, kinfu_frame)")
     ap.add_argument("--no-kinfu", action="store_true", help="skip the kinfu_frame extra (it runs a child process; use under profilers)")
     return ap.parse_args()
@@ -243,9 +246,21 @@ def main():
     vs_z = cfg.size / Z
     trunc_eff = max(cfg.trunc_dist, 2.1 * vs_z)
     halo = sharded.halo_planes(trunc_eff, cfg.raycast_step_factor, cfg.gradient_delta_factor, vs_z)
+    slab_bounds = None
     if dist_on:
-        sharded.validate_slabs(Z, world, halo)             # same verdict on every rank, before the first collective
-        z_own0, z_own_n = sharded.slab_range(Z, rank, world)
+        # the partition is decided once, from the first sensor frame, on rank 0 (which owns the sensor) and broadcast: every rank must
+        # hold the SAME boundaries before the first slab is allocated
+        bt = torch.zeros(world + 1, dtype=torch.int64, device=dev)
+        if rank == 0:
+            wts = None
+            if args.slabs == "balanced" and world > 1:
+                wts = sharded.frustum_plane_weights(cfg.dims, cfg.size, cfg.volume_pose, cam_poses[0], cfg.intr, cfg.cols, cfg.rows,
+                                                    depth_mm=depths_np[0], trunc=trunc_eff, margin=0.3)
+            bt.copy_(torch.tensor(sharded.slab_bounds(Z, world, halo, wts), dtype=torch.int64))
+        dist.broadcast(bt, 0)
+        slab_bounds = [int(v) for v in bt.cpu()]
+        sharded.validate_bounds(slab_bounds, Z, halo)      # same verdict on every rank, before the first data collective
+        z_own0, z_own_n = slab_bounds[rank], slab_bounds[rank + 1] - slab_bounds[rank]
         vol = TsdfVolume(cfg.dims, device=dev, slab=(z_own0, z_own_n, halo))
     else:
         vol = TsdfVolume(cfg.dims, device=dev)
@@ -480,6 +495,7 @@ def main():
             "config": {"workload": cfg.name, "volume_dims": list(cfg.dims), "volume_size_m": cfg.size,
                        "depth": [cfg.cols, cfg.rows], "warp_nodes": cfg.nodes, "k": cfg.k,
                        "parallelism": "zslab%d" % world if dist_on else "single", "halo_planes": halo if dist_on else 0,
+                       "slab_bounds": slab_bounds, "slabs": args.slabs if dist_on else None,
                        "halo": (("integrated redundantly by every rank, no halo collective" if args.halo == "recompute" else
                                  "exchanged after the integrate (paired isend/irecv of %d planes per side)" % halo) if dist_on else None),
                        "frame": "set_transforms + compute_dists + integrate_warped + raycast_points"},

@@ -269,7 +269,9 @@ __device__ __forceinline__ bool tsdf_sample_nb(const DfIntegrateParams& P, f3 vc
 //     quotient through -- what remains is the sequence below, 13 instructions for both quotients instead of 22;
 //   * sqrtf as df_sqrt_short (argument >= vc.z^2 >= 2^-9);
 //   * the pixel clamp by v_med3_f32 (no NaN can reach it), the dists address in 32 bits.
-// dfusion_selftest_sample_forms compares it with tsdf_sample_nb on random in-domain positions.
+// dfusion_selftest_exact_forms (counts[6]) compares it, and the two-stage form below, with tsdf_sample_nb on random in-domain
+// positions and on the domain's edges.  (A numerator of -0 gives +0 here where the IEEE division gives -0; both make the same
+// u = fma(fx, q, cx) because cx > 0, which the callers of this form require.)
 __device__ __forceinline__ float df_div_shared(float n, float d, float r)       // n / d given r = df_rcp_refined(d)
 {
     float q = n * r;

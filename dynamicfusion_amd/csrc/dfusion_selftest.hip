@@ -109,11 +109,89 @@ __global__ __launch_bounds__(256) void df_selftest_fuse_kernel(unsigned per, uns
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&counts[5], bad);
 }
 
+// [6] the projective sample in its short forms vs tsdf_sample_nb (the reference's statements with the generic division / sqrtf):
+//     tsdf_sample_fast (shared refined reciprocal, short sqrtf, one-compare pixel test) and the two-stage form of the rigid sweep
+//     (tsdf_sample_pre + the saturation decision on the approximate root, tsdf_sample_finish otherwise) -- verdict AND tsdf bits.
+//     Positions are random inside the forms' domain and ON ITS EDGES (|x|, |y| = 2^-20 and 2^30, z = 0.05 and 2^30, the 32 m limit of
+//     the saturation shortcut), signs both ways, against a synthetic dists image holding every kind of half (zeros, tiny, finite,
+//     65504, inf, NaN); trunc random in [2^-10, 2^10].   [7] = how many of the compared samples took the update branch.
+__global__ __launch_bounds__(256) void df_selftest_sample_kernel(unsigned long long n, const uint16_t* __restrict__ img, unsigned long long* __restrict__ counts)
+{
+    unsigned long long bad = 0, upd = 0;
+    unsigned long long seed = 0xa0761d6478bd642full * (blockIdx.x * 256ull + threadIdx.x + 1ull);
+    DfIntegrateParams P;
+    P.dists = img; P.pitch = 64 * 2; P.cols = 64; P.rows = 48; P.fx = 57.0342f; P.fy = 57.0342f; P.cx = 32.f; P.cy = 24.f; P.max_weight = 64;
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull) {
+        const unsigned r = st_rng(seed);
+        P.trunc = ldexpf(1.f + (float)(st_rng(seed) >> 9) * 0x1p-23f, (int)(r % 20u) - 10);   // [2^-10, 2^10)
+        if ((r >> 8) % 7u == 0) P.trunc = (r & 1u) ? 0x1p-10f : 0x1p10f;
+        P.trunc_inv = 1.f / P.trunc;
+        auto coord = [&](bool is_z) {
+            const unsigned k = st_rng(seed), m = st_rng(seed);
+            float v;
+            switch (k & 7u) {
+                case 0: v = is_z ? 0.05f : 0x1p-20f; break;                                         // lower edge
+                case 1: v = 0x1p30f; break;                                                         // upper edge
+                case 2: v = 32.f; break;                                                            // the saturation shortcut's limit
+                case 3: v = __uint_as_float((m & 0x007fffffu) | ((127u + (k >> 8) % 6u) << 23)); break;          // 1 .. 64 m
+                default: v = __uint_as_float((m & 0x007fffffu) | ((120u + (k >> 8) % 9u) << 23)); break;         // 2^-7 .. 4 m
+            }
+            if (is_z && v < 0.05f) v = 0.05f + v;
+            return (!is_z && (k & 0x80000000u)) ? -v : v;
+        };
+        const f3 vc = mk3(coord(false), coord(false), coord(true));
+        if (!tsdf_sample_domain_ok(vc, vc)) continue;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        const bool u0 = tsdf_sample_nb(P, vc, &t0);
+        const bool u1 = tsdf_sample_fast(P, vc, &t1);
+        bad += (u0 != u1) || (u0 && !st_same(t0, t1));
+        if (df_sat_trunc_ok(P.trunc) && tsdf_sat_domain_ok(vc, vc)) {
+            const DfSamplePre pre = tsdf_sample_pre(P, vc);
+            const float sdf_a = pre.Dp - pre.s, T = df_sat_threshold(P.trunc);
+            bool u2;
+            if (!(pre.ok & (fabsf(sdf_a) < T))) { u2 = pre.ok & (sdf_a >= T); t2 = 1.f; }         // decided on the approximate root
+            else u2 = tsdf_sample_finish(P, pre, &t2);
+            bad += (u0 != u2) || (u0 && !st_same(t0, t2));
+        }
+        upd += u0;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { bad += __shfl_xor(bad, o, 64); upd += __shfl_xor(upd, o, 64); }
+    if ((threadIdx.x & 63) == 0) { if (bad) atomicAdd(&counts[6], bad); atomicAdd(&counts[7], upd); }
+}
+__global__ __launch_bounds__(256) void df_selftest_sample_image_kernel(uint16_t* __restrict__ img)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= 64u * 48u) return;
+    unsigned long long seed = 0x2545f4914f6cdd1dull * (i + 1ull);
+    const unsigned r = st_rng(seed);
+    uint16_t h;
+    switch (r & 15u) {
+        case 0: h = 0; break;                                  // invalid depth
+        case 1: h = 0x7bff; break;                             // 65504
+        case 2: h = 0x7c00; break;                             // +inf
+        case 3: h = 0x7e00; break;                             // NaN
+        case 4: h = (uint16_t)(r >> 16) & 0x03ff; break;       // subnormal halves
+        case 5: h = 0x8000 | ((uint16_t)(r >> 16) & 0x7bff); break;   // negative lengths (never produced by compute_dists, legal input)
+        default: h = (uint16_t)(0x3000 + ((r >> 8) % 0x2400u)); break;        // 0.125 .. 64 m
+    }
+    img[i] = h;
+}
+
 extern "C" int dfusion_selftest_exact_forms(unsigned long long n_random, unsigned long long* counts_dev, dfStream stream)
 {
     if (!counts_dev) return DF_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    DF_HIP(hipMemsetAsync(counts_dev, 0, 6 * sizeof(unsigned long long), st));
+    DF_HIP(hipMemsetAsync(counts_dev, 0, 8 * sizeof(unsigned long long), st));
+    {
+        uint16_t* img = nullptr;
+        DF_HIP(hipMallocAsync((void**)&img, 64 * 48 * sizeof(uint16_t), st));
+        hipLaunchKernelGGL(df_selftest_sample_image_kernel, dim3(12), dim3(256), 0, st, img);
+        hipLaunchKernelGGL(df_selftest_sample_kernel, dim3(2048), dim3(256), 0, st, n_random, (const uint16_t*)img, counts_dev);
+        const hipError_t e = hipGetLastError();
+        (void)hipFreeAsync(img, st);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(df_selftest_scan_kernel, dim3(4096), dim3(256), 0, st, counts_dev);
     DF_LAUNCH_CHECK();
     hipLaunchKernelGGL(df_selftest_quat_kernel, dim3(2048), dim3(256), 0, st, n_random, counts_dev);

@@ -811,15 +811,26 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     const size_t off_pyr = (off_mask + (size_t)n_items * 4 + 15) / 16 * 16;
     const size_t off_starts = (off_pyr + pyr_elems * sizeof(uint16_t) + 255) / 256 * 256;
     const size_t bytes = off_starts + (DF_RIGID_STARTS ? (size_t)n_pitems * 64 * sizeof(float4) : 0);
+    // (where the runtime has no stream-ordered allocator the scratch is a plain allocation released after a stream synchronise:
+    // correct, slower -- the product boxes have it)
     char* scratch = nullptr;
-    DF_HIP(hipMallocAsync((void**)&scratch, bytes, st));
+    bool scratch_async = true;
+    if (hipMallocAsync((void**)&scratch, bytes, st) != hipSuccess) {
+        (void)hipGetLastError();
+        scratch_async = false;
+        DF_HIP(hipMalloc((void**)&scratch, bytes));
+    }
+    auto release_scratch = [&]() {
+        if (scratch_async) { (void)hipFreeAsync(scratch, st); return; }
+        (void)hipStreamSynchronize(st); (void)hipFree(scratch);
+    };
     DfDistsPyramid Py;
     memset(&Py, 0, sizeof(Py));
     int rc = DF_OK;
     // (levels 1..5 only: the plan reads none above; the pyramid's first workgroup zeroes the plan's counters)
     if (pyr_elems) rc = df_build_dists_pyramid(dists, pitch, cols, rows, (uint16_t*)(scratch + off_pyr), pyr_elems, &Py, st, true, (unsigned int*)(scratch + off_cnt));
     if (rc == DF_OK && Py.top == 0 && hipMemsetAsync(scratch + off_cnt, 0, 256, st) != hipSuccess) rc = (int)hipGetLastError();
-    if (rc != DF_OK) { (void)hipFreeAsync(scratch, st); return rc; }
+    if (rc != DF_OK) { release_scratch(); return rc; }
     unsigned int* cnt = (unsigned int*)(scratch + off_cnt);
     unsigned int* bins = (unsigned int*)(scratch + off_bins);
     unsigned int* pmask = (unsigned int*)(scratch + off_mask);
@@ -857,7 +868,7 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
         free(h);
     }
 #endif
-    (void)hipFreeAsync(scratch, st);
+    release_scratch();
     return rc;
 }
 

@@ -1,6 +1,6 @@
 // zslab_frame.cpp -- the hot-path frame of headless_frame.cpp on a Z-slab-sharded volume, in C++ over RCCL: one process per GPU
 // (RANK / WORLD_SIZE / LOCAL_RANK from the environment, as torchrun and mpirun set them; WORLD_SIZE absent = 1).
-//   zslab_frame <dims> <size_m> <cols> <rows> <frames> <nodes> <k> <in.bin> <out.bin> <id_file> [exchange|recompute] [slab=<r>/<n>]
+//   zslab_frame <dims> <size_m> <cols> <rows> <frames> <nodes> <k> <in.bin> <out.bin> <id_file> [exchange|recompute] [slab=<r>/<n>] [bounds=0,b1,..,Z]
 // in.bin as headless_frame's.  Rank 0 reads it and broadcasts every frame's depth image and node transforms (ZSlabComm::broadcast);
 // every rank integrates the planes it owns (warped when nodes > 0), the halo planes are exchanged (ncclSend/Recv) or recomputed, the
 // ray-cast is the two-stage sharded one.  out.bin (rank 0): points f32[rows*cols*4], normals f32[rows*cols*4] of the last frame, then
@@ -28,12 +28,22 @@ static Affine3f to_affine(const float a[12])
 
 int main(int argc, char** argv)
 {
+    if (argc == 5 && !std::strcmp(argv[1], "bounds")) {     // zslab_frame bounds <world> <halo> <weights.f64>: ZSlabComm::slabBounds of the file's planes
+        std::vector<double> w;
+        if (FILE* f = std::fopen(argv[4], "rb")) { double v; while (std::fread(&v, 8, 1, f) == 1) w.push_back(v); std::fclose(f); }
+        const std::vector<int> b = cuda::ZSlabComm::slabBounds((int)w.size(), std::atoi(argv[2]), std::atoi(argv[3]), w);
+        for (size_t i = 0; i < b.size(); ++i) std::printf("%s%d", i ? "," : "", b[i]);
+        std::printf("\n");
+        return 0;
+    }
     if (argc < 11) { std::fprintf(stderr, "usage: %s dims size cols rows frames nodes k in.bin out.bin id_file [exchange|recompute] [slab=r/n]\n", argv[0]); return 2; }
     const int dims = std::atoi(argv[1]); const float size = (float)std::atof(argv[2]);
     const int cols = std::atoi(argv[3]), rows = std::atoi(argv[4]), frames = std::atoi(argv[5]), M = std::atoi(argv[6]), k = std::atoi(argv[7]);
     bool exchange = true; int only_r = -1, only_n = 0;
+    std::vector<int> bounds;                                // bounds=0,b1,...,Z : explicit slab boundaries (work-balanced partitions)
     for (int i = 11; i < argc; ++i) {
         if (!std::strcmp(argv[i], "recompute")) exchange = false;
+        else if (!std::strncmp(argv[i], "bounds=", 7)) { for (const char* q = argv[i] + 7; *q;) { bounds.push_back(std::atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; } }
         else if (!std::strncmp(argv[i], "slab=", 5)) std::sscanf(argv[i] + 5, "%d/%d", &only_r, &only_n);
     }
     const int world = only_n > 0 ? only_n : env_int("WORLD_SIZE", 1), rank = only_n > 0 ? only_r : env_int("RANK", 0);
@@ -70,6 +80,7 @@ int main(int argc, char** argv)
     std::string why;
     if (!cuda::ZSlabComm::partitionOk(dims, world, halo, &why)) { std::fprintf(stderr, "zslab_frame: %s\n", why.c_str()); return 3; }
     int z0, zn; cuda::ZSlabComm::slabRange(dims, rank, world, z0, zn);
+    if ((int)bounds.size() == world + 1) { z0 = bounds[rank]; zn = bounds[rank + 1] - bounds[rank]; if (zn < 1 || (world > 1 && zn < halo)) { std::fprintf(stderr, "zslab_frame: bad bounds\n"); return 3; } }
     volume.create(Vec3i(dims, dims, dims));
     volume.setSize(Vec3f::all(size)); volume.setTruncDist(0.04f); volume.setMaxWeight(64); volume.setPose(to_affine(pose12));
     volume.setRaycastStepFactor(0.75f); volume.setGradientDeltaFactor(0.5f);

@@ -18,6 +18,7 @@
 // tests and the one-GPU 8-slab emulation exercise; this file is what a C++ host (KinFu) links instead.
 #pragma once
 #include <string>
+#include <vector>
 #include <kfusion/types.hpp>
 #include <kfusion/cuda/tsdf_volume.hpp>
 
@@ -39,6 +40,11 @@ public:
 
     /// planes owned by `rank`: contiguous, brick-aligned (multiples of 8 where Z allows)
     static void slabRange(int Z, int rank, int world, int& z_own0, int& z_own_n);
+    /// the same from WORK weights (one non-negative number per plane: e.g. the share of the plane inside the frustum and in front of
+    /// the first frame's surface -- dynamicfusion_amd/sharded.py frustum_plane_weights): boundaries b[0] = 0 < ... < b[world] = Z,
+    /// multiples of 8 where Z allows, every slab at least max(halo, 8) planes, about the same weight per rank.  Equal plane counts
+    /// leave the far ranks several times the near ranks' work (a frustum's cross-section grows with the square of the depth).
+    static std::vector<int> slabBounds(int Z, int world, int halo, const std::vector<double>& weights);
     /// planes of the neighbour a slab must hold for the ray-cast: the march's `next` sample is one time_step beyond `curr`
     /// (tsdf_volume.cu:378-380), trilinear taps read g+1 (:236-243), gradient probes reach +-gradient_delta (:413-423)
     static int haloPlanes(float trunc_dist, float step_factor, float delta_factor, float voxel_z);

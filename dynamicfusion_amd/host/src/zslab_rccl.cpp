@@ -74,6 +74,29 @@ void ZSlabComm::slabRange(int Z, int rank, int world, int& z_own0, int& z_own_n)
     z_own0 = lo; z_own_n = hi - lo;
 }
 
+std::vector<int> ZSlabComm::slabBounds(int Z, int world, int halo, const std::vector<double>& weights)
+{
+    std::vector<int> b;
+    if ((int)weights.size() != Z) { for (int r = 0; r < world; ++r) { int z0, n; slabRange(Z, r, world, z0, n); b.push_back(z0); } b.push_back(Z); return b; }
+    const int step = (Z % 8 == 0) ? 8 : 1;
+    int min_planes = std::max(halo, step);
+    min_planes = (min_planes + step - 1) / step * step;
+    std::vector<double> cum((size_t)Z + 1, 0.0);
+    for (int z = 0; z < Z; ++z) cum[z + 1] = cum[z] + weights[z];
+    const double total = cum[Z] > 0 ? cum[Z] : 1.0;
+    b.push_back(0);
+    for (int r = 1; r < world; ++r) {
+        const double target = total * r / world;
+        int z = (int)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());      // numpy.searchsorted(cum, target)
+        z = (int)std::nearbyint((double)z / step) * step;                                    // Python's round(): half to even
+        z = std::max(z, b.back() + min_planes);
+        z = std::min(z, Z - (world - r) * min_planes);
+        b.push_back(z);
+    }
+    b.push_back(Z);
+    return b;
+}
+
 int ZSlabComm::haloPlanes(float trunc_dist, float step_factor, float delta_factor, float voxel_z)
 {
     return (int)std::ceil((double)trunc_dist * step_factor / voxel_z + delta_factor) + 2;

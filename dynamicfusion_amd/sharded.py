@@ -60,6 +60,87 @@ def slab_range(Z, rank, world):
     return lo, hi - lo
 
 
+def frustum_plane_weights(dims, size, volume_pose, camera_pose, intr, cols, rows, samples=48, depth_mm=None, trunc=0.04, margin=0.0):
+    """Relative cost of sweeping each Z plane of the volume for a camera at `camera_pose`: the share of the plane that lies inside
+    the image frustum (a `samples` x `samples` lattice of its voxel centres projected with the frame's intrinsics), plus a floor
+    for the planes the launch plans skip.  The integrate's work is proportional to the voxels in front of the camera and inside
+    the frustum, and a frustum's cross-section grows with the square of the depth: equal-plane slabs leave the far rank with
+    several times the near rank's work (measured: 0.73 vs 0.32 ms at two ranks, 512^3 -- DESIGN.md section 5).
+    depth_mm (optional, uint16 [rows, cols], the first sensor frame): samples that the integrate's own test would skip -- no depth
+    at their pixel, or more than `trunc` behind the observed surface (tsdf_volume.cu:86-91) -- do not count either: the planes
+    behind the scene cost a launch plan, not a sweep.  margin (metres): how far the warp field can move a voxel -- the warped
+    sweep must keep everything within that distance of the frustum and of the surface, so its work reaches that much further."""
+    X, Y, Z = [int(d) for d in dims]
+    vs = np.asarray(size, np.float64).reshape(-1)[:3] / np.array([X, Y, Z], np.float64) if np.ndim(size) else np.full(3, float(size)) / np.array([X, Y, Z], np.float64)
+    v2c = np.linalg.inv(np.asarray(camera_pose, np.float64)) @ np.asarray(volume_pose, np.float64)
+    fx, fy, cx, cy = [float(v) for v in intr]
+    gx = (np.arange(samples) + 0.5) * (X / samples) * vs[0]
+    gy = (np.arange(samples) + 0.5) * (Y / samples) * vs[1]
+    px, py = np.meshgrid(gx, gy)
+    w = np.empty(Z, np.float64)
+    for z in range(Z):
+        p = np.stack([px.ravel(), py.ravel(), np.full(px.size, z * vs[2]), np.ones(px.size)])
+        c = v2c @ p
+        zc = c[2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = fx * c[0] / zc + cx
+            v = fy * c[1] / zc + cy
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mu, mv = margin * fx / zc, margin * fy / zc                    # the margin in pixels at this depth
+        inside = (zc > -margin) & (u >= -mu) & (u < cols + mu) & (v >= -mv) & (v < rows + mv)
+        if margin > 0:
+            inside &= zc > 0.05
+        if depth_mm is not None:
+            ui = np.clip(np.nan_to_num(u, nan=0.0, posinf=0.0, neginf=0.0), 0, cols - 1).astype(np.int64)
+            vi = np.clip(np.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0), 0, rows - 1).astype(np.int64)
+            d = np.asarray(depth_mm)[vi, ui].astype(np.float64) * 1e-3
+            lam = np.sqrt(((ui - cx) / fx) ** 2 + ((vi - cy) / fy) ** 2 + 1.0)            # compute_dists, imgproc.cu:259-272
+            rng = np.sqrt(c[0] ** 2 + c[1] ** 2 + zc ** 2)
+            inside &= (d > 0) & (d * lam - rng >= -(trunc + margin))
+        w[z] = inside.mean()
+    return w + 0.02                                       # (plan kernels and culled planes are not free)
+
+
+def slab_bounds(Z, world, halo=0, weights=None):
+    """Slab boundaries b[0] = 0 < b[1] < ... < b[world] = Z (multiples of 8 where Z allows): rank r owns planes [b[r], b[r + 1]).
+    weights = None: equal plane counts (slab_range).  Otherwise planes are dealt out so that every rank gets about the same share
+    of `weights` (one non-negative number per plane, e.g. frustum_plane_weights), every slab keeping at least max(halo, 8) planes."""
+    if weights is None:
+        return [slab_range(Z, r, world)[0] for r in range(world)] + [Z]
+    w = np.asarray(weights, np.float64).reshape(-1)
+    assert w.size == Z and (w >= 0).all()
+    step = 8 if Z % 8 == 0 else 1
+    min_planes = max(int(halo), step)
+    min_planes = (min_planes + step - 1) // step * step
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = cum[-1] if cum[-1] > 0 else 1.0
+    b = [0]
+    for r in range(1, world):
+        target = total * r / world
+        z = int(np.searchsorted(cum, target))
+        z = int(round(z / step)) * step
+        z = max(z, b[-1] + min_planes)                     # this slab is thick enough ...
+        z = min(z, Z - (world - r) * min_planes)           # ... and so can every later one be
+        b.append(z)
+    b.append(Z)
+    return b
+
+
+def validate_bounds(bounds, Z, halo):
+    """The checks of validate_slabs for an explicit boundary list (slab_bounds)."""
+    world = len(bounds) - 1
+    if world < 1 or world > MAX_RANKS:
+        raise ValueError("world size %d: the merge key carries the rank in 7 bits (1..%d ranks)" % (world, MAX_RANKS))
+    if bounds[0] != 0 or bounds[-1] != Z:
+        raise ValueError("slab boundaries must run from 0 to %d" % Z)
+    for r in range(world):
+        n = bounds[r + 1] - bounds[r]
+        if n <= 0:
+            raise ValueError("slab boundaries leave rank %d without planes" % r)
+        if world > 1 and n < halo:
+            raise ValueError("rank %d owns %d planes, fewer than the %d halo planes its neighbours need" % (r, n, halo))
+
+
 def validate_slabs(Z, world, halo):
     """Raise -- identically on every rank, BEFORE any collective is entered -- if the partition cannot work: a rank without planes,
     or a slab thinner than the halo its neighbour needs from it (exchange_halos would otherwise die inside a collective while the

@@ -120,7 +120,11 @@ int dfusion_project_and_remove(const uint16_t *dists_in_dev, size_t in_pitch, ui
 
 /* device::integrate (internal.hpp:106; tsdf_volume.cu:51-112,141-161): rigid projective TSDF
  * update.  proj = {fx, fy, cx, cy} (device::Projector).  n_updated_dev (nullable) is
- * INCREMENTED by the number of voxels whose update branch (tsdf_volume.cu:91) was taken.       */
+ * INCREMENTED by the number of voxels whose update branch (tsdf_volume.cu:91) was taken.
+ * Scratch: the call owns a launch plan, the chunk starts of every column patch and a max-pyramid of `dists`, in stream-ordered
+ * memory (hipMallocAsync / hipFreeAsync on `stream`; a plain allocation + stream synchronise where the runtime has no stream-ordered
+ * allocator) -- 16 bytes per column and 32-plane chunk, 33 MB at 512^3.  Limit: (columns / 64, rounded up to whole patches) x
+ * (32-plane chunks of the slab) < 2^30, i.e. any volume that fits the device.                                                   */
 int dfusion_integrate(const uint16_t *dists_dev, size_t dists_pitch, int cols, int rows, DfVolume v,
                       const DfSlab *slab, const float vol2cam[12], const float proj[4],
                       unsigned long long *n_updated_dev, dfStream stream);
@@ -210,11 +214,13 @@ int dfusion_warp_index_info(const DfWarpField *wf, unsigned long long *total_ent
  * identical, only faster (fewer distinct index bricks per wave).  0 switches it off (default).                                   */
 int dfusion_warp_set_point_tiling(DfWarpField *wf, int image_cols);
 
-/* Device self-test of the sweep's short arithmetic forms (dfusion_device.h) against the generic ones they replace; no reference
- * counterpart, used by the parity tests.  counts_dev[6] (device, SIX entries) receives mismatch counts: [0] short sqrtf over every f32 of its
- * domain, [1] short f64 reciprocal over every positive normal f32, [2] packed quaternion products on n_random random pairs
- * (specials included), [3] near-unit normalisation on the normalised quaternions among them, [4] how many of those there were,
- * [5] the short fuse division on every finite stored half x 97 weights x (n_random >> 21) tsdf values.  counts_dev: 6 entries.      */
+/* Device self-test of the sweeps' short arithmetic forms (dfusion_device.h) against the generic ones they replace; no reference
+ * counterpart, used by the parity tests.  counts_dev: EIGHT device entries (ABI 2; six in ABI 1), cleared by the call, receive
+ * mismatch counts: [0] short sqrtf over every f32 of its domain, [1] short f64 reciprocal over every positive normal f32, [2] packed
+ * quaternion products on n_random random pairs (specials included), [3] near-unit normalisation on the normalised quaternions among
+ * them, [4] how many of those there were, [5] the short fuse division on every finite stored half x 97 weights x (n_random >> 21)
+ * tsdf values, [6] the projective sample -- tsdf_sample_fast and the two-stage saturation form of the rigid sweep -- against the
+ * generic statements on n_random positions inside the forms' domain and on its edges, [7] how many of those samples updated.        */
 int dfusion_selftest_exact_forms(unsigned long long n_random, unsigned long long *counts_dev, dfStream stream);
 
 /* Validation switches of dfusion_integrate, so that tests can assert the volumes are identical with and without them (process-wide,

@@ -302,6 +302,26 @@ def test_cxx_zslab_rccl_path(tmp_path, with_nodes):
         z0 = r_ * cfg.dims[2] // 4
         lo, hi = max(0, z0 - halo), min(cfg.dims[2], z0 + cfg.dims[2] // 4 + halo)
         assert planes.shape[0] == hi - lo and np.array_equal(planes, vol[lo:hi])
+    # work-balanced (unequal) slabs: ZSlabComm::slabBounds gives the boundaries sharded.slab_bounds gives, and shards cut there
+    # still equal the unsharded volume
+    w = sharded.frustum_plane_weights(cfg.dims, cfg.size, sc.pose, sc.cam_poses[0], cfg.intr, cfg.cols, cfg.rows, depth_mm=sc.depths[0],
+                                      trunc=sc.trunc, margin=0.1, samples=16) * np.linspace(0.05, 1.0, cfg.dims[2]) ** 3
+    wf_ = str(tmp_path / "weights.f64")
+    w.astype(np.float64).tofile(wf_)
+    for world in (2, 4):
+        want = sharded.slab_bounds(cfg.dims[2], world, halo, w)
+        r = subprocess.run([build.HOST_ZSLAB_APP, "bounds", str(world), str(halo), wf_], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and [int(x) for x in r.stdout.strip().split(",")] == want, (r.stdout, want)
+    bounds = sharded.slab_bounds(cfg.dims[2], 4, halo, w)
+    assert bounds != sharded.slab_bounds(cfg.dims[2], 4)
+    for r_ in range(4):
+        fout = str(tmp_path / ("slabb%d.bin" % r_))
+        r = subprocess.run(base + [fout, str(tmp_path / "unused_id"), "recompute", "slab=%d/4" % r_, "bounds=" + ",".join(str(b) for b in bounds)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        planes = np.fromfile(fout, np.uint8)[2 * npx * 16:].view(np.uint32).reshape(-1, cfg.dims[1], cfg.dims[0])
+        lo, hi = max(0, bounds[r_] - halo), min(cfg.dims[2], bounds[r_ + 1] + halo)
+        assert planes.shape[0] == hi - lo and np.array_equal(planes, vol[lo:hi])
 
 
 def test_cxx_reference_warp_test_suites():

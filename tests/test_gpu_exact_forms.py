@@ -10,12 +10,15 @@ pytestmark = pytest.mark.gpu
 
 
 def test_short_forms_equal_generic_forms_on_every_input():
-    counts = torch.zeros(6, dtype=torch.int64, device="cuda")
+    counts = torch.zeros(8, dtype=torch.int64, device="cuda")
     capi.check(capi.lib().dfusion_selftest_exact_forms(1 << 27, counts.data_ptr(), None))
     torch.cuda.synchronize()
-    sqrt_bad, rcp_bad, qmul_bad, unit_bad, unit_seen, fuse_bad = [int(c) for c in counts.cpu()]
+    sqrt_bad, rcp_bad, qmul_bad, unit_bad, unit_seen, fuse_bad, sample_bad, sample_upd = [int(c) for c in counts.cpu()]
     assert sqrt_bad == 0          # every finite f32 >= 2^-96 (1.8e9 values)
     assert rcp_bad == 0           # every positive normal f32 as the f64 denominator (2.1e9 values)
     assert qmul_bad == 0          # 2 x 1.3e8 random quaternion products, zeros / infinities / NaNs / denormals included
     assert unit_bad == 0 and unit_seen > (1 << 24)      # second normalisation of already normalised quaternions
     assert fuse_bad == 0          # the fuse division: every finite stored half x 97 weights x 64 tsdf values (4e8 cases)
+    # the projective sample: shared-reciprocal divisions, short sqrtf, one-compare pixel test, and the rigid sweep's saturation
+    # decision on the approximate root -- verdicts and tsdf bits equal to the generic statements, domain edges included
+    assert sample_bad == 0 and sample_upd > (1 << 20)

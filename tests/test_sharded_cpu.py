@@ -39,7 +39,7 @@ def _unsharded(sc):
     return vol, p, n
 
 
-def _worker(rank, world, port, recompute_halo):
+def _worker(rank, world, port, recompute_halo, balanced=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -47,7 +47,21 @@ def _worker(rank, world, port, recompute_halo):
         sc = Scene(CFG, n_frames=FRAMES)
         X, Y, Z = CFG.dims
         halo = sharded.halo_planes(sc.trunc, CFG.raycast_step_factor, CFG.gradient_delta_factor, float(sc.vs[2]))
-        z0, zn = sharded.slab_range(Z, rank, world)
+        if balanced:                                   # work-balanced boundaries: decided on rank 0 from the first frame, broadcast
+            bt = torch.zeros(world + 1, dtype=torch.int64)
+            if rank == 0:
+                w = sharded.frustum_plane_weights(CFG.dims, CFG.size, sc.pose, sc.cam_poses[0], CFG.intr, CFG.cols, CFG.rows,
+                                                  depth_mm=sc.depths[0], trunc=sc.trunc, margin=0.1, samples=16)
+                assert w.shape == (Z,) and (w > 0).all()
+                w = w * np.linspace(0.05, 1.0, Z) ** 3     # (this small scene is nearly uniform in depth: make the far planes dear)
+                bt.copy_(torch.tensor(sharded.slab_bounds(Z, world, halo, w), dtype=torch.int64))
+            dist.broadcast(bt, 0)
+            bounds = [int(v) for v in bt]
+            sharded.validate_bounds(bounds, Z, halo)
+            assert bounds != sharded.slab_bounds(Z, world)          # the scene really asks for unequal slabs
+            z0, zn = bounds[rank], bounds[rank + 1] - bounds[rank]
+        else:
+            z0, zn = sharded.slab_range(Z, rank, world)
         lo, hi = max(0, z0 - halo), min(Z, z0 + zn + halo)
         slab = O.make_slab(lo, hi - lo, z0, zn)
         slab_int = O.make_slab(lo, hi - lo, lo, hi - lo) if recompute_halo else slab     # own := stored planes for the integrate
@@ -97,6 +111,26 @@ def test_zslab_pipeline_over_gloo(world, recompute_halo):
     """halo-recompute: every rank integrates its halo planes itself (the integrate is a pure function of the broadcast inputs, so
     the planes come out bit-identical with the neighbour's) -- no halo collective at all; what bench.py does."""
     mp.spawn(_worker, args=(world, _free_port(), recompute_halo), nprocs=world, join=True)
+
+
+def test_zslab_pipeline_over_gloo_with_work_balanced_slabs():
+    """The same pipeline on UNEQUAL slabs (sharded.slab_bounds on frustum_plane_weights: the far ranks get thin slabs), boundaries
+    decided on rank 0 and broadcast: still bit-identical with the unsharded frame."""
+    mp.spawn(_worker, args=(2, _free_port(), True, True), nprocs=2, join=True)      # (48 planes, halo 11: two ranks leave room to move the boundary)
+
+
+def test_slab_bounds_balance_and_respect_the_halo():
+    w = np.concatenate([np.full(32, 0.02), np.linspace(0.05, 1.0, 96)])
+    for world in (2, 3, 4, 8):
+        b = sharded.slab_bounds(128, world, 8, w)
+        sharded.validate_bounds(b, 128, 8)
+        assert all(x % 8 == 0 for x in b) and b == sorted(b)
+        share = [w[b[r]:b[r + 1]].sum() / w.sum() for r in range(world)]
+        assert max(share) < 2.2 / world                    # no rank far above its fair share (8-plane granularity, 8-plane minimum)
+        assert b[1] - b[0] > b[-1] - b[-2]                 # the cheap near planes make a thick slab, the dense far ones a thin one
+    assert sharded.slab_bounds(128, 4) == [0, 32, 64, 96, 128]
+    with pytest.raises(ValueError):
+        sharded.validate_bounds([0, 60, 64, 128], 128, 8)  # a 4-plane slab cannot serve an 8-plane halo
 
 
 def test_single_rank_is_a_no_op_path():

@@ -10,9 +10,7 @@ from dynamicfusion_amd import Intr, TsdfVolume, WarpField, compute_dists, synth,
 name, tags = sys.argv[1], sys.argv[2:]
 libs = {"product": capi.lib()}
 for t in tags:
-    capi._lib = None
-    B.LIB_PATH = os.path.join(REPO, "build", "libdfusion_hip_%s.so" % t); B._stale = lambda: False
-    libs[t] = capi.lib()
+    libs[t] = capi.load(os.path.join(REPO, "build", "libdfusion_hip_%s.so" % t), strict=False)
 def use(t): capi._lib = libs[t]
 use("product")
 cfg = synth.CONFIGS[name]; intr = Intr(*cfg.intr)

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Predicted frame time of the Z-slab sharded frame at N = 1 / 2 / 4 / 8 GPUs -- the table the driver's SCALE run is to be checked
+against (VERDICT r2 #5 ii; no multi-GPU node is available to the build).
+
+Per-rank KERNEL times are measured, on the one GPU there is: for every rank r of N the slab it would own (own planes + the halo planes
+it integrates itself, bench.py's default --halo recompute) is built and timed alone -- warped integrate, march, shade -- and the frame
+takes the SLOWEST rank (the far slabs hold most of the frustum).  COLLECTIVE times are a model, stated here so that it can be wrong in a
+checkable way:
+    t(collective) = launches * T_LAUNCH + steps * T_HOP + bytes_on_the_busiest_link / LINK_GBPS
+with xGMI ~153 GB/s per link and direction pair (guide), of which a ring step sustains LINK_GBPS = 100; T_HOP = 5 us per ring step
+(RCCL's LL/LL128 protocols for messages of a few MB), T_LAUNCH = 15 us per collective call (host enqueue + kernel start):
+    broadcast  (depth + transforms, 0.68 MB):  N - 1 ring steps, bytes = size
+    all_reduce MIN of the int64 keys (2.46 MB): 2 (N - 1) steps, bytes = 2 (N - 1) / N * size
+    reduce SUM of points + normals to rank 0 (9.83 MB): N - 1 steps, bytes = size
+Usage:  python tools/scale_model.py [CONFIG] [balanced|uniform]     (prints a markdown table, writes gpurun_out/scale_model_<cfg>_<kind>.json)
+`balanced` (bench.py's default): slab boundaries from sharded.slab_bounds on frustum_plane_weights; `uniform`: equal plane counts.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
+from dynamicfusion_amd import Intr, TsdfVolume, WarpField, compute_dists, sharded, synth, upload_u16  # noqa: E402
+
+T_LAUNCH, T_HOP, LINK_GBPS = 15e-6, 5e-6, 100.0
+
+
+def collective(kind, size, n):
+    if n == 1:
+        return 0.0
+    if kind == "broadcast":
+        steps, b = n - 1, size
+    elif kind == "all_reduce":
+        steps, b = 2 * (n - 1), 2.0 * (n - 1) / n * size
+    else:
+        steps, b = n - 1, size
+    return T_LAUNCH + steps * T_HOP + b / (LINK_GBPS * 1e9)
+
+
+def timeit(fn, n=10):
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "512"
+    cfg = synth.CONFIGS[name]; intr = Intr(*cfg.intr)
+    X, Y, Z = cfg.dims
+    vs_z = cfg.size / Z
+    halo = sharded.halo_planes(max(cfg.trunc_dist, 2.1 * vs_z), cfg.raycast_step_factor, cfg.gradient_delta_factor, vs_z)
+    dists = compute_dists(upload_u16(synth.depth_frame(cfg, 0)), intr)
+    cam = synth.camera_pose(cfg, 1)
+    pos, sigma = synth.make_nodes(cfg)
+    dq = torch.from_numpy(synth.node_transforms(cfg, 1)).cuda()
+    px = cfg.rows * cfg.cols
+    sizes = {"broadcast": px * 2 + cfg.nodes * 32, "all_reduce": px * 8, "reduce": px * 32}
+    wts = sharded.frustum_plane_weights(cfg.dims, cfg.size, cfg.volume_pose, synth.camera_pose(cfg, 0), cfg.intr, cfg.cols, cfg.rows,
+                                        depth_mm=synth.depth_frame(cfg, 0), trunc=max(cfg.trunc_dist, 2.1 * vs_z), margin=0.3)
+    kind = sys.argv[2] if len(sys.argv) > 2 else "balanced"
+    rows = []
+    for n in (1, 2, 4, 8):
+        worst = {"integrate": 0.0, "march": 0.0, "shade": 0.0, "sum": 0.0}
+        per_rank = []
+        bounds = sharded.slab_bounds(Z, n, halo, wts if (kind == "balanced" and n > 1) else None)
+        for r in range(n):
+            z0, zn = bounds[r], bounds[r + 1] - bounds[r]
+            vol = TsdfVolume(cfg.dims, slab=(z0, zn, halo if n > 1 else 0))
+            vol.setSize([cfg.size] * 3); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setPose(cfg.volume_pose)
+            vol.setRaycastStepFactor(cfg.raycast_step_factor); vol.setGradientDeltaFactor(cfg.gradient_delta_factor)
+            vol.clear()
+            vint = vol.owning_stored_planes() if n > 1 else vol
+            wf = WarpField(k=cfg.k); wf.init(pos, sigma=sigma, transforms=synth.node_transforms(cfg, 0)); wf.ensure_index(vint, cfg.k)
+            wf.set_transforms(dq)
+            for _ in range(3):
+                vint.integrate_warped(dists, cam, intr, wf, sync=False)
+            keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device="cuda")
+            out = torch.empty((2, cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
+            t_i = timeit(lambda: (wf.set_transforms(dq), vint.integrate_warped(dists, cam, intr, wf, sync=False)))
+            t_m = timeit(lambda: vol.raycast_march(cam, intr, keys, r))
+            t_s = timeit(lambda: vol.raycast_shade(cam, intr, keys, out[0], out[1]))
+            per_rank.append((t_i, t_m, t_s))
+            if t_i + t_m + t_s > worst["sum"]:
+                worst = {"integrate": t_i, "march": t_m, "shade": t_s, "sum": t_i + t_m + t_s}
+            del wf, vol, vint
+            torch.cuda.empty_cache()
+        comm = {k: collective(k, sizes[k], n) for k in sizes}
+        t_frame = worst["sum"] + sum(comm.values())
+        rows.append({"n": n, "halo": halo if n > 1 else 0, "slabs": kind, "bounds": bounds, "kernels_ms": {k: 1e3 * v for k, v in worst.items()},
+                     "collectives_ms": {k: 1e3 * v for k, v in comm.items()}, "frame_ms": 1e3 * t_frame, "frames_per_s": 1.0 / t_frame,
+                     "per_rank_integrate_ms": [1e3 * p[0] for p in per_rank]})
+    base = rows[0]["frames_per_s"]
+    print("| N | planes swept by the slowest rank's kernels: integrate / march / shade (ms, measured on one GPU) | broadcast / all_reduce(MIN) / reduce(SUM) (ms, model) | frame (ms) | frames/s | speed-up |")
+    print("|---|---|---|---|---|---|")
+    for r in rows:
+        k, c = r["kernels_ms"], r["collectives_ms"]
+        print("| %d | %.3f / %.3f / %.3f | %.3f / %.3f / %.3f | %.3f | %.0f | %.2fx |" % (
+            r["n"], k["integrate"], k["march"], k["shade"], c["broadcast"], c["all_reduce"], c["reduce"], r["frame_ms"], r["frames_per_s"],
+            r["frames_per_s"] / base))
+    for r in rows:
+        print("N = %d (%s slabs %s) integrate per rank (ms):" % (r["n"], kind, r["bounds"]), " ".join("%.3f" % v for v in r["per_rank_integrate_ms"]))
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    json.dump({"config": name, "model": {"T_LAUNCH_us": T_LAUNCH * 1e6, "T_HOP_us": T_HOP * 1e6, "LINK_GBPS": LINK_GBPS, "bytes": sizes},
+               "rows": rows}, open(os.path.join(REPO, "gpurun_out", "scale_model_%s_%s.json" % (name, kind)), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
