@@ -13,7 +13,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libdfusion_hip.so")
 
 SOURCES = ["dfusion_volume.hip", "dfusion_warp.hip", "dfusion_raycast.hip", "dfusion_frontend.hip", "dfusion_solver.hip", "dfusion_selftest.hip"]
-HEADERS = ["dfusion_device.h", "dfusion_internal.h", "dfusion_nanoflann.h", "dfusion_pyramid.h", os.path.join(REPO_DIR, "include", "dfusion.h")]
+HEADERS = ["dfusion_device.h", "dfusion_internal.h", "dfusion_nanoflann.h", "dfusion_pyramid.h", "dfusion_warp_blocks.h", os.path.join(REPO_DIR, "include", "dfusion.h")]
 
 # -ffp-contract=off: fused multiply-adds only where the reference writes __fmaf_rn (explicit fmaf);
 # that is what makes the kernels bit-comparable with the IEEE CPU oracle.

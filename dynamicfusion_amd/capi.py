@@ -34,6 +34,8 @@ DF_WARP_NO_LDS = 8
 DF_WARP_NO_PIPELINE = 16
 DF_WARP_NO_ZERO_SKIP = 32
 DF_WARP_NO_DEPTH_PYRAMID = 64
+DF_WARP_NO_BLOCK_MODEL = 128
+DF_WARP_BLOCK_MODEL_NOW = 256
 DF_INDEX_VOXEL_TABLE = 1
 DF_INDEX_WEIGHT_TABLE = 2
 

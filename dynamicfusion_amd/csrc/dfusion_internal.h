@@ -72,4 +72,8 @@ struct DfWarpField {
     DfNfNode* nf_nodes; uint16_t* nf_vpos; size_t nf_nodes_cap, nf_vpos_cap; bool nf_ok; int nf_depth;
     // pipelined warped sweep: the launch plan (verdict masks of the strip items, the alive ones sorted by work), dfusion_warp.hip
     unsigned long long* plan_mask; unsigned int* plan_list; unsigned int* plan_hist; size_t plan_cap; int plan_phase;
+    // block blend models of the weight tables (dfusion_warp_blocks.h): entry-major [DF_BM_NU][bm_cap blocks] node ids, {mid, half width}
+    // half pairs of the normalised and of the raw weights, entry counts, and the frame's verdict bytes.
+    // bm_state: 0 = the tables have not been swept yet, 1 = swept once, 2 = models built
+    uint16_t* bm_idx; uint32_t* bm_lam; uint32_t* bm_w; uint8_t* bm_cnt; uint8_t* bm_alive; size_t bm_cap; int bm_state;
 };

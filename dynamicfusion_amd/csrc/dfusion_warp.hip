@@ -88,6 +88,7 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
     (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids); (void)hipFree(wf->tile_wmax);
+    (void)hipFree(wf->bm_idx); (void)hipFree(wf->bm_lam); (void)hipFree(wf->bm_w); (void)hipFree(wf->bm_cnt); (void)hipFree(wf->bm_alive);
     (void)hipFree(wf->nf_nodes); (void)hipFree(wf->nf_vpos); (void)hipFree(wf->pyr_mem);
     (void)hipFree(wf->plan_mask); (void)hipFree(wf->plan_list); (void)hipFree(wf->plan_hist);
     free(wf);
@@ -162,7 +163,7 @@ extern "C" int dfusion_warp_set_nodes(DfWarpField* wf, const float* pos, const f
     if (rc) return rc;
     wf->M = M;
     wf->index_valid = false;
-    wf->tab_valid = false; wf->w_tab_valid = false;
+    wf->tab_valid = false; wf->w_tab_valid = false; wf->bm_state = 0;
     rc = df_warp_pack(wf, pos, dq, sigma, (hipStream_t)stream);
     if (rc) return rc;
     return df_warp_build_tie_tree(wf, (hipStream_t)stream);
@@ -870,6 +871,9 @@ struct DfWarpedArgs {
 #endif
     // max over the voxels of each table tile of sum_i w_i (written by the table build, frame-invariant); null = no zero-weight test
     float* tile_wmax;
+    // this frame's verdicts of the block blend models (dfusion_warp_blocks.h), one byte per 8 x 8 x 8 block of the table's planes,
+    // x fastest; null = none.  bm_nbx / bm_nby: blocks per row / column (whole table tiles)
+    const uint8_t* bm_alive; int bm_nbx, bm_nby;
 };
 // A tile is ZERO-WEIGHT for a frame when tile_wmax * max_j |rot_j| < 2^-76: every component of every voxel's blend sum
 // sum_i w_i rot_i is then below 2^-75 in magnitude (the 2x margin covers the rounding of the sums), its square below 2^-150
@@ -1014,6 +1018,8 @@ __device__ __forceinline__ bool df_tile_culled(const DfWarpedArgs& a, f3 c, floa
     }
     return out;
 }
+
+#include "dfusion_warp_blocks.h"
 
 // blend -> transform -> project -> fuse for one voxel; returns 1 if the update branch was taken
 template <int K>
@@ -1429,6 +1435,9 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
                 wk = fminf(wk, wmax * 1.0001f);                            // |sum w_i t_i| <= (sum w_i) max |t_i|: far from the nodes the blend barely translates
             }
             keep = keep && !df_tile_culled(a, c, wk);
+            // the block's blend model, where there is one: the box of its warped voxels instead of a ball around the unwarped centre
+            if (keep && a.bm_alive)
+                keep = a.bm_alive[((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3)] != 0;
         }
         m = __builtin_amdgcn_ballot_w64(keep);
         if (a.n_swept) {                                                   // (measurement hook: what the sweep will put through the warp)
@@ -1688,6 +1697,39 @@ extern "C" int dfusion_debug_warp_counters(unsigned long long* swept_dev)
     return DF_OK;
 }
 
+// Block blend models (dfusion_warp_blocks.h) for the pipelined sweep: built from the weight tables the SECOND time a sweep uses them
+// (a node set that changes every frame never pays for models it would use once; `now` builds at the first use), then one verdict
+// pass per frame ahead of the launch plan.
+static int df_block_models(DfWarpField* wf, DfWarpedArgs& a, int k, bool now, hipStream_t st)
+{
+    const int nbx = a.tab_ntx * (DF_TAB_TX / 8), nby = a.tab_nty * (DF_TAB_TY / 8), nbz = wf->tab_zn / 8;
+    const size_t nblk = (size_t)nbx * nby * nbz;
+    if (nblk == 0 || (k != 8 && k != 4)) return DF_OK;
+    if (wf->bm_state < 2) {
+        if (wf->bm_state == 0 && !now) { wf->bm_state = 1; return DF_OK; }
+        if (nblk > wf->bm_cap) {
+            (void)hipFree(wf->bm_idx); (void)hipFree(wf->bm_lam); (void)hipFree(wf->bm_w); (void)hipFree(wf->bm_cnt); (void)hipFree(wf->bm_alive);
+            wf->bm_idx = nullptr; wf->bm_lam = nullptr; wf->bm_w = nullptr; wf->bm_cnt = nullptr; wf->bm_alive = nullptr; wf->bm_cap = 0;
+            DF_HIP(hipMalloc((void**)&wf->bm_idx, nblk * DF_BM_NU * sizeof(uint16_t)));
+            DF_HIP(hipMalloc((void**)&wf->bm_lam, nblk * DF_BM_NU * sizeof(uint32_t)));
+            DF_HIP(hipMalloc((void**)&wf->bm_w, nblk * DF_BM_NU * sizeof(uint32_t)));
+            DF_HIP(hipMalloc((void**)&wf->bm_cnt, nblk));
+            DF_HIP(hipMalloc((void**)&wf->bm_alive, nblk));
+            wf->bm_cap = nblk;
+        }
+        const dim3 grid((unsigned)((nblk + 3) / 4));
+        if (k == 8) hipLaunchKernelGGL(df_block_model_kernel<8>, grid, dim3(256), 0, st, a, nbx, nby, nbz, wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt);
+        else hipLaunchKernelGGL(df_block_model_kernel<4>, grid, dim3(256), 0, st, a, nbx, nby, nbz, wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt);
+        DF_LAUNCH_CHECK();
+        wf->bm_state = 2;
+    }
+    hipLaunchKernelGGL(df_block_alive_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, a, wf->rot, wf->node_t, nbx, nby, nbz,
+                       wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->bm_alive);
+    DF_LAUNCH_CHECK();
+    a.bm_alive = wf->bm_alive; a.bm_nbx = nbx; a.bm_nby = nby;
+    return DF_OK;
+}
+
 extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
                                         const float vol2world[12], const float world2cam[12], const float proj[4],
                                         DfWarpField* wf, int k, unsigned flags, unsigned long long* n_updated, dfStream stream)
@@ -1814,6 +1856,10 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
                 DF_HIP(hipMemsetAsync(wf->plan_hist, 0, 2 * 128 * sizeof(unsigned int), st));
                 wf->plan_phase = 0;
             }
+            if (a.cull && !(flags & DF_WARP_NO_BLOCK_MODEL)) {
+                int rc = df_block_models(wf, a, k, (flags & DF_WARP_BLOCK_MODEL_NOW) != 0, st);
+                if (rc) return rc;
+            }
             unsigned int* cnt = wf->plan_hist + 128 * wf->plan_phase;
             unsigned int* cnt_next = wf->plan_hist + 128 * (wf->plan_phase ^ 1);
             hipLaunchKernelGGL(df_sweep_plan_kernel, dim3((n_items + DF_PLAN_WG / 64 - 1) / (DF_PLAN_WG / 64)), dim3(DF_PLAN_WG), 0, st, a, tiles_x, tiles_y, n_items, wf->plan_mask, cnt,
@@ -1905,5 +1951,6 @@ static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab
     DF_LAUNCH_CHECK();
     DF_HIP(hipStreamSynchronize(st));
     wf->tab_z0 = tz0; wf->tab_zn = tzn; wf->tab_k = k; wf->tab_valid = true; wf->w_tab_valid = weights;
+    wf->bm_state = 0;                                                      // the block models describe the previous tables
     return DF_OK;
 }

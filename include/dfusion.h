@@ -85,6 +85,11 @@ enum {
                                  normalisation divides by zero (they cannot update); validation switch  */
 #define DF_WARP_NO_DEPTH_PYRAMID 64u /* cull against the image-wide maximum of dists only, not against the maximum
                                  over the pixels a tile can project to; validation switch                  */
+#define DF_WARP_NO_BLOCK_MODEL 128u /* launch plan from the ball test alone: do not build / use the per-block blend models
+                                 (bounds of each 8x8x8 block's blend weights, made from the weight table the second
+                                 time a sweep uses it; 10 bytes x 16 per block); validation switch             */
+#define DF_WARP_BLOCK_MODEL_NOW 256u /* build the block models at the FIRST sweep over a new weight table (default:
+                                 the second, so that a node set that changes every frame never pays for them)   */
 /* flags for dfusion_warp_build_index */
 #define DF_INDEX_VOXEL_TABLE 1u /* also cache the exact k-NN of EVERY voxel of the slab in HBM:
                                    k * 2 bytes per voxel (2 GiB at 512^3, k = 8) -- the per-frame

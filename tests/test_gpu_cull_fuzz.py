@@ -1,6 +1,6 @@
-"""Randomised stress of the two result-identical culls: the sweeps' launch plans (df_sweep_plan_kernel: ball around the tile centre,
-frustum side planes, distance bound against the max-pyramid of dists; df_rigid_plan_kernel: the patch's box against the same) must
-never drop a voxel that updates.  Random camera poses (inside / outside / beside the volume, tilted), random volume poses, depth
+"""Randomised stress of the result-identical culls: the sweeps' launch plans (df_sweep_plan_kernel: ball around the tile centre,
+frustum side planes, distance bound against the max-pyramid of dists, and the per-block blend models' boxes of dfusion_warp_blocks.h;
+df_rigid_plan_kernel: the patch's box against the same) must never drop a voxel that updates.  Random camera poses (inside / outside / beside the volume, tilted), random volume poses, depth
 images made of random blocks of near / far / invalid values, strong node motions: the volume with the cull must equal the volume
 without it, bit for bit, update counts included.  (The no-cull sweeps are themselves compared with the oracle elsewhere.)"""
 import numpy as np
@@ -75,7 +75,7 @@ def test_rigid_plan_never_drops_an_update(seed):
         assert np.array_equal(res[0][0], r[0]) and res[0][1] == r[1]
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(24))
 def test_warped_plan_never_drops_an_update(seed):
     rng = np.random.default_rng(500 + seed)
     dims = [(64, 64, 64), (32, 48, 64), (96, 32, 40)][seed % 3]
@@ -94,13 +94,17 @@ def test_warped_plan_never_drops_an_update(seed):
     amp_r, amp_t = [(0.02, 0.005), (0.15, 0.03), (0.5, 0.1)][seed % 3]
     frames = []
     for _ in range(3):
-        dq = synth.dq_from_twist(rng.uniform(-amp_r, amp_r, (M, 3)).astype(F32), rng.uniform(-amp_t, amp_t, (M, 3)).astype(F32))
+        rv, tv = rng.uniform(-amp_r, amp_r, (M, 3)), rng.uniform(-amp_t, amp_t, (M, 3))
+        if seed >= 12:                                        # a coherent motion field (what the block models are tight on) + a little noise
+            rv = rng.uniform(-amp_r, amp_r, 3)[None] + 0.1 * rv; tv = rng.uniform(-amp_t, amp_t, 3)[None] + 0.1 * tv
+        dq = synth.dq_from_twist(rv.astype(F32), tv.astype(F32))
         frames.append((random_pose(rng, centre, 0.0 if seed % 5 == 0 else 0.3 * size, 2.2 * size, 0.5),
                        random_depth(rng, cols, rows, 300, int(3500 * size)), dq))
     wf = WarpField(k=k, voxel_table=(seed % 6 != 5))
     wf.init(pos.astype(F32), sigma=sigma, transforms=frames[0][2])
     res = []
-    for kw in (dict(), dict(depth_pyramid=False), dict(cull=False)):
+    # block models from the first sweep on / by the library's policy (second sweep) / never; image-wide depth bound; no cull at all
+    for kw in (dict(block_model="now"), dict(), dict(block_model=False), dict(depth_pyramid=False, block_model="now"), dict(cull=False)):
         v = TsdfVolume(dims); v.setSize(list(ext)); v.setTruncDist(0.04); v.setMaxWeight(64); v.setPose(vol_pose)
         n = torch.zeros(1, dtype=torch.int64, device="cuda")
         for cam, depth, dq in frames:

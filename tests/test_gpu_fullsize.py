@@ -62,7 +62,7 @@ def test_full_size_properties_and_sampled_oracle(name):
     n_upd = torch.zeros(1, dtype=torch.int64, device="cuda")
     for f in range(2):
         wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
-        a.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, n_updated=n_upd, cull=True)
+        a.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, n_updated=n_upd, cull=True, block_model="now")
         b.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, cull=(f == 1), depth_pyramid=False)     # no cull, then the image-wide depth test only
     assert torch.equal(a.data(), b.data())
     weights = (a.data() >> 16) & 0xFFFF

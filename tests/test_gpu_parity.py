@@ -414,3 +414,29 @@ def test_point_queries_through_the_brick_index_equal_brute_force(cfg):
         assert torch.equal(i3, i0[:m]) and torch.equal(d3.view(torch.int32), d0[:m].view(torch.int32))
         assert torch.equal(p3.view(torch.int32), p0[:m].view(torch.int32)) and torch.equal(n3.view(torch.int32), n0[:m].view(torch.int32))
     wf.set_point_tiling(0)
+
+
+def test_block_models_shrink_the_swept_set_and_change_nothing():
+    """dfusion_warp_blocks.h: the per-block blend models must (i) leave the volume and the update count bit-identical and (ii) actually
+    engage -- the launch plan's swept-voxel counter (dfusion_debug_warp_counters) drops.  BASELINE config 1 (256^3, 500 nodes, k = 4)."""
+    cfg = synth.CONFIGS["256"]
+    sc = Scene(cfg, n_frames=3)
+    intr = Intr(*cfg.intr)
+    wf = WarpField(k=cfg.k)
+    wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
+    swept, vols, upd = [], [], []
+    L = capi.lib()
+    for kw in (dict(block_model=False), dict(block_model="now")):
+        v = make_gpu_volume(sc)
+        cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+        capi.check(L.dfusion_debug_warp_counters(cnt[1:].data_ptr()))
+        try:
+            for f in range(3):
+                wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+                v.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, wf, n_updated=cnt[:1], **kw)
+        finally:
+            capi.check(L.dfusion_debug_warp_counters(None))
+        upd.append(int(cnt[0].item())); swept.append(int(cnt[1].item())); vols.append(v.data().clone())
+    print("swept voxels / updated: ball test %.3f, with block models %.3f" % (swept[0] / upd[0], swept[1] / upd[1]))
+    assert torch.equal(vols[0], vols[1]) and upd[0] == upd[1] and upd[0] > 0
+    assert swept[1] < 0.85 * swept[0] and swept[1] >= upd[1]
