@@ -449,6 +449,7 @@ void WarpField::energy_data(const std::vector<Vec3f>& canonical_vertices, const 
     c.upload(canonical_vertices[0].val, n * 3);
     l.upload(live_vertices[0].val, n * 3);
     energy_data(c, l, (int)n);
+    KF_HIP(hipDeviceSynchronize());                       // the solve reads c and l, which are freed on return (hipFree does not wait for it)
 }
 
 std::vector<Vec3f> WarpField::getNodesAsVector() const                 // warp_field.cpp:284-293
