@@ -38,6 +38,7 @@ DF_WARP_NO_BLOCK_MODEL = 128
 DF_WARP_BLOCK_MODEL_NOW = 256
 DF_INDEX_VOXEL_TABLE = 1
 DF_INDEX_WEIGHT_TABLE = 2
+DF_INDEX_TABLES_ON_DEMAND = 4
 
 # every symbol include/dfusion.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -48,7 +49,7 @@ SYMBOLS = [
     "dfusion_warp_points", "dfusion_integrate_warped", "dfusion_copy_bandwidth_probe", "dfusion_read_bandwidth_probe",
     "dfusion_bilateral_filter", "dfusion_truncate_depth", "dfusion_depth_pyramid", "dfusion_compute_normals_mask_depth",
     "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
-    "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate",
+    "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate", "dfusion_release_scratch",
     "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_debug_rigid", "dfusion_debug_rigid_counters", "dfusion_debug_warp_counters",
     "dfusion_render_image_points", "dfusion_render_image_depth", "dfusion_render_tangent_colors",
 ]

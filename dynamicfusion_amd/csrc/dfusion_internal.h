@@ -51,6 +51,7 @@ struct DfWarpField {
     // index
     uint32_t* brick_off; uint32_t* brick_cnt; uint16_t* brick_list; float* brick_thr;
     size_t off_cap, list_cap;
+    uint32_t* scan_tmp; size_t scan_cap;       // tile sums / tile offsets of the brick-count scan
     int bx, by, bz, k_built;
     int geom_dims[3]; float geom_vs[3]; float geom_aff[12];
     float geom_inv[12]; bool geom_inv_ok;      // world -> volume (locates the brick of a query point)
@@ -72,8 +73,15 @@ struct DfWarpField {
     DfNfNode* nf_nodes; uint16_t* nf_vpos; size_t nf_nodes_cap, nf_vpos_cap; bool nf_ok; int nf_depth;
     // pipelined warped sweep: the launch plan (verdict masks of the strip items, the alive ones sorted by work), dfusion_warp.hip
     unsigned long long* plan_mask; unsigned int* plan_list; unsigned int* plan_hist; size_t plan_cap; int plan_phase;
-    // block blend models of the weight tables (dfusion_warp_blocks.h): entry-major [DF_BM_NU][bm_cap blocks] node ids, {mid, half width}
-    // half pairs of the normalised and of the raw weights, entry counts, and the frame's verdict bytes.
-    // bm_state: 0 = the tables have not been swept yet, 1 = swept once, 2 = models built
-    uint16_t* bm_idx; uint32_t* bm_lam; uint32_t* bm_w; uint8_t* bm_cnt; uint8_t* bm_alive; size_t bm_cap; int bm_state;
+    // per 8x8x8 block of the table planes (dfusion_warp_blocks.h; block grid blk_nbx x blk_nby x tab_zn / 8, whole table tiles):
+    //   blk_state  0 = tables not built (DF_INDEX_TABLES_ON_DEMAND), 1 = built, 2 = built and a blend-model record written
+    //   blk_wmax   max over the block's voxels of the weight sum (0 until built)
+    //   blk_alive  this frame's verdicts ; blk_work [2][blk_cap] the frame's build / model work lists ; blk_cnt [2 sets][4] their
+    //   lengths and the build pass's cursor (the sets alternate between passes: each pass zeroes the other one)
+    // block blend models: entry-major [DF_BM_NU][blk_cap] node ids, {mid, half width} half pairs of the normalised and of the raw
+    // weights (allocated with the first model), bm_cnt entry counts
+    uint8_t* blk_state; float* blk_wmax; uint8_t* blk_alive; uint32_t* blk_work; uint32_t* blk_cnt; size_t blk_cap; int blk_phase;
+    uint16_t* bm_idx; uint32_t* bm_lam; uint32_t* bm_w; uint8_t* bm_cnt; size_t bm_cap;
+    bool tab_complete;           // every block's tables are built
+    int tab_sweeps;              // sweeps over the current tables so far (the models are made from the second one on)
 };

@@ -15,6 +15,8 @@
 //     the traffic the algorithmic-bytes figure 8*N_upd counts.
 #include "dfusion_internal.h"
 #include "dfusion_pyramid.h"
+#include <mutex>
+#include <vector>
 #include <math.h>
 #include <stdlib.h>
 #include <stdio.h>
@@ -756,6 +758,34 @@ static bool df_rigid_depth_cull_disabled()
     return off || g_df_rigid_no_depth_cull;
 }
 
+// The rigid integrate's scratch, cached per (device, stream); dfusion_release_scratch() frees every entry.
+struct DfScratchEntry { int device; hipStream_t stream; char* mem; size_t cap; };
+static std::mutex g_df_scratch_mutex;
+static std::vector<DfScratchEntry> g_df_scratch;
+static char* df_rigid_scratch(hipStream_t st, size_t bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_df_scratch_mutex);
+    DfScratchEntry* e = nullptr;
+    for (DfScratchEntry& c : g_df_scratch) if (c.device == dev && c.stream == st) { e = &c; break; }
+    if (!e) { g_df_scratch.push_back(DfScratchEntry{dev, st, nullptr, 0}); e = &g_df_scratch.back(); }
+    if (bytes > e->cap) {
+        if (e->mem) { (void)hipStreamSynchronize(st); (void)hipFree(e->mem); e->mem = nullptr; e->cap = 0; }
+        const size_t cap = bytes + bytes / 4;
+        if (hipMalloc((void**)&e->mem, cap) != hipSuccess) { (void)hipGetLastError(); e->mem = nullptr; return nullptr; }
+        e->cap = cap;
+    }
+    return e->mem;
+}
+extern "C" int dfusion_release_scratch(void)
+{
+    std::lock_guard<std::mutex> lock(g_df_scratch_mutex);
+    for (DfScratchEntry& c : g_df_scratch) if (c.mem) { (void)hipSetDevice(c.device); (void)hipStreamSynchronize(c.stream); (void)hipFree(c.mem); }
+    g_df_scratch.clear();
+    return DF_OK;
+}
+
 extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
                                  const float vol2cam[12], const float proj[4], unsigned long long* n_updated,
                                  dfStream stream)
@@ -803,27 +833,21 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     const unsigned n_items = n_pitems / DF_RIGID_STRIP;                  // strip items (the plan's entries)
     a.tiles = tiles; a.tiles_x = tiles_x; a.plan_items = n_items;
     hipStream_t st = (hipStream_t)stream;
-    // stream-ordered scratch (no state is kept between calls): the launch plan, and for the behind-the-surface test a max-pyramid of
-    // this frame's dists
+    // scratch: the launch plan, and for the behind-the-surface test a max-pyramid of this frame's dists
     const size_t pyr_elems = df_rigid_depth_cull_disabled() ? 0 : df_pyramid_elems(cols, rows);
     if (n_pitems >= (1u << 30)) return DF_E_INVALID;
     const size_t off_cnt = 0, off_bins = 256, off_mask = off_bins + (size_t)DF_RIGID_BINS * n_items * 4;
     const size_t off_pyr = (off_mask + (size_t)n_items * 4 + 15) / 16 * 16;
     const size_t off_starts = (off_pyr + pyr_elems * sizeof(uint16_t) + 255) / 256 * 256;
     const size_t bytes = off_starts + (DF_RIGID_STARTS ? (size_t)n_pitems * 64 * sizeof(float4) : 0);
-    // (where the runtime has no stream-ordered allocator the scratch is a plain allocation released after a stream synchronise:
-    // correct, slower -- the product boxes have it)
-    char* scratch = nullptr;
-    bool scratch_async = true;
-    if (hipMallocAsync((void**)&scratch, bytes, st) != hipSuccess) {
-        (void)hipGetLastError();
-        scratch_async = false;
-        DF_HIP(hipMalloc((void**)&scratch, bytes));
-    }
-    auto release_scratch = [&]() {
-        if (scratch_async) { (void)hipFreeAsync(scratch, st); return; }
-        (void)hipStreamSynchronize(st); (void)hipFree(scratch);
-    };
+    // One scratch buffer per (device, stream), grown on demand and kept: calls on a stream are ordered, so the next call's kernels
+    // cannot start before this call's have finished with it.  (Round 3 tried the runtime's stream-ordered allocator here,
+    // hipMallocAsync / hipFreeAsync per call: in a process that also allocates and frees with hipMalloc / hipFree between the calls --
+    // the host mirror's reference-shaped flow -- one integrate in ~30 then updated a different set of voxels from identical inputs;
+    // with a plain or a kept allocation never, 200 runs each.)
+    char* scratch = df_rigid_scratch(st, bytes);
+    if (!scratch) return (int)hipErrorOutOfMemory;
+    auto release_scratch = [&]() {};
     DfDistsPyramid Py;
     memset(&Py, 0, sizeof(Py));
     int rc = DF_OK;

@@ -88,7 +88,9 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
     (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids); (void)hipFree(wf->tile_wmax);
-    (void)hipFree(wf->bm_idx); (void)hipFree(wf->bm_lam); (void)hipFree(wf->bm_w); (void)hipFree(wf->bm_cnt); (void)hipFree(wf->bm_alive);
+    (void)hipFree(wf->bm_idx); (void)hipFree(wf->bm_lam); (void)hipFree(wf->bm_w); (void)hipFree(wf->bm_cnt);
+    (void)hipFree(wf->scan_tmp);
+    (void)hipFree(wf->blk_state); (void)hipFree(wf->blk_wmax); (void)hipFree(wf->blk_alive); (void)hipFree(wf->blk_work); (void)hipFree(wf->blk_cnt);
     (void)hipFree(wf->nf_nodes); (void)hipFree(wf->nf_vpos); (void)hipFree(wf->pyr_mem);
     (void)hipFree(wf->plan_mask); (void)hipFree(wf->plan_list); (void)hipFree(wf->plan_hist);
     free(wf);
@@ -163,7 +165,7 @@ extern "C" int dfusion_warp_set_nodes(DfWarpField* wf, const float* pos, const f
     if (rc) return rc;
     wf->M = M;
     wf->index_valid = false;
-    wf->tab_valid = false; wf->w_tab_valid = false; wf->bm_state = 0;
+    wf->tab_valid = false; wf->w_tab_valid = false;
     rc = df_warp_pack(wf, pos, dq, sigma, (hipStream_t)stream);
     if (rc) return rc;
     return df_warp_build_tie_tree(wf, (hipStream_t)stream);
@@ -753,8 +755,45 @@ __global__ __launch_bounds__(1024) void df_scan_kernel(const uint32_t* __restric
     if (t == 1023) off[n] = part[1023];
 }
 
+// The same over tiles of DF_SCAN_TILE counts: sums[b] = sum of tile b; then (after df_scan_kernel over the sums) off[i] = tile offset +
+// exclusive scan inside the tile, off[n] = the total.
+#define DF_SCAN_TILE 2048
+__global__ __launch_bounds__(256) void df_scan_sums_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ sums, int n)
+{
+    __shared__ uint32_t part[4];
+    const int base = blockIdx.x * DF_SCAN_TILE;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < DF_SCAN_TILE / 256; ++i) { const int j = base + i * 256 + (int)threadIdx.x; s += j < n ? cnt[j] : 0u; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(256) void df_scan_apply_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ sums_off,
+                                                            uint32_t* __restrict__ off, int n, int ntile)
+{
+    __shared__ uint32_t wsum[4];
+    constexpr int PER = DF_SCAN_TILE / 256;
+    const int first = blockIdx.x * DF_SCAN_TILE + (int)threadIdx.x * PER;       // a thread owns PER consecutive counts
+    uint32_t v[PER], s = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { v[i] = first + i < n ? cnt[first + i] : 0u; s += v[i]; }
+    uint32_t incl = s;                                                          // inclusive scan of the thread sums: wave, then workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t run = sums_off[blockIdx.x] + incl - s;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wsum[w];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { if (first + i < n) off[first + i] = run; run += v[i]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) off[n] = sums_off[ntile];
+}
+
 static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab& s, const float vol2world[12], int k, bool weights,
-                                hipStream_t st);
+                                bool on_demand, hipStream_t st);
 
 extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const DfSlab* slab, const float vol2world[12], int k,
                                         unsigned flags, dfStream stream)
@@ -795,8 +834,19 @@ extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const DfSla
     DF_DISPATCH_K(k, df_brick_index_kernel<K, false><<<grid, dim3(256), 0, st>>>(wf->pos_sigma, wf->M, g, wf->brick_cnt,
                                                                                  (const uint32_t*)nullptr, (uint16_t*)nullptr, wf->brick_thr));
     DF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(df_scan_kernel, dim3(1), dim3(1024), 0, st, wf->brick_cnt, wf->brick_off, (int)nb);
-    DF_LAUNCH_CHECK();
+    {   // exclusive scan of the counts: tile sums, a one-workgroup scan of those, then the tiles (388 us -> 3 short launches at 512^3)
+        const int ntile = (int)((nb + DF_SCAN_TILE - 1) / DF_SCAN_TILE);
+        if ((size_t)ntile + 1 > wf->scan_cap) {
+            (void)hipFree(wf->scan_tmp); wf->scan_tmp = nullptr; wf->scan_cap = 0;
+            DF_HIP(hipMalloc((void**)&wf->scan_tmp, 2 * ((size_t)ntile + 1) * sizeof(uint32_t)));
+            wf->scan_cap = (size_t)ntile + 1;
+        }
+        uint32_t* sums = wf->scan_tmp; uint32_t* sums_off = wf->scan_tmp + wf->scan_cap;
+        hipLaunchKernelGGL(df_scan_sums_kernel, dim3((unsigned)ntile), dim3(256), 0, st, wf->brick_cnt, sums, (int)nb);
+        hipLaunchKernelGGL(df_scan_kernel, dim3(1), dim3(1024), 0, st, sums, sums_off, ntile);
+        hipLaunchKernelGGL(df_scan_apply_kernel, dim3((unsigned)ntile), dim3(256), 0, st, wf->brick_cnt, sums_off, wf->brick_off, (int)nb, ntile);
+        DF_LAUNCH_CHECK();
+    }
     uint32_t total = 0;
     DF_HIP(hipMemcpyAsync(&total, wf->brick_off + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     DF_HIP(hipStreamSynchronize(st));
@@ -829,7 +879,8 @@ extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const DfSla
     wf->tab_valid = false;
     wf->w_tab_valid = false;
     if (flags & (DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE))
-        return df_build_voxel_table(wf, v, sl, vol2world, k, (flags & DF_INDEX_WEIGHT_TABLE) != 0, st);
+        return df_build_voxel_table(wf, v, sl, vol2world, k, (flags & DF_INDEX_WEIGHT_TABLE) != 0,
+                                    (flags & DF_INDEX_TABLES_ON_DEMAND) != 0 && (flags & DF_INDEX_WEIGHT_TABLE) != 0, st);
     return DF_OK;
 }
 
@@ -874,6 +925,9 @@ struct DfWarpedArgs {
     // this frame's verdicts of the block blend models (dfusion_warp_blocks.h), one byte per 8 x 8 x 8 block of the table's planes,
     // x fastest; null = none.  bm_nbx / bm_nby: blocks per row / column (whole table tiles)
     const uint8_t* bm_alive; int bm_nbx, bm_nby;
+    // table build (df_warp_brick_kernel<K, true>): per-block bound on sum_i w_i (same block grid), and -- when the build is driven by a
+    // work list instead of the launch grid -- the list of packed brick coordinates (x | y << 10 | z << 20) and its length
+    float* blk_wmax; const uint32_t* work; const uint32_t* work_cnt; uint32_t* work_cursor;
 };
 // A tile is ZERO-WEIGHT for a frame when tile_wmax * max_j |rot_j| < 2^-76: every component of every voxel's blend sum
 // sum_i w_i rot_i is then below 2^-75 in magnitude (the 2x margin covers the rounding of the sums), its square below 2^-150
@@ -1049,14 +1103,9 @@ __device__ __forceinline__ void df_count_updates(const DfWarpedArgs& a, unsigned
 // BUILD = false: fused with the TSDF update -- no per-voxel memory ("lean" path, re-ranks ~150 candidates per voxel per frame).
 // BUILD = true : writes the per-voxel k-NN (and weight) tables instead; run when node POSITIONS change, not per frame.
 template <int K, bool BUILD>
-__global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a, const DfWarpView W)
+__device__ __forceinline__ void df_warp_brick_body(const DfWarpedArgs& a, const DfWarpView& W, const int bxx, const int byy, const int bzz,
+                                                   float4* s_pos, uint16_t* s_idx, float* s_key)
 {
-    __shared__ float4 s_pos[DF_CAND_CHUNK];
-    __shared__ uint16_t s_idx[DF_CAND_CHUNK];
-
-    const int bxx = blockIdx.x % W.bx;
-    const int byy = blockIdx.x / W.bx;
-    const int bzz = a.bz0 + blockIdx.y;
     const int b = (bzz * W.by + byy) * W.bx + bxx;
 
     const int t = threadIdx.x;
@@ -1084,14 +1133,36 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
     topk_init<K>(bd1, bi1);
     const uint32_t off = W.brick_off[b];
     const uint32_t cnt = W.brick_off[b + 1] - off;
+    // The candidates are visited NEAREST (to the brick's centre) FIRST: the result does not depend on the order (topk_insert places
+    // equal distances by the reference's rule whatever the arrival order), but the cost does -- an insert runs for the whole wave when
+    // any lane needs it, and with the near nodes seen first the lists are final after a third of the candidates and the rest fail the
+    // first compare in every lane.  A chunk is sorted in LDS by a bitonic network over the next power of two (<= 36 steps).
+    const f3 cb = aff_mul(a.vol2world, mk3(((float)(bxx * DF_BRICK) + 3.5f) * a.vsx, ((float)(byy * DF_BRICK) + 3.5f) * a.vsy,
+                                           ((float)(bzz * DF_BRICK) + 3.5f) * a.vsz));
     for (uint32_t base = 0; base < cnt; base += DF_CAND_CHUNK) {
         const int n = (int)min((uint32_t)DF_CAND_CHUNK, cnt - base);
+        unsigned np2 = 2;
+        while ((int)np2 < n) np2 <<= 1;
         __syncthreads();
-        if (t < n) {
-            const uint16_t j = W.brick_list[off + base + t];
-            s_idx[t] = j;
-            s_pos[t] = W.pos_sigma[j];
+        {
+            uint16_t j = 0; float key = __uint_as_float(0x7f800000u);
+            if (t < n) { j = W.brick_list[off + base + t]; const float4 p = W.pos_sigma[j]; key = knn_dist2(cb, p.x, p.y, p.z); key = key == key ? key : 3.0e38f; }
+            s_key[t] = key; s_idx[t] = j;
         }
+        __syncthreads();
+        for (unsigned k2 = 2; k2 <= np2; k2 <<= 1)
+            for (unsigned j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                const unsigned p = (unsigned)t ^ j2;
+                if ((unsigned)t < np2 && p > (unsigned)t) {
+                    const float ka = s_key[t], kb = s_key[p];
+                    if ((ka > kb) == (((unsigned)t & k2) == 0u)) {
+                        s_key[t] = kb; s_key[p] = ka;
+                        const uint16_t ia = s_idx[t]; s_idx[t] = s_idx[p]; s_idx[p] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        if (t < n) s_pos[t] = W.pos_sigma[s_idx[t]];
         __syncthreads();
         for (int c = 0; c < n; ++c) {
             const float4 p = s_pos[c];                 // broadcast ds_read_b128
@@ -1127,6 +1198,8 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
                 const int zl = bzz * DF_BRICK - a.tab_z0;
                 const size_t tile = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty + (byy * DF_BRICK) / DF_TAB_TY) * a.tab_ntx + (bxx * DF_BRICK) / DF_TAB_TX;
                 atomicMax((unsigned int*)&a.tile_wmax[tile], __float_as_uint(wsum));      // non-negative floats order as uints
+                if (a.blk_wmax)
+                    atomicMax((unsigned int*)&a.blk_wmax[((size_t)(zl / 8) * a.bm_nby + byy) * a.bm_nbx + bxx], __float_as_uint(wsum));
             }
         }
     } else {
@@ -1141,6 +1214,32 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
         }
         df_count_updates(a, my_upd);
     }
+}
+
+template <int K, bool BUILD>
+__global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a, const DfWarpView W)
+{
+    __shared__ float4 s_pos[DF_CAND_CHUNK];
+    __shared__ uint16_t s_idx[DF_CAND_CHUNK];
+    __shared__ float s_key[DF_CAND_CHUNK];
+    if (BUILD && a.work) {                                                 // on-demand build: the bricks of a work list, over a resident grid
+        __shared__ uint32_t s_item;                                        // (drawn one at a time: a brick costs 20-80 us, unevenly)
+        const uint32_t n = *a.work_cnt;
+        for (uint32_t round = 0;; ++round) {
+            uint32_t i = blockIdx.x;                                       // the first brick without an atomic (an empty list costs nothing)
+            if (round) {
+                if (threadIdx.x == 0) s_item = atomicAdd(a.work_cursor, 1u) + gridDim.x;
+                __syncthreads();
+                i = s_item;
+            }
+            if (i >= n) break;
+            const uint32_t code = a.work[i];
+            df_warp_brick_body<K, BUILD>(a, W, (int)(code & 1023u), (int)((code >> 10) & 1023u), (int)(code >> 20), s_pos, s_idx, s_key);
+            __syncthreads();
+        }
+        return;
+    }
+    df_warp_brick_body<K, BUILD>(a, W, (int)(blockIdx.x % (unsigned)W.bx), (int)(blockIdx.x / (unsigned)W.bx), a.bz0 + (int)blockIdx.y, s_pos, s_idx, s_key);
 }
 
 // ---- row-tile kernel: the per-frame sweep when the per-voxel tables are cached in HBM.
@@ -1424,21 +1523,9 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
         const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
         const int x0 = tx * DF_ROW_TX + p * 8, y0 = ty * DF_LDS_TY + (int)half * 8;                  // first column of the patch
         bool keep = l < a.zt && max((lt0 + l) * DF_ROW_TZ, a.z_own0) < min((lt0 + l + 1) * DF_ROW_TZ, own1) && x0 < a.X && y0 < a.Y;
-        if (keep && a.cull) {
-            // the patch's own 8 x 8 x 8 voxels of the layer, not the 32 x 16 x 8 tile: a third of the radius
-            const f3 c = aff_mul(a.vol2world, mk3(((float)x0 + 3.5f) * a.vsx, ((float)y0 + 3.5f) * a.vsy,
-                                                  ((float)((lt0 + l) * DF_ROW_TZ) + 0.5f * (DF_ROW_TZ - 1)) * a.vsz));
-            float wk = a.kf;
-            if (a.tile_wmax) {
-                const float wmax = a.tile_wmax[((size_t)(lt0 + l - a.tab_z0 / DF_TAB_TZ) * a.tab_nty + ty) * a.tab_ntx + tx];
-                keep = !(wmax * a.cull[3] < DF_ZERO_WEIGHT);              // zero-weight tile: nothing in it can update
-                wk = fminf(wk, wmax * 1.0001f);                            // |sum w_i t_i| <= (sum w_i) max |t_i|: far from the nodes the blend barely translates
-            }
-            keep = keep && !df_tile_culled(a, c, wk);
-            // the block's blend model, where there is one: the box of its warped voxels instead of a ball around the unwarped centre
-            if (keep && a.bm_alive)
-                keep = a.bm_alive[((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3)] != 0;
-        }
+        // the verdict pass has judged the patch's 8 x 8 x 8 voxels of the layer (df_block_verdict_kernel: zero-weight, ball, blend-model box)
+        if (keep && a.bm_alive)
+            keep = a.bm_alive[((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3)] != 0;
         m = __builtin_amdgcn_ballot_w64(keep);
         if (a.n_swept) {                                                   // (measurement hook: what the sweep will put through the warp)
             unsigned v = keep ? (unsigned)(64 * (min((lt0 + l + 1) * DF_ROW_TZ, own1) - max((lt0 + l) * DF_ROW_TZ, a.z_own0))) : 0u;
@@ -1697,36 +1784,109 @@ extern "C" int dfusion_debug_warp_counters(unsigned long long* swept_dev)
     return DF_OK;
 }
 
-// Block blend models (dfusion_warp_blocks.h) for the pipelined sweep: built from the weight tables the SECOND time a sweep uses them
-// (a node set that changes every frame never pays for models it would use once; `now` builds at the first use), then one verdict
-// pass per frame ahead of the launch plan.
-static int df_block_models(DfWarpField* wf, DfWarpedArgs& a, int k, bool now, hipStream_t st)
+// The arguments of a table build over the current tables (geometry as dfusion_warp_build_index recorded it).
+static DfWarpedArgs df_table_args(const DfWarpField* wf)
+{
+    DfWarpedArgs a;
+    memset(&a, 0, sizeof(a));
+    const int ntx = (wf->geom_dims[0] + DF_TAB_TX - 1) / DF_TAB_TX, nty = (wf->geom_dims[1] + DF_TAB_TY - 1) / DF_TAB_TY;
+    a.w_tab = wf->w_tab_valid ? wf->w_tab : nullptr;
+    a.tile_wmax = wf->w_tab_valid ? wf->tile_wmax : nullptr;
+    a.blk_wmax = wf->w_tab_valid ? wf->blk_wmax : nullptr;
+    a.X = wf->geom_dims[0]; a.Y = wf->geom_dims[1]; a.Z = wf->geom_dims[2];
+    a.z_store0 = wf->tab_z0; a.z_own0 = wf->tab_z0; a.z_own_n = wf->tab_zn;        // every voxel of the covered bricks gets an entry
+    a.vsx = wf->geom_vs[0]; a.vsy = wf->geom_vs[1]; a.vsz = wf->geom_vs[2];
+    a.vol2world = df_aff(wf->geom_aff);
+    a.knn_tab = wf->knn_tab; a.tab_z0 = wf->tab_z0; a.tab_ntx = ntx; a.tab_nty = nty;
+    a.tab_nvox = (size_t)ntx * DF_TAB_TX * nty * DF_TAB_TY * wf->tab_zn;
+    a.bz0 = wf->tab_z0 / DF_BRICK;
+    a.bm_nbx = ntx * (DF_TAB_TX / 8); a.bm_nby = nty * (DF_TAB_TY / 8);
+    return a;
+}
+// Workgroups of a list-driven pass: as many as are resident at once (workgroup i takes entries i, i + grid, ...: a second round of
+// workgroups would start when the first has finished its whole share).  An empty list costs their launch.
+static unsigned df_work_grid(const void* kernel)
+{
+    int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return 512u;
+    return (unsigned)per_cu * (unsigned)prop.multiProcessorCount;
+}
+
+// the build of the bricks on work list 0 (length cnt[0])
+static int df_build_listed(DfWarpField* wf, const uint32_t* cnt, hipStream_t st)
+{
+    DfWarpedArgs b = df_table_args(wf);
+    b.work = wf->blk_work; b.work_cnt = cnt; b.work_cursor = const_cast<uint32_t*>(cnt) + 2;
+    const DfWarpView W = df_view(wf);
+    static unsigned grid[9] = {0};
+    DF_DISPATCH_K(wf->tab_k, {
+        if (!grid[K]) grid[K] = df_work_grid((const void*)df_warp_brick_kernel<K, true>);
+        df_warp_brick_kernel<K, true><<<dim3(grid[K]), dim3(256), 0, st>>>(b, W);
+    });
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+// On-demand tables (DF_INDEX_TABLES_ON_DEMAND) hold only the blocks some sweep's verdict pass has asked for.  A sweep that takes
+// no verdicts (cull switched off, or a kernel other than the pipelined one) needs them all: build what is missing.
+static int df_tables_complete(DfWarpField* wf, hipStream_t st)
+{
+    if (wf->tab_complete) return DF_OK;
+    const DfWarpedArgs b = df_table_args(wf);
+    const int nbz = wf->tab_zn / 8;
+    const size_t nblk = (size_t)b.bm_nbx * b.bm_nby * nbz;
+    uint32_t* cnt = wf->blk_cnt + 4 * wf->blk_phase;
+    uint32_t* cnt_next = wf->blk_cnt + 4 * (wf->blk_phase ^ 1);
+    hipLaunchKernelGGL(df_blocks_unbuilt_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, b.bm_nbx, b.bm_nby, nbz, wf->bx, wf->by,
+                       wf->tab_z0 / 8, wf->blk_state, wf->blk_work, cnt, cnt_next);
+    DF_LAUNCH_CHECK();
+    wf->blk_phase ^= 1;
+    int rc = df_build_listed(wf, cnt, st);
+    if (rc) return rc;
+    wf->tab_complete = true;
+    return DF_OK;
+}
+
+// The verdict pass of the pipelined sweep (dfusion_warp_blocks.h) and the on-demand work it finds: table builds for alive blocks that
+// have none yet, blend models for alive blocks that have tables but no model (from the second sweep over the tables on, so that a node
+// set that changes every frame never pays for models; `now` = from the first).
+static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned flags, hipStream_t st)
 {
     const int nbx = a.tab_ntx * (DF_TAB_TX / 8), nby = a.tab_nty * (DF_TAB_TY / 8), nbz = wf->tab_zn / 8;
     const size_t nblk = (size_t)nbx * nby * nbz;
-    if (nblk == 0 || (k != 8 && k != 4)) return DF_OK;
-    if (wf->bm_state < 2) {
-        if (wf->bm_state == 0 && !now) { wf->bm_state = 1; return DF_OK; }
-        if (nblk > wf->bm_cap) {
-            (void)hipFree(wf->bm_idx); (void)hipFree(wf->bm_lam); (void)hipFree(wf->bm_w); (void)hipFree(wf->bm_cnt); (void)hipFree(wf->bm_alive);
-            wf->bm_idx = nullptr; wf->bm_lam = nullptr; wf->bm_w = nullptr; wf->bm_cnt = nullptr; wf->bm_alive = nullptr; wf->bm_cap = 0;
-            DF_HIP(hipMalloc((void**)&wf->bm_idx, nblk * DF_BM_NU * sizeof(uint16_t)));
-            DF_HIP(hipMalloc((void**)&wf->bm_lam, nblk * DF_BM_NU * sizeof(uint32_t)));
-            DF_HIP(hipMalloc((void**)&wf->bm_w, nblk * DF_BM_NU * sizeof(uint32_t)));
-            DF_HIP(hipMalloc((void**)&wf->bm_cnt, nblk));
-            DF_HIP(hipMalloc((void**)&wf->bm_alive, nblk));
-            wf->bm_cap = nblk;
-        }
-        const dim3 grid((unsigned)((nblk + 3) / 4));
-        if (k == 8) hipLaunchKernelGGL(df_block_model_kernel<8>, grid, dim3(256), 0, st, a, nbx, nby, nbz, wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt);
-        else hipLaunchKernelGGL(df_block_model_kernel<4>, grid, dim3(256), 0, st, a, nbx, nby, nbz, wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt);
-        DF_LAUNCH_CHECK();
-        wf->bm_state = 2;
+    if (nblk == 0 || nblk > wf->blk_cap) return DF_E_INVALID;
+    const bool use_models = !(flags & DF_WARP_NO_BLOCK_MODEL) && (k == 8 || k == 4);
+    const int want_models = !use_models ? 0 : (flags & DF_WARP_BLOCK_MODEL_NOW) ? 2 : wf->tab_sweeps >= 1 ? 1 : 0;
+    if (want_models && nblk > wf->bm_cap) {
+        (void)hipFree(wf->bm_idx); (void)hipFree(wf->bm_lam); (void)hipFree(wf->bm_w); (void)hipFree(wf->bm_cnt);
+        wf->bm_idx = nullptr; wf->bm_lam = nullptr; wf->bm_w = nullptr; wf->bm_cnt = nullptr; wf->bm_cap = 0;
+        DF_HIP(hipMalloc((void**)&wf->bm_idx, nblk * DF_BM_NU * sizeof(uint16_t)));
+        DF_HIP(hipMalloc((void**)&wf->bm_lam, nblk * DF_BM_NU * sizeof(uint32_t)));
+        DF_HIP(hipMalloc((void**)&wf->bm_w, nblk * DF_BM_NU * sizeof(uint32_t)));
+        DF_HIP(hipMalloc((void**)&wf->bm_cnt, nblk));
+        wf->bm_cap = nblk;
     }
-    hipLaunchKernelGGL(df_block_alive_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, a, wf->rot, wf->node_t, nbx, nby, nbz,
-                       wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->bm_alive);
+    uint32_t* cnt = wf->blk_cnt + 4 * wf->blk_phase;
+    uint32_t* cnt_next = wf->blk_cnt + 4 * (wf->blk_phase ^ 1);
+    hipLaunchKernelGGL(df_block_verdict_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, a, wf->rot, wf->node_t, nbx, nby, nbz,
+                       wf->blk_state, wf->blk_wmax, a.tile_wmax != nullptr ? 1 : 0, use_models && wf->bm_cap >= nblk ? 1 : 0, want_models,
+                       wf->tab_complete ? 0 : 1, wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_alive, wf->blk_work, wf->blk_work + wf->blk_cap,
+                       cnt, cnt_next);
     DF_LAUNCH_CHECK();
-    a.bm_alive = wf->bm_alive; a.bm_nbx = nbx; a.bm_nby = nby;
+    wf->blk_phase ^= 1;
+    if (!wf->tab_complete) { int rc = df_build_listed(wf, cnt, st); if (rc) return rc; }
+    if (want_models) {
+        const DfWarpedArgs b = df_table_args(wf);
+        static unsigned g8 = 0, g4 = 0;
+        if (!g8) { g8 = df_work_grid((const void*)df_block_model_kernel<8>); g4 = df_work_grid((const void*)df_block_model_kernel<4>); }
+        if (k == 8) hipLaunchKernelGGL(df_block_model_kernel<8>, dim3(g8), dim3(256), 0, st, b, nbx, nby, nbz, wf->blk_work + wf->blk_cap, cnt + 1,
+                                       wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_state);
+        else hipLaunchKernelGGL(df_block_model_kernel<4>, dim3(g4), dim3(256), 0, st, b, nbx, nby, nbz, wf->blk_work + wf->blk_cap, cnt + 1,
+                                wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_state);
+        DF_LAUNCH_CHECK();
+    }
+    a.bm_alive = wf->blk_alive; a.bm_nbx = nbx; a.bm_nby = nby;
     return DF_OK;
 }
 
@@ -1840,6 +2000,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
         else { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, false, 1>)); }
         DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (!pipe) { int rc = df_tables_complete(wf, st); if (rc) return rc; }
         if (pipe) {
             // the launch plan: verdict masks of all strip items (one wave each), the alive ones sorted by work; then one workgroup per
             // 2 (4) plan entries.  The grid is sized for every strip -- nothing is read back -- and the workgroups past the plan's end
@@ -1856,10 +2017,9 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
                 DF_HIP(hipMemsetAsync(wf->plan_hist, 0, 2 * 128 * sizeof(unsigned int), st));
                 wf->plan_phase = 0;
             }
-            if (a.cull && !(flags & DF_WARP_NO_BLOCK_MODEL)) {
-                int rc = df_block_models(wf, a, k, (flags & DF_WARP_BLOCK_MODEL_NOW) != 0, st);
-                if (rc) return rc;
-            }
+            if (a.cull) { int rc = df_block_verdicts(wf, a, k, flags, st); if (rc) return rc; }
+            else { int rc = df_tables_complete(wf, st); if (rc) return rc; }
+            ++wf->tab_sweeps;
             unsigned int* cnt = wf->plan_hist + 128 * wf->plan_phase;
             unsigned int* cnt_next = wf->plan_hist + 128 * (wf->plan_phase ^ 1);
             hipLaunchKernelGGL(df_sweep_plan_kernel, dim3((n_items + DF_PLAN_WG / 64 - 1) / (DF_PLAN_WG / 64)), dim3(DF_PLAN_WG), 0, st, a, tiles_x, tiles_y, n_items, wf->plan_mask, cnt,
@@ -1890,6 +2050,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         }
         kern<<<grid, dim3(wide ? 1024 : 512), lds, st>>>(a, W, tiles_x);
     } else if (use_tab) {
+        { int rc = df_tables_complete(wf, st); if (rc) return rc; }
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_ROW_TY - 1) / DF_ROW_TY;
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
         a.bz0 = zt_lo;
@@ -1906,15 +2067,18 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     return DF_OK;
 }
 
-// Per-voxel k-NN (and weight) tables for planes [z_own0, z_own0 + z_own_n) (this rank's slab).
+// Per-voxel k-NN (and weight) tables for planes [z_own0, z_own0 + z_own_n) (this rank's slab): allocated here; built here (every brick)
+// or, with `on_demand`, block by block as the sweeps' verdict passes ask for them.
 static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab& s, const float vol2world[12], int k, bool weights,
-                                hipStream_t st)
+                                bool on_demand, hipStream_t st)
 {
+    (void)vol2world;
     if (s.z_own_n == 0) return DF_OK;
     // table planes are brick-aligned so that both voxels of a build thread (z, z+4) index inside it
     const int bz_lo = s.z_own0 / DF_BRICK, bz_hi = (s.z_own0 + s.z_own_n - 1) / DF_BRICK;
     const int tz0 = bz_lo * DF_BRICK, tzn = (bz_hi - bz_lo + 1) * DF_BRICK;
     const int ntx = (v.dims[0] + DF_TAB_TX - 1) / DF_TAB_TX, nty = (v.dims[1] + DF_TAB_TY - 1) / DF_TAB_TY;
+    if (ntx * (DF_TAB_TX / 8) > 1023 || nty * (DF_TAB_TY / 8) > 1023 || bz_hi > 4095) return DF_E_INVALID;    // packed brick coordinates of the work lists
     const size_t nvox = (size_t)ntx * DF_TAB_TX * nty * DF_TAB_TY * tzn;          // padded to whole tiles
     const size_t need = nvox * k;
     if (need > wf->knn_tab_cap) {
@@ -1936,21 +2100,29 @@ static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab
         }
         DF_HIP(hipMemsetAsync(wf->tile_wmax, 0, ntile * sizeof(float), st));
     }
-    DfWarpedArgs a;
-    memset(&a, 0, sizeof(a));
-    a.w_tab = weights ? wf->w_tab : nullptr;
-    a.tile_wmax = weights ? wf->tile_wmax : nullptr;
-    a.X = v.dims[0]; a.Y = v.dims[1]; a.Z = v.dims[2];
-    a.z_store0 = tz0; a.z_own0 = tz0; a.z_own_n = tzn;        // every voxel of the covered bricks gets an entry
-    a.vsx = v.voxel_size[0]; a.vsy = v.voxel_size[1]; a.vsz = v.voxel_size[2];
-    a.vol2world = df_aff(vol2world);
-    a.knn_tab = wf->knn_tab; a.tab_z0 = tz0; a.tab_nvox = nvox; a.tab_ntx = ntx; a.tab_nty = nty; a.bz0 = bz_lo;
+    const size_t nblk = (size_t)ntx * (DF_TAB_TX / 8) * nty * (DF_TAB_TY / 8) * (tzn / 8);
+    if (nblk > wf->blk_cap) {
+        (void)hipFree(wf->blk_state); (void)hipFree(wf->blk_wmax); (void)hipFree(wf->blk_alive); (void)hipFree(wf->blk_work);
+        wf->blk_state = nullptr; wf->blk_wmax = nullptr; wf->blk_alive = nullptr; wf->blk_work = nullptr; wf->blk_cap = 0;
+        DF_HIP(hipMalloc((void**)&wf->blk_state, nblk));
+        DF_HIP(hipMalloc((void**)&wf->blk_wmax, nblk * sizeof(float)));
+        DF_HIP(hipMalloc((void**)&wf->blk_alive, nblk));
+        DF_HIP(hipMalloc((void**)&wf->blk_work, 2 * nblk * sizeof(uint32_t)));
+        wf->blk_cap = nblk;
+    }
+    if (!wf->blk_cnt) DF_HIP(hipMalloc((void**)&wf->blk_cnt, 8 * sizeof(uint32_t)));
+    DF_HIP(hipMemsetAsync(wf->blk_cnt, 0, 8 * sizeof(uint32_t), st));
+    DF_HIP(hipMemsetAsync(wf->blk_state, on_demand ? 0 : 1, nblk, st));
+    DF_HIP(hipMemsetAsync(wf->blk_wmax, 0, nblk * sizeof(float), st));
+    wf->blk_phase = 0;
+    wf->tab_z0 = tz0; wf->tab_zn = tzn; wf->tab_k = k; wf->tab_valid = true; wf->w_tab_valid = weights;
+    wf->tab_complete = !on_demand; wf->tab_sweeps = 0;
+    if (on_demand) return DF_OK;
+    const DfWarpedArgs a = df_table_args(wf);
     DfWarpView W = df_view(wf);
     dim3 grid((unsigned)(W.bx * W.by), (unsigned)(bz_hi - bz_lo + 1));
     DF_DISPATCH_K(k, df_warp_brick_kernel<K, true><<<grid, dim3(256), 0, st>>>(a, W));
     DF_LAUNCH_CHECK();
     DF_HIP(hipStreamSynchronize(st));
-    wf->tab_z0 = tz0; wf->tab_zn = tzn; wf->tab_k = k; wf->tab_valid = true; wf->w_tab_valid = weights;
-    wf->bm_state = 0;                                                      // the block models describe the previous tables
     return DF_OK;
 }

@@ -12,10 +12,10 @@
 // With lambda_i = w_i / sum w (normalised weights; the rotation does not see the scale) and r_i = (s_i, v_i), s_i > 0:
 //     the rotation's Gibbs vector  u = N / D,   N = sum lambda_i v_i,  D = sum lambda_i s_i   -- LINEAR in lambda over LINEAR in lambda,
 //     the translation              T = sum w_i t_i                                             -- linear in w.
-// MODEL of a block (built once per weight table by df_block_model_kernel): the union of its 512 voxels' neighbour sets (<= 16 nodes,
+// MODEL of a block (built once per weight table, for the blocks a sweep finds alive, by df_block_model_kernel): the union of its 512 voxels' neighbour sets (<= 16 nodes,
 // mean 11; larger unions -> no model, the ball test alone decides) and for every node of it an interval [mid - hw, mid + hw] that
 // holds lambda_i(q) of every voxel of the block (0 where the node is not a neighbour), and one for w_i(q).  10 bytes per entry.
-// VERDICT per frame (df_block_alive_kernel, one lane per block): with the frame's node transforms,
+// VERDICT per frame (df_block_verdict_kernel, one lane per block, after the ball test): with the frame's node transforms,
 //     N_c in  sum mid_i v_ic + (1 - sum mid_i) v*_c  +-  sum hw_i |v_ic - v*_c|          (sum lambda_i = 1; v* = entry 0's value)
 //     D   in  [min s_i, max s_i]                                                          (a convex combination)
 //     T_c in  sum wmid_i t_ic  +-  sum whw_i |t_ic|
@@ -69,20 +69,23 @@ __device__ __forceinline__ uint32_t df_bm_pack(float lo, float hi)          // {
     return (uint32_t)__builtin_bit_cast(unsigned short, m) | (df_f2h_up(hw) << 16);
 }
 
-// ---- the model build: one wave per 8 x 8 x 8 block (lane = column (x, y), 8 voxels each), four blocks per workgroup.
+// ---- the model build: one wave per 8 x 8 x 8 block (lane = column (x, y), 8 voxels each), four blocks per workgroup round; the
+// blocks come from a work list (`list`, `*count` entries: the blocks the verdict pass found alive and built but without a model).
 // The union of the neighbour sets comes out in ascending node order: each round takes the smallest id above the last one over all
 // 512 x K table entries (a wave minimum), then the range of that node's lambda and w over the voxels.
 template <int K>
-__global__ __launch_bounds__(256) void df_block_model_kernel(const DfWarpedArgs a, int nbx, int nby, int nbz, uint16_t* __restrict__ bm_idx,
+__global__ __launch_bounds__(256) void df_block_model_kernel(const DfWarpedArgs a, int nbx, int nby, int nbz, const uint32_t* __restrict__ list,
+                                                             const uint32_t* __restrict__ count, uint16_t* __restrict__ bm_idx,
                                                              uint32_t* __restrict__ bm_lam, uint32_t* __restrict__ bm_w,
-                                                             uint8_t* __restrict__ bm_cnt)
+                                                             uint8_t* __restrict__ bm_cnt, uint8_t* __restrict__ blk_state)
 {
     __shared__ uint32_t s_idx[4][DF_BM_NU], s_lam[4][DF_BM_NU], s_w[4][DF_BM_NU];
     __shared__ float s_hw[4][DF_BM_NU];
     const int wave = threadIdx.x >> 6, ln = threadIdx.x & 63;
     const size_t nblk = (size_t)nbx * nby * nbz;
-    const size_t blk = (size_t)blockIdx.x * 4 + wave;
-    if (blk >= nblk) return;                                               // wave-uniform
+    const uint32_t n_work = *count;
+    for (uint32_t it = blockIdx.x * 4 + wave; it < n_work; it += gridDim.x * 4) {    // (waves are independent: no workgroup barrier below)
+    const size_t blk = list[it];
     const int bx = (int)(blk % (size_t)nbx), by = (int)((blk / (size_t)nbx) % (size_t)nby), bz = (int)(blk / ((size_t)nbx * nby));
     const int x = bx * 8 + (ln & 7), y = by * 8 + (ln >> 3), z0 = a.tab_z0 + bz * 8;
     const bool col_in = x < a.X && y < a.Y;
@@ -145,7 +148,8 @@ __global__ __launch_bounds__(256) void df_block_model_kernel(const DfWarpedArgs 
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (bad || overflow || n == 0) { if (ln == 0) bm_cnt[blk] = DF_BM_NONE; return; }
+    if (ln == 0) blk_state[blk] = 2;                                       // a model record exists (possibly "none")
+    if (bad || overflow || n == 0) { if (ln == 0) bm_cnt[blk] = DF_BM_NONE; continue; }
     // entry 0 = the node with the widest lambda interval: its value is the reference v* of the verdict, its own error term vanishes
     float h = ln < n ? s_hw[wave][ln] : -1.f;
     int e0 = ln;
@@ -161,20 +165,15 @@ __global__ __launch_bounds__(256) void df_block_model_kernel(const DfWarpedArgs 
         bm_w[(size_t)dst * nblk + blk] = s_w[wave][ln];
     }
     if (ln == 0) bm_cnt[blk] = (uint8_t)n;
+    __builtin_amdgcn_wave_barrier();                                       // (the next round reuses the wave's LDS rows)
+    }
 }
 
-// ---- the per-frame verdict: one lane per block of the table's planes; alive[blk] = 0 where no voxel of the block can update
-__global__ __launch_bounds__(256) void df_block_alive_kernel(const DfWarpedArgs a, const float4* __restrict__ rot, const float4* __restrict__ node_t,
-                                                             int nbx, int nby, int nbz, const uint16_t* __restrict__ bm_idx,
-                                                             const uint32_t* __restrict__ bm_lam, const uint32_t* __restrict__ bm_w,
-                                                             const uint8_t* __restrict__ bm_cnt, uint8_t* __restrict__ alive)
+// ---- the box test of one block against its model (n entries): true = no voxel of the block can update this frame
+__device__ __forceinline__ bool df_block_box_dead(const DfWarpedArgs& a, const float4* __restrict__ rot, const float4* __restrict__ node_t,
+                                                  int nbx, int nby, size_t nblk, size_t blk, unsigned n, const uint16_t* __restrict__ bm_idx,
+                                                  const uint32_t* __restrict__ bm_lam, const uint32_t* __restrict__ bm_w)
 {
-    const size_t nblk = (size_t)nbx * nby * nbz;
-    const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (blk >= nblk) return;
-    const unsigned n = bm_cnt[blk];
-    const float sin_half = a.cull[1];
-    if (n == DF_BM_NONE || !(sin_half <= 1.0f)) { alive[blk] = 1; return; }        // no model / a rotation with s < 0 or not finite
     float slm = 0.f, Nx = 0.f, Ny = 0.f, Nz = 0.f, Ex = 0.f, Ey = 0.f, Ez = 0.f, Dmin = 3.0e38f, Dmax = 0.f;
     float Tx = 0.f, Ty = 0.f, Tz = 0.f, Fx = 0.f, Fy = 0.f, Fz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
     for (unsigned e = 0; e < n; ++e) {
@@ -256,5 +255,94 @@ __global__ __launch_bounds__(256) void df_block_alive_kernel(const DfWarpedArgs 
         }
         dead = dead && ok;
     }
-    alive[blk] = dead ? 0 : 1;
+    return dead;
+}
+
+// ---- the per-frame verdict pass: one lane per 8 x 8 x 8 block of the table's planes (x fastest: every array below is read coalesced).
+//   alive[blk] = 0 where no voxel of the block can update this frame: outside this launch's planes, zero-weight (see DF_ZERO_WEIGHT),
+//   culled by the ball test (df_tile_culled, with the block's own bound on sum w_i), or by the box of its blend model.
+// It also feeds the ON-DEMAND work of the frame (dfusion_warp.hip, df_block_verdicts): an alive block whose tables are not built yet
+// goes on the build list (packed brick coordinates), a built one without a model record on the model list (when `want_models`).
+// The list lengths are counter set `cnt` ([0] build, [1] model, [2] the build pass's cursor; this pass zeroes the other set, `cnt_next`).
+__global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArgs a, const float4* __restrict__ rot, const float4* __restrict__ node_t,
+                                                               int nbx, int nby, int nbz, uint8_t* __restrict__ blk_state,
+                                                               const float* __restrict__ blk_wmax, int zero_skip, int use_models, int want_models,
+                                                               int build_on_demand, const uint16_t* __restrict__ bm_idx,
+                                                               const uint32_t* __restrict__ bm_lam, const uint32_t* __restrict__ bm_w,
+                                                               const uint8_t* __restrict__ bm_cnt, uint8_t* __restrict__ alive,
+                                                               uint32_t* __restrict__ build_list, uint32_t* __restrict__ model_list,
+                                                               uint32_t* __restrict__ cnt, uint32_t* __restrict__ cnt_next)
+{
+    const size_t nblk = (size_t)nbx * nby * nbz;
+    const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 4) cnt_next[threadIdx.x] = 0u;
+    bool keep = false, need_build = false, need_model = false;
+    int bx = 0, by = 0, bz = 0;
+    if (blk < nblk) {
+        bx = (int)(blk % (size_t)nbx); by = (int)((blk / (size_t)nbx) % (size_t)nby); bz = (int)(blk / ((size_t)nbx * nby));
+        const int x0 = bx * 8, y0 = by * 8, z0 = a.tab_z0 + bz * 8;
+        const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
+        keep = x0 < a.X && y0 < a.Y && max(z0, a.z_own0) < min(z0 + 8, own1);
+        const unsigned st = keep ? blk_state[blk] : 0u;
+        if (keep) {
+            float wk = a.kf;
+            if (zero_skip && st >= 1u) {
+                const float wmax = blk_wmax[blk];
+                keep = !(wmax * a.cull[3] < DF_ZERO_WEIGHT);               // nothing in the block can update
+                wk = fminf(wk, wmax * 1.0001f);                            // |sum w_i t_i| <= (sum w_i) max |t_i|
+            }
+            if (keep) {
+                const f3 c = aff_mul(a.vol2world, mk3(((float)x0 + 3.5f) * a.vsx, ((float)y0 + 3.5f) * a.vsy, ((float)z0 + 3.5f) * a.vsz));
+                keep = !df_tile_culled(a, c, wk);
+            }
+        }
+        if (keep && st == 2u && use_models) {
+            const unsigned n = bm_cnt[blk];
+            if (n != DF_BM_NONE && a.cull[1] <= 1.0f) keep = !df_block_box_dead(a, rot, node_t, nbx, nby, nblk, blk, n, bm_idx, bm_lam, bm_w);
+        }
+        alive[blk] = keep ? 1 : 0;
+        need_build = keep && build_on_demand && st == 0u;
+        need_model = keep && want_models && (st == 1u || (need_build && want_models > 1));
+        if (need_build) blk_state[blk] = 1;
+    }
+    // one counter bump per wave and list
+    const unsigned long long mb = __builtin_amdgcn_ballot_w64(need_build), mm = __builtin_amdgcn_ballot_w64(need_model);
+    const unsigned long long below = ((unsigned long long)1 << (threadIdx.x & 63)) - 1ull;
+    if (mb) {
+        unsigned base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(&cnt[0], (unsigned)__popcll(mb));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (need_build) build_list[base + (unsigned)__popcll(mb & below)] = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)(a.tab_z0 / 8 + bz) << 20);
+    }
+    if (mm) {
+        unsigned base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(&cnt[1], (unsigned)__popcll(mm));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (need_model) model_list[base + (unsigned)__popcll(mm & below)] = (unsigned)blk;
+    }
+}
+
+// ---- every block whose tables are not built yet, onto the build list (completing on-demand tables for a sweep that has no verdicts)
+__global__ __launch_bounds__(256) void df_blocks_unbuilt_kernel(int nbx, int nby, int nbz, int vbx, int vby, int tab_bz0, uint8_t* __restrict__ blk_state,
+                                                                uint32_t* __restrict__ build_list, uint32_t* __restrict__ cnt,
+                                                                uint32_t* __restrict__ cnt_next)
+{
+    const size_t nblk = (size_t)nbx * nby * nbz;
+    const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 4) cnt_next[threadIdx.x] = 0u;
+    bool need = false;
+    int bx = 0, by = 0, bz = 0;
+    if (blk < nblk) {
+        bx = (int)(blk % (size_t)nbx); by = (int)((blk / (size_t)nbx) % (size_t)nby); bz = (int)(blk / ((size_t)nbx * nby));
+        need = blk_state[blk] == 0 && bx < vbx && by < vby;               // (blocks of the table's padding hold no voxels)
+        if (blk_state[blk] == 0) blk_state[blk] = 1;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+    if (m) {
+        unsigned base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(&cnt[0], (unsigned)__popcll(m));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (need) build_list[base + (unsigned)__popcll(m & (((unsigned long long)1 << (threadIdx.x & 63)) - 1ull))] =
+                      (unsigned)bx | ((unsigned)by << 10) | ((unsigned)(tab_bz0 + bz) << 20);
+    }
 }

@@ -54,6 +54,17 @@ int main(int argc, char** argv)
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (f >= 2) { total_ms += ms; ++timed; }
         float pose[12]; affine_to_aff12(kinfu.getCameraPose(), pose);
+        if (mode.find("trace") != std::string::npos) {                      // per-frame checksums (debugging aid): volume, node transforms
+            std::vector<unsigned int> v((size_t)dims * dims * dims);
+            kinfu.tsdf().data().download(v.data());
+            unsigned long long hv = 1469598103934665603ull, hn = hv;
+            for (unsigned int w : v) { hv ^= w; hv *= 1099511628211ull; }
+            for (const auto& nd : *kinfu.getWarp().getNodes()) {
+                const unsigned int* r = (const unsigned int*)nd.transform.raw();
+                for (int i = 0; i < 8; ++i) { hn ^= r[i]; hn *= 1099511628211ull; }
+            }
+            std::fprintf(stderr, "trace frame %d volume %016llx nodes %016llx pose %08x\n", f, hv, hn, *(unsigned int*)&pose[9]);
+        }
         std::fwrite(&tracked, 4, 1, out);
         std::fwrite(pose, 4, 12, out);
     }

@@ -487,7 +487,7 @@ void WarpField::ensureIndex(const cuda::TsdfVolume& volume, bool tables) const
     const bool same = index_ok_ && index_volume_ == &volume && std::memcmp(key, index_key_, sizeof(key)) == 0;
     if (same && (index_tables_ || !tables)) return;
     std::memcpy(index_key_, key, sizeof(key));
-    KF_DF(dfusion_warp_build_index(handle_, c_volume(volume), c_slab_integrate(volume).ptr(), v2w, k_, tables ? (DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE) : 0u, nullptr));
+    KF_DF(dfusion_warp_build_index(handle_, c_volume(volume), c_slab_integrate(volume).ptr(), v2w, k_, tables ? (DF_INDEX_VOXEL_TABLE | DF_INDEX_WEIGHT_TABLE | DF_INDEX_TABLES_ON_DEMAND) : 0u, nullptr));
     index_ok_ = true; index_volume_ = &volume; index_tables_ = tables;
 }
 

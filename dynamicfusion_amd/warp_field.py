@@ -18,8 +18,11 @@ KNN_NEIGHBOURS = 8           # warp_field.hpp:10 (compile-time there, runtime he
 
 
 class WarpField:
-    def __init__(self, k=KNN_NEIGHBOURS, device="cuda", voxel_table=True, weight_table=True):
+    def __init__(self, k=KNN_NEIGHBOURS, device="cuda", voxel_table=True, weight_table=True, tables_on_demand=True):
         self.k = int(k)
+        # fill the per-voxel tables block by block as the sweeps' launch plans first need them (DF_INDEX_TABLES_ON_DEMAND) instead of
+        # all at once when the index is built; same results
+        self.tables_on_demand = bool(tables_on_demand)
         self.voxel_table = bool(voxel_table)     # cache the per-voxel k-NN in HBM (k*2 B/voxel); False = re-rank per frame
         self.weight_table = bool(weight_table) and self.voxel_table   # also cache the k blend weights (k*4 B/voxel)
         self.device = torch.device(device)
@@ -73,7 +76,8 @@ class WarpField:
         capi.check(capi.lib().dfusion_warp_build_index(self.handle, volume.c_volume(), volume.c_slab(),
                                                        capi.floats(aff12(volume.getPose())), int(k),
                                                        (capi.DF_INDEX_VOXEL_TABLE if self.voxel_table else 0) |
-                                                       (capi.DF_INDEX_WEIGHT_TABLE if self.weight_table else 0), _stream()),
+                                                       (capi.DF_INDEX_WEIGHT_TABLE if self.weight_table else 0) |
+                                                       (capi.DF_INDEX_TABLES_ON_DEMAND if self.tables_on_demand else 0), _stream()),
                    "dfusion_warp_build_index")
         self._index_key = key
 

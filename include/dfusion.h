@@ -25,9 +25,9 @@
  *     scratch it owns (the point queries' fallback list, the solver workspace, the cull's device
  *     scalars, the dists max-pyramid and the launch plan of the warped sweep), so calls on the same
  *     DfWarpField must be issued on one stream or serialised by the caller.  dfusion_integrate keeps
- *     nothing between calls: its pyramid and launch plan live in stream-ordered scratch
- *     (hipMallocAsync / hipFreeAsync on `stream`).  (dfusion_debug_rigid is a process-wide validation
- *     switch, off the product path.)
+ *     its pyramid and launch plan in a scratch buffer cached per (device, stream) -- calls on one
+ *     stream are ordered, calls on different streams use different buffers; dfusion_release_scratch()
+ *     frees them.  (dfusion_debug_rigid is a process-wide validation switch, off the product path.)
  */
 #ifndef DFUSION_H
 #define DFUSION_H
@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 2   /* 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
+#define DFUSION_ABI_VERSION 3   /* 3: dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
@@ -86,10 +86,11 @@ enum {
 #define DF_WARP_NO_DEPTH_PYRAMID 64u /* cull against the image-wide maximum of dists only, not against the maximum
                                  over the pixels a tile can project to; validation switch                  */
 #define DF_WARP_NO_BLOCK_MODEL 128u /* launch plan from the ball test alone: do not build / use the per-block blend models
-                                 (bounds of each 8x8x8 block's blend weights, made from the weight table the second
-                                 time a sweep uses it; 10 bytes x 16 per block); validation switch             */
-#define DF_WARP_BLOCK_MODEL_NOW 256u /* build the block models at the FIRST sweep over a new weight table (default:
-                                 the second, so that a node set that changes every frame never pays for them)   */
+                                 (bounds of each 8x8x8 block's blend weights, made from the weight table for the blocks
+                                 a sweep finds alive, from the second sweep over a table on; 10 bytes x 16 per block);
+                                 validation switch                                                              */
+#define DF_WARP_BLOCK_MODEL_NOW 256u /* make block models from the FIRST sweep over a new weight table on (default: the
+                                 second, so that a node set that changes every frame never pays for them)       */
 /* flags for dfusion_warp_build_index */
 #define DF_INDEX_VOXEL_TABLE 1u /* also cache the exact k-NN of EVERY voxel of the slab in HBM:
                                    k * 2 bytes per voxel (2 GiB at 512^3, k = 8) -- the per-frame
@@ -97,6 +98,11 @@ enum {
 #define DF_INDEX_WEIGHT_TABLE 2u /* implies the above, and also caches the k blend weights
                                    exp(-d^2/(2 dg_w^2)) of every voxel (k * 4 bytes per voxel, 4 GiB
                                    at 512^3, k = 8): they too depend only on canonical geometry     */
+#define DF_INDEX_TABLES_ON_DEMAND 4u /* with DF_INDEX_WEIGHT_TABLE: allocate the tables but fill them 8x8x8 block by
+                                   block, when a warped integrate's launch plan first finds a block alive (a frame
+                                   sweeps a third of the volume; the build is the cost of a node-set change).
+                                   Sweeps that take no verdicts (DF_WARP_NO_CULL, DF_WARP_NO_PIPELINE, ...) build what
+                                   is missing first.  Results are identical either way                          */
 
 int dfusion_abi_version(void);
 const char *dfusion_error_string(int err);
@@ -126,13 +132,18 @@ int dfusion_project_and_remove(const uint16_t *dists_in_dev, size_t in_pitch, ui
 /* device::integrate (internal.hpp:106; tsdf_volume.cu:51-112,141-161): rigid projective TSDF
  * update.  proj = {fx, fy, cx, cy} (device::Projector).  n_updated_dev (nullable) is
  * INCREMENTED by the number of voxels whose update branch (tsdf_volume.cu:91) was taken.
- * Scratch: the call owns a launch plan, the chunk starts of every column patch and a max-pyramid of `dists`, in stream-ordered
- * memory (hipMallocAsync / hipFreeAsync on `stream`; a plain allocation + stream synchronise where the runtime has no stream-ordered
- * allocator) -- 16 bytes per column and 32-plane chunk, 33 MB at 512^3.  Limit: (columns / 64, rounded up to whole patches) x
+ * Scratch: a launch plan, the chunk starts of every column patch and a max-pyramid of `dists` -- 16 bytes per column and 32-plane
+ * chunk, 33 MB at 512^3 -- in a buffer the library keeps per (device, stream) and grows on demand (dfusion_release_scratch frees
+ * them all; the runtime's stream-ordered allocator was tried and gave wrong plans in processes that also hipMalloc / hipFree
+ * between the calls).  Limit: (columns / 64, rounded up to whole patches) x
  * (32-plane chunks of the slab) < 2^30, i.e. any volume that fits the device.                                                   */
 int dfusion_integrate(const uint16_t *dists_dev, size_t dists_pitch, int cols, int rows, DfVolume v,
                       const DfSlab *slab, const float vol2cam[12], const float proj[4],
                       unsigned long long *n_updated_dev, dfStream stream);
+
+/* Frees the scratch buffers dfusion_integrate keeps per (device, stream); synchronises those streams first.  Optional (they are
+ * small and reused); for hosts that tear devices down or count allocations.                                                     */
+int dfusion_release_scratch(void);
 
 /* device::raycast, Points variant (internal.hpp:113-114; tsdf_volume.cu:340-405,459-474).
  * points/normals: float4 per pixel, byte pitches, misses = all-NaN.  reproj = {1/fx, 1/fy, cx,

@@ -100,7 +100,7 @@ def test_warped_plan_never_drops_an_update(seed):
         dq = synth.dq_from_twist(rv.astype(F32), tv.astype(F32))
         frames.append((random_pose(rng, centre, 0.0 if seed % 5 == 0 else 0.3 * size, 2.2 * size, 0.5),
                        random_depth(rng, cols, rows, 300, int(3500 * size)), dq))
-    wf = WarpField(k=k, voxel_table=(seed % 6 != 5))
+    wf = WarpField(k=k, voxel_table=(seed % 6 != 5), tables_on_demand=(seed % 4 < 2))
     wf.init(pos.astype(F32), sigma=sigma, transforms=frames[0][2])
     res = []
     # block models from the first sweep on / by the library's policy (second sweep) / never; image-wide depth bound; no cull at all

@@ -58,7 +58,7 @@ def assert_volume_parity(gpu_u32, ref_u32, exact=True):
 
 
 def test_library_is_the_hip_build():
-    assert capi.lib().dfusion_abi_version() == 2
+    assert capi.lib().dfusion_abi_version() == 3
     assert torch.cuda.is_available()
 
 
@@ -416,27 +416,58 @@ def test_point_queries_through_the_brick_index_equal_brute_force(cfg):
     wf.set_point_tiling(0)
 
 
+def test_tables_on_demand_equal_tables_built_at_once():
+    """DF_INDEX_TABLES_ON_DEMAND: the per-voxel tables are filled block by block as the launch plans first find blocks alive.  Over a
+    camera sweep (new blocks every frame) the volume must equal the one made with tables built at once, and a sweep without verdicts
+    (cull off: the missing blocks are built first) and one through the batched kernel must agree too."""
+    cfg = synth.CONFIGS["256"]
+    frames = [0, 8, 16, 24, 40]                                            # camera_pose(f): 0.25 degrees per frame
+    intr = Intr(*cfg.intr)
+    pos, sigma = synth.make_nodes(cfg)
+    vols = []
+    for on_demand in (False, True, True):
+        wf = WarpField(k=cfg.k, tables_on_demand=on_demand)
+        wf.init(pos, sigma=sigma, transforms=synth.node_transforms(cfg, 0))
+        v = TsdfVolume(cfg.dims); v.setSize([cfg.size] * 3); v.setTruncDist(cfg.trunc_dist); v.setMaxWeight(cfg.max_weight); v.setPose(cfg.volume_pose)
+        v.clear()
+        n = torch.zeros(1, dtype=torch.int64, device="cuda")
+        for i, f in enumerate(frames):
+            wf.set_transforms(torch.from_numpy(synth.node_transforms(cfg, f)).cuda())
+            d = compute_dists(upload_u16(synth.depth_frame(cfg, f)), intr)
+            kw = dict()
+            if len(vols) == 2 and i == 2: kw = dict(cull=False)             # third variant: completes the tables in mid-sequence,
+            if len(vols) == 2 and i == 3: kw = dict(pipelined=False)        # then the batched kernel
+            v.integrate_warped(d, synth.camera_pose(cfg, f), intr, wf, n_updated=n, **kw)
+        vols.append((v.data().clone(), int(n.item())))
+    assert vols[0][1] > 0
+    for other in vols[1:]:
+        assert torch.equal(vols[0][0], other[0]) and vols[0][1] == other[1]
+
+
 def test_block_models_shrink_the_swept_set_and_change_nothing():
     """dfusion_warp_blocks.h: the per-block blend models must (i) leave the volume and the update count bit-identical and (ii) actually
-    engage -- the launch plan's swept-voxel counter (dfusion_debug_warp_counters) drops.  BASELINE config 1 (256^3, 500 nodes, k = 4)."""
+    engage -- the launch plan's swept-voxel counter (dfusion_debug_warp_counters) drops.  BASELINE config 1 (256^3, 500 nodes, k = 4);
+    tables built at once and on demand; the counter is read on the last of four frames (a block's model serves from the frame after
+    the one that made it)."""
     cfg = synth.CONFIGS["256"]
-    sc = Scene(cfg, n_frames=3)
+    sc = Scene(cfg, n_frames=4)
     intr = Intr(*cfg.intr)
-    wf = WarpField(k=cfg.k)
-    wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
-    swept, vols, upd = [], [], []
     L = capi.lib()
-    for kw in (dict(block_model=False), dict(block_model="now")):
-        v = make_gpu_volume(sc)
-        cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
-        capi.check(L.dfusion_debug_warp_counters(cnt[1:].data_ptr()))
-        try:
-            for f in range(3):
+    for on_demand in (False, True):
+        wf = WarpField(k=cfg.k, tables_on_demand=on_demand)
+        wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
+        swept, vols, upd = [], [], []
+        for kw in (dict(block_model=False), dict(block_model="now")):
+            v = make_gpu_volume(sc)
+            cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+            for f in range(4):
                 wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
-                v.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, wf, n_updated=cnt[:1], **kw)
-        finally:
-            capi.check(L.dfusion_debug_warp_counters(None))
-        upd.append(int(cnt[0].item())); swept.append(int(cnt[1].item())); vols.append(v.data().clone())
-    print("swept voxels / updated: ball test %.3f, with block models %.3f" % (swept[0] / upd[0], swept[1] / upd[1]))
-    assert torch.equal(vols[0], vols[1]) and upd[0] == upd[1] and upd[0] > 0
-    assert swept[1] < 0.85 * swept[0] and swept[1] >= upd[1]
+                if f == 3: cnt.zero_(); capi.check(L.dfusion_debug_warp_counters(cnt[1:].data_ptr()))
+                try:
+                    v.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, wf, n_updated=cnt[:1], **kw)
+                finally:
+                    capi.check(L.dfusion_debug_warp_counters(None))
+            upd.append(int(cnt[0].item())); swept.append(int(cnt[1].item())); vols.append(v.data().clone())
+        print("on demand %d: swept voxels / updated: ball test %.3f, with block models %.3f" % (on_demand, swept[0] / upd[0], swept[1] / upd[1]))
+        assert torch.equal(vols[0], vols[1]) and upd[0] == upd[1] and upd[0] > 0
+        assert swept[1] < 0.85 * swept[0] and swept[1] >= upd[1]
