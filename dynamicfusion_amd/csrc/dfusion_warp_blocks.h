@@ -176,18 +176,30 @@ __device__ __forceinline__ bool df_block_box_dead(const DfWarpedArgs& a, const f
 {
     float slm = 0.f, Nx = 0.f, Ny = 0.f, Nz = 0.f, Ex = 0.f, Ey = 0.f, Ez = 0.f, Dmin = 3.0e38f, Dmax = 0.f;
     float Tx = 0.f, Ty = 0.f, Tz = 0.f, Fx = 0.f, Fy = 0.f, Fz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
-    for (unsigned e = 0; e < n; ++e) {
-        const unsigned id = bm_idx[(size_t)e * nblk + blk];
-        const uint32_t lp = bm_lam[(size_t)e * nblk + blk], wp = bm_w[(size_t)e * nblk + blk];
-        const float4 r4 = rot[id], t4 = node_t[id];                        // float4 .x = the quaternion's scalar part
-        if (e == 0) { sx = r4.y; sy = r4.z; sz = r4.w; }
-        const float lm = h2f_bits(lp), lh = h2f_bits(lp >> 16), wm = h2f_bits(wp), wh = h2f_bits(wp >> 16);
-        slm += lm;
-        Nx += lm * r4.y; Ny += lm * r4.z; Nz += lm * r4.w;
-        Ex += lh * fabsf(r4.y - sx); Ey += lh * fabsf(r4.z - sy); Ez += lh * fabsf(r4.w - sz);
-        Dmin = fminf(Dmin, r4.x); Dmax = fmaxf(Dmax, r4.x);
-        Tx += wm * t4.y; Ty += wm * t4.z; Tz += wm * t4.w;
-        Fx += wh * fabsf(t4.y); Fy += wh * fabsf(t4.z); Fz += wh * fabsf(t4.w);
+    {   const float4 r0 = rot[bm_idx[blk]]; sx = r0.y; sy = r0.z; sz = r0.w; }         // entry 0's value is the reference v*
+    // four entries at a time: their records, then their nodes, are requested together (a lane per block walks a chain of dependent
+    // loads otherwise -- 35 us for the pass at 512^3); entries past n are clamped to the last one and given zero weight
+    for (unsigned e0 = 0; e0 < n; e0 += 4) {
+        unsigned id[4]; uint32_t lp[4], wp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t at = (size_t)min(e0 + (unsigned)i, n - 1u) * nblk + blk;
+            id[i] = bm_idx[at]; lp[i] = bm_lam[at]; wp[i] = bm_w[at];
+        }
+        float4 r4[4], t4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r4[i] = rot[id[i]]; t4[i] = node_t[id[i]]; }       // float4 .x = the quaternion's scalar part
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool on = e0 + (unsigned)i < n;
+            const float lm = on ? h2f_bits(lp[i]) : 0.f, lh = on ? h2f_bits(lp[i] >> 16) : 0.f, wm = on ? h2f_bits(wp[i]) : 0.f, wh = on ? h2f_bits(wp[i] >> 16) : 0.f;
+            slm += lm;
+            Nx += lm * r4[i].y; Ny += lm * r4[i].z; Nz += lm * r4[i].w;
+            Ex += lh * fabsf(r4[i].y - sx); Ey += lh * fabsf(r4[i].z - sy); Ez += lh * fabsf(r4[i].w - sz);
+            Dmin = fminf(Dmin, r4[i].x); Dmax = fmaxf(Dmax, r4[i].x);                    // (a clamped entry repeats a real one: harmless)
+            Tx += wm * t4[i].y; Ty += wm * t4[i].z; Tz += wm * t4[i].w;
+            Fx += wh * fabsf(t4[i].y); Fy += wh * fabsf(t4[i].z); Fz += wh * fabsf(t4[i].w);
+        }
     }
     const float rest = 1.f - slm;                                          // sum lambda_i = 1, the mids need not
     Nx += rest * sx; Ny += rest * sy; Nz += rest * sz;
@@ -261,12 +273,12 @@ __device__ __forceinline__ bool df_block_box_dead(const DfWarpedArgs& a, const f
 // ---- the per-frame verdict pass: one lane per 8 x 8 x 8 block of the table's planes (x fastest: every array below is read coalesced).
 //   alive[blk] = 0 where no voxel of the block can update this frame: outside this launch's planes, zero-weight (see DF_ZERO_WEIGHT),
 //   culled by the ball test (df_tile_culled, with the block's own bound on sum w_i), or by the box of its blend model.
-// It also feeds the ON-DEMAND work of the frame (dfusion_warp.hip, df_block_verdicts): an alive block whose tables are not built yet
+// (bx < vbx, by < vby: the brick grid of the index.)  It also feeds the ON-DEMAND work of the frame (dfusion_warp.hip, df_block_verdicts): an alive block whose tables are not built yet
 // goes on the build list (packed brick coordinates), a built one without a model record on the model list (when `want_models`).
 // The list lengths are counter set `cnt` ([0] build, [1] model, [2] the build pass's cursor; this pass zeroes the other set, `cnt_next`).
 __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArgs a, const float4* __restrict__ rot, const float4* __restrict__ node_t,
                                                                int nbx, int nby, int nbz, uint8_t* __restrict__ blk_state,
-                                                               const float* __restrict__ blk_wmax, int zero_skip, int use_models, int want_models,
+                                                               const float* __restrict__ blk_wmax, const float* __restrict__ brick_d1, int vbx, int vby, int zero_skip, int use_models, int want_models,
                                                                int build_on_demand, const uint16_t* __restrict__ bm_idx,
                                                                const uint32_t* __restrict__ bm_lam, const uint32_t* __restrict__ bm_w,
                                                                const uint8_t* __restrict__ bm_cnt, uint8_t* __restrict__ alive,
@@ -290,6 +302,15 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
                 const float wmax = blk_wmax[blk];
                 keep = !(wmax * a.cull[3] < DF_ZERO_WEIGHT);               // nothing in the block can update
                 wk = fminf(wk, wmax * 1.0001f);                            // |sum w_i t_i| <= (sum w_i) max |t_i|
+            } else if (zero_skip && a.cull[4] < 1.0e30f && a.cull[4] > 0.f) {
+                // tables not built: every weight of the block is exp(-d^2 / (2 dg_w^2)) with d >= (distance of the nearest node from
+                // the brick's centre) - (the lattice's half diagonal) and dg_w <= the node set's largest -- a bound on sum w_i that
+                // needs no table.  A third of the volume is zero-weight (farther than ~10 sigma from every node): never built.
+                const float dmin = fmaxf(brick_d1[((size_t)(a.tab_z0 / 8 + bz) * vby + by) * vbx + bx] - a.tile_r, 0.f) * 0.999f;
+                const float sg = a.cull[4];
+                const float wmax = a.kf * 1.001f * __expf(-(dmin * dmin) / (2.f * sg * sg) * 0.998f);
+                keep = !(wmax * a.cull[3] < DF_ZERO_WEIGHT);
+                wk = fminf(wk, wmax);
             }
             if (keep) {
                 const f3 c = aff_mul(a.vol2world, mk3(((float)x0 + 3.5f) * a.vsx, ((float)y0 + 3.5f) * a.vsy, ((float)z0 + 3.5f) * a.vsz));
