@@ -17,7 +17,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/pmc/$tag -o p -- python $R/tools/pmc_run.py 512 3 tables > $R/gpurun_out/pmc_$tag.log 2>&1)
   tail -1 gpurun_out/pmc_$tag.log | cut -c1-120
 done
-python tools/pmc_summary.py gpurun_out/pmc --json gpurun_out/pmc_latest.json --config 512 --tag "round ${T#r0}" > gpurun_out/${T}_pmc_512.txt 2>&1; tail -3 gpurun_out/${T}_pmc_512.txt
+python tools/pmc_summary.py gpurun_out/pmc --last 3 --json gpurun_out/pmc_latest.json --config 512 --tag "round ${T#r0}" > gpurun_out/${T}_pmc_512.txt 2>&1; tail -3 gpurun_out/${T}_pmc_512.txt
 cp gpurun_out/pmc_latest.json profiles/pmc_latest.json      # bench.py reads roofline.traffic from here (this run's counters, stamped with the source's sha256)
 echo "== bench 512"; timeout 900 python bench.py --steps 40 --warmup 5 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/${T}_bench_512.json; cut -c1-400 gpurun_out/${T}_bench_512.json
 echo "== bench 256"; timeout 300 python bench.py --steps 40 --warmup 5 --config 256 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/${T}_bench_256.json; cut -c1-300 gpurun_out/${T}_bench_256.json
@@ -34,6 +34,13 @@ python tools/build_variant.py trace --only dfusion_volume.hip,dfusion_warp.hip -
 (timeout 300 python tools/trace_sweep.py 512 2>&1 | grep -v amdgpu.ids) > gpurun_out/${T}_trace_sweep_512.txt; head -2 gpurun_out/${T}_trace_sweep_512.txt
 (timeout 300 python tools/trace_sweep.py 512 rigid 2>&1 | grep -v amdgpu.ids) > gpurun_out/${T}_trace_rigid_512.txt; head -1 gpurun_out/${T}_trace_rigid_512.txt
 echo "== predicted Z-slab scaling (measured per-slab kernels + collective model)"
-(timeout 900 python tools/scale_model.py 512 2>&1 | grep -v amdgpu.ids) | tee gpurun_out/${T}_scale_model_512.txt | head -8
+for kind in balanced uniform; do
+  (timeout 600 python tools/scale_model.py 512 $kind 2>&1 | grep -v amdgpu.ids) | tee gpurun_out/${T}_scale_model_512_$kind.txt | head -7
+  cp gpurun_out/scale_model_512_$kind.json gpurun_out/${T}_scale_model_512_$kind.json
+done
+echo "== the frame after a node-set change, per kernel"
+rm -rf gpurun_out/prof_nc
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_nc -o trace -- python $R/tools/nodes_changed.py 512 3 > $R/gpurun_out/${T}_nodes_changed.txt 2>&1)
+cp $(find gpurun_out/prof_nc -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_nodes_changed_kernel_stats.csv; grep "set_nodes" gpurun_out/${T}_nodes_changed.txt
 echo "== N = 8 code path on one GPU (gloo stand-in)"
 (timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 tools/bench_multi_smoke.py --gpus 8 --steps 3 --warmup 1 --config 512 --no-extras --no-cpu-baseline 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -2 | cut -c1-600) > gpurun_out/${T}_bench_n8_one_gpu_smoke.txt; cut -c1-200 gpurun_out/${T}_bench_n8_one_gpu_smoke.txt

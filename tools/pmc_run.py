@@ -13,7 +13,7 @@ vol.setRaycastStepFactor(cfg.raycast_step_factor); vol.setGradientDeltaFactor(cf
 pos, sigma = synth.make_nodes(cfg); dq = synth.node_transforms(cfg, 1)
 wf = WarpField(k=cfg.k, voxel_table=(mode != "lean"), weight_table=(mode == "tables")); wf.init(pos, sigma=sigma, transforms=dq)
 pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
-for _ in range(n):
+for _ in range(3 + n):        # 3 warm-up launches (on-demand tables, then the blocks' blend models, are made by the first two); pmc_summary --last n
     vol.integrate_warped(dists, cam, intr, wf, sync=False)
 for _ in range(n):
     vol.raycast(cam, intr, pts, nrm)

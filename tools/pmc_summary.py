@@ -22,15 +22,23 @@ ap.add_argument("root", nargs="?", default="gpurun_out/pmc")
 ap.add_argument("--json", default=None)
 ap.add_argument("--config", default="512")
 ap.add_argument("--tag", default="round 1")
+ap.add_argument("--last", type=int, default=0, help="use only the last N launches of every kernel in each pass (the ones after the warm-up)")
 args = ap.parse_args()
 
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(args.root, "*", "*counter_collection.csv"))):
-    for r in csv.DictReader(open(f)):
+    per_file = collections.defaultdict(lambda: collections.defaultdict(list))
+    recs = list(csv.DictReader(open(f)))
+    if recs and "Dispatch_Id" in recs[0]:
+        recs.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in recs:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if not k.startswith("df_"):
             continue
-        rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        per_file[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k in per_file:
+        for c, v in per_file[k].items():
+            rows[k][c].extend(v[-args.last:] if args.last else v)
 
 out = {}
 for k in sorted(rows):
