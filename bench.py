@@ -310,7 +310,8 @@ def main():
             sharded.exchange_halos(vol.data(), vol.z_store0, vol.z_own0, vol.z_own_n, Z, halo, rank, world)
         if dist_on:
             out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, rank),
-                                          lambda mk: (vol.raycast_shade(cam_poses[f], intr, mk, pts, nrm), out2)[1],
+                                          lambda mk: vol.raycast_shade(cam_poses[f], intr, mk, None, nrm)[1],
+                                          lambda mk, n: vol.raycast_points_of_keys(cam_poses[f], intr, mk, n, pts),
                                           rank, world, collectives=True)
         else:
             vol.raycast(cam_poses[f], intr, pts, nrm)

@@ -89,6 +89,7 @@ struct DfRayHit { uint32_t key; bool hit; float t_hit; f3 p_curr, p_next, org, d
 #define DF_RC_WINDOW 4
 #endif
 // :353-404 minus the refinement: first event on a step this slab owns.
+template <bool SLAB>
 __device__ __forceinline__ DfRayHit rc_march(const DfRayArgs& a, int x, int y)
 {
     DfRayHit h;
@@ -144,8 +145,22 @@ __device__ __forceinline__ DfRayHit rc_march(const DfRayArgs& a, int x, int y)
             }
             tcurr = t;
         }
+        // A slab's march tests only the steps whose current sample lies in a plane it owns: the value of step j's next sample is
+        // needed for step j's own test and as step j + 1's current value, nothing else.  A window none of whose values is needed
+        // by any lane of the wave (the ray is outside the slab's planes: (N - 1) / N of the march on N slabs) issues no loads.
+        bool any_need = !SLAB;                                                         // (the unsharded cast owns every plane)
+        if (SLAB) {
 #pragma unroll
-        for (int j = 0; j < DF_RC_WINDOW; ++j) tv[j] = h2f_bits(*addr[j]);             // :380, all in flight together
+            for (int j = 0; j < DF_RC_WINDOW; ++j) any_need = any_need || (live[j] && (ownc[j] || (znn[j] >= a.z_own0 && znn[j] < a.z_own1)));
+            any_need = __builtin_amdgcn_ballot_w64(any_need) != 0ull;
+        }
+        if (any_need) {
+#pragma unroll
+            for (int j = 0; j < DF_RC_WINDOW; ++j) tv[j] = h2f_bits(*addr[j]);         // :380, all in flight together
+        } else {
+#pragma unroll
+            for (int j = 0; j < DF_RC_WINDOW; ++j) tv[j] = 0.f;                        // (never looked at)
+        }
         float tsdf_curr = tsdf_next;
         f3 curr = next;
 #pragma unroll
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(256) void df_raycast_kernel(const DfRayArgs a)
     int x, y;
     if (!rc_pixel(a, &x, &y)) return;
     const float qn = qnanf_();
-    const DfRayHit h = rc_march(a, x, y);
+    const DfRayHit h = rc_march<false>(a, x, y);                                       // (launched on whole volumes; a slab's keys come from the march kernel)
     float4 out_p = make_float4(qn, qn, qn, qn), out_n = make_float4(qn, qn, qn, qn);   // :351
     uint16_t out_d = 0;                                                               // :283
     if (h.hit) rc_shade(a, rc_locate(a, h), &out_p, &out_n, &out_d);                   // refinement after the loop: wave reconverged
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(256) void df_raycast_march_kernel(const DfRayArgs a
 {
     int x, y;
     if (!rc_pixel(a, &x, &y)) return;
-    const DfRayHit h = rc_march(a, x, y);
+    const DfRayHit h = rc_march<true>(a, x, y);
     unsigned long long k64 = 0x7fffffffffffffffull;
     if (h.key != 0xffffffffu) {
         const float ts = h.hit ? rc_locate_ts(a, h) : 0.f;
@@ -278,6 +293,31 @@ __global__ __launch_bounds__(256) void df_raycast_shade_kernel(const DfRayArgs a
         out_p = make_float4(qn, qn, qn, qn); out_n = out_p;
     }
     *reinterpret_cast<float4*>((char*)a.nrm + (size_t)y * a.npitch + 16 * (size_t)x) = out_n;
+    if (a.pts) *reinterpret_cast<float4*>((char*)a.pts + (size_t)y * a.ppitch + 16 * (size_t)x) = out_p;
+}
+
+// ---- sharded cast, stage 3 (on the rank that wants the image): the POINTS need no exchange.  The merged key holds the winner's Ts,
+// the vertex is origin + direction * Ts from the pixel (:390), the camera-frame point Rinv * (vertex - origin) (:396) -- what
+// rc_shade writes -- and whether the hit stands is written in the summed normals: a valid normal has 0 in its 4th component, the
+// NaN fill has a NaN there (:394 decides on the volume-frame normal, which only the vertex' owner can compute).  So only the normals
+// cross GPUs (4.9 MB instead of 9.8).
+__global__ __launch_bounds__(256) void df_raycast_points_of_keys_kernel(const DfRayArgs a, const unsigned long long* __restrict__ merged_keys)
+{
+    int x, y;
+    if (!rc_pixel(a, &x, &y)) return;
+    const unsigned long long k64 = merged_keys[(size_t)y * a.cols + x];
+    const float qn = qnanf_();
+    float4 out_p = make_float4(qn, qn, qn, qn);
+    if (k64 != 0x7fffffffffffffffull && ((k64 >> 39) & 1ull)) {
+        const float nw = reinterpret_cast<const float4*>((const char*)a.nrm + (size_t)y * a.npitch)[x].w;
+        if (nw == nw) {
+            f3 org, dir;
+            rc_ray_of_pixel(a, x, y, &org, &dir);
+            const f3 vertex = rc_vertex(org, dir, __uint_as_float((unsigned int)k64));
+            const f3 v = mat3_mul(a.Rinv, sub3(vertex, org));                              // as rc_shade
+            out_p = make_float4(v.x, v.y, v.z, 0.f);
+        }
+    }
     *reinterpret_cast<float4*>((char*)a.pts + (size_t)y * a.ppitch + 16 * (size_t)x) = out_p;
 }
 
@@ -350,12 +390,30 @@ extern "C" int dfusion_raycast_shade(DfVolume v, const DfSlab* slab, const float
                                      size_t ppitch, float* normals, size_t npitch, int cols, int rows, float delta_factor,
                                      dfStream stream)
 {
-    if (!merged_keys || !points || !normals) return DF_E_INVALID;
+    if (!merged_keys || !normals) return DF_E_INVALID;                  // points nullable: see dfusion_raycast_points_of_keys
     DfRayArgs a;
     int rc = df_raycast_setup(a, v, slab, cam2vol, Rinv, reproj, cols, rows, 0.75f, delta_factor);
     if (rc) return rc;
     a.pts = points; a.ppitch = ppitch; a.nrm = normals; a.npitch = npitch;
     hipLaunchKernelGGL(df_raycast_shade_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, merged_keys);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
+extern "C" int dfusion_raycast_points_of_keys(const float cam2vol[12], const float Rinv[9], const float reproj[4],
+                                              const unsigned long long* merged_keys, const float* normals, size_t npitch, float* points,
+                                              size_t ppitch, int cols, int rows, dfStream stream)
+{
+    if (!cam2vol || !Rinv || !reproj || !merged_keys || !normals || !points || cols <= 0 || rows <= 0) return DF_E_INVALID;
+    DfRayArgs a;
+    memset(&a, 0, sizeof(a));
+    a.aff = df_aff(cam2vol);
+    memcpy(a.Rinv, Rinv, sizeof(a.Rinv));
+    a.finvx = reproj[0]; a.finvy = reproj[1]; a.cx = reproj[2]; a.cy = reproj[3];
+    a.cols = cols; a.rows = rows;
+    a.tiles_x = (cols + 15) / 16; a.tiles_y = (rows + 15) / 16;
+    a.pts = points; a.ppitch = ppitch; a.nrm = const_cast<float*>(normals); a.npitch = npitch;
+    hipLaunchKernelGGL(df_raycast_points_of_keys_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, merged_keys);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }

@@ -63,6 +63,10 @@ public:
     void raycastMarch(const Affine3f& camera_pose, const Intr& intr, int cols, int rows, unsigned rank, DeviceArray<unsigned long long>& keys64) const;
     void raycastShade(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64, Cloud& points,
                       Normals& normals) const;
+    // normals only (the points need no exchange), and the points from the merged keys + the SUMMED normals on the rank that wants them
+    void raycastShadeNormals(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64, Normals& normals) const;
+    void raycastPointsOfKeys(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64, const Normals& normals,
+                             Cloud& points) const;
 
     // ---- fusion
     virtual void integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr);                        // rigid, tsdf_volume.cpp:110-122

@@ -11,8 +11,9 @@
 //                    (tsdf_volume.cu:389): march on the global step lattice (each rank evaluates only the steps whose sample lies
 //                    in a plane it owns) -> ONE ncclAllReduce(MIN) of the int64 merge keys [step | hit | rank | Ts bits]
 //                    (include/dfusion.h): first event along every ray, its owner, and its refined ray parameter Ts, from which
-//                    every rank recomputes the vertex -> the owner of the vertex' plane shades -> ONE ncclReduce(SUM) of the int32
-//                    view of points + normals to rank `dst` (every summand but one is integer zero): bit-identical with the
+//                    every rank recomputes the vertex -> the owner of the vertex' plane computes the normal -> ONE ncclReduce(SUM) of the
+//                    int32 view of the NORMALS to rank `dst` (every summand but one is integer zero) -> rank `dst` makes the points
+//                    from the merged keys (vertex = origin + direction * Ts; a hit stands iff its normal does): bit-identical with the
 //                    unsharded ray-cast.  (Round 2 exchanged the winners' vertices with a second all-reduce, 4.9 MB per frame.)
 // The same sequence, collective for collective, as dynamicfusion_amd/sharded.py (torch.distributed), which the world-size-2/3 gloo
 // tests and the one-GPU 8-slab emulation exercise; this file is what a C++ host (KinFu) links instead.
@@ -70,7 +71,7 @@ private:
     bool ok_;
     std::string error_;
     DeviceArray<unsigned long long> keys64_;
-    DeviceArray<Point> out_;     // points, then normals
+    DeviceArray<Point> out_;     // normals (summed over the ranks), then the points (made from the merged keys on rank dst)
     DeviceArray<int> token_;
 };
 

@@ -196,6 +196,23 @@ void TsdfVolume::raycastShade(const Affine3f& camera_pose, const Intr& intr, con
                                 gradient_delta_factor_, nullptr));
 }
 
+void TsdfVolume::raycastShadeNormals(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64,
+                                     Normals& normals) const
+{
+    float aff[12], Rinv[9], reproj[4];
+    raycast_args(pose_, camera_pose, intr, aff, Rinv, reproj);
+    KF_DF(dfusion_raycast_shade(c_volume(*this), c_slab(*this).ptr(), aff, Rinv, reproj, merged_keys64.ptr(), nullptr, 0,
+                                (float*)normals.ptr(), normals.step(), normals.cols(), normals.rows(), gradient_delta_factor_, nullptr));
+}
+void TsdfVolume::raycastPointsOfKeys(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64,
+                                     const Normals& normals, Cloud& points) const
+{
+    float aff[12], Rinv[9], reproj[4];
+    raycast_args(pose_, camera_pose, intr, aff, Rinv, reproj);
+    KF_DF(dfusion_raycast_points_of_keys(aff, Rinv, reproj, merged_keys64.ptr(), (const float*)normals.ptr(), normals.step(), (float*)points.ptr(),
+                                         points.step(), points.cols(), points.rows(), nullptr));
+}
+
 void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr)   // :110-122
 {
     const Affine3f vol2cam = camera_pose.inv() * pose_;

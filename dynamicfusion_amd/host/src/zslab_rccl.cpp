@@ -154,11 +154,13 @@ bool ZSlabComm::raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Int
     slab.raycastMarch(camera_pose, intr, cols, rows, (unsigned)rank_, keys64_);
     // ONE merge collective: the per-pixel MIN of the keys is the first event along every ray, its owner and its Ts (dfusion.h)
     if (world_ > 1) ZS_NCCL(ncclAllReduce(keys64_.ptr(), keys64_.ptr(), px, ncclInt64, ncclMin, c, st));
-    out_.create(2 * px);                                            // points then normals: one buffer, one reduce
-    points = Cloud(rows, cols, out_.ptr(), (size_t)cols * sizeof(Point));
-    normals = Normals(rows, cols, out_.ptr() + px, (size_t)cols * sizeof(Normal));
-    slab.raycastShade(camera_pose, intr, keys64_, points, normals);
-    if (world_ > 1) ZS_NCCL(ncclReduce(out_.ptr(), out_.ptr(), 2 * px * 4, ncclInt32, ncclSum, dst, c, st));   // every summand but one is integer zero
+    out_.create(2 * px);                                            // normals (what the reduce sums), then the points
+    normals = Normals(rows, cols, out_.ptr(), (size_t)cols * sizeof(Normal));
+    points = Cloud(rows, cols, out_.ptr() + px, (size_t)cols * sizeof(Point));
+    slab.raycastShadeNormals(camera_pose, intr, keys64_, normals);
+    // only the normals cross GPUs (4.9 MB at 640 x 480; every summand but one is integer zero): the points follow from the merged keys
+    if (world_ > 1) ZS_NCCL(ncclReduce(out_.ptr(), out_.ptr(), px * 4, ncclInt32, ncclSum, dst, c, st));
+    if (rank_ == dst) slab.raycastPointsOfKeys(camera_pose, intr, keys64_, normals, points);
     return true;
 }
 

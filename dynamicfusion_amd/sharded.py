@@ -190,24 +190,26 @@ def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, 
         r.wait()
 
 
-def raycast_sharded(march_fn, shade_fn, rank, world, dst=0, group=None, collectives=None):
-    """Two-stage sharded ray-cast (include/dfusion.h: dfusion_raycast_march / _shade).
+def raycast_sharded(march_fn, shade_fn, points_fn, rank, world, dst=0, group=None, collectives=None):
+    """Sharded ray-cast (include/dfusion.h: dfusion_raycast_march / _shade / _points_of_keys).
 
-    march_fn()        -> keys64 int64 [rows, cols]: the merge keys of this slab (first event | rank | Ts bits)
-    shade_fn(keys64)  -> out float32 [2, rows, cols, 4] (points, normals); all-zero bits for pixels this slab does not resolve
+    march_fn()                  -> keys64 int64 [rows, cols]: the merge keys of this slab (first event | rank | Ts bits)
+    shade_fn(keys64)            -> normals float32 [rows, cols, 4]; all-zero bits for pixels this slab does not resolve
+    points_fn(keys64, normals)  -> points float32 [rows, cols, 4], called on rank `dst` only, with the summed normals
     Returns (points, normals) of the merged cast on rank `dst`, (None, None) elsewhere.
 
-    TWO collectives per frame: all_reduce(MIN) of the int64 keys (2.4 MB at 640x480) -- which also delivers the winners' Ts, so no
-    vertex image is exchanged (round 2 did, 4.9 MB more) -- and reduce(SUM) of the final point/normal bits (9.8 MB).  Every summand
-    but one is integer zero, so the result is bit-identical with the unsharded cast.  collectives: None = only when world > 1;
-    True = also with one rank (an RCCL dry run of the dtypes and ops)."""
+    TWO collectives per frame: all_reduce(MIN) of the int64 keys (2.4 MB at 640x480) -- which also delivers the winners' Ts -- and
+    reduce(SUM) of the NORMAL bits (4.9 MB; every summand but one is integer zero, so the sum is the owner's value, NaN fill
+    included).  The points cross no link: vertex = origin + direction * Ts from the pixel, and whether a hit stands is in the
+    normal's 4th component (round 2 exchanged vertices, 4.9 MB, and points, another 4.9 MB).  collectives: None = only when
+    world > 1; True = also with one rank (an RCCL dry run of the dtypes and ops)."""
     on = world > 1 if collectives is None else collectives
     keys64 = march_fn()
     if on:
         dist.all_reduce(keys64, op=dist.ReduceOp.MIN, group=group)
-    out = shade_fn(keys64)
+    normals = shade_fn(keys64)
     if on:
-        dist.reduce(out.view(torch.int32), dst=dst, op=dist.ReduceOp.SUM, group=group)
+        dist.reduce(normals.view(torch.int32), dst=dst, op=dist.ReduceOp.SUM, group=group)
         if rank != dst:
             return None, None
-    return out[0], out[1]
+    return points_fn(keys64, normals), normals

@@ -245,13 +245,22 @@ class TsdfVolume:
         return keys64
 
     def raycast_shade(self, camera_pose, intr, merged_keys64, points, normals):
+        """points may be None: only the normals cross GPUs, the points follow from the merged keys (raycast_points_of_keys)."""
         aff, Rinv = self._raycast_args(camera_pose)
         rows, cols = merged_keys64.shape
         capi.check(capi.lib().dfusion_raycast_shade(self.c_volume(), self.c_slab(), aff, Rinv, intr.as_reproj(),
-                                                    _ptr(merged_keys64), _ptr(points), cols * 16,
+                                                    _ptr(merged_keys64), _ptr(points) if points is not None else None, cols * 16,
                                                     _ptr(normals), cols * 16, cols, rows, self.gradient_delta_factor_,
                                                     _stream()), "dfusion_raycast_shade")
         return points, normals
+
+    def raycast_points_of_keys(self, camera_pose, intr, merged_keys64, normals, points):
+        """Stage 3 of the sharded cast, on the rank that wants the image: points from the merged keys (Ts) and the summed normals."""
+        aff, Rinv = self._raycast_args(camera_pose)
+        rows, cols = merged_keys64.shape
+        capi.check(capi.lib().dfusion_raycast_points_of_keys(aff, Rinv, intr.as_reproj(), _ptr(merged_keys64), _ptr(normals), cols * 16,
+                                                             _ptr(points), cols * 16, cols, rows, _stream()), "dfusion_raycast_points_of_keys")
+        return points
 
     # ---- tsdf_volume.cpp:181-218 fetchCloud / fetchNormals (device tensors; count read back like the reference does)
     def fetchCloud(self, cloud_buffer=None):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 3   /* 3: dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
+#define DFUSION_ABI_VERSION 3   /* 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
@@ -182,6 +182,13 @@ int dfusion_raycast_shade(DfVolume v, const DfSlab *slab, const float cam2vol[12
                           const float reproj[4], const unsigned long long *merged_keys64_dev,
                           float *points_dev, size_t points_pitch, float *normals_dev, size_t normals_pitch, int cols,
                           int rows, float delta_factor, dfStream stream);
+/* Stage 3, on the rank that wants the image: the camera-frame POINTS from the merged keys and the summed normals -- they need no
+ * exchange (the vertex is origin + direction * Ts, and a hit stands iff the owner's normal is not the NaN fill: 4th component 0), so
+ * dfusion_raycast_shade may be given points_dev = NULL and only the normals cross GPUs.  Equals the points image of the unsharded
+ * cast bit for bit.  Needs no volume.                                                                                            */
+int dfusion_raycast_points_of_keys(const float cam2vol[12], const float Rinv[9], const float reproj[4],
+                                   const unsigned long long *merged_keys64_dev, const float *normals_dev, size_t normals_pitch,
+                                   float *points_dev, size_t points_pitch, int cols, int rows, dfStream stream);
 
 /* ---- surface extraction -------------------------------------------------------
  * device::extractCloud (internal.hpp:142; tsdf_volume.cu:511-710,798-817): zero crossings between every voxel and its

@@ -906,6 +906,30 @@ ORC_API void orc_raycast_shade(OrcVolume v, const OrcSlab *slab, const float cam
     }
 }
 
+/* Stage 3 of the sharded cast (dfusion_raycast_points_of_keys): the camera-frame points from the merged events, their Ts and the
+ * summed normals -- Rinv * (vertex - origin) as ray_shade writes it (:396), for the hits whose normal stands (4th component 0;
+ * the NaN fill has a NaN there).  No volume involved.                                                                            */
+ORC_API void orc_raycast_points_of_keys(const float cam2vol[12], const float Rinv[9], const float reproj[4], const float *ts,
+                                        const uint32_t *merged_keys, const float *normals, size_t npitch, float *points, size_t ppitch,
+                                        int cols, int rows)
+{
+    const float qn = qnanf();
+    for (int y = 0; y < rows; ++y) {
+        float *prow = (float *)((char *)points + (size_t)y * ppitch);
+        const float *nrow = (const float *)((const char *)normals + (size_t)y * npitch);
+        for (int x = 0; x < cols; ++x) {
+            const uint32_t key = merged_keys[(size_t)y * cols + x];
+            for (int i = 0; i < 4; ++i) prow[4 * x + i] = qn;
+            if (key != ORC_RC_NO_EVENT && (key & 1u) && nrow[4 * x + 3] == nrow[4 * x + 3]) {
+                f3 org, dir; ray_of_pixel(cam2vol, reproj, x, y, &org, &dir);
+                const f3 vv = ray_vertex(org, dir, ts[(size_t)y * cols + x]);
+                const f3 v = mat3_mul(Rinv, sub3(vv, mk3(cam2vol[9], cam2vol[10], cam2vol[11])));
+                prow[4 * x] = v.x; prow[4 * x + 1] = v.y; prow[4 * x + 2] = v.z; prow[4 * x + 3] = 0.f;
+            }
+        }
+    }
+}
+
 /* ================================================================ cloud / normal extraction
  * tsdf_volume.cu:511-710 FullScan6: every voxel with W != 0 && F != 1 is compared with its +x, +y, +z neighbour;
  * a sign change emits the linearly interpolated crossing, in voxel-CORNER convention ((i+0.5)*vs, :549-550,566 -- the

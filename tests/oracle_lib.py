@@ -90,6 +90,8 @@ def lib():
                                         C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float]
         L.orc_raycast_march.restype = None
         L.orc_raycast_march.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, C.c_int, C.c_int, C.c_float, u32p, f32p]
+        L.orc_raycast_points_of_keys.restype = None
+        L.orc_raycast_points_of_keys.argtypes = [f32p, f32p, f32p, f32p, u32p, f32p, C.c_size_t, f32p, C.c_size_t, C.c_int, C.c_int]
         L.orc_raycast_shade.restype = None
         L.orc_raycast_shade.argtypes = [Volume, C.POINTER(Slab), f32p, f32p, f32p, f32p, u32p, f32p, C.c_size_t, f32p, C.c_size_t,
                                         C.c_int, C.c_int, C.c_float]
@@ -360,6 +362,14 @@ def raycast_shade(volume, cam2vol, Rinv, reproj, ts, merged_keys, cols, rows, de
                             np.ascontiguousarray(ts, np.float32).reshape(-1), np.ascontiguousarray(merged_keys, np.uint32).reshape(-1),
                             pts.reshape(-1), cols * 16, nrm.reshape(-1), cols * 16, cols, rows, delta_factor)
     return pts, nrm
+
+
+def raycast_points_of_keys(cam2vol, Rinv, reproj, ts, merged_keys, normals, cols, rows):
+    pts = np.empty((rows, cols, 4), np.float32)
+    lib().orc_raycast_points_of_keys(f32(cam2vol).reshape(-1), f32(Rinv).reshape(-1), f32(reproj), np.ascontiguousarray(ts, np.float32).reshape(-1),
+                                     np.ascontiguousarray(merged_keys, np.uint32).reshape(-1), np.ascontiguousarray(normals, np.float32).reshape(-1),
+                                     cols * 16, pts.reshape(-1), cols * 16, cols, rows)
+    return pts
 
 
 def raycast_depth(volume, cam2vol, Rinv, reproj, cols, rows, step_factor, delta_factor, slab=None):

@@ -115,9 +115,12 @@ def test_full_size_properties_and_sampled_oracle(name):
         v.raycast_shade(sc.cam_poses[1], intr, merged, p, n)
         acc[0] += p.view(torch.int32)
         acc[1] += n.view(torch.int32)
+    p3 = torch.empty_like(fp)
+    slabs[0].raycast_points_of_keys(sc.cam_poses[1], intr, merged, acc[1].view(torch.float32), p3)     # stage 3: points from keys + summed normals
     del slabs
     assert (~torch.isnan(fp)).float().mean() > 0.3
     assert torch.equal(acc[0], fp.view(torch.int32)) and torch.equal(acc[1], fn.view(torch.int32))
+    assert torch.equal(p3.view(torch.int32), fp.view(torch.int32))
 
     # ---- ray-cast vs the oracle on a sample of rows (oracle casts the full image on the downloaded volume only
     # at 256^3; at 512^3 the download is 512 MiB -- still fine on the GPU box)

@@ -51,7 +51,13 @@ def run_sharded(sc, world, frames, k=None, recompute_halo=False):
         v.raycast_shade(sc.cam_poses[f], intr, merged, p, n)
         acc[0] += p.view(torch.int32)
         acc[1] += n.view(torch.int32)
+    # stage 3: the points need no exchange -- from the merged keys and the SUMMED normals they come out as the sum of the slabs' points
+    p3 = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
+    vols[0].raycast_points_of_keys(sc.cam_poses[f], intr, merged, acc[1].view(torch.float32), p3)
+    n_only = torch.empty_like(p3)
+    vols[-1].raycast_shade(sc.cam_poses[f], intr, merged, None, n_only)          # (points_dev = NULL is accepted)
     torch.cuda.synchronize()
+    assert torch.equal(p3.view(torch.int32), acc[0])
     return vols, acc[0], acc[1], best
 
 

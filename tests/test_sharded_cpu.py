@@ -86,11 +86,16 @@ def _worker(rank, world, port, recompute_halo, balanced=False):
 
             def shade(k64):
                 merged, ts, _ = sharded.unpack_merge_keys(k64.numpy())
-                p, n = O.raycast_shade(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.reproj, ts, merged, CFG.cols, CFG.rows,
+                _, n = O.raycast_shade(sc.ovol(vol), synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.reproj, ts, merged, CFG.cols, CFG.rows,
                                        CFG.gradient_delta_factor, slab=slab)
-                return torch.from_numpy(np.stack([p, n]))
+                return torch.from_numpy(n)
 
-            pts, nrm = sharded.raycast_sharded(march, shade, rank, world)
+            def points(k64, normals):                                          # rank 0 only: no point crosses a link
+                merged, ts, _ = sharded.unpack_merge_keys(k64.numpy())
+                return torch.from_numpy(O.raycast_points_of_keys(synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.reproj, ts, merged, normals.numpy(),
+                                                                 CFG.cols, CFG.rows))
+
+            pts, nrm = sharded.raycast_sharded(march, shade, points, rank, world)
         # every rank checks its slab (own + halo planes) against the unsharded volume; rank 0 checks the merged cast
         full, fp, fn = _unsharded(sc)
         assert np.array_equal(vol, full[lo:hi]), "rank %d: slab (incl. halos) differs from the unsharded volume" % rank
@@ -135,8 +140,8 @@ def test_slab_bounds_balance_and_respect_the_halo():
 
 def test_single_rank_is_a_no_op_path():
     p = torch.zeros((4, 4, 4))
-    out = sharded.raycast_sharded(lambda: None, lambda k: (p, p), 0, 1)
-    assert out[0] is p
+    out = sharded.raycast_sharded(lambda: None, lambda k: p, lambda k, n: n, 0, 1)
+    assert out[0] is p and out[1] is p
     sharded.exchange_halos(None, 0, 0, 4, 4, 2, 0, 1)
 
 

@@ -11,7 +11,7 @@ with xGMI ~153 GB/s per link and direction pair (guide), of which a ring step su
 (RCCL's LL/LL128 protocols for messages of a few MB), T_LAUNCH = 15 us per collective call (host enqueue + kernel start):
     broadcast  (depth + transforms, 0.68 MB):  N - 1 ring steps, bytes = size
     all_reduce MIN of the int64 keys (2.46 MB): 2 (N - 1) steps, bytes = 2 (N - 1) / N * size
-    reduce SUM of points + normals to rank 0 (9.83 MB): N - 1 steps, bytes = size
+    reduce SUM of the normals to rank 0 (4.92 MB; the points follow from the merged keys): N - 1 steps, bytes = size
 Usage:  python tools/scale_model.py [CONFIG] [balanced|uniform]     (prints a markdown table, writes gpurun_out/scale_model_<cfg>_<kind>.json)
 `balanced` (bench.py's default): slab boundaries from sharded.slab_bounds on frustum_plane_weights; `uniform`: equal plane counts.
 """
@@ -40,7 +40,7 @@ def collective(kind, size, n):
     return T_LAUNCH + steps * T_HOP + b / (LINK_GBPS * 1e9)
 
 
-def timeit(fn, n=10):
+def timeit(fn, n=30):
     for _ in range(2):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,7 +62,7 @@ def main():
     pos, sigma = synth.make_nodes(cfg)
     dq = torch.from_numpy(synth.node_transforms(cfg, 1)).cuda()
     px = cfg.rows * cfg.cols
-    sizes = {"broadcast": px * 2 + cfg.nodes * 32, "all_reduce": px * 8, "reduce": px * 32}
+    sizes = {"broadcast": px * 2 + cfg.nodes * 32, "all_reduce": px * 8, "reduce": px * 16}        # (the reduce sums the normals only)
     wts = sharded.frustum_plane_weights(cfg.dims, cfg.size, cfg.volume_pose, synth.camera_pose(cfg, 0), cfg.intr, cfg.cols, cfg.rows,
                                         depth_mm=synth.depth_frame(cfg, 0), trunc=max(cfg.trunc_dist, 2.1 * vs_z), margin=0.3)
     kind = sys.argv[2] if len(sys.argv) > 2 else "balanced"
@@ -86,7 +86,7 @@ def main():
             out = torch.empty((2, cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
             t_i = timeit(lambda: (wf.set_transforms(dq), vint.integrate_warped(dists, cam, intr, wf, sync=False)))
             t_m = timeit(lambda: vol.raycast_march(cam, intr, keys, r))
-            t_s = timeit(lambda: vol.raycast_shade(cam, intr, keys, out[0], out[1]))
+            t_s = timeit(lambda: (vol.raycast_shade(cam, intr, keys, None, out[1]), vol.raycast_points_of_keys(cam, intr, keys, out[1], out[0])))   # (rank 0's share)
             per_rank.append((t_i, t_m, t_s))
             if t_i + t_m + t_s > worst["sum"]:
                 worst = {"integrate": t_i, "march": t_m, "shade": t_s, "sum": t_i + t_m + t_s}
