@@ -472,12 +472,12 @@ def main():
             ent = pm.get(args.config, {}).get(kernel_name.split("<")[0])
             # the counters belong to ONE build of the kernel: the file carries the sha256 of the source it was taken from, and a
             # figure from another build is not reported
-            import hashlib
-            src_sha = hashlib.sha256(open(os.path.join(REPO, "dynamicfusion_amd", "csrc", "dfusion_warp.hip"), "rb").read()).hexdigest()
+            from dynamicfusion_amd import build as _build
+            src_sha = _build.kernel_source_sha("df_warp_rows_pipe_kernel")
             if ent and ent.get("source_sha256") == src_sha:
                 traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/pmc_latest.json (%s)" % ent.get("how", "rocprofv3 --pmc")
             elif ent:
-                traffic_src = "profiles/pmc_latest.json is from another build of dfusion_warp.hip (sha256 %s...): traffic dropped" % str(ent.get("source_sha256"))[:12]
+                traffic_src = "profiles/pmc_latest.json is from another build of the sweep's sources (sha256 %s...): traffic dropped" % str(ent.get("source_sha256"))[:12]
         except Exception:
             pass
     if rank == 0:

@@ -36,6 +36,21 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def kernel_source_sha(kernel):
+    """sha256 over the sources a kernel (by name) is built from: its .hip plus the device headers.  Stamps profiles/pmc_latest.json
+    (tools/pmc_summary.py); bench.py drops counters whose stamp is not the tree's."""
+    import hashlib
+    k = kernel.replace("void ", "")
+    f = ("dfusion_warp.hip" if k.startswith(("df_warp", "df_sweep", "df_block", "df_blocks", "df_brick", "df_scan", "df_pack", "df_node", "df_points"))
+         else "dfusion_raycast.hip" if k.startswith(("df_raycast", "df_extract"))
+         else "dfusion_solver.hip" if k.startswith("df_sv")
+         else "dfusion_volume.hip")
+    h = hashlib.sha256()
+    for name in (f, "dfusion_warp_blocks.h", "dfusion_device.h", "dfusion_internal.h", "dfusion_pyramid.h"):
+        h.update(open(os.path.join(CSRC, name), "rb").read())
+    return h.hexdigest()
+
+
 def build_library(force=False, verbose=False):
     """Compile every HIP source for gfx950 into dynamicfusion_amd/libdfusion_hip.so."""
     if not force and not _stale():

@@ -7,15 +7,17 @@ HBM bytes per launch follow MI355X_MICROARCH.md's HBM section: FETCH_SIZE / WRIT
 FETCH_SIZE counts a 128-byte request as 64 bytes for wide coalesced reads, so fetch bytes = 2 * FETCH_SIZE * 1024
 (cross-checked against TCC_EA0_RDREQ * 128, collected in its own pass); write bytes = WRITE_SIZE * 1024.
 """
-import argparse, collections, csv, glob, hashlib, json, os
+import argparse, sys, collections, csv, glob, hashlib, json, os
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def source_sha(kernel):
-    """sha256 of the .hip the kernel lives in: bench.py only reports counters taken from the build it runs"""
-    f = "dfusion_warp.hip" if kernel.startswith(("df_warp", "df_sweep")) else ("dfusion_raycast.hip" if kernel.startswith(("df_raycast", "df_extract")) else "dfusion_volume.hip")
-    return hashlib.sha256(open(os.path.join(REPO, "dynamicfusion_amd", "csrc", f), "rb").read()).hexdigest()
+    """sha256 of the sources a kernel is built from -- its .hip and the device headers: bench.py only reports counters taken from the
+    build it runs (dynamicfusion_amd.build.kernel_source_sha is the same function)"""
+    sys.path.insert(0, REPO)
+    from dynamicfusion_amd import build as B
+    return B.kernel_source_sha(kernel)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("root", nargs="?", default="gpurun_out/pmc")
