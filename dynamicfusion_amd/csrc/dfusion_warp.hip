@@ -1064,7 +1064,7 @@ struct DfWarpedArgs {
     float* tile_wmax;
     // this frame's verdicts of the block blend models (dfusion_warp_blocks.h), one byte per 8 x 8 x 8 block of the table's planes,
     // x fastest; null = none.  bm_nbx / bm_nby: blocks per row / column (whole table tiles)
-    const uint8_t* bm_alive; int bm_nbx, bm_nby;
+    const uint8_t* blk_alive; int bm_nbx, bm_nby;
     // table build (df_warp_brick_kernel<K, true>): per-block bound on sum_i w_i (same block grid), and -- when the build is driven by a
     // work list instead of the launch grid -- the list of packed brick coordinates (x | y << 10 | z << 20) and its length
     float* blk_wmax; const uint32_t* work; const uint32_t* work_cnt; uint32_t* work_cursor;
@@ -1664,8 +1664,8 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
         const int x0 = tx * DF_ROW_TX + p * 8, y0 = ty * DF_LDS_TY + (int)half * 8;                  // first column of the patch
         bool keep = l < a.zt && max((lt0 + l) * DF_ROW_TZ, a.z_own0) < min((lt0 + l + 1) * DF_ROW_TZ, own1) && x0 < a.X && y0 < a.Y;
         // the verdict pass has judged the patch's 8 x 8 x 8 voxels of the layer (df_block_verdict_kernel: zero-weight, ball, blend-model box)
-        if (keep && a.bm_alive)
-            keep = a.bm_alive[((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3)] != 0;
+        if (keep && a.blk_alive)
+            keep = a.blk_alive[((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3)] != 0;
         m = __builtin_amdgcn_ballot_w64(keep);
         if (a.n_swept) {                                                   // (measurement hook: what the sweep will put through the warp)
             unsigned v = keep ? (unsigned)(64 * (min((lt0 + l + 1) * DF_ROW_TZ, own1) - max((lt0 + l) * DF_ROW_TZ, a.z_own0))) : 0u;
@@ -2027,7 +2027,7 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
                                 wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_state);
         DF_LAUNCH_CHECK();
     }
-    a.bm_alive = wf->blk_alive; a.bm_nbx = nbx; a.bm_nby = nby;
+    a.blk_alive = wf->blk_alive; a.bm_nbx = nbx; a.bm_nby = nby;
     return DF_OK;
 }
 
