@@ -243,3 +243,30 @@ def test_depth_footprint_cull_with_near_occluders_matches_oracle(k, lean):
     for v, kw, c in zip(vols, kws, n):
         assert compare_volumes(v.download(), ref)["bits_mismatch"] == 0, kw
         assert int(c.item()) == n_ref, kw
+
+
+def test_rigid_scratch_is_kept_per_stream_and_can_be_released():
+    """dfusion_integrate keeps its plan / pyramid scratch per (device, stream) (round 3: the stream-ordered allocator gave wrong plans in
+    processes that also hipMalloc / hipFree between calls); dfusion_release_scratch frees it, the next call allocates again, on a
+    second stream a second buffer is used -- same volume every time."""
+    from dynamicfusion_amd import capi
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=0, k=4)
+    intr = Intr(*cfg.intr)
+    d = compute_dists(upload_u16(synth.depth_frame(cfg, 0)), intr)
+    outs = []
+    side = torch.cuda.Stream()
+    for i in range(4):
+        v = TsdfVolume(cfg.dims); v.setSize([cfg.size] * 3); v.setTruncDist(cfg.trunc_dist); v.setMaxWeight(cfg.max_weight); v.setPose(cfg.volume_pose); v.clear()
+        torch.cuda.synchronize()
+        if i == 1: capi.check(capi.lib().dfusion_release_scratch())
+        if i == 3:
+            with torch.cuda.stream(side):
+                v.integrate(d, synth.camera_pose(cfg, 0), intr)
+            side.synchronize()
+        else:
+            v.integrate(d, synth.camera_pose(cfg, 0), intr)
+        outs.append(v.download())
+    assert (outs[0] >> 16).max() == 1
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
+    capi.check(capi.lib().dfusion_release_scratch())
