@@ -114,3 +114,42 @@ def test_warped_plan_never_drops_an_update(seed):
     print("warped fuzz seed", seed, "updates", res[0][1])
     for r in res[1:]:
         assert np.array_equal(res[0][0], r[0]) and res[0][1] == r[1]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_block_models_on_surface_node_sets(seed):
+    """The block blend models where they are at their tightest and hence their riskiest: a dense node set on the observed surface
+    (128^3, 600 nodes, k = 8: unions of 8-16 nodes per block), node motions from nearly rigid to incoherent and up to 0.6 rad,
+    cameras that move between frames, tables built at once or on demand.  Volumes and update counts with the models must equal those
+    without any cull; and the models must have engaged (fewer swept voxels than the ball test alone)."""
+    rng = np.random.default_rng(900 + seed)
+    cfg = synth.Config(128, 1.0, cols=320, rows=240, nodes=600, k=8)
+    intr = Intr(*cfg.intr)
+    pos, sigma = synth.make_nodes(cfg)
+    amp_r, amp_t, noise = [(0.05, 0.01, 1.0), (0.3, 0.05, 0.1), (0.6, 0.1, 0.02), (0.1, 0.02, 0.5)][seed % 4]
+    frames = []
+    for i in range(4):
+        rv = rng.uniform(-amp_r, amp_r, 3)[None] + noise * rng.uniform(-amp_r, amp_r, (cfg.nodes, 3))
+        tv = rng.uniform(-amp_t, amp_t, 3)[None] + noise * rng.uniform(-amp_t, amp_t, (cfg.nodes, 3))
+        frames.append((synth.camera_pose(cfg, 6 * i + seed), compute_dists(upload_u16(synth.depth_frame(cfg, 6 * i + seed)), intr),
+                       synth.dq_from_twist(rv.astype(F32), tv.astype(F32))))
+    wf = WarpField(k=cfg.k, tables_on_demand=(seed % 2 == 0))
+    wf.init(pos, sigma=sigma, transforms=frames[0][2])
+    L = capi.lib()
+    res = []
+    for kw in (dict(block_model="now"), dict(block_model=False), dict(cull=False)):
+        v = make_volume(cfg.dims, cfg.size, cfg.volume_pose, cfg.trunc_dist)
+        cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+        capi.check(L.dfusion_debug_warp_counters(cnt[1:].data_ptr()))
+        try:
+            for cam, d, dq in frames:
+                wf.set_transforms(torch.from_numpy(dq).cuda())
+                v.integrate_warped(d, cam, intr, wf, n_updated=cnt[:1], **kw)
+        finally:
+            capi.check(L.dfusion_debug_warp_counters(None))
+        res.append((v.download(), int(cnt[0].item()), int(cnt[1].item())))
+    print("surface fuzz seed", seed, "updates", res[0][1], "swept with models / ball / none: %d / %d / %d" % (res[0][2], res[1][2], res[2][2]))
+    assert res[0][1] > 0
+    for r in res[1:]:
+        assert np.array_equal(res[0][0], r[0]) and res[0][1] == r[1]
+    assert res[0][2] < res[1][2] <= res[2][2]
