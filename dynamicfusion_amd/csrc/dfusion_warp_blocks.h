@@ -12,9 +12,10 @@
 // With lambda_i = w_i / sum w (normalised weights; the rotation does not see the scale) and r_i = (s_i, v_i), s_i > 0:
 //     the rotation's Gibbs vector  u = N / D,   N = sum lambda_i v_i,  D = sum lambda_i s_i   -- LINEAR in lambda over LINEAR in lambda,
 //     the translation              T = sum w_i t_i                                             -- linear in w.
-// MODEL of a block (built once per weight table, for the blocks a sweep finds alive, by df_block_model_kernel): the union of its 512 voxels' neighbour sets (<= 16 nodes,
-// mean 11; larger unions -> no model, the ball test alone decides) and for every node of it an interval [mid - hw, mid + hw] that
-// holds lambda_i(q) of every voxel of the block (0 where the node is not a neighbour), and one for w_i(q).  10 bytes per entry.
+// MODEL of a block (built once per weight table, for the blocks a sweep finds alive, by df_block_model_kernel): the union of its
+// 512 voxels' neighbour sets (<= 16 nodes, mean 11; larger unions -> no model, the ball test alone decides) and for every node of it
+// an interval [mid - hw, mid + hw] that holds lambda_i(q) of every voxel of the block (0 where the node is not a neighbour), and one
+// for w_i(q).  10 bytes per entry.
 // VERDICT per frame (df_block_verdict_kernel, one lane per block, after the ball test): with the frame's node transforms,
 //     N_c in  sum mid_i v_ic + (1 - sum mid_i) v*_c  +-  sum hw_i |v_ic - v*_c|          (sum lambda_i = 1; v* = entry 0's value)
 //     D   in  [min s_i, max s_i]                                                          (a convex combination)
@@ -25,6 +26,8 @@
 // blocks stay alive (the exact bounding boxes of the warped voxels would keep 29 %).
 // Everything is evaluated in f32 without directed rounding; the box is inflated by 1 mm + 1e-5 of the coordinates' magnitude, three
 // orders of magnitude above the rounding of either side.  Any comparison that involves a NaN / inf keeps the block alive.
+// (The sweep forms the translation as (0.5 tsum rn) * 2 conj(rn): its vector part is tsum's whatever tsum's scalar part, up to
+// rounding relative to |tsum| -- inside the inflation for any translation the volume could hold.)
 #pragma once
 
 #define DF_BM_NU 16                 // entries per block model
