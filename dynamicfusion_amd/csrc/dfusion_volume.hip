@@ -15,6 +15,7 @@
 //     the traffic the algorithmic-bytes figure 8*N_upd counts.
 #include "dfusion_internal.h"
 #include "dfusion_pyramid.h"
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <math.h>
@@ -256,8 +257,9 @@ __global__ __launch_bounds__(256) void df_pyramid_top_kernel(const DfDistsPyrami
     }
 }
 // ------------------------------------------------------------------------------------------ integrate (rigid)
-static bool g_df_rigid_no_depth_cull = false, g_df_rigid_no_fast_forms = false, g_df_rigid_keep_all = false, g_df_rigid_no_sat = false;
-static unsigned long long* g_df_rigid_swept = nullptr;
+// (validation switches, process-wide: atomics, so that a test thread flipping them while another thread integrates is a defined race)
+static std::atomic<bool> g_df_rigid_no_depth_cull{false}, g_df_rigid_no_fast_forms{false}, g_df_rigid_keep_all{false}, g_df_rigid_no_sat{false};
+static std::atomic<unsigned long long*> g_df_rigid_swept{nullptr};
 // bit 0: behind-the-surface test, bit 1: short arithmetic forms, bit 2 SET: the plan keeps every sub-chunk (no frustum test either),
 // bit 3 SET: no saturated-sample shortcuts (every sample takes the exact square root and the fuse division);
 // default 3 (validation switches, results must not change)
@@ -861,8 +863,8 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     float4* starts = (float4*)(scratch + off_starts);
     const int cpw = 64 / (zc / DF_RIGID_SUB);
     const unsigned plan_waves = (unsigned)tiles * (unsigned)((chunks + cpw - 1) / cpw);
-    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((plan_waves + 15) / 16), dim3(1024), 0, st, a, F, Py, n_items, chunks, g_df_rigid_keep_all, cnt, bins, pmask, starts);
-    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((plan_waves + 15) / 16), dim3(1024), 0, st, a, F, Py, n_items, chunks, g_df_rigid_keep_all, cnt, bins, pmask, starts);
+    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((plan_waves + 15) / 16), dim3(1024), 0, st, a, F, Py, n_items, chunks, g_df_rigid_keep_all.load(), cnt, bins, pmask, starts);
+    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((plan_waves + 15) / 16), dim3(1024), 0, st, a, F, Py, n_items, chunks, g_df_rigid_keep_all.load(), cnt, bins, pmask, starts);
     a.plan_bins = bins; a.plan_cnt = cnt; a.plan_mask = pmask; a.plan_starts = starts;
     // short arithmetic forms (tsdf_sample_fast): 32-bit dists offsets, sane intrinsics; the value domain is tested per run in the kernel
     const bool fast_ok = (unsigned long long)rows * pitch < (1ull << 31) && proj[0] == proj[0] && proj[1] == proj[1] && proj[2] > 0.f && proj[3] > 0.f &&

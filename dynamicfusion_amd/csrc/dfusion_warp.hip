@@ -18,6 +18,7 @@
 //     running top-k of its voxel in registers.
 #include "dfusion_internal.h"
 #include "dfusion_pyramid.h"
+#include <atomic>
 #include <stdlib.h>
 #include <stdio.h>
 #include <math.h>
@@ -1917,7 +1918,7 @@ static double df_tile_radius(const float vol2world[12], double nx, double ny, do
 }
 
 // measurement hook, the warped sweep's counterpart of dfusion_debug_rigid_counters (process-wide, off the product path)
-static unsigned long long* g_df_warp_swept = nullptr;
+static std::atomic<unsigned long long*> g_df_warp_swept{nullptr};
 extern "C" int dfusion_debug_warp_counters(unsigned long long* swept_dev)
 {
     g_df_warp_swept = swept_dev;
