@@ -7,6 +7,16 @@ A "step" = one frame of the hot path on device-resident synthetic inputs:
 Workload = BASELINE.json configs[2] (headline): 640x480 depth -> 512^3 TSDF (3 m), ~2000 warp nodes,
 k = 8.  N>1 shards the SAME volume by Z-slab (strong scaling).
 
+The camera goes somewhere: frame f looks from 0.25 deg * f (SURVEY.md 8d; KinFu::operator() never revisits a pose,
+/root/reference/kfusion/src/kinfu.cpp:274-297), priming, warm-up and timed frames are consecutive frames of ONE monotone sweep, so
+the blocks the moving camera brings into view pay for their on-demand k-NN / weight tables and blend models INSIDE the timed frames.
+(`--frames F` cycles F poses instead -- round 3's steady-state loop; the default run reports it as frame_stats.steady_state_loop_ms.)
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own ranks (torch.distributed.run, one per
+GPU, rendezvous on 127.0.0.1), prints rank 0's ONE JSON line last and exits with the ranks' status; under torchrun it is a rank.
+A box with fewer GPUs than ranks runs the same code over gloo with host-staged collectives (a smoke of the code path, flagged
+`oversubscribed`); a box with no GPU runs the launcher and the frame's collectives only (`dry_run`, value null).
+
 Prints ONE JSON line (rank 0) with `roofline` (integrate kernel, HIP-event timed inside the timed
 region) and `cpu_baseline` (the oracle timed on a bounded sample of the same workload, N=1 only).
 """
@@ -17,36 +27,121 @@ import sys
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from dynamicfusion_amd import Intr, TsdfVolume, WarpField, capi, compute_dists, sharded, synth, upload_u16  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_PRIME = 3                 # untimed frames after the index build (first tables, first blend models), volume cleared after them
+MIN_STAT_FRAMES = 40        # frame_stats percentiles are taken over at least this many consecutive frames of the sweep
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="512", choices=sorted(synth.CONFIGS))
-    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
+    ap.add_argument("--config", default="512", choices=["cpu128", "256", "512", "1024"])
+    ap.add_argument("--frames", type=int, default=0,
+                    help="0 (default): a monotone camera sweep, one new pose per frame (0.25 deg / frame); F > 0: F synthetic frames cycled "
+                         "(a steady-state loop: every table and block model exists before the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rigid", action="store_true", help="(kept for old command lines; the extra kernels are timed by default)")
     ap.add_argument("--halo", choices=["recompute", "exchange"], default="recompute",
                     help="N>1: how a rank gets its neighbours' boundary planes for the ray-cast -- recompute them (default: every rank "
                          "integrates its halo planes too, no collective) or exchange them after the integrate (paired isend/irecv over RCCL, "
                          "the north star's wording; one more collective per frame, 2*H fewer planes to sweep)")
-    ap.add_argument("--slabs", choices=["balanced", "uniform"], default="balanced",
-                    help="N>1: Z-slab boundaries -- equal shares of the integrate's WORK (planes weighted by how much of them lies inside the frustum "
-                         "and in front of the first frame's surface; the far slabs are thin) or equal plane counts")
+    ap.add_argument("--slabs", choices=["balanced", "uniform", "measured"], default="measured",
+                    help="N>1: Z-slab boundaries -- `balanced`: equal shares of an a-priori work model (planes weighted by how much of them lies "
+                         "inside the frustum and in front of the first frame's surface); `measured` (default): start from `balanced`, then "
+                         "re-cut once after the priming frames from the verdict pass's alive-block counts per plane (what the sweep really "
+                         "visits), slabs re-allocated; `uniform`: equal plane counts")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (rigid_integrate, extract_cloud, kinfu_frame)")
     ap.add_argument("--no-kinfu", action="store_true", help="skip the kinfu_frame extra (it runs a child process; use under profilers)")
-    return ap.parse_args()
+    ap.add_argument("--no-verify-cull", action="store_true",
+                    help="skip the untimed pass that re-integrates every timed frame with the launch plan's cull switched off, from the same "
+                         "start volume, and compares the volumes bit for bit (cull_bit_identical)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a rank environment: become the launcher.  Re-executes this file under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1 at a free port), relays everything the ranks print except rank 0's JSON line to
+    stderr, prints that line LAST on stdout and returns the ranks' exit status (non-zero if any rank failed or no line came)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, DFUSION_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    out, _ = p.communicate()
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    sys.stderr.flush()
+    if line is not None:
+        print(line, flush=True)
+    if p.returncode != 0:
+        return p.returncode
+    return 0 if line is not None else 1
+
+
+def dry_run(args, rank, world):
+    """No GPU on this box: run what can be run without one -- the launcher, the rendezvous, the slab partition and EVERY collective of
+    the sharded frame with the frame's shapes, dtypes and ops (over gloo, host tensors) -- and say so.  No kernel runs and nothing is
+    measured: value is null.  (The HIP path has no CPU fallback; this exists so that `bench.py --gpus N` is exercised end to end by
+    the CPU test suite.)"""
+    import torch
+    import torch.distributed as dist
+    from dynamicfusion_amd import sharded, synth
+    cfg = synth.CONFIGS[args.config]
+    if world > 1 or os.environ.get("DFUSION_BENCH_FORCE_DIST") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, Y, Z = cfg.dims
+    vs_z = cfg.size / Z
+    halo = sharded.halo_planes(max(cfg.trunc_dist, 2.1 * vs_z), cfg.raycast_step_factor, cfg.gradient_delta_factor, vs_z)
+    bt = torch.zeros(world + 1, dtype=torch.int64)
+    if rank == 0:
+        wts = None
+        if args.slabs != "uniform" and world > 1:
+            wts = sharded.frustum_plane_weights(cfg.dims, cfg.size, cfg.volume_pose, synth.camera_pose(cfg, 0), cfg.intr, cfg.cols, cfg.rows,
+                                                depth_mm=synth.depth_frame(cfg, 0), trunc=max(cfg.trunc_dist, 2.1 * vs_z), margin=0.3)
+        bt.copy_(torch.tensor(sharded.slab_bounds(Z, world, halo, wts), dtype=torch.int64))
+    if dist.is_initialized():
+        dist.broadcast(bt, 0)
+    bounds = [int(v) for v in bt]
+    sharded.validate_bounds(bounds, Z, halo)
+    bundle = torch.zeros(cfg.rows * cfg.cols * 2 + cfg.nodes * 32, dtype=torch.uint8)
+    keys = torch.full((cfg.rows, cfg.cols), sharded.KEY_NONE, dtype=torch.int64)
+    nrm = torch.zeros((cfg.rows, cfg.cols, 4), dtype=torch.float32)
+    alive = torch.zeros(Z // 8 if Z % 8 == 0 else Z, dtype=torch.int64)
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        if dist.is_initialized():
+            dist.broadcast(bundle, 0)
+            dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+            dist.reduce(nrm.view(torch.int32), dst=0, op=dist.ReduceOp.SUM)
+    if dist.is_initialized():
+        dist.all_reduce(alive, op=dist.ReduceOp.SUM)       # the re-balance's per-plane alive counts
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec integrate+raycast, %dx%d->%d^3 TSDF" % (cfg.cols, cfg.rows, cfg.dims[0]), "value": None,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "synthetic",
+                          "dry_run": "no GPU visible: launcher, rendezvous, slab partition and the frame's collectives (gloo, host tensors) only; "
+                                     "no kernel ran, nothing was measured",
+                          "config": {"workload": cfg.name, "parallelism": "zslab%d" % world, "halo_planes": halo, "slab_bounds": bounds}}), flush=True)
+    return 0
 
 
 def measured_copy_gbps(nbytes=1 << 30, iters=10):
@@ -209,76 +304,119 @@ def kinfu_frame_ms(cfg, frames=12):
                     "2x WarpField::warp, psdf, fusion, extract, ray-cast, resize (device-resident data flow)"}
 
 
+def _imports():
+    global torch, dist, Intr, TsdfVolume, WarpField, capi, compute_dists, sharded, synth, upload_u16
+    import torch
+    import torch.distributed as dist
+    from dynamicfusion_amd import Intr, TsdfVolume, WarpField, capi, compute_dists, sharded, synth, upload_u16
+
+
 def main():
     args = parse()
+    force_dist = os.environ.get("DFUSION_BENCH_FORCE_DIST") == "1"
+    if (args.gpus > 1 or force_dist) and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    _imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # never die on this: the rank environment decides (the driver's 8-GPU run must produce a line whichever way it launches)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: running %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
+    if os.environ.get("DFUSION_BENCH_TEST_FAIL_RANK") == str(rank):          # test hook: the launcher must report a failing rank
+        raise RuntimeError("DFUSION_BENCH_TEST_FAIL_RANK: rank %d fails on purpose" % rank)
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev == 0:
+        return dry_run(args, rank, world)
     # DFUSION_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL process group, slab volume, broadcast, the merge collectives) with
     # whatever WORLD_SIZE is -- with one rank it is an RCCL dry run of every collective, dtype and op of the sharded frame
     # (tests/test_gpu_sharded.py runs it), since an 8-GPU node is only ever seen by the driver
-    dist_on = world > 1 or os.environ.get("DFUSION_BENCH_FORCE_DIST") == "1"
+    dist_on = world > 1 or force_dist
+    # fewer GPUs than ranks (a one-GPU box asked for N ranks): RCCL refuses two ranks on one device, so the ranks share the devices
+    # round-robin and the collectives run over gloo with host staging -- the same sharded code, as a smoke of the path, not a timing
+    oversub = dist_on and world > n_dev
     if dist_on:
-        torch.cuda.set_device(local_rank)
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % n_dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        if oversub:
+            sharded.set_host_staging(True)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     cfg = synth.CONFIGS[args.config]
     intr = Intr(*cfg.intr)
     X, Y, Z = cfg.dims
-    F = args.frames
+    # ---- the frame sequence: N_PRIME priming + warm-up + timed + (so that the percentiles have >= MIN_STAT_FRAMES samples) extra frames,
+    # all consecutive poses of one sweep unless --frames F asks for F cycled poses
+    n_extra = max(0, MIN_STAT_FRAMES - args.steps)
+    n_seq = N_PRIME + args.warmup + args.steps + n_extra
+    F = args.frames if args.frames > 0 else n_seq
+    monotone = args.frames <= 0
 
-    # ---- synthetic inputs, resident in HBM before the timed region
-    depths_np = [synth.depth_frame(cfg, f) for f in range(F)]
-    depths = [upload_u16(d, dev) for d in depths_np]
+    # ---- synthetic inputs, resident in HBM before the timed region (rank 0 owns the sensor and the solver output)
     cam_poses = [synth.camera_pose(cfg, f) for f in range(F)]
     pos, sigma = synth.make_nodes(cfg)
-    dqs_np = [synth.node_transforms(cfg, f) for f in range(F)]
-    dqs = [torch.from_numpy(d).to(dev) for d in dqs_np]
+    dqs_np0 = synth.node_transforms(cfg, 0)
+    depth0_np = synth.depth_frame(cfg, 0)
+    if rank == 0 or not dist_on:
+        depths_np = [depth0_np] + [synth.depth_frame(cfg, f) for f in range(1, F)]
+        depths = [upload_u16(d, dev) for d in depths_np]
+        dqs = [torch.from_numpy(synth.node_transforms(cfg, f)).to(dev) for f in range(F)]
+    else:
+        depths, dqs = None, None
 
     vs_z = cfg.size / Z
     trunc_eff = max(cfg.trunc_dist, 2.1 * vs_z)
     halo = sharded.halo_planes(trunc_eff, cfg.raycast_step_factor, cfg.gradient_delta_factor, vs_z)
     slab_bounds = None
-    if dist_on:
-        # the partition is decided once, from the first sensor frame, on rank 0 (which owns the sensor) and broadcast: every rank must
-        # hold the SAME boundaries before the first slab is allocated
+
+    def make_volume(bounds):
+        if dist_on:
+            v = TsdfVolume(cfg.dims, device=dev, slab=(bounds[rank], bounds[rank + 1] - bounds[rank], halo))
+        else:
+            v = TsdfVolume(cfg.dims, device=dev)
+        v.setSize([cfg.size] * 3); v.setTruncDist(cfg.trunc_dist); v.setMaxWeight(cfg.max_weight)
+        v.setPose(cfg.volume_pose)
+        v.setRaycastStepFactor(cfg.raycast_step_factor); v.setGradientDeltaFactor(cfg.gradient_delta_factor)
+        v.clear()
+        # N > 1: every rank also integrates its halo planes (a pure function of the broadcast inputs: bit-identical with the
+        # neighbour's planes), so the frame has NO halo collective; `vi` is the same blob seen as owner of all its stored planes.
+        vi = v.owning_stored_planes() if (dist_on and args.halo == "recompute") else v
+        return v, vi
+
+    def share_bounds(b):
         bt = torch.zeros(world + 1, dtype=torch.int64, device=dev)
         if rank == 0:
-            wts = None
-            if args.slabs == "balanced" and world > 1:
-                wts = sharded.frustum_plane_weights(cfg.dims, cfg.size, cfg.volume_pose, cam_poses[0], cfg.intr, cfg.cols, cfg.rows,
-                                                    depth_mm=depths_np[0], trunc=trunc_eff, margin=0.3)
-            bt.copy_(torch.tensor(sharded.slab_bounds(Z, world, halo, wts), dtype=torch.int64))
-        dist.broadcast(bt, 0)
-        slab_bounds = [int(v) for v in bt.cpu()]
-        sharded.validate_bounds(slab_bounds, Z, halo)      # same verdict on every rank, before the first data collective
-        z_own0, z_own_n = slab_bounds[rank], slab_bounds[rank + 1] - slab_bounds[rank]
-        vol = TsdfVolume(cfg.dims, device=dev, slab=(z_own0, z_own_n, halo))
-    else:
-        vol = TsdfVolume(cfg.dims, device=dev)
-    vol.setSize([cfg.size] * 3); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight)
-    vol.setPose(cfg.volume_pose)
-    vol.setRaycastStepFactor(cfg.raycast_step_factor); vol.setGradientDeltaFactor(cfg.gradient_delta_factor)
-    vol.clear()
+            bt.copy_(torch.tensor(b, dtype=torch.int64))
+        sharded.coll_broadcast(bt, 0)
+        b = [int(v) for v in bt.cpu()]
+        sharded.validate_bounds(b, Z, halo)                 # same verdict on every rank, before the first data collective
+        return b
 
-    # N > 1: every rank also integrates its halo planes (a pure function of the broadcast inputs: bit-identical with the neighbour's
-    # planes), so the frame has NO halo collective; `vol_int` is the same blob seen as owner of all its stored planes.
-    vol_int = vol.owning_stored_planes() if (dist_on and args.halo == "recompute") else vol
+    if dist_on:
+        # the partition is decided on rank 0 (which owns the sensor) and broadcast: every rank must hold the SAME boundaries before
+        # the first slab is allocated
+        b0 = None
+        if rank == 0:
+            wts = None
+            if args.slabs != "uniform" and world > 1:
+                wts = sharded.frustum_plane_weights(cfg.dims, cfg.size, cfg.volume_pose, cam_poses[0], cfg.intr, cfg.cols, cfg.rows,
+                                                    depth_mm=depth0_np, trunc=trunc_eff, margin=0.3)
+            b0 = sharded.slab_bounds(Z, world, halo, wts)
+        slab_bounds = share_bounds(b0)
+    vol, vol_int = make_volume(slab_bounds)
+
     wf = WarpField(k=cfg.k, device=dev)
-    wf.init(pos, sigma=sigma, transforms=dqs_np[0])
+    wf.init(pos, sigma=sigma, transforms=dqs_np0)
     t0_index = time.time()
     wf.ensure_index(vol_int, cfg.k)
     torch.cuda.synchronize()
 
-    dists = torch.empty_like(depths[0])
+    dists = torch.empty((cfg.rows, cfg.cols), dtype=torch.int16, device=dev)
     keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device=dev) if dist_on else None
     out2 = torch.empty((2, cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev)
     pts, nrm = out2[0], out2[1]
@@ -288,23 +426,20 @@ def main():
     depth_in = bundle[:n_depth].view(torch.int16).view(cfg.rows, cfg.cols)
     dq_in = bundle[n_depth:].view(torch.float32).view(cfg.nodes, 8)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-
-    def step(i, timed_idx=None):
+    def step(i, ev=None):
         f = i % F
         if dist_on:                                    # rank 0 owns the sensor frame and the solver output
             if rank == 0:
                 depth_in.copy_(depths[f]); dq_in.copy_(dqs[f])
-            dist.broadcast(bundle, 0)
+            sharded.coll_broadcast(bundle, 0)
             d_in, q_in = depth_in, dq_in
         else:
             d_in, q_in = depths[f], dqs[f]
         wf.set_transforms(q_in)
         compute_dists(d_in, intr, dists)
-        if timed_idx is not None: ev[timed_idx][0].record()
+        if ev is not None: ev[0].record()
         vol_int.integrate_warped(dists, cam_poses[f], intr, wf, sync=False)
-        if timed_idx is not None: ev[timed_idx][1].record()
+        if ev is not None: ev[1].record()
         if dist_on and args.halo == "exchange":
             sharded.exchange_halos(vol.data(), vol.z_store0, vol.z_own0, vol.z_own_n, Z, halo, rank, world)
         if dist_on:
@@ -315,7 +450,7 @@ def main():
         else:
             vol.raycast(cam_poses[f], intr, pts, nrm)
             out = (pts, nrm)
-        if timed_idx is not None: ev[timed_idx][2].record()
+        if ev is not None: ev[2].record()
         return out
 
     def barrier():
@@ -323,79 +458,164 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def events(n):
+        return [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(n)]
+
     # The per-node-set work: with tables on demand (the mirrors' default) `ensure_index` above only builds the brick index; the tables,
-    # then the blend models, of the blocks the launch plans find alive are made by the first sweeps.  Three untimed frames pay that
-    # here, whatever --warmup is (what newly alive blocks cost as the camera moves stays inside the timed frames); the volume is
-    # cleared again.  `index_build_once_s` covers index + these frames.
-    for i in range(3):
+    # then the blend models, of the blocks the launch plans find alive are made by the first sweeps.  N_PRIME untimed frames pay for
+    # the FIRST alive set here, whatever --warmup is; what the moving camera brings in afterwards is paid inside the warm-up and
+    # timed frames.  The volume is cleared again.  `index_build_once_s` covers index + these frames.
+    for i in range(N_PRIME):
         step(i)
+    rebalance = None
+    if dist_on and world > 1 and args.slabs == "measured":
+        # ---- re-cut the slabs ONCE from what the verdict pass found alive: the a-priori frustum weights do not
+        # describe a sweep the block verdicts have thinned.  Every rank counts the alive 8x8x8 blocks of its OWN layers, one
+        # all_reduce(SUM) makes the global per-layer profile, every rank computes the same new boundaries, slabs and index are re-made.
+        layers = torch.zeros(Z // 8, dtype=torch.int64, device=dev)
+        wf.alive_blocks_per_layer(vol, layers)
+        sharded.coll_all_reduce(layers, dist.ReduceOp.SUM)
+        w_layer = layers.cpu().numpy().astype(np.float64)
+        new_bounds = sharded.slab_bounds(Z, world, halo, sharded.layer_weights_to_planes(w_layer, Z))
+        sharded.validate_bounds(new_bounds, Z, halo)
+        rebalance = {"from": slab_bounds, "to": new_bounds, "alive_blocks_per_8_planes": [int(v) for v in w_layer]}
+        if new_bounds != slab_bounds:
+            slab_bounds = new_bounds
+            del vol, vol_int
+            vol, vol_int = make_volume(slab_bounds)
+            wf.ensure_index(vol_int, cfg.k)
+            for i in range(N_PRIME):
+                step(i)
     vol.clear()
     barrier()
     t_index = time.time() - t0_index
+    i0 = N_PRIME
     for i in range(args.warmup):
-        step(i)
+        step(i0 + i)
+    verify = not args.no_verify_cull
+    vol_start = vol.data().clone() if verify else None
+    i0 += args.warmup
+    ev = events(args.steps)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i, timed_idx=i)
+        step(i0 + i, ev[i])
     barrier()
     elapsed = time.perf_counter() - t0
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sharded.coll_all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    vol_end = vol.data().clone() if verify else None
+    timed_frames = [(i0 + i) % F for i in range(args.steps)]
 
+    # ---- the sweep goes on (untimed by the wall clock, HIP events per frame) until the percentiles have MIN_STAT_FRAMES samples
+    ev_more = events(n_extra)
+    for i in range(n_extra):
+        step(i0 + args.steps + i, ev_more[i])
+    torch.cuda.synchronize()
     ms_int = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ms_ray = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     # per-frame spread (integrate + ray-cast between HIP events on the launch stream) and the reference-shaped frame
     # (KinFu::dynamicfusion integrates once and ray-casts twice)
-    per_frame = np.array([e[0].elapsed_time(e[2]) for e in ev], np.float64)
+    per_frame = np.array([e[0].elapsed_time(e[2]) for e in ev + ev_more], np.float64)
+    per_int = np.array([e[0].elapsed_time(e[1]) for e in ev + ev_more], np.float64)
     frame_stats = {"integrate+raycast_ms": {"p10": float(np.percentile(per_frame, 10)), "median": float(np.median(per_frame)),
-                                            "p90": float(np.percentile(per_frame, 90))},
+                                            "p90": float(np.percentile(per_frame, 90)), "max": float(per_frame.max()), "frames": int(per_frame.size)},
+                   "integrate_warped_ms": {"p10": float(np.percentile(per_int, 10)), "median": float(np.median(per_int)),
+                                           "p90": float(np.percentile(per_int, 90)), "max": float(per_int.max())},
+                   "trajectory": ("monotone sweep, 0.25 deg per frame: %d priming + %d warm-up + %d timed + %d more frames, poses %d..%d timed"
+                                  % (N_PRIME, args.warmup, args.steps, n_extra, i0, i0 + args.steps - 1)) if monotone else "%d poses cycled" % F,
                    "reference_shaped_ms": ms_int + 2.0 * ms_ray}
+    if monotone:
+        # round 3's headline for comparison: the last four poses cycled -- every table and block model they need exists
+        loop = [n_seq - 4 + j for j in range(4)]
+        for j in range(4):
+            step(loop[j])
+        barrier()
+        t1 = time.perf_counter()
+        for j in range(20):
+            step(loop[j % 4])
+        barrier()
+        frame_stats["steady_state_loop_ms"] = 1e3 * (time.perf_counter() - t1) / 20
 
-    # ---- algorithmic bytes of one integrate launch: 8*N_upd + 2*W*H + 48*M.
-    # N_upd counted by the kernel itself (parity-checked against the oracle's count in tests/), untimed pass.
-    n_upd = torch.zeros(2, dtype=torch.int64, device=dev)          # [0] updated, [1] swept (the plan's alive cells, dfusion_debug_warp_counters)
-    capi.check(capi.lib().dfusion_debug_warp_counters(n_upd[1:].data_ptr()))
-    for f in range(F):
-        vol.integrate_warped(compute_dists(depths[f], intr, dists), cam_poses[f], intr, wf, n_updated=n_upd[:1], sync=False)
-    torch.cuda.synchronize()
-    capi.check(capi.lib().dfusion_debug_warp_counters(None))
-    n_upd_launch = float(n_upd[0].item()) / F
-    n_swept_launch = float(n_upd[1].item()) / F
+    # ---- algorithmic bytes of one integrate launch: 8*N_upd + 2*W*H + 48*M, over the TIMED frames' poses.
+    # N_upd counted by the kernel itself (parity-checked against the oracle's count in tests/), untimed pass; whether a voxel updates
+    # depends on the frame's geometry and depth only, not on what the volume holds.
+    n_upd = torch.zeros(2, dtype=torch.int64, device=dev)          # [0] updated, [1] swept (the plan's alive cells, dfusion_warp_debug_counters)
+
+    def replay(cull, counters):
+        """the timed frames' integrates again (inputs as rank 0 broadcast them: every rank keeps what it needs to replay locally)"""
+        for f in timed_frames:
+            if dist_on:
+                if rank == 0:
+                    depth_in.copy_(depths[f]); dq_in.copy_(dqs[f])
+                sharded.coll_broadcast(bundle, 0)
+                d_in, q_in = depth_in, dq_in
+            else:
+                d_in, q_in = depths[f], dqs[f]
+            wf.set_transforms(q_in)
+            vol_int.integrate_warped(compute_dists(d_in, intr, dists), cam_poses[f], intr, wf, n_updated=counters, cull=cull, sync=False)
+        torch.cuda.synchronize()
+
+    wf.debug_counters(n_upd[1:])
+    replay(True, n_upd[:1])
+    wf.debug_counters(None)
+    n_upd_launch = float(n_upd[0].item()) / len(timed_frames)
+    n_swept_launch = float(n_upd[1].item()) / len(timed_frames)
     if dist_on:
         t = torch.tensor([n_upd_launch], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        sharded.coll_all_reduce(t, dist.ReduceOp.SUM)
         n_upd_total = float(t.item())
     else:
         n_upd_total = n_upd_launch
     alg_bytes = 8.0 * n_upd_launch + 2.0 * cfg.cols * cfg.rows + 48.0 * cfg.nodes
     achieved = alg_bytes / (ms_int * 1e-3) / 1e9
 
+    # ---- the launch plan's cull, verified on the timed frames themselves: the same frames from the same start volume with the cull
+    # switched off (every voxel goes through the reference's own tests, tsdf_volume.cu:77-93) must leave the same bits
+    verify_cull = None
+    if verify:
+        vol.data().copy_(vol_start)
+        n_nc = torch.zeros(1, dtype=torch.int64, device=dev)
+        replay(False, n_nc)
+        same = bool(torch.equal(vol.data(), vol_end))
+        n_diff = 0 if same else int((vol.data() != vol_end).sum().item())
+        flag = torch.tensor([1 if same else 0, int(n_nc.item()), int(n_upd[0].item()), n_diff], dtype=torch.int64, device=dev)
+        if dist_on:
+            mn = flag[:1].clone(); sharded.coll_all_reduce(mn, dist.ReduceOp.MIN)
+            sharded.coll_all_reduce(flag, dist.ReduceOp.SUM)
+            flag[0] = mn[0]
+        flag = [int(v) for v in flag.cpu()]
+        verify_cull = {"cull_bit_identical": bool(flag[0]), "frames": len(timed_frames), "voxels_differing": flag[3],
+                       "updates_with_cull": flag[2], "updates_without_cull": flag[1],
+                       "what": "the timed frames re-integrated from the volume they started on with DF_WARP_NO_CULL (no launch plan: every voxel of the "
+                               "slab is warped and tested); volumes compared bit for bit, update counts side by side"}
+        vol.data().copy_(vol_end)
+        del vol_start, vol_end
+
     extra = {}
     if not args.no_extras and not dist_on:
         vol2 = TsdfVolume(cfg.dims, device=dev)
         vol2.setSize([cfg.size] * 3); vol2.setTruncDist(cfg.trunc_dist); vol2.setMaxWeight(cfg.max_weight); vol2.setPose(cfg.volume_pose)
-        nr = torch.zeros(2, dtype=torch.int64, device=dev)       # [0] updated, [1] swept (dfusion_debug_rigid_counters)
-        for f in range(2):
+        nr = torch.zeros(2, dtype=torch.int64, device=dev)       # [0] updated, [1] swept (dfusion_integrate_ex)
+        tf = timed_frames
+        for f in tf[:2]:
             vol2.integrate(dists, cam_poses[f], intr, sync=False)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(20):
-            vol2.integrate(dists, cam_poses[i % F], intr, sync=False)
+            vol2.integrate(dists, cam_poses[tf[i % len(tf)]], intr, sync=False)
         e1.record()
         torch.cuda.synchronize()
-        capi.check(capi.lib().dfusion_debug_rigid_counters(nr[1:].data_ptr()))
-        for f in range(F):
-            vol2.integrate(dists, cam_poses[f], intr, n_updated=nr[:1], sync=False)
+        for i in range(20):
+            vol2.integrate(dists, cam_poses[tf[i % len(tf)]], intr, n_updated=nr[:1], n_swept=nr[1:], sync=False)
         torch.cuda.synchronize()
-        capi.check(capi.lib().dfusion_debug_rigid_counters(None))
         ms_r = e0.elapsed_time(e1) / 20
-        b_r = 8.0 * float(nr[0].item()) / F + 2.0 * cfg.cols * cfg.rows
+        b_r = 8.0 * float(nr[0].item()) / 20 + 2.0 * cfg.cols * cfg.rows
         extra["rigid_integrate"] = {"kernel": "df_integrate_rigid_kernel<2, true, false> (+ df_rigid_plan_kernel, df_pyramid_tiles_kernel)",
                                     "ms": ms_r, "achieved_GBps": b_r / (ms_r * 1e-3) / 1e9, "frac_of_peak": b_r / (ms_r * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                    "n_updated": float(nr[0].item()) / F, "n_swept": float(nr[1].item()) / F,
+                                    "n_updated": float(nr[0].item()) / 20, "n_swept": float(nr[1].item()) / 20,
                                     "swept_over_updated": float(nr[1].item()) / max(float(nr[0].item()), 1.0),
                                     "algorithmic_bytes_per_launch": b_r}
         del vol2
@@ -443,12 +663,12 @@ def main():
             extra["frame_nodes_changed_ms"] = {"ms": float(np.median(reb)), "what": "set_nodes (incl. the nanoflann tree replica, built on the host) + brick index "
                                                "+ per-voxel k-NN / weight tables rebuilt + the frame itself; wall clock, median of 3"}
             lean = WarpField(k=cfg.k, device=dev, voxel_table=False)
-            lean.init(pos, sigma=sigma, transforms=dqs_np[0])
+            lean.init(pos, sigma=sigma, transforms=dqs_np0)
             lean.ensure_index(vol, cfg.k)
             vol.integrate_warped(dists, cam_poses[0], intr, lean, sync=False)
             e0.record()
             for i in range(5):
-                vol.integrate_warped(dists, cam_poses[i % F], intr, lean, sync=False)
+                vol.integrate_warped(dists, cam_poses[tf[i % len(tf)]], intr, lean, sync=False)
             e1.record(); torch.cuda.synchronize()
             extra["lean_path_ms"] = {"integrate_warped_ms": e0.elapsed_time(e1) / 5, "what": "no per-voxel cache (brick candidate lists only, ~80 MB): exact top-k "
                                      "over ~150 candidates per voxel and the weights' exp() every frame (df_warp_brick_kernel)"}
@@ -472,7 +692,7 @@ def main():
     else:
         kernel_name = "df_warp_rows_kernel<%d, true, 4>" % cfg.k
     table_bytes = int(X) * Y * vol.z_own_n * cfg.k * 6
-    traffic, traffic_src = None, None
+    traffic, traffic_src, compute = None, None, None
     pmc_file = os.path.join(REPO, "profiles", "pmc_latest.json")
     if not dist_on and os.path.exists(pmc_file):
         try:
@@ -484,6 +704,29 @@ def main():
             src_sha = _build.kernel_source_sha("df_warp_rows_pipe_kernel")
             if ent and ent.get("source_sha256") == src_sha:
                 traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/pmc_latest.json (%s)" % ent.get("how", "rocprofv3 --pmc")
+                c = ent.get("counters", {})
+                if all(k in c for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES")) and ent.get("n_swept_per_launch"):
+                    # The compute ceiling beside the HBM one (same file, same sha stamp).  One VALU wave64 instruction occupies a
+                    # SIMD's 16 lanes for 4 cycles, so a SIMD issues at most clock/4 of them per second; 1024 SIMDs.  The counters
+                    # are per LAUNCH of tools/pmc_run.py's frame (its swept-voxel count rides along); SQ_ACTIVE_INST_VALU is
+                    # summed over the 4 SIMDs of a CU in units of 4 cycles and SQ_BUSY_CYCLES over 32 shader-engine halves
+                    # ("in counters"), hence the two scalings.
+                    clock_hz, simds = 2.4e9, 1024
+                    peak_issue = simds * clock_hz / 4.0
+                    launch_cycles = c["SQ_BUSY_CYCLES"] / 32.0
+                    insts = c["SQ_INSTS_VALU"]
+                    compute = {"valu_insts_per_swept_voxel": insts * 64.0 / ent["n_swept_per_launch"],
+                               "valu_wave_insts_per_launch": insts, "salu_wave_insts_per_launch": c.get("SQ_INSTS_SALU"),
+                               "valu_busy_frac": 4.0 * c["SQ_ACTIVE_INST_VALU"] / simds / launch_cycles,
+                               "peak_issue_rate": peak_issue, "unit": "VALU wave64 instructions/s (1024 SIMDs x 2.4 GHz / 4 cycles)",
+                               # this run's frames: the profiled instructions per swept voxel x the voxels THIS run's launches sweep, over
+                               # this run's HIP-event integrate time (which includes the verdict pass and the plan, ~5 %)
+                               "achieved_issue_rate": insts / ent["n_swept_per_launch"] * n_swept_launch / (ms_int * 1e-3),
+                               "waves_per_simd": (c["SQ_WAVE_CYCLES"] * 4.0 / simds / launch_cycles) if "SQ_WAVE_CYCLES" in c else None,
+                               "n_swept_per_launch_profiled": ent["n_swept_per_launch"],
+                               "source": "profiles/pmc_latest.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES, separate pass; "
+                                         "same source sha256 as traffic)"}
+                    compute["achieved_frac"] = compute["achieved_issue_rate"] / peak_issue
             elif ent:
                 traffic_src = "profiles/pmc_latest.json is from another build of the sweep's sources (sha256 %s...): traffic dropped" % str(ent.get("source_sha256"))[:12]
         except Exception:
@@ -512,7 +755,7 @@ def main():
             "frame_stats": frame_stats,
             "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "compute": compute,
                          "algorithmic_bytes_per_launch": alg_bytes, "n_updated_per_launch": n_upd_launch,
                          "n_swept_per_launch": n_swept_launch, "swept_over_updated": (n_swept_launch / n_upd_launch) if n_upd_launch else None,
                          "n_updated_all_ranks": n_upd_total, "measured_copy_GBps": copy_gbps,
@@ -527,14 +770,24 @@ def main():
                                  "also streams its per-voxel k-NN + weight cache (48 B/voxel at k=8), see DESIGN.md"},
         }
         out.update(extra)
+        if verify_cull is not None:
+            out["verify_cull"] = verify_cull
+        if rebalance is not None:
+            out["config"]["rebalance"] = rebalance
+        if oversub:
+            out["oversubscribed"] = ("%d ranks on %d GPU(s): gloo with host-staged collectives, ranks share devices -- a smoke of the "
+                                     "sharded code path, NOT a measurement" % (world, n_dev))
         if not dist_on and not args.no_cpu_baseline:
             vol_host = vol.download()
             # the same frame on the GPU from the same start volume (for cpu_baseline.integrate_bit_identical)
-            wf.set_transforms(dqs[0])
-            vol.integrate_warped(compute_dists(depths[0], intr, dists), cam_poses[0], intr, wf)
+            fr = timed_frames[0]                        # the first timed pose of the sweep
+            dq_fr = synth.node_transforms(cfg, fr)
+            wf.set_transforms(dqs[fr])
+            vol.integrate_warped(compute_dists(depths[fr], intr, dists), cam_poses[fr], intr, wf)
             vol_after = vol.download()
-            out["cpu_baseline"] = cpu_baseline(cfg, (depths_np[0], None, cfg.volume_pose, cam_poses[0], pos, sigma, dqs_np[0]), vol_host,
+            out["cpu_baseline"] = cpu_baseline(cfg, (depths_np[fr], None, cfg.volume_pose, cam_poses[fr], pos, sigma, dq_fr), vol_host,
                                                gpu_after=vol_after)
+            out["cpu_baseline"]["frame"] = fr
             del vol_after
             rcb = out["cpu_baseline"].pop("raycast_algorithmic_bytes")
             out["raycast"] = {"kernel": "df_raycast_kernel<0>", "ms": ms_ray, "algorithmic_bytes": rcb,
@@ -542,8 +795,7 @@ def main():
                               "achieved_GBps": rcb / (ms_ray * 1e-3) / 1e9,
                               "note": "gather-latency bound (one dependent 4-byte fetch per march step); reported, no roofline target (SURVEY 8d)"}
             try:
-                wf.set_transforms(dqs[0])
-                rw = reference_warp_baseline(cfg, pts, pos, sigma, dqs_np[0], wf)
+                rw = reference_warp_baseline(cfg, pts, pos, sigma, dq_fr, wf)
                 if rw:
                     out["cpu_baseline"]["reference_warp"] = rw
             except Exception as e:                      # the reference build is optional; never lose the bench line over it
@@ -562,5 +814,8 @@ def main():
         print(line, flush=True)
 
 
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

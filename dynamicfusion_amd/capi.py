@@ -36,6 +36,10 @@ DF_WARP_NO_ZERO_SKIP = 32
 DF_WARP_NO_DEPTH_PYRAMID = 64
 DF_WARP_NO_BLOCK_MODEL = 128
 DF_WARP_BLOCK_MODEL_NOW = 256
+DF_RIGID_NO_DEPTH_CULL = 1
+DF_RIGID_NO_SHORT_FORMS = 2
+DF_RIGID_KEEP_ALL = 4
+DF_RIGID_NO_SAT = 8
 DF_INDEX_VOXEL_TABLE = 1
 DF_INDEX_WEIGHT_TABLE = 2
 DF_INDEX_TABLES_ON_DEMAND = 4
@@ -50,7 +54,7 @@ SYMBOLS = [
     "dfusion_bilateral_filter", "dfusion_truncate_depth", "dfusion_depth_pyramid", "dfusion_compute_normals_mask_depth",
     "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
     "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate", "dfusion_release_scratch", "dfusion_raycast_points_of_keys",
-    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_debug_rigid", "dfusion_debug_rigid_counters", "dfusion_debug_warp_counters",
+    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_integrate_ex", "dfusion_warp_debug_counters", "dfusion_warp_alive_blocks",
     "dfusion_render_image_points", "dfusion_render_image_depth", "dfusion_render_tangent_colors",
 ]
 
@@ -140,9 +144,9 @@ def load(path, strict=True):
     L.dfusion_render_image_points.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, fp, vp, sz, vp]
     L.dfusion_render_image_depth.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, fp, fp, vp, sz, vp]
     L.dfusion_render_tangent_colors.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp]
-    L.dfusion_debug_rigid.argtypes = [C.c_int]
-    L.dfusion_debug_rigid_counters.argtypes = [vp]
-    L.dfusion_debug_warp_counters.argtypes = [vp]
+    L.dfusion_integrate_ex.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, DfVolume, C.POINTER(DfSlab), fp, fp, C.c_uint, vp, vp, vp]
+    L.dfusion_warp_debug_counters.argtypes = [vp, vp]
+    L.dfusion_warp_alive_blocks.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
     L.dfusion_copy_bandwidth_probe.argtypes = [vp, vp, C.c_size_t, vp]
     L.dfusion_read_bandwidth_probe.argtypes = [vp, C.c_size_t, vp, vp]
     for s in SYMBOLS:

@@ -84,4 +84,6 @@ struct DfWarpField {
     uint16_t* bm_idx; uint32_t* bm_lam; uint32_t* bm_w; uint8_t* bm_cnt; size_t bm_cap;
     bool tab_complete;           // every block's tables are built
     int tab_sweeps;              // sweeps over the current tables so far (the models are made from the second one on)
+    unsigned long long* dbg_swept;   // dfusion_warp_debug_counters: nullable device counter the sweeps through this handle add to
+    bool alive_valid;            // blk_alive holds the verdicts of a sweep over the current tables (dfusion_warp_alive_blocks)
 };

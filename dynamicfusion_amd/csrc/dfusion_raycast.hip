@@ -380,6 +380,12 @@ extern "C" int dfusion_raycast_march(DfVolume v, const DfSlab* slab, const float
     const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     int rc = df_raycast_setup(a, v, slab, cam2vol, ident, reproj, cols, rows, step_factor, 0.5f);
     if (rc) return rc;
+    // the merge key carries the step index in 23 bits: a ray's march is tmax - tmin <= the volume's diagonal long, in steps of
+    // time_step -- refuse a step so small (or a volume so deep) that the index could reach 2^23 and wrap the ordering
+    {
+        const double diag = sqrt((double)a.sizex * a.sizex + (double)a.sizey * a.sizey + (double)a.sizez * a.sizez);
+        if (!(a.time_step > 0.f) || !(diag / (double)a.time_step < 8388608.0 - 4.0)) return DF_E_INVALID;
+    }
     hipLaunchKernelGGL(df_raycast_march_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, keys, rank_tag);
     DF_LAUNCH_CHECK();
     return DF_OK;

@@ -257,26 +257,7 @@ __global__ __launch_bounds__(256) void df_pyramid_top_kernel(const DfDistsPyrami
     }
 }
 // ------------------------------------------------------------------------------------------ integrate (rigid)
-// (validation switches, process-wide: atomics, so that a test thread flipping them while another thread integrates is a defined race)
-static std::atomic<bool> g_df_rigid_no_depth_cull{false}, g_df_rigid_no_fast_forms{false}, g_df_rigid_keep_all{false}, g_df_rigid_no_sat{false};
-static std::atomic<unsigned long long*> g_df_rigid_swept{nullptr};
-// bit 0: behind-the-surface test, bit 1: short arithmetic forms, bit 2 SET: the plan keeps every sub-chunk (no frustum test either),
-// bit 3 SET: no saturated-sample shortcuts (every sample takes the exact square root and the fuse division);
-// default 3 (validation switches, results must not change)
-extern "C" int dfusion_debug_rigid(int flags)
-{
-    g_df_rigid_no_depth_cull = !(flags & 1); g_df_rigid_no_fast_forms = !(flags & 2); g_df_rigid_keep_all = (flags & 4) != 0;
-    g_df_rigid_no_sat = (flags & 8) != 0;
-    return DF_OK;
-}
-// measurement hook: while set (device pointer, nullable), every dfusion_integrate launch adds the number of voxels its sweep put
-// through the sample chain to *swept_dev -- the denominator of "swept / updated" next to n_updated_dev
-extern "C" int dfusion_debug_rigid_counters(unsigned long long* swept_dev)
-{
-    g_df_rigid_swept = swept_dev;
-    return DF_OK;
-}
-
+// Validation switches and the swept-voxel counter are PER CALL (dfusion_integrate_ex's flags / n_swept_dev): nothing process-wide.
 struct DfRigidArgs {
     uint32_t* vol;            // first stored plane
     int X, Y;
@@ -710,7 +691,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.n_upd, (unsigned long long)s);
     }
-    if (COUNT && a.n_swept) {                                          // (validation / measurement hook: dfusion_debug_rigid_counters)
+    if (COUNT && a.n_swept) {                                          // (validation / measurement hook: dfusion_integrate_ex n_swept_dev)
         const unsigned long long s = (unsigned long long)my_swept * (unsigned)__popcll(__builtin_amdgcn_ballot_w64(active));
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(a.n_swept, s);
     }
@@ -753,17 +734,26 @@ size_t df_pyramid_elems(int cols, int rows)
     return n;
 }
 
-// DFUSION_RIGID_NO_DEPTH_CULL=1 switches the behind-the-surface test off (validation: the volumes must be identical)
-static bool df_rigid_depth_cull_disabled()
-{
-    static const bool off = [] { const char* e = getenv("DFUSION_RIGID_NO_DEPTH_CULL"); return e && e[0] == '1'; }();
-    return off || g_df_rigid_no_depth_cull;
-}
 
-// The rigid integrate's scratch, cached per (device, stream); dfusion_release_scratch() frees every entry.
-struct DfScratchEntry { int device; hipStream_t stream; char* mem; size_t cap; };
+// The rigid integrate's scratch, cached per (device, stream) and kept until dfusion_release_scratch(): at most DF_SCRATCH_MAX entries,
+// the least recently used one is evicted (a host that makes a stream per frame would otherwise leave ~84 MB behind per stream at
+// 512^3).  A cached stream handle may have been destroyed by the host since: entries are freed after a DEVICE synchronise, never
+// through the stored handle.
+#define DF_SCRATCH_MAX 8
+struct DfScratchEntry { int device; hipStream_t stream; char* mem; size_t cap; unsigned long long used; };
 static std::mutex g_df_scratch_mutex;
 static std::vector<DfScratchEntry> g_df_scratch;
+static unsigned long long g_df_scratch_clock = 0;
+static void df_scratch_free_entry(DfScratchEntry& c)
+{
+    if (!c.mem) return;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    if (hipSetDevice(c.device) == hipSuccess) { (void)hipDeviceSynchronize(); (void)hipFree(c.mem); }
+    (void)hipGetLastError();
+    if (have_cur) (void)hipSetDevice(cur);
+    c.mem = nullptr; c.cap = 0;
+}
 static char* df_rigid_scratch(hipStream_t st, size_t bytes)
 {
     int dev = 0;
@@ -771,7 +761,17 @@ static char* df_rigid_scratch(hipStream_t st, size_t bytes)
     std::lock_guard<std::mutex> lock(g_df_scratch_mutex);
     DfScratchEntry* e = nullptr;
     for (DfScratchEntry& c : g_df_scratch) if (c.device == dev && c.stream == st) { e = &c; break; }
-    if (!e) { g_df_scratch.push_back(DfScratchEntry{dev, st, nullptr, 0}); e = &g_df_scratch.back(); }
+    if (!e) {
+        if (g_df_scratch.size() >= DF_SCRATCH_MAX) {                       // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < g_df_scratch.size(); ++i) if (g_df_scratch[i].used < g_df_scratch[lru].used) lru = i;
+            df_scratch_free_entry(g_df_scratch[lru]);
+            g_df_scratch.erase(g_df_scratch.begin() + (long)lru);
+        }
+        g_df_scratch.push_back(DfScratchEntry{dev, st, nullptr, 0, 0});
+        e = &g_df_scratch.back();
+    }
+    e->used = ++g_df_scratch_clock;
     if (bytes > e->cap) {
         if (e->mem) { (void)hipStreamSynchronize(st); (void)hipFree(e->mem); e->mem = nullptr; e->cap = 0; }
         const size_t cap = bytes + bytes / 4;
@@ -783,7 +783,7 @@ static char* df_rigid_scratch(hipStream_t st, size_t bytes)
 extern "C" int dfusion_release_scratch(void)
 {
     std::lock_guard<std::mutex> lock(g_df_scratch_mutex);
-    for (DfScratchEntry& c : g_df_scratch) if (c.mem) { (void)hipSetDevice(c.device); (void)hipStreamSynchronize(c.stream); (void)hipFree(c.mem); }
+    for (DfScratchEntry& c : g_df_scratch) df_scratch_free_entry(c);      // (restores the caller's current device)
     g_df_scratch.clear();
     return DF_OK;
 }
@@ -792,6 +792,15 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
                                  const float vol2cam[12], const float proj[4], unsigned long long* n_updated,
                                  dfStream stream)
 {
+    return dfusion_integrate_ex(dists, pitch, cols, rows, v, slab, vol2cam, proj, 0u, n_updated, nullptr, stream);
+}
+
+extern "C" int dfusion_integrate_ex(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
+                                    const float vol2cam[12], const float proj[4], unsigned flags, unsigned long long* n_updated,
+                                    unsigned long long* n_swept, dfStream stream)
+{
+    const bool no_depth_cull = (flags & DF_RIGID_NO_DEPTH_CULL) != 0, no_fast_forms = (flags & DF_RIGID_NO_SHORT_FORMS) != 0;
+    const bool keep_all = (flags & DF_RIGID_KEEP_ALL) != 0, no_sat = (flags & DF_RIGID_NO_SAT) != 0;
     if (!dists || !vol2cam || !proj || cols <= 0 || rows <= 0 || !df_volume_valid(v)) return DF_E_INVALID;
     DfSlab s = df_slab_or_full(v, slab);
     if (!df_slab_valid(v, s)) return DF_E_INVALID;
@@ -807,7 +816,7 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     a.P.trunc = v.trunc_dist; a.P.trunc_inv = 1.f / v.trunc_dist;       // tsdf_volume.cu:147
     a.P.max_weight = v.max_weight;
     a.n_upd = n_updated;
-    a.n_swept = g_df_rigid_swept;
+    a.n_swept = n_swept;
 
     DfFrustum F;
     {
@@ -836,7 +845,7 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     a.tiles = tiles; a.tiles_x = tiles_x; a.plan_items = n_items;
     hipStream_t st = (hipStream_t)stream;
     // scratch: the launch plan, and for the behind-the-surface test a max-pyramid of this frame's dists
-    const size_t pyr_elems = df_rigid_depth_cull_disabled() ? 0 : df_pyramid_elems(cols, rows);
+    const size_t pyr_elems = no_depth_cull ? 0 : df_pyramid_elems(cols, rows);
     if (n_pitems >= (1u << 30)) return DF_E_INVALID;
     const size_t off_cnt = 0, off_bins = 256, off_mask = off_bins + (size_t)DF_RIGID_BINS * n_items * 4;
     const size_t off_pyr = (off_mask + (size_t)n_items * 4 + 15) / 16 * 16;
@@ -863,12 +872,12 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     float4* starts = (float4*)(scratch + off_starts);
     const int cpw = 64 / (zc / DF_RIGID_SUB);
     const unsigned plan_waves = (unsigned)tiles * (unsigned)((chunks + cpw - 1) / cpw);
-    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((plan_waves + 15) / 16), dim3(1024), 0, st, a, F, Py, n_items, chunks, g_df_rigid_keep_all.load(), cnt, bins, pmask, starts);
-    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((plan_waves + 15) / 16), dim3(1024), 0, st, a, F, Py, n_items, chunks, g_df_rigid_keep_all.load(), cnt, bins, pmask, starts);
+    if (Py.top) hipLaunchKernelGGL((df_rigid_plan_kernel<true>), dim3((plan_waves + 15) / 16), dim3(1024), 0, st, a, F, Py, n_items, chunks, keep_all, cnt, bins, pmask, starts);
+    else hipLaunchKernelGGL((df_rigid_plan_kernel<false>), dim3((plan_waves + 15) / 16), dim3(1024), 0, st, a, F, Py, n_items, chunks, keep_all, cnt, bins, pmask, starts);
     a.plan_bins = bins; a.plan_cnt = cnt; a.plan_mask = pmask; a.plan_starts = starts;
     // short arithmetic forms (tsdf_sample_fast): 32-bit dists offsets, sane intrinsics; the value domain is tested per run in the kernel
     const bool fast_ok = (unsigned long long)rows * pitch < (1ull << 31) && proj[0] == proj[0] && proj[1] == proj[1] && proj[2] > 0.f && proj[3] > 0.f &&
-                         !g_df_rigid_no_fast_forms;          // (cx, cy > 0: the one-compare pixel range test of tsdf_sample_fast)
+                         !no_fast_forms;          // (cx, cy > 0: the one-compare pixel range test of tsdf_sample_fast)
     const dim3 grid((n_items * DF_RIGID_STRIP + 3) / 4);             // 4 waves per workgroup; those past the plan's end return at once
 #ifdef DF_TRACE_WG
     static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;
@@ -877,7 +886,7 @@ extern "C" int dfusion_integrate(const uint16_t* dists, size_t pitch, int cols, 
     DF_HIP(hipMemsetAsync(trace_dev, 0, trace_n * 8, st));
     a.trace = trace_dev;
 #endif
-    const bool sat_ok = fast_ok && !g_df_rigid_no_sat && df_sat_trunc_ok(v.trunc_dist);
+    const bool sat_ok = fast_ok && !no_sat && df_sat_trunc_ok(v.trunc_dist);
     const bool count = a.n_upd || a.n_swept;
     if (sat_ok && !count) hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U, true, false>), grid, dim3(256), 0, st, a, fast_ok);
     else if (sat_ok) hipLaunchKernelGGL((df_integrate_rigid_kernel<DF_RIGID_U, true, true>), grid, dim3(256), 0, st, a, fast_ok);

@@ -1034,7 +1034,7 @@ struct DfWarpedArgs {
     DfAff vol2world, world2cam;
     DfIntegrateParams P;
     unsigned long long* n_upd;
-    unsigned long long* n_swept;   // nullable (dfusion_debug_warp_counters): += voxels of the plan's alive (patch, layer) cells
+    unsigned long long* n_swept;   // nullable (dfusion_warp_debug_counters): += voxels of the plan's alive (patch, layer) cells
     // conservative cull (disabled when cull == null).  cull[0] = max |t_i|, cull[1] = max sin(theta_i/2)
     // (> 1 => bound unavailable), cull[2] = max dists value of this frame; all produced on the stream, so the
     // frame needs no host round trip.
@@ -1917,11 +1917,42 @@ static double df_tile_radius(const float vol2world[12], double nx, double ny, do
     return r;
 }
 
-// measurement hook, the warped sweep's counterpart of dfusion_debug_rigid_counters (process-wide, off the product path)
-static std::atomic<unsigned long long*> g_df_warp_swept{nullptr};
-extern "C" int dfusion_debug_warp_counters(unsigned long long* swept_dev)
+// measurement hook of the warped sweep, per handle (the handle is single-stream: no race with its own launches)
+extern "C" int dfusion_warp_debug_counters(DfWarpField* wf, unsigned long long* swept_dev)
 {
-    g_df_warp_swept = swept_dev;
+    if (!wf) return DF_E_INVALID;
+    wf->dbg_swept = swept_dev;
+    return DF_OK;
+}
+
+// alive 8 x 8 x 8 blocks per 8-plane layer, from the verdict bytes of the last sweep: one workgroup per layer of the table
+__global__ __launch_bounds__(256) void df_alive_per_layer_kernel(const uint8_t* __restrict__ alive, unsigned per_layer, int layer0, int l_lo, int l_hi,
+                                                                 unsigned long long* __restrict__ out)
+{
+    __shared__ unsigned s[4];
+    const int layer = layer0 + (int)blockIdx.x;
+    if (layer < l_lo || layer >= l_hi) return;
+    const uint8_t* a = alive + (size_t)blockIdx.x * per_layer;
+    unsigned n = 0;
+    for (unsigned i = threadIdx.x; i < per_layer; i += 256) n += a[i] ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[layer], (unsigned long long)(s[0] + s[1] + s[2] + s[3]));
+}
+extern "C" int dfusion_warp_alive_blocks(DfWarpField* wf, int z0, int zn, unsigned long long* per_layer_dev, int n_layers, dfStream stream)
+{
+    if (!wf || !per_layer_dev || n_layers <= 0 || z0 < 0 || zn < 0) return DF_E_INVALID;
+    if (!wf->tab_valid || !wf->alive_valid || !wf->blk_alive) return DF_E_NO_INDEX;
+    const int ntx = (wf->geom_dims[0] + DF_TAB_TX - 1) / DF_TAB_TX, nty = (wf->geom_dims[1] + DF_TAB_TY - 1) / DF_TAB_TY;
+    const unsigned per_layer = (unsigned)(ntx * (DF_TAB_TX / 8)) * (unsigned)(nty * (DF_TAB_TY / 8));
+    const int nbz = wf->tab_zn / 8, layer0 = wf->tab_z0 / 8;
+    const int l_lo = (z0 + 7) / 8, l_hi = min((z0 + zn) / 8, n_layers);                 // layers entirely inside [z0, z0 + zn)
+    if (nbz <= 0 || l_hi <= l_lo) return DF_OK;
+    hipLaunchKernelGGL(df_alive_per_layer_kernel, dim3((unsigned)nbz), dim3(256), 0, (hipStream_t)stream, wf->blk_alive, per_layer, layer0, l_lo, l_hi,
+                       per_layer_dev);
+    DF_LAUNCH_CHECK();
     return DF_OK;
 }
 
@@ -2029,6 +2060,7 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
         DF_LAUNCH_CHECK();
     }
     a.blk_alive = wf->blk_alive; a.bm_nbx = nbx; a.bm_nby = nby;
+    wf->alive_valid = true;
     return DF_OK;
 }
 
@@ -2060,7 +2092,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     a.P.fx = proj[0]; a.P.fy = proj[1]; a.P.cx = proj[2]; a.P.cy = proj[3];
     a.P.trunc = v.trunc_dist; a.P.trunc_inv = 1.f / v.trunc_dist; a.P.max_weight = v.max_weight;
     a.n_upd = n_updated;
-    a.n_swept = g_df_warp_swept;
+    a.n_swept = wf->dbg_swept;
     a.kf = (float)k; a.cam_scale = 1.f; a.origin_cam = -1.f;
     const bool use_tab = wf->tab_valid && wf->tab_k == k && !(flags & DF_WARP_NO_TABLE) && s.z_own0 >= wf->tab_z0 &&
                          s.z_own0 + s.z_own_n <= wf->tab_z0 + wf->tab_zn;
@@ -2258,13 +2290,17 @@ static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab
     DF_HIP(hipMemsetAsync(wf->blk_wmax, 0, nblk * sizeof(float), st));
     wf->blk_phase = 0;
     wf->tab_z0 = tz0; wf->tab_zn = tzn; wf->tab_k = k; wf->tab_valid = true; wf->w_tab_valid = weights;
-    wf->tab_complete = !on_demand; wf->tab_sweeps = 0;
+    wf->tab_complete = !on_demand; wf->tab_sweeps = 0; wf->alive_valid = false;
     if (on_demand) return DF_OK;
-    const DfWarpedArgs a = df_table_args(wf);
+    const DfWarpedArgs a = df_table_args(wf);                  // (reads the fields just set)
     DfWarpView W = df_view(wf);
     dim3 grid((unsigned)(W.bx * W.by), (unsigned)(bz_hi - bz_lo + 1));
     DF_DISPATCH_K(k, df_warp_brick_kernel<K, true><<<grid, dim3(256), 0, st>>>(a, W));
-    DF_LAUNCH_CHECK();
-    DF_HIP(hipStreamSynchronize(st));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {                                     // the tables were not built: the handle must not claim them
+        wf->tab_valid = false; wf->w_tab_valid = false; wf->tab_complete = false;
+        return (int)e;
+    }
     return DF_OK;
 }

@@ -27,6 +27,42 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+# Host staging of the collectives: a process group whose backend cannot take device tensors (gloo, used when a box has fewer
+# GPUs than ranks -- bench.py's oversubscribed smoke mode and the CPU tests) gets them as host copies, copied back afterwards.
+# Off (the default) the device tensors go to the backend as they are (RCCL).
+HOST_STAGED = False
+
+
+def set_host_staging(on):
+    global HOST_STAGED
+    HOST_STAGED = bool(on)
+
+
+def _staged(t):
+    return HOST_STAGED and t.is_cuda
+
+
+def coll_broadcast(t, src=0, group=None):
+    if _staged(t):
+        c = t.cpu(); dist.broadcast(c, src, group=group); t.copy_(c)
+    else:
+        dist.broadcast(t, src, group=group)
+
+
+def coll_all_reduce(t, op, group=None):
+    if _staged(t):
+        c = t.cpu(); dist.all_reduce(c, op=op, group=group); t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def coll_reduce(t, dst, op, group=None):
+    if _staged(t):
+        c = t.cpu(); dist.reduce(c, dst=dst, op=op, group=group); t.copy_(c)
+    else:
+        dist.reduce(t, dst=dst, op=op, group=group)
+
+
 NO_EVENT = 0xFFFFFFFF                 # per-slab event key (step << 1 | hit): none
 KEY_NONE = 0x7FFFFFFFFFFFFFFF         # merge key: no event (include/dfusion.h DF_RC_KEY_NONE)
 MAX_RANKS = 128                       # the merge key carries the rank in 7 bits
@@ -126,6 +162,16 @@ def slab_bounds(Z, world, halo=0, weights=None):
     return b
 
 
+def layer_weights_to_planes(w_layer, Z):
+    """per-8-plane-layer work (e.g. alive block counts, WarpField.alive_blocks_per_layer summed over the ranks) -> one weight per plane
+    for slab_bounds, with the same small floor frustum_plane_weights gives culled planes (plan kernels are not free)."""
+    w = np.repeat(np.asarray(w_layer, np.float64).reshape(-1), 8)[:Z]
+    if w.size < Z:
+        w = np.concatenate([w, np.zeros(Z - w.size)])
+    peak = w.max() if w.size and w.max() > 0 else 1.0
+    return w / peak + 0.02
+
+
 def validate_bounds(bounds, Z, halo):
     """The checks of validate_slabs for an explicit boundary list (slab_bounds)."""
     world = len(bounds) - 1
@@ -165,7 +211,7 @@ def halo_planes(trunc_dist, step_factor, delta_factor, voxel_z):
 def broadcast_bytes(t, src=0, group=None):
     """Broadcast any contiguous tensor as raw bytes (RCCL/gloo have no 16-bit integer type; the depth image
     is uint16)."""
-    dist.broadcast(t.view(torch.uint8), src, group=group)
+    coll_broadcast(t.view(torch.uint8), src, group=group)
 
 
 def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, group=None):
@@ -186,6 +232,18 @@ def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, 
         assert n_hi == halo and z_own_n >= halo, "slab thinner than the halo"
         ops.append(dist.P2POp(dist.isend, vol_tensor[hi_local - halo:hi_local], rank + 1, group))
         ops.append(dist.P2POp(dist.irecv, vol_tensor[hi_local:hi_local + n_hi], rank + 1, group))
+    if HOST_STAGED and vol_tensor.is_cuda:
+        host_ops, backs = [], []
+        for op in ops:
+            c = op.tensor.cpu()
+            host_ops.append(dist.P2POp(op.op, c, op.peer, group))
+            if op.op is dist.irecv:
+                backs.append((op.tensor, c))
+        for r in dist.batch_isend_irecv(host_ops):
+            r.wait()
+        for t, c in backs:
+            t.copy_(c)
+        return
     for r in dist.batch_isend_irecv(ops):
         r.wait()
 
@@ -206,10 +264,10 @@ def raycast_sharded(march_fn, shade_fn, points_fn, rank, world, dst=0, group=Non
     on = world > 1 if collectives is None else collectives
     keys64 = march_fn()
     if on:
-        dist.all_reduce(keys64, op=dist.ReduceOp.MIN, group=group)
+        coll_all_reduce(keys64, dist.ReduceOp.MIN, group=group)
     normals = shade_fn(keys64)
     if on:
-        dist.reduce(normals.view(torch.int32), dst=dst, op=dist.ReduceOp.SUM, group=group)
+        coll_reduce(normals.view(torch.int32), dst, dist.ReduceOp.SUM, group=group)
         if rank != dst:
             return None, None
     return points_fn(keys64, normals), normals

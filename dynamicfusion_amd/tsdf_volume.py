@@ -179,13 +179,22 @@ class TsdfVolume:
         capi.check(capi.lib().dfusion_clear(self.c_volume(), self.c_slab(), _stream()), "dfusion_clear")
 
     # ---- tsdf_volume.cpp:110-122
-    def integrate(self, dists, camera_pose, intr, n_updated=None, sync=True):
+    def integrate(self, dists, camera_pose, intr, n_updated=None, sync=True, flags=0, n_swept=None):
+        """flags: capi.DF_RIGID_* validation switches of THIS call (0 = the product path); n_swept: device int64[1], += the voxels
+        the sweep put through the projective sample."""
         vol2cam = affine_mul(affine_inv(np.asarray(camera_pose, F32)), self.pose_)
         rows, cols = dists.shape
-        capi.check(capi.lib().dfusion_integrate(_ptr(dists), cols * 2, cols, rows, self.c_volume(), self.c_slab(),
-                                                capi.floats(aff12(vol2cam)), intr.as_proj(),
-                                                _ptr(n_updated) if n_updated is not None else None, _stream()),
-                   "dfusion_integrate")
+        if flags == 0 and n_swept is None:
+            capi.check(capi.lib().dfusion_integrate(_ptr(dists), cols * 2, cols, rows, self.c_volume(), self.c_slab(),
+                                                    capi.floats(aff12(vol2cam)), intr.as_proj(),
+                                                    _ptr(n_updated) if n_updated is not None else None, _stream()),
+                       "dfusion_integrate")
+        else:
+            capi.check(capi.lib().dfusion_integrate_ex(_ptr(dists), cols * 2, cols, rows, self.c_volume(), self.c_slab(),
+                                                       capi.floats(aff12(vol2cam)), intr.as_proj(), int(flags),
+                                                       _ptr(n_updated) if n_updated is not None else None,
+                                                       _ptr(n_swept) if n_swept is not None else None, _stream()),
+                       "dfusion_integrate_ex")
         if sync:                   # device::integrate ends with cudaDeviceSynchronize (tsdf_volume.cu:160)
             torch.cuda.current_stream().synchronize()
 

@@ -102,6 +102,19 @@ class WarpField:
 
     # ---- WarpField::energy_data (warp_field.cpp:117-163) / WarpFieldOptimiser::optimiseWarpData: the data term, on the GPU
 
+    def debug_counters(self, swept_dev=None):
+        """Measurement hook (include/dfusion.h dfusion_warp_debug_counters): while set (device int64[1]), every warped integrate through
+        THIS field adds the voxels its launch plan keeps; None switches it off."""
+        capi.check(capi.lib().dfusion_warp_debug_counters(self.handle, _ptr(swept_dev) if swept_dev is not None else None),
+                   "dfusion_warp_debug_counters")
+
+    def alive_blocks_per_layer(self, volume, layers_dev):
+        """layers_dev (device int64 [Z / 8]) += the 8x8x8 blocks the last sweep's verdict pass kept, per 8-plane layer, for the layers
+        inside `volume`'s OWN planes (Z-slab re-balancing; include/dfusion.h dfusion_warp_alive_blocks)."""
+        capi.check(capi.lib().dfusion_warp_alive_blocks(self.handle, int(volume.z_own0), int(volume.z_own_n), _ptr(layers_dev),
+                                                        int(layers_dev.numel()), _stream()), "dfusion_warp_alive_blocks")
+        return layers_dev
+
     def set_point_tiling(self, image_cols):
         """Locality hint (include/dfusion.h dfusion_warp_set_point_tiling): point queries are row-major images `image_cols` wide and are
         processed in 8x8 pixel tiles per wave; 0 = off.  Results do not change."""

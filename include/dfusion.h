@@ -27,7 +27,7 @@
  *     DfWarpField must be issued on one stream or serialised by the caller.  dfusion_integrate keeps
  *     its pyramid and launch plan in a scratch buffer cached per (device, stream) -- calls on one
  *     stream are ordered, calls on different streams use different buffers; dfusion_release_scratch()
- *     frees them.  (dfusion_debug_rigid is a process-wide validation switch, off the product path.)
+ *     frees them.  Validation switches and measurement counters are per call / per handle (ABI 4).
  */
 #ifndef DFUSION_H
 #define DFUSION_H
@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 3   /* 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
+#define DFUSION_ABI_VERSION 4   /* 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
@@ -132,17 +132,33 @@ int dfusion_project_and_remove(const uint16_t *dists_in_dev, size_t in_pitch, ui
 /* device::integrate (internal.hpp:106; tsdf_volume.cu:51-112,141-161): rigid projective TSDF
  * update.  proj = {fx, fy, cx, cy} (device::Projector).  n_updated_dev (nullable) is
  * INCREMENTED by the number of voxels whose update branch (tsdf_volume.cu:91) was taken.
- * Scratch: a launch plan, the chunk starts of every column patch and a max-pyramid of `dists` -- 16 bytes per column and 32-plane
- * chunk, 33 MB at 512^3 -- in a buffer the library keeps per (device, stream) and grows on demand (dfusion_release_scratch frees
- * them all; the runtime's stream-ordered allocator was tried and gave wrong plans in processes that also hipMalloc / hipFree
- * between the calls).  Limit: (columns / 64, rounded up to whole patches) x
+ * Scratch: a launch plan, the chunk starts of every column patch (16 bytes per column and 32-plane chunk: 64 MiB at 512^3, 512 MiB at
+ * 1024^3), the plan's bins and a max-pyramid of `dists`, + 25 % growth headroom -- about 84 MB at 512^3, 0.65 GB at 1024^3 -- in a
+ * buffer the library keeps per (device, stream) and grows on demand.  It is KEPT until dfusion_release_scratch(); at most 8
+ * (device, stream) pairs are cached, the least recently used one is evicted (the runtime's stream-ordered allocator was tried and
+ * gave wrong plans in processes that also hipMalloc / hipFree between the calls).  Limit: (columns / 64, rounded up to whole patches) x
  * (32-plane chunks of the slab) < 2^30, i.e. any volume that fits the device.                                                   */
 int dfusion_integrate(const uint16_t *dists_dev, size_t dists_pitch, int cols, int rows, DfVolume v,
                       const DfSlab *slab, const float vol2cam[12], const float proj[4],
                       unsigned long long *n_updated_dev, dfStream stream);
 
-/* Frees the scratch buffers dfusion_integrate keeps per (device, stream); synchronises those streams first.  Optional (they are
- * small and reused); for hosts that tear devices down or count allocations.                                                     */
+/* The same with the validation switches and the measurement counter of THIS call (no reference counterpart; tests assert the
+ * volumes are identical with and without each switch).  flags = 0: everything on.  n_swept_dev (nullable, device, 8 bytes) is
+ * INCREMENTED by the number of voxels the sweep put through the projective sample (tsdf_volume.cu:77-93) -- the voxels of the
+ * launch plan's alive sub-chunks; beside n_updated_dev this gives swept / updated, the sweep's over-work.                        */
+#define DF_RIGID_NO_DEPTH_CULL 1u  /* no behind-the-surface test (a conservative skip of voxels more than trunc_dist behind every
+                                      depth value they can be compared with; per-frame max-pyramid of dists)                     */
+#define DF_RIGID_NO_SHORT_FORMS 2u /* the generic correctly rounded divisions / square root everywhere                           */
+#define DF_RIGID_KEEP_ALL 4u       /* the launch plan keeps every sub-chunk (no frustum test either): every voxel goes through the
+                                      reference's own tests                                                                       */
+#define DF_RIGID_NO_SAT 8u         /* no saturated-sample shortcuts (batches of voxels all farther than trunc_dist from the surface
+                                      skip the exact square root and, onto stored 1.0 / cleared voxels, the fuse division)        */
+int dfusion_integrate_ex(const uint16_t *dists_dev, size_t dists_pitch, int cols, int rows, DfVolume v,
+                         const DfSlab *slab, const float vol2cam[12], const float proj[4], unsigned flags,
+                         unsigned long long *n_updated_dev, unsigned long long *n_swept_dev, dfStream stream);
+
+/* Frees the scratch buffers dfusion_integrate keeps per (device, stream), after a device synchronise (a cached stream handle may no
+ * longer exist); the caller's current device is restored.  Optional; for hosts that tear devices down or count allocations.       */
 int dfusion_release_scratch(void);
 
 /* device::raycast, Points variant (internal.hpp:113-114; tsdf_volume.cu:340-405,459-474).
@@ -172,7 +188,8 @@ int dfusion_raycast_depth(DfVolume v, const DfSlab *slab, const float cam2vol[12
  *
  * key layout (a non-negative int64, so ncclMin on ncclInt64 orders it):
  *   bit 63 = 0 | bits 62..40 step index k | bit 39 kind (1 = hit, 0 = back-face break) | bits 38..32 rank_tag | bits 31..0 Ts (f32 bits)
- * DF_RC_KEY_NONE (no event on this slab's steps) is larger than every event key.                          */
+ * DF_RC_KEY_NONE (no event on this slab's steps) is larger than every event key.  dfusion_raycast_march returns DF_E_INVALID when
+ * (volume diagonal) / (trunc_dist * step_factor) could reach 2^23 steps -- the index would not fit its field.                   */
 #define DF_RC_KEY_NONE 0x7fffffffffffffffull
 #define DF_RC_KEY_MAX_RANK 127u
 int dfusion_raycast_march(DfVolume v, const DfSlab *slab, const float cam2vol[12], const float reproj[4], int cols,
@@ -246,21 +263,16 @@ int dfusion_warp_set_point_tiling(DfWarpField *wf, int image_cols);
  * generic statements on n_random positions inside the forms' domain and on its edges, [7] how many of those samples updated.        */
 int dfusion_selftest_exact_forms(unsigned long long n_random, unsigned long long *counts_dev, dfStream stream);
 
-/* Validation switches of dfusion_integrate, so that tests can assert the volumes are identical with and without them (process-wide,
- * default 3; no reference counterpart).  bit 0: the behind-the-surface test (a conservative, result-identical skip of voxels that
- * lie more than trunc_dist behind every depth value they can be compared with; per-frame max-pyramid of dists); bit 1: the short
- * forms of the correctly rounded divisions / square root on runs of voxels whose coordinates are inside their domain; bit 2 SET:
- * the launch plan keeps every sub-chunk (no frustum test either: every voxel goes through the reference's own tests); bit 3 SET:
- * no saturated-sample shortcuts (batches of voxels all farther than trunc_dist from the surface skip the exact square root -- their
- * tsdf is exactly 1 or they do not update -- and, onto stored 1.0 / cleared voxels, the fuse division).                            */
-int dfusion_debug_rigid(int flags);
-/* Measurement hook of dfusion_integrate (process-wide, like the switches above; NULL switches it off): while set, every launch ADDS
- * to *swept_dev (device, 8 bytes) the number of voxels its sweep put through the projective sample (tsdf_volume.cu:77-93) -- the
- * voxels of the launch plan's alive sub-chunks.  Beside n_updated_dev this gives swept / updated, the sweep's over-work.          */
-int dfusion_debug_rigid_counters(unsigned long long *swept_dev);
-/* The same for dfusion_integrate_warped's cached sweep (the pipelined kernel): += the voxels of the (8 x 8 column patch, 8-plane
- * layer) cells its launch plan keeps, i.e. the voxels that go through blend -> transform -> project.                              */
-int dfusion_debug_warp_counters(unsigned long long *swept_dev);
+/* Measurement hook of dfusion_integrate_warped's cached sweep, per warp-field handle (NULL switches it off): while set, every
+ * launch through this handle ADDS to *swept_dev (device, 8 bytes) the voxels of the (8 x 8 column patch, 8-plane layer) cells its
+ * launch plan keeps, i.e. the voxels that go through blend -> transform -> project.                                              */
+int dfusion_warp_debug_counters(DfWarpField *wf, unsigned long long *swept_dev);
+
+/* What the last dfusion_integrate_warped through this handle found alive: per_layer_dev[l] (device, n_layers entries, l = global
+ * plane / 8) is INCREMENTED by the number of 8 x 8 x 8 blocks of layer l that its verdict pass kept, for the layers that lie
+ * entirely inside planes [z0, z0 + zn).  Z-slab re-balancing reads it (one all-reduce over the ranks gives the global profile of the
+ * sweep's real work per plane).  DF_E_NO_INDEX when no sweep with verdicts has run since the index was built.                       */
+int dfusion_warp_alive_blocks(DfWarpField *wf, int z0, int zn, unsigned long long *per_layer_dev, int n_layers, dfStream stream);
 
 /* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k], ascending distance; exactly
  * equidistant nodes in the order the reference's nanoflann walk meets them (nanoflann.hpp:110-131,1200-1254).                    */

@@ -60,16 +60,12 @@ def test_rigid_plan_never_drops_an_update(seed):
     res = []
     frames = [(random_pose(rng, centre, 0.0 if seed % 4 == 0 else 0.3 * size, 2.2 * size, 0.5), random_depth(rng, cols, rows, 300, int(3500 * size)))
               for _ in range(3)]
-    try:
-        for flags in (3, 2, 6):                               # the plan's tests: both, frustum only, none (every sub-chunk swept)
-            capi.check(L.dfusion_debug_rigid(flags))
-            v = make_volume(dims, size, vol_pose)
-            n = torch.zeros(1, dtype=torch.int64, device="cuda")
-            for cam, depth in frames:
-                v.integrate(compute_dists(upload_u16(depth), intr), cam, intr, n_updated=n)
-            res.append((v.download(), int(n.item())))
-    finally:
-        capi.check(L.dfusion_debug_rigid(3))
+    for flags in (0, capi.DF_RIGID_NO_DEPTH_CULL, capi.DF_RIGID_NO_DEPTH_CULL | capi.DF_RIGID_KEEP_ALL):   # the plan's tests: both, frustum only, none (every sub-chunk swept)
+        v = make_volume(dims, size, vol_pose)
+        n = torch.zeros(1, dtype=torch.int64, device="cuda")
+        for cam, depth in frames:
+            v.integrate(compute_dists(upload_u16(depth), intr), cam, intr, n_updated=n, flags=flags)
+        res.append((v.download(), int(n.item())))
     print("rigid fuzz seed", seed, "updates", res[0][1])
     for r in res[1:]:
         assert np.array_equal(res[0][0], r[0]) and res[0][1] == r[1]
@@ -140,13 +136,13 @@ def test_block_models_on_surface_node_sets(seed):
     for kw in (dict(block_model="now"), dict(block_model=False), dict(cull=False)):
         v = make_volume(cfg.dims, cfg.size, cfg.volume_pose, cfg.trunc_dist)
         cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
-        capi.check(L.dfusion_debug_warp_counters(cnt[1:].data_ptr()))
+        wf.debug_counters(cnt[1:])
         try:
             for cam, d, dq in frames:
                 wf.set_transforms(torch.from_numpy(dq).cuda())
                 v.integrate_warped(d, cam, intr, wf, n_updated=cnt[:1], **kw)
         finally:
-            capi.check(L.dfusion_debug_warp_counters(None))
+            wf.debug_counters(None)
         res.append((v.download(), int(cnt[0].item()), int(cnt[1].item())))
     print("surface fuzz seed", seed, "updates", res[0][1], "swept with models / ball / none: %d / %d / %d" % (res[0][2], res[1][2], res[2][2]))
     assert res[0][1] > 0

@@ -135,12 +135,8 @@ def test_full_size_properties_and_sampled_oracle(name):
     r_full = setup(cfg)
     r_full.integrate(dists[0], sc.cam_poses[0], intr)
     from dynamicfusion_amd import capi
-    try:
-        capi.check(capi.lib().dfusion_debug_rigid(4))           # every sub-chunk swept, generic arithmetic
-        r_nocull = setup(cfg)
-        r_nocull.integrate(dists[0], sc.cam_poses[0], intr)
-    finally:
-        capi.check(capi.lib().dfusion_debug_rigid(3))
+    r_nocull = setup(cfg)                                       # every sub-chunk swept, generic arithmetic
+    r_nocull.integrate(dists[0], sc.cam_poses[0], intr, flags=capi.DF_RIGID_NO_DEPTH_CULL | capi.DF_RIGID_NO_SHORT_FORMS | capi.DF_RIGID_KEEP_ALL)
     assert torch.equal(r_nocull.data(), r_full.data())
     del r_nocull
     zs, zn = sharded.slab_range(Z, 5, 8)

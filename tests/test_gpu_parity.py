@@ -104,20 +104,17 @@ def test_integrate_rigid_depth_cull_is_result_identical(cfg):
     intr = Intr(*cfg.intr)
     L = capi.lib()
     vols = []
-    try:
-        for flags in (3, 0, 1, 2, 6, 4):                 # bit 0: depth cull, bit 1: short arithmetic forms, bit 2 set: the plan keeps everything
-            capi.check(L.dfusion_debug_rigid(flags))
-            vol = make_gpu_volume(sc)
-            n_upd = torch.zeros(1, dtype=torch.int64, device="cuda")
-            for f in range(3):
-                vol.integrate(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, n_updated=n_upd)
-            empty = np.zeros_like(sc.dists[0])
-            vol.integrate(upload_u16(empty), sc.cam_poses[0], intr, n_updated=n_upd)          # Dp == 0 everywhere: nothing updates
-            one = empty.copy(); one[cfg.rows // 2, cfg.cols // 2] = sc.dists[0][cfg.rows // 2, cfg.cols // 2]
-            vol.integrate(upload_u16(one), sc.cam_poses[0], intr, n_updated=n_upd)
-            vols.append((vol.download(), int(n_upd.item())))
-    finally:
-        capi.check(L.dfusion_debug_rigid(3))
+    ND, NS, KA = capi.DF_RIGID_NO_DEPTH_CULL, capi.DF_RIGID_NO_SHORT_FORMS, capi.DF_RIGID_KEEP_ALL
+    for flags in (0, ND | NS, NS, ND, ND | KA, ND | NS | KA, capi.DF_RIGID_NO_SAT):        # per-call validation switches (dfusion_integrate_ex)
+        vol = make_gpu_volume(sc)
+        n_upd = torch.zeros(1, dtype=torch.int64, device="cuda")
+        for f in range(3):
+            vol.integrate(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, n_updated=n_upd, flags=flags)
+        empty = np.zeros_like(sc.dists[0])
+        vol.integrate(upload_u16(empty), sc.cam_poses[0], intr, n_updated=n_upd, flags=flags)          # Dp == 0 everywhere: nothing updates
+        one = empty.copy(); one[cfg.rows // 2, cfg.cols // 2] = sc.dists[0][cfg.rows // 2, cfg.cols // 2]
+        vol.integrate(upload_u16(one), sc.cam_poses[0], intr, n_updated=n_upd, flags=flags)
+        vols.append((vol.download(), int(n_upd.item())))
     for other in vols[1:]:
         assert np.array_equal(vols[0][0], other[0]) and vols[0][1] == other[1]
     assert (vols[0][0] >> 16).max() == 4
@@ -446,7 +443,7 @@ def test_tables_on_demand_equal_tables_built_at_once():
 
 def test_block_models_shrink_the_swept_set_and_change_nothing():
     """dfusion_warp_blocks.h: the per-block blend models must (i) leave the volume and the update count bit-identical and (ii) actually
-    engage -- the launch plan's swept-voxel counter (dfusion_debug_warp_counters) drops.  BASELINE config 1 (256^3, 500 nodes, k = 4);
+    engage -- the launch plan's swept-voxel counter (dfusion_warp_debug_counters) drops.  BASELINE config 1 (256^3, 500 nodes, k = 4);
     tables built at once and on demand; the counter is read on the last of four frames (a block's model serves from the frame after
     the one that made it)."""
     cfg = synth.CONFIGS["256"]
@@ -462,11 +459,11 @@ def test_block_models_shrink_the_swept_set_and_change_nothing():
             cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
             for f in range(4):
                 wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
-                if f == 3: cnt.zero_(); capi.check(L.dfusion_debug_warp_counters(cnt[1:].data_ptr()))
+                if f == 3: cnt.zero_(); wf.debug_counters(cnt[1:])
                 try:
                     v.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, wf, n_updated=cnt[:1], **kw)
                 finally:
-                    capi.check(L.dfusion_debug_warp_counters(None))
+                    wf.debug_counters(None)
             upd.append(int(cnt[0].item())); swept.append(int(cnt[1].item())); vols.append(v.data().clone())
         print("on demand %d: swept voxels / updated: ball test %.3f, with block models %.3f" % (on_demand, swept[0] / upd[0], swept[1] / upd[1]))
         assert torch.equal(vols[0], vols[1]) and upd[0] == upd[1] and upd[0] > 0

@@ -112,3 +112,45 @@ def test_bench_sharded_branch_runs_over_rccl_with_one_rank():
         # same frames, same inputs: the sharded path updates exactly the voxels the unsharded one does
         assert d["roofline"]["n_updated_all_ranks"] == one["roofline"]["n_updated_per_launch"]
         assert d["value"] > 0
+
+
+def _bench(args, env_extra=None, drop_rank_env=True):
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not (drop_rank_env and k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"))}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith('{"metric"'), r.stdout[-600:]
+    return json.loads(last)
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus N` with NO rank environment (how the driver starts N = 1) must not die on the launch.  On this
+    one-GPU box the self-launched ranks share cuda:0 and the collectives run over gloo with host staging (RCCL refuses two ranks on a
+    device): the whole sharded frame -- measured re-balance of the slabs, frame-input broadcast, halo recompute, march / merge / shade,
+    verify-cull pass -- runs end to end, and updates exactly the voxels the single-GPU run does."""
+    common = ["--config", "256", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    one = _bench(common)
+    assert one["n_gpus"] == 1 and one["verify_cull"]["cull_bit_identical"] and one["frame_stats"]["integrate+raycast_ms"]["frames"] >= 40
+    for n, extra in ((2, []), (3, ["--halo", "exchange", "--slabs", "balanced"])):
+        d = _bench(["--gpus", str(n)] + common + extra)
+        assert d["n_gpus"] == n and d["config"]["parallelism"] == "zslab%d" % n and "oversubscribed" in d
+        assert d["roofline"]["n_updated_all_ranks"] >= one["roofline"]["n_updated_per_launch"]      # (+ the halo planes every rank also integrates)
+        if not extra:
+            assert d["roofline"]["n_updated_all_ranks"] > one["roofline"]["n_updated_per_launch"]
+            rb = d["config"]["rebalance"]
+            assert rb["to"][0] == 0 and rb["to"][-1] == 256 and sum(rb["alive_blocks_per_8_planes"]) > 0
+        assert d["verify_cull"]["cull_bit_identical"] and d["verify_cull"]["updates_with_cull"] == d["verify_cull"]["updates_without_cull"] > 0
+        assert d["value"] > 0
+
+
+def test_bench_force_dist_self_launch_is_one_real_rccl_rank():
+    """the same launcher with one rank: torch.distributed.run -> init_process_group("nccl") -> every collective of the frame over RCCL"""
+    d = _bench(["--gpus", "1", "--config", "256", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], {"DFUSION_BENCH_FORCE_DIST": "1"})
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "zslab1" and "oversubscribed" not in d
+    assert d["verify_cull"]["cull_bit_identical"] and d["value"] > 0

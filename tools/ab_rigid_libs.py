@@ -10,16 +10,17 @@ from dynamicfusion_amd import capi
 from dynamicfusion_amd import Intr, TsdfVolume, compute_dists, synth, upload_u16
 name, tags = sys.argv[1], sys.argv[2:]
 libs = {"product": capi.lib()}
-nosat = {}                                  # TAG/nosat: the same build with the saturated-sample shortcuts switched off (dfusion_debug_rigid bit 3)
+nosat = {}                                  # TAG/nosat: the same build with the saturated-sample shortcuts switched off (DF_RIGID_NO_SAT, per call)
 for t in tags:
     base = t.split("/")[0]
     if base != "product" and base not in libs:
         libs[base] = capi.load(os.path.join(REPO, "build", "libdfusion_hip_%s.so" % base), strict=False)
     if t.endswith("/nosat"):
         nosat[t] = True; libs[t] = libs[base]
+FLAGS = {}
 def use(t):
     capi._lib = libs[t]
-    libs[t].dfusion_debug_rigid(3 | (8 if t in nosat else 0))
+    FLAGS["f"] = capi.DF_RIGID_NO_SAT if t in nosat else 0
 cfg = synth.CONFIGS[name]; intr = Intr(*cfg.intr); F = 4
 dists = [compute_dists(upload_u16(synth.depth_frame(cfg, f)), intr) for f in range(F)]
 cams = [synth.camera_pose(cfg, f) for f in range(F)]
@@ -30,13 +31,12 @@ ref = None
 for t in libs:
     use(t); v = mkvol()
     n = torch.zeros(2, dtype=torch.int64, device="cuda")
-    has_cnt = not getattr(libs[t].dfusion_debug_rigid_counters, "missing", False)
-    if has_cnt: libs[t].dfusion_debug_rigid_counters(n[1:].data_ptr())
+    has_cnt = True
     snaps = []
     for f in range(11):
-        v.integrate(dists[f % F], cams[f % F], intr, n_updated=n[:1] if f % 2 == 0 else None)     # (both the counting and the plain kernels)
+        v.integrate(dists[f % F], cams[f % F], intr, n_updated=n[:1] if f % 2 == 0 else None, n_swept=n[1:] if f % 2 == 0 else None,
+                    flags=FLAGS["f"])     # (both the counting and the plain kernels)
         if f in (0, 2, 10): snaps.append(v.data().clone())
-    if has_cnt: libs[t].dfusion_debug_rigid_counters(None)
     upd, swept = int(n[0]), int(n[1])
     msg = "updated %d" % upd + (", swept %d = %.3f x updated" % (swept, swept / upd) if has_cnt else "")
     if ref is None: ref = (snaps, upd)
@@ -52,10 +52,10 @@ res = {t: [] for t in libs}
 for rnd in range(8):
     for t in libs:
         use(t)
-        for i in range(4): vol.integrate(dists[i % F], cams[i % F], intr, sync=False)
+        for i in range(4): vol.integrate(dists[i % F], cams[i % F], intr, sync=False, flags=FLAGS["f"])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for i in range(20): vol.integrate(dists[i % F], cams[i % F], intr, sync=False)
+        for i in range(20): vol.integrate(dists[i % F], cams[i % F], intr, sync=False, flags=FLAGS["f"])
         e1.record(); torch.cuda.synchronize()
         res[t].append(e0.elapsed_time(e1) / 20)
 for t, v in res.items():

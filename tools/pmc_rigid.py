@@ -10,13 +10,12 @@ name = sys.argv[1] if len(sys.argv) > 1 else "512"
 tag = sys.argv[2] if len(sys.argv) > 2 else "-"
 if tag != "-":
     capi._lib = capi.load(os.path.join(REPO, "build", "libdfusion_hip_%s.so" % tag), strict=False)
-if len(sys.argv) > 3 and sys.argv[3] == "nosat":
-    capi.lib().dfusion_debug_rigid(3 | 8)
+FL = capi.DF_RIGID_NO_SAT if (len(sys.argv) > 3 and sys.argv[3] == "nosat") else 0
 cfg = synth.CONFIGS[name]; intr = Intr(*cfg.intr); F = 4
 dists = [compute_dists(upload_u16(synth.depth_frame(cfg, f)), intr) for f in range(F)]
 cams = [synth.camera_pose(cfg, f) for f in range(F)]
 vol = TsdfVolume(cfg.dims); vol.setSize([cfg.size] * 3); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setPose(cfg.volume_pose)
 vol.clear()
-for i in range(10): vol.integrate(dists[i % F], cams[i % F], intr, sync=False)
+for i in range(10): vol.integrate(dists[i % F], cams[i % F], intr, sync=False, flags=FL)
 torch.cuda.synchronize()
 print("done", cfg.name, tag)
