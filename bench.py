@@ -61,6 +61,8 @@ def parse(argv=None):
     ap.add_argument("--no-verify-cull", action="store_true",
                     help="skip the untimed pass that re-integrates every timed frame with the launch plan's cull switched off, from the same "
                          "start volume, and compares the volumes bit for bit (cull_bit_identical)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="A/B switch: DF_WARP_NO_PREFETCH on every warped integrate (no look-ahead table / model builds on the handle's side stream)")
     return ap.parse_args(argv)
 
 
@@ -438,7 +440,7 @@ def main():
         wf.set_transforms(q_in)
         compute_dists(d_in, intr, dists)
         if ev is not None: ev[0].record()
-        vol_int.integrate_warped(dists, cam_poses[f], intr, wf, sync=False)
+        vol_int.integrate_warped(dists, cam_poses[f], intr, wf, sync=False, prefetch=not args.no_prefetch)
         if ev is not None: ev[1].record()
         if dist_on and args.halo == "exchange":
             sharded.exchange_halos(vol.data(), vol.z_store0, vol.z_own0, vol.z_own_n, Z, halo, rank, world)
@@ -555,7 +557,8 @@ def main():
             else:
                 d_in, q_in = depths[f], dqs[f]
             wf.set_transforms(q_in)
-            vol_int.integrate_warped(compute_dists(d_in, intr, dists), cam_poses[f], intr, wf, n_updated=counters, cull=cull, sync=False)
+            vol_int.integrate_warped(compute_dists(d_in, intr, dists), cam_poses[f], intr, wf, n_updated=counters, cull=cull, sync=False,
+                                     prefetch=not args.no_prefetch)
         torch.cuda.synchronize()
 
     wf.debug_counters(n_upd[1:])
@@ -579,8 +582,11 @@ def main():
         vol.data().copy_(vol_start)
         n_nc = torch.zeros(1, dtype=torch.int64, device=dev)
         replay(False, n_nc)
-        same = bool(torch.equal(vol.data(), vol_end))
-        n_diff = 0 if same else int((vol.data() != vol_end).sum().item())
+        # (the planes this rank's integrate owns: with --halo exchange the halo planes come from the neighbours, not from the replay)
+        o0 = vol_int.z_own0 - vol_int.z_store0
+        got, want = vol.data()[o0:o0 + vol_int.z_own_n], vol_end[o0:o0 + vol_int.z_own_n]
+        same = bool(torch.equal(got, want))
+        n_diff = 0 if same else int((got != want).sum().item())
         flag = torch.tensor([1 if same else 0, int(n_nc.item()), int(n_upd[0].item()), n_diff], dtype=torch.int64, device=dev)
         if dist_on:
             mn = flag[:1].clone(); sharded.coll_all_reduce(mn, dist.ReduceOp.MIN)

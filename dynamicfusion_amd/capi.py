@@ -36,10 +36,12 @@ DF_WARP_NO_ZERO_SKIP = 32
 DF_WARP_NO_DEPTH_PYRAMID = 64
 DF_WARP_NO_BLOCK_MODEL = 128
 DF_WARP_BLOCK_MODEL_NOW = 256
+DF_WARP_NO_PREFETCH = 512
 DF_RIGID_NO_DEPTH_CULL = 1
 DF_RIGID_NO_SHORT_FORMS = 2
 DF_RIGID_KEEP_ALL = 4
 DF_RIGID_NO_SAT = 8
+DF_RIGID_POISON_SCRATCH = 16
 DF_INDEX_VOXEL_TABLE = 1
 DF_INDEX_WEIGHT_TABLE = 2
 DF_INDEX_TABLES_ON_DEMAND = 4

@@ -8,6 +8,11 @@
 #include "dfusion_nanoflann.h"
 
 #define DF_BRICK 8                    // k-NN index brick edge (voxels)
+// Look-ahead margin of the warped sweep's verdict pass (metres): blocks that would be alive with every cull radius widened by this much
+// get their tables / blend models made on the handle's side stream before a sweep needs them.  A camera turning 0.25 degrees per frame
+// moves a voxel 2 m from its axis by 9 mm, the benchmark's warp amplitude moves the cull radii by up to 2 cm per frame: 5 cm is two to
+// five frames of lead, and widens the set that is ever built by a few per cent.
+#define DF_WARP_PREFETCH_MARGIN_M 0.05f
 
 #define DF_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (int)e__; } while (0)
 #define DF_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
@@ -76,8 +81,8 @@ struct DfWarpField {
     // per 8x8x8 block of the table planes (dfusion_warp_blocks.h; block grid blk_nbx x blk_nby x tab_zn / 8, whole table tiles):
     //   blk_state  0 = tables not built (DF_INDEX_TABLES_ON_DEMAND), 1 = built, 2 = built and a blend-model record written
     //   blk_wmax   max over the block's voxels of the weight sum (0 until built)
-    //   blk_alive  this frame's verdicts ; blk_work [2][blk_cap] the frame's build / model work lists ; blk_cnt [2 sets][4] their
-    //   lengths and the build pass's cursor (the sets alternate between passes: each pass zeroes the other one)
+    //   blk_alive  this frame's verdicts ; blk_work [3][blk_cap] the frame's urgent-build / look-ahead-build / model work lists ;
+    //   blk_cnt [2 sets][8] their lengths and the build passes' cursors (the sets alternate between passes: each pass zeroes the other one)
     // block blend models: entry-major [DF_BM_NU][blk_cap] node ids, {mid, half width} half pairs of the normalised and of the raw
     // weights (allocated with the first model), bm_cnt entry counts
     uint8_t* blk_state; float* blk_wmax; uint8_t* blk_alive; uint32_t* blk_work; uint32_t* blk_cnt; size_t blk_cap; int blk_phase;
@@ -86,4 +91,12 @@ struct DfWarpField {
     int tab_sweeps;              // sweeps over the current tables so far (the models are made from the second one on)
     unsigned long long* dbg_swept;   // dfusion_warp_debug_counters: nullable device counter the sweeps through this handle add to
     bool alive_valid;            // blk_alive holds the verdicts of a sweep over the current tables (dfusion_warp_alive_blocks)
+    // look-ahead work (tables / models of blocks a sweep does not need yet) runs on a side stream the handle owns, beside the sweep on
+    // the caller's stream: ev_fork (caller's stream, after the verdict pass) releases it, ev_join (side stream, after its last kernel)
+    // is waited for by the next call that touches the tables
+    hipStream_t side; hipEvent_t ev_fork, ev_join; bool side_pending;
+    // the verdict pass's list lengths, reported to pinned host memory by the plan kernel ([0] urgent builds, [1] models, [2] look-ahead
+    // builds, [3] sweep number): read WITHOUT synchronisation by a later call -- a hint whether on-demand work is going on (then the side
+    // stream is worth its fork / join, ~13 us per frame), never a condition of correctness
+    volatile uint32_t* host_report;
 };

@@ -13,15 +13,21 @@ struct DfDistsPyramid {
     const uint16_t* mem;                     // levels 1..top, dense, level l at off[l] with width w[l]
     int off[DF_PYR_MAX_LEVELS], w[DF_PYR_MAX_LEVELS], h[DF_PYR_MAX_LEVELS];
     int top;                                 // coarsest level (1 x 1); 0 = no pyramid (test disabled)
+    // levels above 5 NOT built (one launch instead of two): the image-wide maximum (what the 1 x 1 level holds) is then *max_bits,
+    // accumulated by the tile kernel's workgroups with one atomicMax each; df_pyramid_max_fine callers cap the level at 5 (`capped`)
+    const uint32_t* max_bits; int capped;
 };
+__device__ __forceinline__ uint32_t df_pyramid_image_max(const DfDistsPyramid& P) { return P.capped ? *P.max_bits : (uint32_t)P.mem[P.off[P.top]]; }
 
 
 // Builds levels 1..top into `mem` (df_pyramid_elems(cols, rows) uint16 entries) on `st`; out->top == 0 when the image is too small
 // (< 32 px) or too large for a pyramid: the callers then run without the test.
 // `levels_to_5`: build levels 1..5 only (one launch; the descriptor still names `top`, whose levels above 5 are then NOT valid);
 // `zero16`: 16 32-bit words the first workgroup also zeroes (a caller's counters, saving it a memset), or null.
+// `max_word` (with levels_to_5): a device word that is 0 on entry and receives the image-wide maximum of the half bits (out->max_bits;
+// the descriptor is then `capped`); the caller zeroes it again once its readers are done (df_sweep_plan_kernel does).
 int df_build_dists_pyramid(const uint16_t* dists, size_t pitch, int cols, int rows, uint16_t* mem, size_t mem_elems,
-                           DfDistsPyramid* out, hipStream_t st, bool levels_to_5 = false, unsigned int* zero16 = nullptr);
+                           DfDistsPyramid* out, hipStream_t st, bool levels_to_5 = false, unsigned int* zero16 = nullptr, unsigned int* max_word = nullptr);
 size_t df_pyramid_elems(int cols, int rows);
 
 // max of the dists half bits over the pixel rectangle [u0, u1] x [v0, v1] (inclusive, inside the image) or a superset of it: the texels
@@ -32,6 +38,11 @@ __device__ __forceinline__ uint32_t df_pyramid_max_fine(const DfDistsPyramid& P,
 {
     const int ext = max(u1 - u0, v1 - v0);
     int L = ext == 0 ? 0 : 32 - __clz(ext);
+    if (P.capped) {
+        max_level = min(max_level, 5);
+        // a rectangle that would span more than 5 x 5 texels of level 5: the image-wide maximum instead (a superset of the rectangle)
+        if ((u1 >> 5) - (u0 >> 5) >= 5 || (v1 >> 5) - (v0 >> 5) >= 5) return *P.max_bits;
+    }
     L = min(min(max(L - shift, 0), P.top), max_level);
     const int a0 = u0 >> L, a1 = u1 >> L, b0 = v0 >> L, b1 = v1 >> L;
     uint32_t m = 0;

@@ -190,7 +190,8 @@ extern "C" int dfusion_project_and_remove(const uint16_t* dists_in, size_t in_pi
 
 // ------------------------------------------------------------------------------------------ max-pyramid of the dists image (dfusion_pyramid.h)
 // levels 1..5 of one 32 x 32 pixel tile per workgroup
-__global__ __launch_bounds__(256) void df_pyramid_tiles_kernel(const DfDistsPyramid P, uint16_t* __restrict__ out, unsigned int* __restrict__ zero16)
+__global__ __launch_bounds__(256) void df_pyramid_tiles_kernel(const DfDistsPyramid P, uint16_t* __restrict__ out, unsigned int* __restrict__ zero16,
+                                                               unsigned int* __restrict__ max_word)
 {
     if (zero16 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) zero16[threadIdx.x] = 0u;     // (the rigid plan's 64 counters)
     __shared__ uint16_t s[16 * 16];
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(256) void df_pyramid_tiles_kernel(const DfDistsPyra
             s[cy * n + cx] = (uint16_t)v;
             const int X = blockIdx.x * n + cx, Y = blockIdx.y * n + cy;
             if (l <= P.top && X < P.w[l] && Y < P.h[l]) out[P.off[l] + Y * P.w[l] + X] = (uint16_t)v;
+            if (l == 5 && max_word) atomicMax(max_word, v);                  // (t == 0: the tile's maximum; one atomic per workgroup)
         }
         __syncthreads();
     }
@@ -400,7 +402,10 @@ __device__ __forceinline__ void df_rigid_issue(const DfRigidArgs& a, f3& vc, f3 
         const DfSamplePre pre = tsdf_sample_pre(a.P, vc);                   // (issues the dists gather)
         P.Dp[u] = pre.Dp; P.d2[u] = pre.d2; P.s[u] = pre.s; P.ok[u] = pre.ok && active;
         P.v[u] = 0u;
-        if (active) P.v[u] = p[(size_t)u * plane];                          // the voxel word, unconditionally
+        // the voxel word, unconditionally.  (Round 4 measured the obvious refinement -- only for voxels that project into the image, a
+        // test on the geometry alone, so the load still goes out with the dists gather: 0.1123 against 0.1122 ms, same box,
+        // volumes identical.  The words not read were never what the sweep waited for; left out.)
+        if (active) P.v[u] = p[(size_t)u * plane];
         vc = add3(vc, zstep);                                               // :75
     }
 }
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
 
 // the dists max-pyramid of one frame into `mem` (levels 1..top); returns the descriptor
 int df_build_dists_pyramid(const uint16_t* dists, size_t pitch, int cols, int rows, uint16_t* mem, size_t mem_elems,
-                           DfDistsPyramid* out, hipStream_t st, bool levels_to_5, unsigned int* zero16)
+                           DfDistsPyramid* out, hipStream_t st, bool levels_to_5, unsigned int* zero16, unsigned int* max_word)
 {
     DfDistsPyramid P;
     memset(&P, 0, sizeof(P));
@@ -712,7 +717,8 @@ int df_build_dists_pyramid(const uint16_t* dists, size_t pitch, int cols, int ro
     }
     if (l >= DF_PYR_MAX_LEVELS || (size_t)off > mem_elems || l < 5) { out->top = 0; return DF_OK; }     // (images below 32 px: no test)
     P.top = l;
-    hipLaunchKernelGGL(df_pyramid_tiles_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, P, mem, zero16);
+    if (levels_to_5 && max_word) { P.max_bits = max_word; P.capped = 1; }
+    hipLaunchKernelGGL(df_pyramid_tiles_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, P, mem, zero16, P.capped ? max_word : nullptr);
     DF_LAUNCH_CHECK();
     if (P.top > 5 && !levels_to_5) {
         const size_t lds = 2 * (size_t)P.w[5] * P.h[5] * sizeof(uint16_t);
@@ -858,6 +864,9 @@ extern "C" int dfusion_integrate_ex(const uint16_t* dists, size_t pitch, int col
     // with a plain or a kept allocation never, 200 runs each.)
     char* scratch = df_rigid_scratch(st, bytes);
     if (!scratch) return (int)hipErrorOutOfMemory;
+    // validation: the kept buffer still holds the previous call's plan -- exactly what would hide a read of plan data this call did
+    // not write.  Poisoned (every byte 0xFF: NaN starts, out-of-range items, full masks), such a read cannot go unnoticed.
+    if (flags & DF_RIGID_POISON_SCRATCH) DF_HIP(hipMemsetAsync(scratch, 0xFF, bytes, st));
     auto release_scratch = [&]() {};
     DfDistsPyramid Py;
     memset(&Py, 0, sizeof(Py));

@@ -83,9 +83,42 @@ extern "C" int dfusion_warp_create(DfWarpField** out)
     return DF_OK;
 }
 
+// The handle's side stream (look-ahead table / model builds): made on first use; df_side_join makes `st` wait for whatever is still
+// running there (a device-side wait, nothing blocks the host), df_side_drain blocks until it is idle (before tables are re-made).
+static int df_side_init(DfWarpField* wf)
+{
+    if (wf->side) return DF_OK;
+    DF_HIP(hipStreamCreateWithFlags(&wf->side, hipStreamNonBlocking));
+    DF_HIP(hipEventCreateWithFlags(&wf->ev_fork, hipEventDisableTiming));
+    DF_HIP(hipEventCreateWithFlags(&wf->ev_join, hipEventDisableTiming));
+    if (!wf->host_report) {
+        void* h = nullptr;
+        DF_HIP(hipHostMalloc(&h, 4 * sizeof(uint32_t), hipHostMallocDefault));
+        wf->host_report = (volatile uint32_t*)h;
+        wf->host_report[0] = wf->host_report[1] = wf->host_report[2] = 1u;       // nothing reported yet: assume work
+        wf->host_report[3] = 0u;
+    }
+    return DF_OK;
+}
+static int df_side_join(DfWarpField* wf, hipStream_t st)
+{
+    if (!wf->side_pending) return DF_OK;
+    DF_HIP(hipStreamWaitEvent(st, wf->ev_join, 0));
+    wf->side_pending = false;
+    return DF_OK;
+}
+static void df_side_drain(DfWarpField* wf)
+{
+    if (wf->side) (void)hipStreamSynchronize(wf->side);
+    wf->side_pending = false;
+}
+
 extern "C" int dfusion_warp_destroy(DfWarpField* wf)
 {
     if (!wf) return DF_OK;
+    df_side_drain(wf);
+    if (wf->side) { (void)hipEventDestroy(wf->ev_fork); (void)hipEventDestroy(wf->ev_join); (void)hipStreamDestroy(wf->side); }
+    if (wf->host_report) (void)hipHostFree((void*)wf->host_report);
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
     (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids); (void)hipFree(wf->tile_wmax);
@@ -108,7 +141,7 @@ static int df_warp_reserve(DfWarpField* wf, int M)
     DF_HIP(hipMalloc((void**)&wf->rot, bytes));
     DF_HIP(hipMalloc((void**)&wf->dual, bytes));
     DF_HIP(hipMalloc((void**)&wf->node_t, bytes));
-    if (!wf->bounds_dev) DF_HIP(hipMalloc((void**)&wf->bounds_dev, 8 * sizeof(float)));
+    if (!wf->bounds_dev) { DF_HIP(hipMalloc((void**)&wf->bounds_dev, 8 * sizeof(float))); DF_HIP(hipMemset(wf->bounds_dev, 0, 8 * sizeof(float))); }   // ([6]: the capped pyramid's image-wide maximum, 0 between frames)
     wf->cap = M;
     return DF_OK;
 }
@@ -213,6 +246,7 @@ extern "C" int dfusion_warp_set_nodes(DfWarpField* wf, const float* pos, const f
                                       dfStream stream)
 {
     if (!wf || !pos || !dq || !sigma || M <= 0 || M > 65535) return DF_E_INVALID;
+    df_side_drain(wf);                                         // (look-ahead builds read the node arrays)
     int rc = df_warp_reserve(wf, M);
     if (rc) return rc;
     wf->M = M;
@@ -928,6 +962,7 @@ extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const DfSla
     DfSlab sl = df_slab_or_full(v, slab);
     if (sl.z_own_n < 0 || sl.z_own0 < 0 || sl.z_own0 + sl.z_own_n > v.dims[2]) return DF_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    df_side_drain(wf);                                         // (look-ahead builds of the tables about to be re-made)
     DfIndexGeom g;
     g.X = v.dims[0]; g.Y = v.dims[1]; g.Z = v.dims[2];
     g.bx = (g.X + DF_BRICK - 1) / DF_BRICK; g.by = (g.Y + DF_BRICK - 1) / DF_BRICK; g.bz = (g.Z + DF_BRICK - 1) / DF_BRICK;
@@ -1058,6 +1093,8 @@ struct DfWarpedArgs {
     // bits set are listed in bin w (plan_bins[w * plan_items ...], plan_cnt[w] of them) -- all made on the stream by
     // df_sweep_plan_kernel, so the sweep's workgroups are full of work from the first to the last, whatever the frustum cuts out.
     const unsigned long long* plan_mask; const unsigned int* plan_bins; const unsigned int* plan_cnt; unsigned int plan_items; int plan_tiles_y;
+    // the verdict pass's list lengths (device, this frame's counter set) and where the plan kernel reports them to the host (pinned; both nullable)
+    const uint32_t* blk_cnt; uint32_t* host_report; uint32_t sweep_no;
 #ifdef DF_TRACE_WG
     unsigned long long* trace;     // [waves][4]: start, end (s_memrealtime), hw id, alive layers
 #endif
@@ -1069,6 +1106,9 @@ struct DfWarpedArgs {
     // table build (df_warp_brick_kernel<K, true>): per-block bound on sum_i w_i (same block grid), and -- when the build is driven by a
     // work list instead of the launch grid -- the list of packed brick coordinates (x | y << 10 | z << 20) and its length
     float* blk_wmax; const uint32_t* work; const uint32_t* work_cnt; uint32_t* work_cursor;
+    // verdict pass: look-ahead margin (metres; 0 = none).  Blocks that are not alive this frame but would be with every radius
+    // widened by this much are "near": their tables / blend models are made off the critical path (dfusion_warp_blocks.h)
+    float pf_margin;
 };
 // A tile is ZERO-WEIGHT for a frame when tile_wmax * max_j |rot_j| < 2^-76: every component of every voxel's blend sum
 // sum_i w_i rot_i is then below 2^-75 in magnitude (the 2x margin covers the rounding of the sums), its square below 2^-150
@@ -1165,17 +1205,18 @@ __device__ __forceinline__ void w_tab_load(const float* tab, size_t nvox, size_t
 // "The largest dists value it can meet" is the maximum over the pixel rectangle the ball projects into (max-pyramid of the frame's
 // dists, dfusion_pyramid.h), or over the whole image where there is no pyramid or the ball reaches the camera plane.
 // wk >= sum_i w_i of every voxel of the tile: (float)k always (w_i <= 1), the table build's per-tile bound where there is one
-__device__ __forceinline__ bool df_tile_culled(const DfWarpedArgs& a, f3 c, float wk)
+// `extra` (metres, >= 0) widens every radius: the verdict pass's look-ahead test ("could be alive within the next few frames").
+__device__ __forceinline__ bool df_tile_culled(const DfWarpedArgs& a, f3 c, float wk, float extra = 0.f)
 {
     const float max_t = a.cull[0], sin_half = a.cull[1];
     if (!(sin_half <= 1.0f && max_t < 1.0e30f)) return false;
     float max_dist;                                                              // image-wide: the pyramid's top texel, or df_dists_max_kernel's result
-    if (a.py.top != 0) { const uint32_t tb = a.py.mem[a.py.off[a.py.top]]; max_dist = tb < 0x7c00u ? h2f_bits((uint16_t)tb) : 3.0e38f; }
+    if (a.py.top != 0) { const uint32_t tb = df_pyramid_image_max(a.py); max_dist = tb < 0x7c00u ? h2f_bits((uint16_t)tb) : 3.0e38f; }
     else max_dist = a.cull[2];
     const float cn = sqrtf(dot3(c, c));
     const float delta = 2.f * sin_half * (cn + a.tile_r) + wk * max_t;
-    const float rho = a.cam_scale * (a.tile_r + delta) * 1.002f + 1e-3f;
-    const float rho_r = a.origin_cam >= 0.f ? fminf(rho, (a.tile_r + 2.f * sin_half * a.origin_cam + wk * max_t) * 1.002f + 1e-3f) : rho;   // (both bounds hold)
+    const float rho = a.cam_scale * (a.tile_r + delta + extra) * 1.002f + 1e-3f;
+    const float rho_r = a.origin_cam >= 0.f ? fminf(rho, (a.tile_r + 2.f * sin_half * a.origin_cam + wk * max_t + extra) * 1.002f + 1e-3f) : rho;   // (both bounds hold)
     const f3 cc = aff_mul(a.world2cam, c);
     const float rmin = sqrtf(dot3(cc, cc)) - rho_r;                              // no warped voxel of the tile is nearer to the camera centre
     bool out = false;
@@ -1652,6 +1693,10 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
 {
     __shared__ unsigned int s_cnt[DF_PLAN_BINS], s_base[DF_PLAN_BINS];
     if (threadIdx.x < DF_PLAN_BINS) { s_cnt[threadIdx.x] = 0u; if (blockIdx.x == 0) cnt_next[threadIdx.x] = 0u; }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.py.capped) *const_cast<uint32_t*>(a.py.max_bits) = 0u;     // (its readers, the verdict pass, are done: 0 again for the next frame's pyramid)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_report && a.blk_cnt) {      // (the verdict pass is complete: this kernel follows it in the stream)
+        a.host_report[0] = a.blk_cnt[0]; a.host_report[1] = a.blk_cnt[1]; a.host_report[2] = a.blk_cnt[3]; a.host_report[3] = a.sweep_no;
+    }
     __syncthreads();
     const unsigned item = blockIdx.x * (DF_PLAN_WG / 64) + (threadIdx.x >> 6);
     const int ln = threadIdx.x & 63, p = ln >> 4, l = ln & 15;
@@ -1985,11 +2030,11 @@ static unsigned df_work_grid(const void* kernel)
     return (unsigned)per_cu * (unsigned)prop.multiProcessorCount;
 }
 
-// the build of the bricks on work list 0 (length cnt[0])
-static int df_build_listed(DfWarpField* wf, const uint32_t* cnt, hipStream_t st)
+// the build of the bricks on a work list: list 0 (urgent; length cnt[0], cursor cnt[2]) or list 1 (look-ahead; cnt[3], cnt[4])
+static int df_build_listed(DfWarpField* wf, const uint32_t* cnt, hipStream_t st, int list = 0)
 {
     DfWarpedArgs b = df_table_args(wf);
-    b.work = wf->blk_work; b.work_cnt = cnt; b.work_cursor = const_cast<uint32_t*>(cnt) + 2;
+    b.work = wf->blk_work + (size_t)list * wf->blk_cap; b.work_cnt = cnt + (list ? 3 : 0); b.work_cursor = const_cast<uint32_t*>(cnt) + (list ? 4 : 2);
     const DfWarpView W = df_view(wf);
     static unsigned grid[9] = {0};
     DF_DISPATCH_K(wf->tab_k, {
@@ -2008,8 +2053,8 @@ static int df_tables_complete(DfWarpField* wf, hipStream_t st)
     const DfWarpedArgs b = df_table_args(wf);
     const int nbz = wf->tab_zn / 8;
     const size_t nblk = (size_t)b.bm_nbx * b.bm_nby * nbz;
-    uint32_t* cnt = wf->blk_cnt + 4 * wf->blk_phase;
-    uint32_t* cnt_next = wf->blk_cnt + 4 * (wf->blk_phase ^ 1);
+    uint32_t* cnt = wf->blk_cnt + 8 * wf->blk_phase;
+    uint32_t* cnt_next = wf->blk_cnt + 8 * (wf->blk_phase ^ 1);
     hipLaunchKernelGGL(df_blocks_unbuilt_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, b.bm_nbx, b.bm_nby, nbz, wf->bx, wf->by,
                        wf->tab_z0 / 8, wf->blk_state, wf->blk_work, cnt, cnt_next);
     DF_LAUNCH_CHECK();
@@ -2039,26 +2084,56 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
         DF_HIP(hipMalloc((void**)&wf->bm_cnt, nblk));
         wf->bm_cap = nblk;
     }
-    uint32_t* cnt = wf->blk_cnt + 4 * wf->blk_phase;
-    uint32_t* cnt_next = wf->blk_cnt + 4 * (wf->blk_phase ^ 1);
+    // look-ahead: with on-demand tables or models still to make, blocks NEAR the alive set get theirs on the side
+    // stream while the sweep runs -- unless the caller wants models made at once (then everything stays on the launch stream, in order)
+    bool ahead = !(flags & (DF_WARP_NO_PREFETCH | DF_WARP_BLOCK_MODEL_NOW));
+    if (ahead) { int rc = df_side_init(wf); if (rc) return rc; }
+    // The side stream costs a fork and a join (~13 us of barrier packets per frame): worth it while blocks are being built or modelled,
+    // not on a scene at rest.  Whether anything was listed lately comes from the plan kernel's host report -- read without a
+    // synchronisation, so it may be frames old; it only decides WHERE optional work runs.  On from the first sweeps over new tables,
+    // while the last report listed anything, and every 8th sweep as a probe (a camera that starts to move is picked up by the urgent
+    // list at once, by the look-ahead within the report's age).
+    if (ahead && wf->tab_sweeps >= 8 && (wf->tab_sweeps & 7) != 0 && wf->host_report &&
+        wf->host_report[0] == 0u && wf->host_report[1] == 0u && wf->host_report[2] == 0u) ahead = false;
+    const bool quiet = !ahead && !(flags & (DF_WARP_NO_PREFETCH | DF_WARP_BLOCK_MODEL_NOW));      // a frame at rest: optional work waits for the next probe
+    const int want_models_policy = want_models;
+    const int want_models_now = quiet ? 0 : want_models_policy;
+    a.pf_margin = ahead && !wf->tab_complete ? DF_WARP_PREFETCH_MARGIN_M : 0.f;
+    uint32_t* cnt = wf->blk_cnt + 8 * wf->blk_phase;
+    uint32_t* cnt_next = wf->blk_cnt + 8 * (wf->blk_phase ^ 1);
+    uint32_t* list_urgent = wf->blk_work, *list_ahead = wf->blk_work + wf->blk_cap, *list_model = wf->blk_work + 2 * wf->blk_cap;
     hipLaunchKernelGGL(df_block_verdict_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, a, wf->rot, wf->node_t, nbx, nby, nbz,
-                       wf->blk_state, wf->blk_wmax, wf->brick_thr + wf->off_cap, wf->bx, wf->by, a.tile_wmax != nullptr ? 1 : 0, use_models && wf->bm_cap >= nblk ? 1 : 0, want_models,
-                       wf->tab_complete ? 0 : 1, wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_alive, wf->blk_work, wf->blk_work + wf->blk_cap,
+                       wf->blk_state, wf->blk_wmax, wf->brick_thr + wf->off_cap, wf->bx, wf->by, a.tile_wmax != nullptr ? 1 : 0, use_models && wf->bm_cap >= nblk ? 1 : 0, want_models_now,
+                       wf->tab_complete ? 0 : 1, wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_alive, list_urgent, list_ahead, list_model,
                        cnt, cnt_next);
+    a.blk_cnt = cnt; a.host_report = (uint32_t*)wf->host_report; a.sweep_no = (uint32_t)wf->tab_sweeps;
     DF_LAUNCH_CHECK();
     wf->blk_phase ^= 1;
-    if (!wf->tab_complete) { int rc = df_build_listed(wf, cnt, st); if (rc) return rc; }
     // (every frame: running this pass only every 4th frame saved its 4.6 us launch and cost 3 % more swept voxels, 18 us, on a moving camera)
-    if (want_models) {
+    auto launch_models = [&](hipStream_t s2) -> int {
         const DfWarpedArgs b = df_table_args(wf);
         static unsigned g8 = 0, g4 = 0;
         if (!g8) { g8 = df_work_grid((const void*)df_block_model_kernel<8>); g4 = df_work_grid((const void*)df_block_model_kernel<4>); }
-        if (k == 8) hipLaunchKernelGGL(df_block_model_kernel<8>, dim3(g8), dim3(256), 0, st, b, nbx, nby, nbz, wf->blk_work + wf->blk_cap, cnt + 1,
+        if (k == 8) hipLaunchKernelGGL(df_block_model_kernel<8>, dim3(g8), dim3(256), 0, s2, b, nbx, nby, nbz, list_model, cnt + 1,
                                        wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_state);
-        else hipLaunchKernelGGL(df_block_model_kernel<4>, dim3(g4), dim3(256), 0, st, b, nbx, nby, nbz, wf->blk_work + wf->blk_cap, cnt + 1,
+        else hipLaunchKernelGGL(df_block_model_kernel<4>, dim3(g4), dim3(256), 0, s2, b, nbx, nby, nbz, list_model, cnt + 1,
                                 wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_state);
         DF_LAUNCH_CHECK();
+        return DF_OK;
+    };
+    const bool side_work = ahead && (!wf->tab_complete || want_models_now);
+    if (side_work) {
+        // fork: the side stream starts once the verdict pass has written the lists; its kernels touch only blocks this frame's sweep
+        // does not read (near, not alive) or structures the sweep never reads (model records, state bytes)
+        DF_HIP(hipEventRecord(wf->ev_fork, st));
+        DF_HIP(hipStreamWaitEvent(wf->side, wf->ev_fork, 0));
+        if (!wf->tab_complete) { int rc = df_build_listed(wf, cnt, wf->side, 1); if (rc) return rc; }
+        if (want_models_now) { int rc = launch_models(wf->side); if (rc) return rc; }
+        DF_HIP(hipEventRecord(wf->ev_join, wf->side));
+        wf->side_pending = true;                                           // joined by the next call that touches the tables
     }
+    if (!wf->tab_complete) { int rc = df_build_listed(wf, cnt, st, 0); if (rc) return rc; }      // urgent: before this frame's sweep
+    if (want_models_now && !ahead) { int rc = launch_models(st); if (rc) return rc; }
     a.blk_alive = wf->blk_alive; a.bm_nbx = nbx; a.bm_nby = nby;
     wf->alive_valid = true;
     return DF_OK;
@@ -2077,6 +2152,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         return DF_E_NO_INDEX;
     if (s.z_own_n == 0) return DF_OK;
     hipStream_t st = (hipStream_t)stream;
+    { int rc = df_side_join(wf, st); if (rc) return rc; }     // the previous call's look-ahead builds (tables, models, state bytes)
 
     DfWarpedArgs a;
     memset(&a, 0, sizeof(a));
@@ -2112,7 +2188,12 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
                 DF_HIP(hipMalloc((void**)&wf->pyr_mem, elems * sizeof(uint16_t)));
                 wf->pyr_cap = elems;
             }
-            int rc = df_build_dists_pyramid(dists, pitch, cols, rows, wf->pyr_mem, wf->pyr_cap, &a.py, st);
+            // the pipelined sweep (the product path) reads the pyramid in its verdict pass only, and its plan kernel re-arms the
+            // image-maximum word: levels 1..5 in ONE launch.  The other kernels take the full pyramid (two launches).
+            const bool pipe_path = use_w && (size_t)wf->M * 32 <= 160 * 1024 && !(flags & (DF_WARP_NO_LDS | DF_WARP_NO_PIPELINE)) && (k == 8 || k == 4) &&
+                                   pitch < (1u << 24) && rows < (1 << 24) && (unsigned long long)rows * pitch < (1ull << 32);
+            int rc = df_build_dists_pyramid(dists, pitch, cols, rows, wf->pyr_mem, wf->pyr_cap, &a.py, st, pipe_path, nullptr,
+                                            pipe_path ? (unsigned int*)(wf->bounds_dev + 6) : nullptr);
             if (rc) return rc;
         }
         if (a.py.top == 0) {                                      // no pyramid (switched off, or an image under 32 px): the image-wide maximum alone
@@ -2281,11 +2362,11 @@ static int df_build_voxel_table(DfWarpField* wf, const DfVolume& v, const DfSlab
         DF_HIP(hipMalloc((void**)&wf->blk_state, nblk));
         DF_HIP(hipMalloc((void**)&wf->blk_wmax, nblk * sizeof(float)));
         DF_HIP(hipMalloc((void**)&wf->blk_alive, nblk));
-        DF_HIP(hipMalloc((void**)&wf->blk_work, 2 * nblk * sizeof(uint32_t)));
+        DF_HIP(hipMalloc((void**)&wf->blk_work, 3 * nblk * sizeof(uint32_t)));
         wf->blk_cap = nblk;
     }
-    if (!wf->blk_cnt) DF_HIP(hipMalloc((void**)&wf->blk_cnt, 8 * sizeof(uint32_t)));
-    DF_HIP(hipMemsetAsync(wf->blk_cnt, 0, 8 * sizeof(uint32_t), st));
+    if (!wf->blk_cnt) DF_HIP(hipMalloc((void**)&wf->blk_cnt, 16 * sizeof(uint32_t)));
+    DF_HIP(hipMemsetAsync(wf->blk_cnt, 0, 16 * sizeof(uint32_t), st));
     DF_HIP(hipMemsetAsync(wf->blk_state, on_demand ? 0 : 1, nblk, st));
     DF_HIP(hipMemsetAsync(wf->blk_wmax, 0, nblk * sizeof(float), st));
     wf->blk_phase = 0;

@@ -250,7 +250,7 @@ __device__ __forceinline__ bool df_block_box_dead(const DfWarpedArgs& a, const f
                     nz = (zl <= 0.f && zh >= 0.f) ? 0.f : fminf(fabsf(zl), fabsf(zh));
         const float rmin = sqrtf(nx * nx + ny * ny + nz * nz) * 0.9999f;
         float max_dist;
-        if (a.py.top != 0) { const uint32_t tb = a.py.mem[a.py.off[a.py.top]]; max_dist = tb < 0x7c00u ? h2f_bits((uint16_t)tb) : 3.0e38f; }
+        if (a.py.top != 0) { const uint32_t tb = df_pyramid_image_max(a.py); max_dist = tb < 0x7c00u ? h2f_bits((uint16_t)tb) : 3.0e38f; }
         else max_dist = a.cull[2];
         if (rmin > max_dist * 1.002f + a.P.trunc) dead = true;             // sdf < -trunc whatever pixel it meets (:91)
         if (!dead && ok && zl > 0.05f) {
@@ -276,22 +276,28 @@ __device__ __forceinline__ bool df_block_box_dead(const DfWarpedArgs& a, const f
 // ---- the per-frame verdict pass: one lane per 8 x 8 x 8 block of the table's planes (x fastest: every array below is read coalesced).
 //   alive[blk] = 0 where no voxel of the block can update this frame: outside this launch's planes, zero-weight (see DF_ZERO_WEIGHT),
 //   culled by the ball test (df_tile_culled, with the block's own bound on sum w_i), or by the box of its blend model.
-// (bx < vbx, by < vby: the brick grid of the index.)  It also feeds the ON-DEMAND work of the frame (dfusion_warp.hip, df_block_verdicts): an alive block whose tables are not built yet
-// goes on the build list (packed brick coordinates), a built one without a model record on the model list (when `want_models`).
-// The list lengths are counter set `cnt` ([0] build, [1] model, [2] the build pass's cursor; this pass zeroes the other set, `cnt_next`).
+// (bx < vbx, by < vby: the brick grid of the index.)  It also feeds the ON-DEMAND work of the frame (dfusion_warp.hip, df_block_verdicts):
+//   list 0 (URGENT builds)   alive blocks whose tables are not built: built on the launch stream before the sweep;
+//   list 1 (LOOK-AHEAD builds, a.pf_margin > 0) blocks that are not alive now but pass the ball test with every radius widened by
+//          a.pf_margin -- what a moving camera / a changing warp brings in over the next few frames: built on the handle's SIDE stream
+//          while this frame's sweep runs, so that a block is usually built (and modelled) before it is first swept;
+//   list 2 (models, when `want_models`) built blocks without a model record that are alive or near: also side-stream work (a model
+//          only serves from the next frame on).  With a.pf_margin == 0 list 1 stays empty and everything runs on the launch stream.
+// Builds are packed brick coordinates, models block indices.  Counter set `cnt`: [0] urgent builds, [1] models, [2] the urgent build
+// pass's cursor, [3] look-ahead builds, [4] their pass's cursor; this pass zeroes the other set, `cnt_next`.
 __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArgs a, const float4* __restrict__ rot, const float4* __restrict__ node_t,
                                                                int nbx, int nby, int nbz, uint8_t* __restrict__ blk_state,
                                                                const float* __restrict__ blk_wmax, const float* __restrict__ brick_d1, int vbx, int vby, int zero_skip, int use_models, int want_models,
                                                                int build_on_demand, const uint16_t* __restrict__ bm_idx,
                                                                const uint32_t* __restrict__ bm_lam, const uint32_t* __restrict__ bm_w,
                                                                const uint8_t* __restrict__ bm_cnt, uint8_t* __restrict__ alive,
-                                                               uint32_t* __restrict__ build_list, uint32_t* __restrict__ model_list,
+                                                               uint32_t* __restrict__ build_list, uint32_t* __restrict__ ahead_list, uint32_t* __restrict__ model_list,
                                                                uint32_t* __restrict__ cnt, uint32_t* __restrict__ cnt_next)
 {
     const size_t nblk = (size_t)nbx * nby * nbz;
     const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x < 4) cnt_next[threadIdx.x] = 0u;
-    bool keep = false, need_build = false, need_model = false;
+    if (blockIdx.x == 0 && threadIdx.x < 8) cnt_next[threadIdx.x] = 0u;
+    bool keep = false, near = false, need_build = false, need_ahead = false, need_model = false;
     int bx = 0, by = 0, bz = 0;
     if (blk < nblk) {
         bx = (int)(blk % (size_t)nbx); by = (int)((blk / (size_t)nbx) % (size_t)nby); bz = (int)(blk / ((size_t)nbx * nby));
@@ -317,7 +323,12 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
             }
             if (keep) {
                 const f3 c = aff_mul(a.vol2world, mk3(((float)x0 + 3.5f) * a.vsx, ((float)y0 + 3.5f) * a.vsy, ((float)z0 + 3.5f) * a.vsz));
-                keep = !df_tile_culled(a, c, wk);
+                if (a.pf_margin > 0.f && st < 2u) {
+                    // (only blocks that still lack something can be look-ahead work: the widened test first, the frame's own
+                    // test for those that pass it)
+                    near = !df_tile_culled(a, c, wk, a.pf_margin);
+                    keep = near && !df_tile_culled(a, c, wk);
+                } else keep = !df_tile_culled(a, c, wk);
             }
         }
         if (keep && st == 2u && use_models) {
@@ -326,17 +337,25 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
         }
         alive[blk] = keep ? 1 : 0;
         need_build = keep && build_on_demand && st == 0u;
-        need_model = keep && want_models && (st == 1u || (need_build && want_models > 1));
-        if (need_build) blk_state[blk] = 1;
+        need_ahead = !keep && near && build_on_demand && st == 0u;
+        need_model = (keep || near) && want_models && (st == 1u || (need_build && want_models > 1));
+        if (need_build || need_ahead) blk_state[blk] = 1;
     }
     // one counter bump per wave and list
-    const unsigned long long mb = __builtin_amdgcn_ballot_w64(need_build), mm = __builtin_amdgcn_ballot_w64(need_model);
+    const unsigned long long mb = __builtin_amdgcn_ballot_w64(need_build), ma = __builtin_amdgcn_ballot_w64(need_ahead), mm = __builtin_amdgcn_ballot_w64(need_model);
     const unsigned long long below = ((unsigned long long)1 << (threadIdx.x & 63)) - 1ull;
+    const unsigned code = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)(a.tab_z0 / 8 + bz) << 20);
     if (mb) {
         unsigned base = 0;
         if ((threadIdx.x & 63) == 0) base = atomicAdd(&cnt[0], (unsigned)__popcll(mb));
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        if (need_build) build_list[base + (unsigned)__popcll(mb & below)] = (unsigned)bx | ((unsigned)by << 10) | ((unsigned)(a.tab_z0 / 8 + bz) << 20);
+        if (need_build) build_list[base + (unsigned)__popcll(mb & below)] = code;
+    }
+    if (ma) {
+        unsigned base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(&cnt[3], (unsigned)__popcll(ma));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (need_ahead) ahead_list[base + (unsigned)__popcll(ma & below)] = code;
     }
     if (mm) {
         unsigned base = 0;
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(256) void df_blocks_unbuilt_kernel(int nbx, int nby
 {
     const size_t nblk = (size_t)nbx * nby * nbz;
     const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x < 4) cnt_next[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 8) cnt_next[threadIdx.x] = 0u;
     bool need = false;
     int bx = 0, by = 0, bz = 0;
     if (blk < nblk) {

@@ -24,7 +24,9 @@
  *     warp_field.cpp:11-15).  ONE warp-field handle, though, is single-stream: its calls rewrite
  *     scratch it owns (the point queries' fallback list, the solver workspace, the cull's device
  *     scalars, the dists max-pyramid and the launch plan of the warped sweep), so calls on the same
- *     DfWarpField must be issued on one stream or serialised by the caller.  dfusion_integrate keeps
+ *     DfWarpField must be issued on one stream or serialised by the caller.  (The handle also owns one
+ *     internal side stream, on which dfusion_integrate_warped makes look-ahead tables beside its sweep;
+ *     the next call on the handle waits for it on the device -- invisible to the caller.)  dfusion_integrate keeps
  *     its pyramid and launch plan in a scratch buffer cached per (device, stream) -- calls on one
  *     stream are ordered, calls on different streams use different buffers; dfusion_release_scratch()
  *     frees them.  Validation switches and measurement counters are per call / per handle (ABI 4).
@@ -91,6 +93,10 @@ enum {
                                  validation switch                                                              */
 #define DF_WARP_BLOCK_MODEL_NOW 256u /* make block models from the FIRST sweep over a new weight table on (default: the
                                  second, so that a node set that changes every frame never pays for them)       */
+#define DF_WARP_NO_PREFETCH 512u /* everything on the caller's stream, in order: no look-ahead builds on the handle's side stream
+                                 (by default the tables / blend models of blocks NEAR the frame's alive set -- what a moving camera
+                                 or a changing warp brings in over the next few frames -- are made beside the sweep, on a stream the
+                                 handle owns, so that a block is usually built before it is first swept); validation switch     */
 /* flags for dfusion_warp_build_index */
 #define DF_INDEX_VOXEL_TABLE 1u /* also cache the exact k-NN of EVERY voxel of the slab in HBM:
                                    k * 2 bytes per voxel (2 GiB at 512^3, k = 8) -- the per-frame
@@ -153,6 +159,9 @@ int dfusion_integrate(const uint16_t *dists_dev, size_t dists_pitch, int cols, i
                                       reference's own tests                                                                       */
 #define DF_RIGID_NO_SAT 8u         /* no saturated-sample shortcuts (batches of voxels all farther than trunc_dist from the surface
                                       skip the exact square root and, onto stored 1.0 / cleared voxels, the fuse division)        */
+#define DF_RIGID_POISON_SCRATCH 16u /* fill the call's scratch (launch plan, chunk starts, pyramid) with 0xFF bytes first: the buffer is
+                                      kept between calls, and a read of plan data THIS call did not write would otherwise see the
+                                      previous call's valid-looking values                                                        */
 int dfusion_integrate_ex(const uint16_t *dists_dev, size_t dists_pitch, int cols, int rows, DfVolume v,
                          const DfSlab *slab, const float vol2cam[12], const float proj[4], unsigned flags,
                          unsigned long long *n_updated_dev, unsigned long long *n_swept_dev, dfStream stream);

@@ -13,8 +13,11 @@ vol.setRaycastStepFactor(cfg.raycast_step_factor); vol.setGradientDeltaFactor(cf
 pos, sigma = synth.make_nodes(cfg); dq = synth.node_transforms(cfg, 1)
 wf = WarpField(k=cfg.k, voxel_table=(mode != "lean"), weight_table=(mode == "tables")); wf.init(pos, sigma=sigma, transforms=dq)
 pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
-for _ in range(3 + n):        # 3 warm-up launches (on-demand tables, then the blocks' blend models, are made by the first two); pmc_summary --last n
+swept = torch.zeros(1, dtype=torch.int64, device="cuda")
+for i in range(3 + n):        # 3 warm-up launches (on-demand tables, then the blocks' blend models, are made by the first two); pmc_summary --last n
+    if i == 3: wf.debug_counters(swept)       # (the PLAN kernel counts the voxels it keeps: the sweep kernel itself is unchanged)
     vol.integrate_warped(dists, cam, intr, wf, sync=False)
+wf.debug_counters(None)
 for _ in range(n):
     vol.raycast(cam, intr, pts, nrm)
 for _ in range(n):
@@ -22,4 +25,10 @@ for _ in range(n):
 for _ in range(n):
     vol.fetchCloud()
 torch.cuda.synchronize()
-print("done", cfg.name, mode)
+import json
+os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+wl = os.path.join(REPO, "gpurun_out", "pmc_workload.json")
+doc = json.load(open(wl)) if os.path.exists(wl) else {}
+doc[name] = {"n_swept_per_launch": float(swept.item()) / n, "launches": n}
+json.dump(doc, open(wl, "w"))
+print("done", cfg.name, mode, "swept/launch", float(swept.item()) / n)

@@ -42,6 +42,11 @@ for f in sorted(glob.glob(os.path.join(args.root, "*", "*counter_collection.csv"
         for c, v in per_file[k].items():
             rows[k][c].extend(v[-args.last:] if args.last else v)
 
+workload = {}
+try:
+    workload = json.load(open(os.path.join(REPO, "gpurun_out", "pmc_workload.json"))).get(args.config, {})
+except Exception:
+    pass
 out = {}
 for k in sorted(rows):
     print(k)
@@ -55,7 +60,12 @@ for k in sorted(rows):
               ("hbm_bytes/launch", (fetch + write) / 1e9, fetch / 1e9, write / 1e9, rd / 1e9))
         out[k.split("<")[0]] = {"kernel": k, "hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
                                 "tcc_ea0_rdreq_x128": rd, "source_sha256": source_sha(k),
-                                "how": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, %s" % args.tag}
+                                "how": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, %s" % args.tag,
+                                # every counter collected for the kernel (mean per launch, separate --pmc passes): bench.py's
+                                # roofline.compute reads SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES from here
+                                "counters": {c: mean[c] for c in sorted(mean)}}
+        if k.startswith("df_warp_rows_pipe_kernel") and workload.get("n_swept_per_launch"):
+            out[k.split("<")[0]]["n_swept_per_launch"] = workload["n_swept_per_launch"]
     if "SQ_BUSY_CYCLES" in mean and "SQ_ACTIVE_INST_VALU" in mean and "SQ_WAVES" in mean:
         print("    %-22s %.4g per wave" % ("VALU instr", mean.get("SQ_INSTS_VALU", 0) / max(mean["SQ_WAVES"], 1)))
 
