@@ -131,6 +131,16 @@ int main(int argc, char** argv)
     }
     if (comm) { if (!comm->barrier()) { std::fprintf(stderr, "zslab_frame: %s\n", comm->lastError().c_str()); return 4; } } else cuda::waitAllDefaultStream();
 
+    if (comm && rank > 0) {                                 // the other ranks leave their OWN planes beside rank 0's file (tests): <out>.r<rank>
+        const std::string name = std::string(argv[9]) + ".r" + std::to_string(rank);
+        if (FILE* out = std::fopen(name.c_str(), "wb")) {
+            const size_t plane = (size_t)dims * dims;
+            std::vector<unsigned int> vol(plane * (size_t)volume.slabStoreN());
+            volume.data().download(vol.data());
+            std::fwrite(vol.data() + (size_t)(z0 - volume.slabStore0()) * plane, 4, plane * (size_t)zn, out);
+            std::fclose(out);
+        }
+    }
     if (rank == 0 || !comm) {
         FILE* out = std::fopen(argv[9], "wb");
         if (!out) { std::perror("out"); return 2; }
@@ -149,8 +159,10 @@ int main(int argc, char** argv)
         }
         std::fclose(out);
     }
-    std::printf("zslab_frame ok: rank %d of %d, planes [%d, %d), halo %d (%s), %d frames, %d nodes\n", rank, world, z0, z0 + zn, halo,
-                exchange ? "exchanged" : "recomputed", frames, M);
+    unsigned long long alive = 0;                           // the re-balance's input: what the last sweep's verdict pass kept, per 8-plane layer
+    if (M > 0) for (unsigned long long a : warp.aliveBlocksPerLayer(volume)) alive += a;
+    std::printf("zslab_frame ok: rank %d of %d, planes [%d, %d), halo %d (%s), %d frames, %d nodes, %llu alive blocks in the own planes\n", rank, world, z0,
+                z0 + zn, halo, exchange ? "exchanged" : "recomputed", frames, M, alive);
     delete comm;
     return 0;
 }

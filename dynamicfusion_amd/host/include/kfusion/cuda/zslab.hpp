@@ -28,11 +28,17 @@ namespace kfusion { namespace cuda {
 class ZSlabComm
 {
 public:
+    /// What carries the collectives.  RCCL: one rank per GPU over xGMI (the product).  HOST_STAGED: every collective staged through a
+    /// shared-memory segment on the host (device -> host, a barrier, host -> device) -- slow, but it lets N processes share ONE GPU
+    /// (RCCL refuses two ranks on a device), so the C++ collective SEQUENCE runs with N > 1 on a one-GPU box (tests) and on nodes
+    /// without a working RCCL.  FROM_ENV: DFUSION_ZSLAB_BACKEND=host selects HOST_STAGED, anything else RCCL.
+    enum Backend { FROM_ENV = 0, RCCL = 1, HOST_STAGED = 2 };
     /// Collective over all ranks of the node.  `id_path`: a file every rank can read (e.g. under /tmp): rank 0 publishes the RCCL
     /// unique id there (removing a stale one first, and the file itself once every rank is in), the others wait for it; give every
     /// rank of a run the same DFUSION_ZSLAB_NONCE (e.g. the launcher's pid) and a leftover file of another run is never accepted.
     /// The calling thread's current HIP device is the rank's GPU.  Check ok() afterwards.
-    ZSlabComm(int rank, int world, const std::string& id_path);
+    ZSlabComm(int rank, int world, const std::string& id_path, Backend backend = FROM_ENV);
+    Backend backend() const { return backend_; }
     ~ZSlabComm();
     ZSlabComm(const ZSlabComm&) = delete;
     ZSlabComm& operator=(const ZSlabComm&) = delete;
@@ -65,6 +71,12 @@ public:
     bool barrier();
 private:
     bool fail(const std::string& what);
+    bool initRccl(const std::string& id_path);
+    bool initHost(const std::string& id_path);
+    bool hostBarrier();
+    char* hostSlot(int rank) const;
+    Backend backend_;
+    void* seg_; size_t seg_bytes_, slot_bytes_;   // HOST_STAGED: the mapped segment {header, world slots}
     int rank_, world_;
     void* comm_;                 // ncclComm_t
     void* stream_;               // hipStream_t: the null stream (the C++ mirror enqueues everything there)

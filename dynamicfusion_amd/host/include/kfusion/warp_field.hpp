@@ -83,6 +83,11 @@ namespace kfusion
         /// `tables` = also the per-voxel k-NN + weight caches the warped integrate streams (6 GiB at 512^3); without them only the
         /// brick candidate lists are built, which is all point queries (KNN, warp, energy_data) need
         void ensureIndex(const cuda::TsdfVolume& volume, bool tables = true) const;
+        /// What the last warped integrate of `volume` found alive: 8 x 8 x 8 blocks kept by its verdict pass, per 8-plane layer of the
+        /// GLOBAL volume (dims.z / 8 entries; zero outside the slab's own planes).  Summed over the ranks it is the measured profile of
+        /// the sweep's work along z -- the weights cuda::ZSlabComm::slabBounds wants for a re-balance after the first frames
+        /// (one weight per plane: repeat every entry 8 times).  Empty when no warped integrate with a launch plan has run yet.
+        std::vector<unsigned long long> aliveBlocksPerLayer(const cuda::TsdfVolume& volume) const;
     private:
         void pullNodes() const;                              // device transforms -> nodes_ when a solve has made them newer
         mutable std::vector<deformation_node> nodes_;

@@ -508,6 +508,20 @@ void WarpField::ensureIndex(const cuda::TsdfVolume& volume, bool tables) const
     index_ok_ = true; index_volume_ = &volume; index_tables_ = tables;
 }
 
+std::vector<unsigned long long> WarpField::aliveBlocksPerLayer(const cuda::TsdfVolume& volume) const
+{
+    const int layers = volume.getDims()[2] / 8;
+    std::vector<unsigned long long> out;
+    if (layers <= 0) return out;
+    cuda::DeviceArray<unsigned long long> dev((size_t)layers);
+    if (hipMemset(dev.ptr(), 0, (size_t)layers * sizeof(unsigned long long)) != hipSuccess) return out;
+    const int z0 = volume.isSlab() ? volume.slabOwn0() : 0, zn = volume.isSlab() ? volume.slabOwnN() : volume.getDims()[2];
+    if (dfusion_warp_alive_blocks(handle_, z0, zn, dev.ptr(), layers, nullptr) != DF_OK) return out;      // (DF_E_NO_INDEX: nothing swept yet)
+    out.resize((size_t)layers);
+    dev.download(out.data());
+    return out;
+}
+
 void WarpField::KNN(Vec3f point) const
 {
     DeviceArray<float> q; q.upload(point.val, 3);

@@ -5,7 +5,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <thread>
+#include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -30,19 +35,27 @@ bool ZSlabComm::fail(const std::string& what)
 // one the launcher gave every rank (DFUSION_ZSLAB_NONCE, default 0) -- so ranks of a new run cannot pick up the id of an old one.
 namespace { struct IdFile { unsigned long long magic, nonce; ncclUniqueId id; }; const unsigned long long ID_MAGIC = 0x44465a534c414231ull; }
 
-ZSlabComm::ZSlabComm(int rank, int world, const std::string& id_path) : rank_(rank), world_(world), comm_(nullptr), stream_(nullptr), ok_(true)
+ZSlabComm::ZSlabComm(int rank, int world, const std::string& id_path, Backend backend)
+    : backend_(backend), seg_(nullptr), seg_bytes_(0), slot_bytes_(0), rank_(rank), world_(world), comm_(nullptr), stream_(nullptr), ok_(true)
 {
     if (world < 1 || world > 128 || rank < 0 || rank >= world) { fail("ZSlabComm: rank " + std::to_string(rank) + " of " + std::to_string(world) + " (1..128 ranks: the merge key carries the rank in 7 bits)"); return; }
+    if (backend_ == FROM_ENV) { const char* b = std::getenv("DFUSION_ZSLAB_BACKEND"); backend_ = (b && !std::strcmp(b, "host")) ? HOST_STAGED : RCCL; }
+    if (backend_ == HOST_STAGED) initHost(id_path); else initRccl(id_path);
+}
+
+bool ZSlabComm::initRccl(const std::string& id_path)
+{
+    const int rank = rank_, world = world_;
     const char* ne = std::getenv("DFUSION_ZSLAB_NONCE");
     IdFile f; f.magic = ID_MAGIC; f.nonce = ne ? std::strtoull(ne, nullptr, 10) : 0ull;
     if (rank == 0) {
         (void)std::remove(id_path.c_str());                                  // a stale id of an earlier run
-        if (ncclGetUniqueId(&f.id) != ncclSuccess) { fail("ncclGetUniqueId"); return; }
+        if (ncclGetUniqueId(&f.id) != ncclSuccess) return fail("ncclGetUniqueId");
         const std::string tmp = id_path + ".tmp." + std::to_string((long long)getpid());
         FILE* fp = std::fopen(tmp.c_str(), "wb");
-        if (!fp || std::fwrite(&f, sizeof(f), 1, fp) != 1) { if (fp) std::fclose(fp); fail("ZSlabComm: cannot write " + tmp); return; }
+        if (!fp || std::fwrite(&f, sizeof(f), 1, fp) != 1) { if (fp) std::fclose(fp); return fail("ZSlabComm: cannot write " + tmp); }
         std::fclose(fp);
-        if (std::rename(tmp.c_str(), id_path.c_str()) != 0) { fail("ZSlabComm: cannot publish " + id_path); return; }   // atomic publish
+        if (std::rename(tmp.c_str(), id_path.c_str()) != 0) return fail("ZSlabComm: cannot publish " + id_path);   // atomic publish
     } else {
         for (int tries = 0;; ++tries) {
             IdFile g;
@@ -51,20 +64,86 @@ ZSlabComm::ZSlabComm(int rank, int world, const std::string& id_path) : rank_(ra
                 const size_t n = std::fread(&g, sizeof(g), 1, fp); std::fclose(fp);
                 if (n == 1 && g.magic == ID_MAGIC && g.nonce == f.nonce) { f = g; break; }
             }
-            if (tries > 6000) { fail("ZSlabComm: no RCCL id for this run at " + id_path + " after 60 s"); return; }
+            if (tries > 6000) return fail("ZSlabComm: no RCCL id for this run at " + id_path + " after 60 s");
             std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
     }
     ncclComm_t c;
-    if (ncclCommInitRank(&c, world, f.id, rank) != ncclSuccess) { fail("ncclCommInitRank"); return; }
+    if (ncclCommInitRank(&c, world, f.id, rank) != ncclSuccess) return fail("ncclCommInitRank");
     comm_ = c;
     token_.create(1);
     if (rank == 0) (void)std::remove(id_path.c_str());                       // every rank is in: the file has done its job
+    return true;
+}
+
+// ---- HOST_STAGED: a file-backed shared segment {header, one slot per rank}.  Rank 0 creates it (a stale one removed first) and
+// publishes it by rename, with the run's nonce in the header; the others map it once magic and nonce match.  The barrier is a
+// sense-reversing counter in the header (lock-free atomics on MAP_SHARED memory are process-shared on this platform).
+namespace { struct SegHeader { unsigned long long magic, nonce; unsigned long long slot_bytes; std::atomic<unsigned> arrive, gen, attached; char pad[24]; }; const unsigned long long SEG_MAGIC = 0x44465a53484d3031ull; }
+
+bool ZSlabComm::initHost(const std::string& id_path)
+{
+    const char* ne = std::getenv("DFUSION_ZSLAB_NONCE");
+    const unsigned long long nonce = ne ? std::strtoull(ne, nullptr, 10) : 0ull;
+    const char* sm = std::getenv("DFUSION_ZSLAB_HOST_SLOT_MB");
+    const size_t slot = (size_t)(sm ? std::max(1, std::atoi(sm)) : 64) << 20;            // sparse: only touched pages exist
+    const std::string path = id_path + ".shm";
+    const size_t bytes = sizeof(SegHeader) + (size_t)world_ * slot;
+    int fd = -1;
+    if (rank_ == 0) {
+        (void)std::remove(path.c_str());
+        const std::string tmp = path + ".tmp." + std::to_string((long long)getpid());
+        fd = ::open(tmp.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { if (fd >= 0) ::close(fd); return fail("ZSlabComm(host): cannot create " + tmp); }
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return fail("ZSlabComm(host): mmap");
+        SegHeader* h = new (m) SegHeader();
+        h->magic = SEG_MAGIC; h->nonce = nonce; h->slot_bytes = slot; h->arrive = 0; h->gen = 0; h->attached = 1;
+        seg_ = m; seg_bytes_ = bytes; slot_bytes_ = slot;
+        if (std::rename(tmp.c_str(), path.c_str()) != 0) return fail("ZSlabComm(host): cannot publish " + path);
+    } else {
+        for (int tries = 0;; ++tries) {
+            fd = ::open(path.c_str(), O_RDWR);
+            if (fd >= 0) {
+                struct stat sb;
+                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size == bytes) {
+                    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                    ::close(fd);
+                    if (m != MAP_FAILED) {
+                        SegHeader* h = (SegHeader*)m;
+                        if (h->magic == SEG_MAGIC && h->nonce == nonce && h->slot_bytes == slot) { seg_ = m; seg_bytes_ = bytes; slot_bytes_ = slot; h->attached.fetch_add(1); break; }
+                        munmap(m, bytes);
+                    }
+                } else ::close(fd);
+            }
+            if (tries > 6000) return fail("ZSlabComm(host): no segment for this run at " + path + " after 60 s");
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+    }
+    if (!hostBarrier()) return false;
+    if (rank_ == 0) (void)std::remove(path.c_str());                          // everybody has it mapped: the name has done its job
+    return true;
+}
+
+char* ZSlabComm::hostSlot(int rank) const { return (char*)seg_ + sizeof(SegHeader) + (size_t)rank * slot_bytes_; }
+
+bool ZSlabComm::hostBarrier()
+{
+    SegHeader* h = (SegHeader*)seg_;
+    const unsigned g = h->gen.load();
+    if (h->arrive.fetch_add(1) + 1 == (unsigned)world_) { h->arrive.store(0); h->gen.store(g + 1); return true; }
+    for (long spins = 0; h->gen.load() == g; ++spins) {
+        if (spins > 1200000) return fail("ZSlabComm(host): barrier timed out after 120 s (a rank is gone)");
+        if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(100)); else std::this_thread::yield();
+    }
+    return true;
 }
 
 ZSlabComm::~ZSlabComm()
 {
     if (comm_) { (void)hipDeviceSynchronize(); (void)ncclCommDestroy((ncclComm_t)comm_); }
+    if (seg_) munmap(seg_, seg_bytes_);
 }
 
 void ZSlabComm::slabRange(int Z, int rank, int world, int& z_own0, int& z_own_n)
@@ -116,6 +195,13 @@ bool ZSlabComm::broadcast(void* device_ptr, size_t bytes, int root)
 {
     if (!ok_) return false;
     if (world_ == 1 || !bytes) return true;
+    if (backend_ == HOST_STAGED) {
+        if (bytes > slot_bytes_) return fail("ZSlabComm(host): broadcast larger than a slot (DFUSION_ZSLAB_HOST_SLOT_MB)");
+        if (rank_ == root) ZS_HIP(hipMemcpy(hostSlot(root), device_ptr, bytes, hipMemcpyDeviceToHost));
+        if (!hostBarrier()) return false;
+        if (rank_ != root) ZS_HIP(hipMemcpy(device_ptr, hostSlot(root), bytes, hipMemcpyHostToDevice));
+        return hostBarrier();
+    }
     ZS_NCCL(ncclBroadcast(device_ptr, device_ptr, bytes, ncclUint8, root, (ncclComm_t)comm_, (hipStream_t)stream_));
     return true;
 }
@@ -132,17 +218,34 @@ bool ZSlabComm::exchangeHalos(TsdfVolume& slab, int halo)
     // (a local precondition, checked the same way on every rank by partitionOk: no collective has been entered yet)
     if ((rank_ > 0 && (n_lo != halo || slab.slabOwnN() < halo)) || (rank_ < world_ - 1 && (n_hi != halo || slab.slabOwnN() < halo)))
         return fail("ZSlabComm::exchangeHalos: the slab does not hold " + std::to_string(halo) + " halo planes (ask partitionOk first)");
+    if (backend_ == HOST_STAGED) {
+        // my first `halo` own planes at the front of my slot, my last ones behind them; then each neighbour's facing half comes in
+        const size_t hb = (size_t)halo * plane * sizeof(int);
+        if (2 * hb > slot_bytes_) return fail("ZSlabComm(host): halo planes larger than a slot (DFUSION_ZSLAB_HOST_SLOT_MB)");
+        ZS_HIP(hipMemcpy(hostSlot(rank_), base + (size_t)lo_local * plane, hb, hipMemcpyDeviceToHost));
+        ZS_HIP(hipMemcpy(hostSlot(rank_) + hb, base + (size_t)(hi_local - halo) * plane, hb, hipMemcpyDeviceToHost));
+        if (!hostBarrier()) return false;
+        if (rank_ > 0) ZS_HIP(hipMemcpy(base, hostSlot(rank_ - 1) + hb, hb, hipMemcpyHostToDevice));                       // its last own planes
+        if (rank_ < world_ - 1) ZS_HIP(hipMemcpy(base + (size_t)hi_local * plane, hostSlot(rank_ + 1), hb, hipMemcpyHostToDevice));   // its first ones
+        return hostBarrier();
+    }
     ncclComm_t c = (ncclComm_t)comm_; hipStream_t st = (hipStream_t)stream_;
-    ZS_NCCL(ncclGroupStart());
-    if (rank_ > 0) {                                                // lower neighbour: my first own planes out, its last ones in
-        ZS_NCCL(ncclSend(base + (size_t)lo_local * plane, (size_t)halo * plane, ncclInt32, rank_ - 1, c, st));
-        ZS_NCCL(ncclRecv(base, (size_t)n_lo * plane, ncclInt32, rank_ - 1, c, st));
+    // (a failed send / receive must not leave the group open: close it, then report the first error)
+    ncclResult_t first = ncclGroupStart();
+    auto acc = [&](ncclResult_t r) { if (first == ncclSuccess) first = r; };
+    if (first == ncclSuccess) {
+        if (rank_ > 0) {                                            // lower neighbour: my first own planes out, its last ones in
+            acc(ncclSend(base + (size_t)lo_local * plane, (size_t)halo * plane, ncclInt32, rank_ - 1, c, st));
+            acc(ncclRecv(base, (size_t)n_lo * plane, ncclInt32, rank_ - 1, c, st));
+        }
+        if (rank_ < world_ - 1) {
+            acc(ncclSend(base + (size_t)(hi_local - halo) * plane, (size_t)halo * plane, ncclInt32, rank_ + 1, c, st));
+            acc(ncclRecv(base + (size_t)hi_local * plane, (size_t)n_hi * plane, ncclInt32, rank_ + 1, c, st));
+        }
+        const ncclResult_t end = ncclGroupEnd();
+        acc(end);
     }
-    if (rank_ < world_ - 1) {
-        ZS_NCCL(ncclSend(base + (size_t)(hi_local - halo) * plane, (size_t)halo * plane, ncclInt32, rank_ + 1, c, st));
-        ZS_NCCL(ncclRecv(base + (size_t)hi_local * plane, (size_t)n_hi * plane, ncclInt32, rank_ + 1, c, st));
-    }
-    ZS_NCCL(ncclGroupEnd());
+    if (first != ncclSuccess) return fail(std::string("RCCL: ") + ncclGetErrorString(first) + " in exchangeHalos");
     return true;
 }
 
@@ -153,13 +256,30 @@ bool ZSlabComm::raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Int
     const size_t px = (size_t)cols * rows;
     slab.raycastMarch(camera_pose, intr, cols, rows, (unsigned)rank_, keys64_);
     // ONE merge collective: the per-pixel MIN of the keys is the first event along every ray, its owner and its Ts (dfusion.h)
-    if (world_ > 1) ZS_NCCL(ncclAllReduce(keys64_.ptr(), keys64_.ptr(), px, ncclInt64, ncclMin, c, st));
+    if (world_ > 1 && backend_ == HOST_STAGED) {
+        if (px * 16 > slot_bytes_) return fail("ZSlabComm(host): image larger than a slot (DFUSION_ZSLAB_HOST_SLOT_MB)");
+        ZS_HIP(hipMemcpy(hostSlot(rank_), keys64_.ptr(), px * 8, hipMemcpyDeviceToHost));
+        if (!hostBarrier()) return false;
+        std::vector<long long> m((const long long*)hostSlot(0), (const long long*)hostSlot(0) + px);
+        for (int r = 1; r < world_; ++r) { const long long* o = (const long long*)hostSlot(r); for (size_t i = 0; i < px; ++i) m[i] = std::min(m[i], o[i]); }
+        if (!hostBarrier()) return false;                           // (everybody has read every slot before anyone reuses its own)
+        ZS_HIP(hipMemcpy(keys64_.ptr(), m.data(), px * 8, hipMemcpyHostToDevice));
+    } else if (world_ > 1) ZS_NCCL(ncclAllReduce(keys64_.ptr(), keys64_.ptr(), px, ncclInt64, ncclMin, c, st));
     out_.create(2 * px);                                            // normals (what the reduce sums), then the points
     normals = Normals(rows, cols, out_.ptr(), (size_t)cols * sizeof(Normal));
     points = Cloud(rows, cols, out_.ptr() + px, (size_t)cols * sizeof(Point));
     slab.raycastShadeNormals(camera_pose, intr, keys64_, normals);
     // only the normals cross GPUs (4.9 MB at 640 x 480; every summand but one is integer zero): the points follow from the merged keys
-    if (world_ > 1) ZS_NCCL(ncclReduce(out_.ptr(), out_.ptr(), px * 4, ncclInt32, ncclSum, dst, c, st));
+    if (world_ > 1 && backend_ == HOST_STAGED) {
+        ZS_HIP(hipMemcpy(hostSlot(rank_), out_.ptr(), px * 16, hipMemcpyDeviceToHost));
+        if (!hostBarrier()) return false;
+        if (rank_ == dst) {
+            std::vector<int> sum((const int*)hostSlot(0), (const int*)hostSlot(0) + px * 4);
+            for (int r = 1; r < world_; ++r) { const int* o = (const int*)hostSlot(r); for (size_t i = 0; i < px * 4; ++i) sum[i] = (int)((unsigned)sum[i] + (unsigned)o[i]); }
+            ZS_HIP(hipMemcpy(out_.ptr(), sum.data(), px * 16, hipMemcpyHostToDevice));
+        }
+        if (!hostBarrier()) return false;
+    } else if (world_ > 1) ZS_NCCL(ncclReduce(out_.ptr(), out_.ptr(), px * 4, ncclInt32, ncclSum, dst, c, st));
     if (rank_ == dst) slab.raycastPointsOfKeys(camera_pose, intr, keys64_, normals, points);
     return true;
 }
@@ -167,6 +287,7 @@ bool ZSlabComm::raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Int
 bool ZSlabComm::barrier()
 {
     if (!ok_) return false;
+    if (backend_ == HOST_STAGED) { ZS_HIP(hipDeviceSynchronize()); return world_ > 1 ? hostBarrier() : true; }
     if (world_ > 1) ZS_NCCL(ncclAllReduce(token_.ptr(), token_.ptr(), 1, ncclInt32, ncclSum, (ncclComm_t)comm_, (hipStream_t)stream_));
     ZS_HIP(hipDeviceSynchronize());
     return true;

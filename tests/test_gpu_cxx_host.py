@@ -326,6 +326,42 @@ def test_cxx_zslab_rccl_path(tmp_path, with_nodes):
         assert planes.shape[0] == hi - lo and np.array_equal(planes, vol[lo:hi])
 
 
+@pytest.mark.parametrize("world,mode", [(2, "exchange"), (2, "recompute"), (3, "recompute")])
+def test_cxx_zslab_collectives_with_more_than_one_rank(tmp_path, world, mode):
+    """VERDICT r3 #6 iii: the C++ collective SEQUENCE (ZSlabComm: frame-input broadcasts, halo exchange or recompute, march ->
+    all-reduce(MIN) of the keys -> shade -> reduce(SUM) of the normals -> points of the keys) with MORE THAN ONE rank.  RCCL refuses two
+    ranks on one device, so the ranks -- real processes, each with its own slab, all on cuda:0 -- use ZSlabComm's HOST_STAGED backend
+    (DFUSION_ZSLAB_BACKEND=host: every collective staged through a shared-memory segment).  Rank 0's image and every rank's own
+    planes must be the unsharded harness's bytes."""
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=100, k=8)
+    frames = 2
+    sc = Scene(cfg, n_frames=frames)
+    vol, pts, nrm, _, _ = run_harness(tmp_path, cfg, sc, frames, True)
+    build.build_host()
+    fin, fout, idf = str(tmp_path / "in.bin"), str(tmp_path / "zn.bin"), str(tmp_path / "idn")
+    cmd = [build.HOST_ZSLAB_APP, str(cfg.dims[0]), str(cfg.size), str(cfg.cols), str(cfg.rows), str(frames), str(cfg.nodes), str(cfg.k), fin, fout, idf, mode]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK="0", DFUSION_ZSLAB_BACKEND="host",
+                                       DFUSION_ZSLAB_NONCE=str(os.getpid()), DFUSION_ZSLAB_HOST_SLOT_MB="16")) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    import re
+    alive = []
+    for r, p in enumerate(procs):
+        assert p.returncode == 0 and "zslab_frame ok: rank %d of %d" % (r, world) in outs[r], outs[r]
+        alive.append(int(re.search(r"(\d+) alive blocks", outs[r]).group(1)))
+    assert sum(alive) > 0                                    # WarpField::aliveBlocksPerLayer: the measured work profile of the re-balance
+    npx = cfg.rows * cfg.cols
+    raw = np.fromfile(fout, np.uint8)
+    img = raw[:2 * npx * 16].view(np.float32).reshape(2, cfg.rows, cfg.cols, 4)
+    assert np.array_equal(img[0].view(np.uint32), pts.view(np.uint32)) and np.array_equal(img[1].view(np.uint32), nrm.view(np.uint32))
+    assert (~np.isnan(pts)).mean() > 0.2
+    from dynamicfusion_amd import sharded
+    for r in range(world):
+        z0, zn = sharded.slab_range(cfg.dims[2], r, world)
+        planes = (raw[2 * npx * 16:] if r == 0 else np.fromfile(fout + ".r%d" % r, np.uint8)).view(np.uint32).reshape(-1, cfg.dims[1], cfg.dims[0])
+        assert planes.shape[0] == zn and np.array_equal(planes, vol[z0:z0 + zn])
+
+
 def test_cxx_reference_warp_test_suites():
     """The reference's own solver tests (tests/ceres_warp_test.cpp, tests/warp_test.cpp) compiled against the C++ mirror: same
     WarpField calls and inputs, same 1e-3 bound (WarpAndReverseTest: the data term's least-squares optimum, see the source)."""

@@ -154,3 +154,28 @@ def test_bench_force_dist_self_launch_is_one_real_rccl_rank():
     d = _bench(["--gpus", "1", "--config", "256", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], {"DFUSION_BENCH_FORCE_DIST": "1"})
     assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "zslab1" and "oversubscribed" not in d
     assert d["verify_cull"]["cull_bit_identical"] and d["value"] > 0
+
+
+def test_alive_block_profile_of_slabs_adds_up_to_the_unsharded_one():
+    """dfusion_warp_alive_blocks (the measured re-balance's input): per 8-plane layer, the blocks a sweep's verdict pass kept.  With the
+    ball test alone (no block models: a verdict then depends on the block and the frame only) the profiles of two slabs, each counting
+    its OWN layers, add up to the unsharded volume's; and re-cutting the slabs by it moves the boundary towards the thin side."""
+    sc = Scene(MID, n_frames=1)
+    intr = Intr(*MID.intr)
+    Z = MID.dims[2]
+    d = upload_u16(sc.dists[0])
+
+    def profile(slab):
+        v = make_gpu_volume(sc, slab=slab) if slab else make_gpu_volume(sc)
+        wf = make_gpu_warp(sc)
+        v.integrate_warped(d, sc.cam_poses[0], intr, wf, block_model=False)
+        out = torch.zeros(Z // 8, dtype=torch.int64, device="cuda")
+        wf.alive_blocks_per_layer(v, out)
+        return out.cpu().numpy()
+    full = profile(None)
+    halves = profile((0, Z // 2, 0)) + profile((Z // 2, Z // 2, 0))
+    assert full.sum() > 0 and np.array_equal(full, halves)
+    b = sharded.slab_bounds(Z, 2, 8, sharded.layer_weights_to_planes(full, Z))
+    assert b[0] == 0 and b[2] == Z and b[1] % 8 == 0
+    w = sharded.layer_weights_to_planes(full, Z)
+    assert abs(w[:b[1]].sum() - w[b[1]:].sum()) <= abs(w[:Z // 2].sum() - w[Z // 2:].sum()) + 1e-9

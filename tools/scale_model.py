@@ -13,7 +13,9 @@ with xGMI ~153 GB/s per link and direction pair (guide), of which a ring step su
     all_reduce MIN of the int64 keys (2.46 MB): 2 (N - 1) steps, bytes = 2 (N - 1) / N * size
     reduce SUM of the normals to rank 0 (4.92 MB; the points follow from the merged keys): N - 1 steps, bytes = size
 Usage:  python tools/scale_model.py [CONFIG] [balanced|uniform]     (prints a markdown table, writes gpurun_out/scale_model_<cfg>_<kind>.json)
-`balanced` (bench.py's default): slab boundaries from sharded.slab_bounds on frustum_plane_weights; `uniform`: equal plane counts.
+`measured` (bench.py's default, round 4): slab boundaries re-cut from the verdict pass's alive-block counts per 8-plane layer after three
+priming frames on the unsharded volume (what bench.py's ranks all-reduce); `balanced`: from the a-priori frustum_plane_weights;
+`uniform`: equal plane counts.
 """
 import json
 import os
@@ -65,12 +67,23 @@ def main():
     sizes = {"broadcast": px * 2 + cfg.nodes * 32, "all_reduce": px * 8, "reduce": px * 16}        # (the reduce sums the normals only)
     wts = sharded.frustum_plane_weights(cfg.dims, cfg.size, cfg.volume_pose, synth.camera_pose(cfg, 0), cfg.intr, cfg.cols, cfg.rows,
                                         depth_mm=synth.depth_frame(cfg, 0), trunc=max(cfg.trunc_dist, 2.1 * vs_z), margin=0.3)
-    kind = sys.argv[2] if len(sys.argv) > 2 else "balanced"
+    kind = sys.argv[2] if len(sys.argv) > 2 else "measured"
+    if kind == "measured":                                  # the profile bench.py's ranks measure and sum: alive blocks per 8-plane layer
+        v0 = TsdfVolume(cfg.dims); v0.setSize([cfg.size] * 3); v0.setTruncDist(cfg.trunc_dist); v0.setMaxWeight(cfg.max_weight); v0.setPose(cfg.volume_pose)
+        w0 = WarpField(k=cfg.k); w0.init(pos, sigma=sigma, transforms=synth.node_transforms(cfg, 0))
+        for f in range(3):
+            w0.set_transforms(torch.from_numpy(synth.node_transforms(cfg, f)).cuda())
+            v0.integrate_warped(compute_dists(upload_u16(synth.depth_frame(cfg, f)), intr), synth.camera_pose(cfg, f), intr, w0)
+        layers = torch.zeros(Z // 8, dtype=torch.int64, device="cuda")
+        w0.alive_blocks_per_layer(v0, layers)
+        wts = sharded.layer_weights_to_planes(layers.cpu().numpy(), Z)
+        del v0, w0
+        torch.cuda.empty_cache()
     rows = []
     for n in (1, 2, 4, 8):
         worst = {"integrate": 0.0, "march": 0.0, "shade": 0.0, "sum": 0.0}
         per_rank = []
-        bounds = sharded.slab_bounds(Z, n, halo, wts if (kind == "balanced" and n > 1) else None)
+        bounds = sharded.slab_bounds(Z, n, halo, wts if (kind in ("balanced", "measured") and n > 1) else None)
         for r in range(n):
             z0, zn = bounds[r], bounds[r + 1] - bounds[r]
             vol = TsdfVolume(cfg.dims, slab=(z0, zn, halo if n > 1 else 0))
