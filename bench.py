@@ -56,6 +56,9 @@ def parse(argv=None):
                          "inside the frustum and in front of the first frame's surface); `measured` (default): start from `balanced`, then "
                          "re-cut once after the priming frames from the verdict pass's alive-block counts per plane (what the sweep really "
                          "visits), slabs re-allocated; `uniform`: equal plane counts")
+    ap.add_argument("--merge", choices=["rows", "root"], default="rows",
+                    help="N>1: the ray-cast's second collective -- `rows` (default): reduce_scatter of the normals by pixel rows, every rank finishes "
+                         "its band (image stays row-sharded; 1/N of the bytes lands on a rank); `root`: reduce(SUM) to rank 0, which makes the whole image")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (rigid_integrate, extract_cloud, kinfu_frame)")
     ap.add_argument("--no-kinfu", action="store_true", help="skip the kinfu_frame extra (it runs a child process; use under profilers)")
     ap.add_argument("--no-verify-cull", action="store_true",
@@ -201,17 +204,17 @@ def cpu_baseline(cfg, sc_inputs, vol_u32, target_s=10.0, gpu_after=None):
             used = int(O.lib().orc_num_threads())
         return time.time() - t0, used
 
-    def sized_band(mode, budget_s):
+    def sized_band(mode, budget_s, min_planes=4):
         planes, (t, used) = 4, timed_band(4, mode)
         for _ in range(2):                                  # grow the band until it is about budget_s of work (or the whole volume)
-            if t >= 0.5 * budget_s or planes >= Z:
+            if (t >= 0.5 * budget_s and planes >= min_planes) or planes >= Z:
                 break
-            planes = int(min(Z, max(planes + 4, 4 * round(planes * budget_s / max(t, 1e-3) / 4))))
+            planes = int(min(Z, max(planes + 4, min_planes, 4 * round(planes * budget_s / max(t, 1e-3) / 4))))
             t, used = timed_band(planes, mode)
         return planes, t, used
 
     kind = "reference" if have_ref else "port"
-    planes, t_band, cores = sized_band(kind, target_s)
+    planes, t_band, cores = sized_band(kind, target_s, min_planes=64 if Z >= 1024 else 4)      # (1024^3: at least 64 planes through the reference classes)
     t_int = t_band * (Z / planes)
     full = O.make_volume(vol_u32, cfg.dims, vs, trunc, cfg.max_weight)
     cam2vol = synth.affine_mul(synth.affine_inv(pose), cam_pose)
@@ -422,6 +425,12 @@ def main():
     keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device=dev) if dist_on else None
     out2 = torch.empty((2, cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev)
     pts, nrm = out2[0], out2[1]
+    rows_merge = dist_on and args.merge == "rows"
+    if rows_merge:       # the normals buffer the reduce_scatter splits: world * per rows (rows past the image stay zero), + this rank's band
+        per_rows, _ = sharded.row_bands(cfg.rows, world)
+        nrm_pad = torch.zeros((world * per_rows, cfg.cols, 4), dtype=torch.float32, device=dev)
+        nrm_band = torch.empty((per_rows, cfg.cols, 4), dtype=torch.float32, device=dev)
+        pts_band = torch.empty((per_rows, cfg.cols, 4), dtype=torch.float32, device=dev)
     # frame inputs travel as ONE byte bundle (depth image + node transforms): one ncclBroadcast per frame
     n_depth = cfg.rows * cfg.cols * 2
     bundle = torch.empty(n_depth + cfg.nodes * 32, dtype=torch.uint8, device=dev)
@@ -444,7 +453,14 @@ def main():
         if ev is not None: ev[1].record()
         if dist_on and args.halo == "exchange":
             sharded.exchange_halos(vol.data(), vol.z_store0, vol.z_own0, vol.z_own_n, Z, halo, rank, world)
-        if dist_on:
+        if rows_merge:
+            def shade_padded(mk):
+                vol.raycast_shade(cam_poses[f], intr, mk, None, nrm_pad[:cfg.rows])
+                return nrm_pad
+            out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, rank), shade_padded,
+                                          lambda mk, nb, r0, nr: vol.raycast_points_of_keys(cam_poses[f], intr, mk, nb, pts_band[:nr], r0, nr),
+                                          rank, world, collectives=True, merge="rows", band_out=nrm_band)
+        elif dist_on:
             out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, rank),
                                           lambda mk: vol.raycast_shade(cam_poses[f], intr, mk, None, nrm)[1],
                                           lambda mk, n: vol.raycast_points_of_keys(cam_poses[f], intr, mk, n, pts),
@@ -756,6 +772,9 @@ def main():
                        "slab_bounds": slab_bounds, "slabs": args.slabs if dist_on else None,
                        "halo": (("integrated redundantly by every rank, no halo collective" if args.halo == "recompute" else
                                  "exchanged after the integrate (paired isend/irecv of %d planes per side)" % halo) if dist_on else None),
+                       "raycast_merge": (("all_reduce(MIN) of the keys + reduce_scatter(SUM) of the normals by pixel rows: every rank finishes its band "
+                                          "of %d rows, the image stays row-sharded" % sharded.row_bands(cfg.rows, world)[0]) if args.merge == "rows" else
+                                         "all_reduce(MIN) of the keys + reduce(SUM) of the normals to rank 0") if dist_on else None,
                        "frame": "set_transforms + compute_dists + integrate_warped + raycast_points"},
             "kernel_ms": {"integrate_warped": ms_int, "raycast(+merge)": ms_ray, "index_build_once_s": t_index},
             "frame_stats": frame_stats,

@@ -56,7 +56,7 @@ SYMBOLS = [
     "dfusion_bilateral_filter", "dfusion_truncate_depth", "dfusion_depth_pyramid", "dfusion_compute_normals_mask_depth",
     "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
     "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate", "dfusion_release_scratch", "dfusion_raycast_points_of_keys",
-    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_integrate_ex", "dfusion_warp_debug_counters", "dfusion_warp_alive_blocks",
+    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_integrate_ex", "dfusion_warp_debug_counters", "dfusion_warp_alive_blocks", "dfusion_raycast_points_of_keys_rows",
     "dfusion_render_image_points", "dfusion_render_image_depth", "dfusion_render_tangent_colors",
 ]
 
@@ -115,6 +115,7 @@ def load(path, strict=True):
     L.dfusion_raycast_shade.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, vp, C.c_size_t, vp, C.c_size_t,
                                         C.c_int, C.c_int, C.c_float, vp]
     L.dfusion_raycast_points_of_keys.argtypes = [fp, fp, fp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, vp]
+    L.dfusion_raycast_points_of_keys_rows.argtypes = [fp, fp, fp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.dfusion_extract_cloud.argtypes = [DfVolume, C.POINTER(DfSlab), fp, vp, C.c_ulonglong, vp, vp]
     L.dfusion_extract_normals.argtypes = [DfVolume, C.POINTER(DfSlab), fp, fp, vp, C.c_ulonglong, C.c_float, vp, vp]
     L.dfusion_warp_create.argtypes = [C.POINTER(vp)]

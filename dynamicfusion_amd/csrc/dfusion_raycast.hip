@@ -29,6 +29,7 @@ struct DfRayArgs {
     float* pts; size_t ppitch; float* nrm; size_t npitch; uint16_t* depth; size_t dpitch;
     uint32_t* keys;
     int tiles_x, tiles_y;
+    int row0;                     // points-of-keys over a band of pixel rows: image row of the band's first row (0 otherwise)
 };
 
 __device__ __forceinline__ const uint32_t* rc_vox_addr(const DfRayArgs& a, int x, int y, int z)
@@ -304,15 +305,16 @@ __global__ __launch_bounds__(256) void df_raycast_shade_kernel(const DfRayArgs a
 __global__ __launch_bounds__(256) void df_raycast_points_of_keys_kernel(const DfRayArgs a, const unsigned long long* __restrict__ merged_keys)
 {
     int x, y;
-    if (!rc_pixel(a, &x, &y)) return;
-    const unsigned long long k64 = merged_keys[(size_t)y * a.cols + x];
+    if (!rc_pixel(a, &x, &y)) return;                                      // (y: row inside the band; a.rows = rows of the band)
+    const int yi = y + a.row0;                                             // image row: the keys are the whole image's, normals / points the band's
+    const unsigned long long k64 = merged_keys[(size_t)yi * a.cols + x];
     const float qn = qnanf_();
     float4 out_p = make_float4(qn, qn, qn, qn);
     if (k64 != 0x7fffffffffffffffull && ((k64 >> 39) & 1ull)) {
         const float nw = reinterpret_cast<const float4*>((const char*)a.nrm + (size_t)y * a.npitch)[x].w;
         if (nw == nw) {
             f3 org, dir;
-            rc_ray_of_pixel(a, x, y, &org, &dir);
+            rc_ray_of_pixel(a, x, yi, &org, &dir);
             const f3 vertex = rc_vertex(org, dir, __uint_as_float((unsigned int)k64));
             const f3 v = mat3_mul(a.Rinv, sub3(vertex, org));                              // as rc_shade
             out_p = make_float4(v.x, v.y, v.z, 0.f);
@@ -410,7 +412,16 @@ extern "C" int dfusion_raycast_points_of_keys(const float cam2vol[12], const flo
                                               const unsigned long long* merged_keys, const float* normals, size_t npitch, float* points,
                                               size_t ppitch, int cols, int rows, dfStream stream)
 {
-    if (!cam2vol || !Rinv || !reproj || !merged_keys || !normals || !points || cols <= 0 || rows <= 0) return DF_E_INVALID;
+    return dfusion_raycast_points_of_keys_rows(cam2vol, Rinv, reproj, merged_keys, normals, npitch, points, ppitch, cols, rows, 0, rows, stream);
+}
+
+extern "C" int dfusion_raycast_points_of_keys_rows(const float cam2vol[12], const float Rinv[9], const float reproj[4],
+                                                   const unsigned long long* merged_keys, const float* normals, size_t npitch, float* points,
+                                                   size_t ppitch, int cols, int image_rows, int row0, int rows, dfStream stream)
+{
+    if (!cam2vol || !Rinv || !reproj || !merged_keys || !normals || !points || cols <= 0 || image_rows <= 0) return DF_E_INVALID;
+    if (row0 < 0 || rows < 0 || row0 + rows > image_rows) return DF_E_INVALID;
+    if (rows == 0) return DF_OK;
     DfRayArgs a;
     memset(&a, 0, sizeof(a));
     a.aff = df_aff(cam2vol);
@@ -418,6 +429,7 @@ extern "C" int dfusion_raycast_points_of_keys(const float cam2vol[12], const flo
     a.finvx = reproj[0]; a.finvy = reproj[1]; a.cx = reproj[2]; a.cy = reproj[3];
     a.cols = cols; a.rows = rows;
     a.tiles_x = (cols + 15) / 16; a.tiles_y = (rows + 15) / 16;
+    a.row0 = row0;
     a.pts = points; a.ppitch = ppitch; a.nrm = const_cast<float*>(normals); a.npitch = npitch;
     hipLaunchKernelGGL(df_raycast_points_of_keys_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, merged_keys);
     DF_LAUNCH_CHECK();

@@ -39,10 +39,11 @@ int main(int argc, char** argv)
     if (argc < 11) { std::fprintf(stderr, "usage: %s dims size cols rows frames nodes k in.bin out.bin id_file [exchange|recompute] [slab=r/n]\n", argv[0]); return 2; }
     const int dims = std::atoi(argv[1]); const float size = (float)std::atof(argv[2]);
     const int cols = std::atoi(argv[3]), rows = std::atoi(argv[4]), frames = std::atoi(argv[5]), M = std::atoi(argv[6]), k = std::atoi(argv[7]);
-    bool exchange = true; int only_r = -1, only_n = 0;
+    bool exchange = true, row_bands = false; int only_r = -1, only_n = 0;
     std::vector<int> bounds;                                // bounds=0,b1,...,Z : explicit slab boundaries (work-balanced partitions)
     for (int i = 11; i < argc; ++i) {
         if (!std::strcmp(argv[i], "recompute")) exchange = false;
+        else if (!std::strcmp(argv[i], "rows")) row_bands = true;         // the ray-cast's normals reduce-scattered by pixel rows: every rank writes its band
         else if (!std::strncmp(argv[i], "bounds=", 7)) { for (const char* q = argv[i] + 7; *q;) { bounds.push_back(std::atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; } }
         else if (!std::strncmp(argv[i], "slab=", 5)) std::sscanf(argv[i] + 5, "%d/%d", &only_r, &only_n);
     }
@@ -78,7 +79,7 @@ int main(int argc, char** argv)
     const float trunc = std::max(0.04f, 2.1f * vz);
     const int halo = world > 1 ? cuda::ZSlabComm::haloPlanes(trunc, 0.75f, 0.5f, vz) : 0;
     std::string why;
-    if (!cuda::ZSlabComm::partitionOk(dims, world, halo, &why)) { std::fprintf(stderr, "zslab_frame: %s\n", why.c_str()); return 3; }
+    if ((int)bounds.size() != world + 1 && !cuda::ZSlabComm::partitionOk(dims, world, halo, &why)) { std::fprintf(stderr, "zslab_frame: %s\n", why.c_str()); return 3; }
     int z0, zn; cuda::ZSlabComm::slabRange(dims, rank, world, z0, zn);
     if ((int)bounds.size() == world + 1) { z0 = bounds[rank]; zn = bounds[rank + 1] - bounds[rank]; if (zn < 1 || (world > 1 && zn < halo)) { std::fprintf(stderr, "zslab_frame: bad bounds\n"); return 3; } }
     volume.create(Vec3i(dims, dims, dims));
@@ -126,11 +127,22 @@ int main(int argc, char** argv)
             volume.integrate(dists, cam[f], intr);
         }
         if (comm && exchange) comm->exchangeHalos(volume, halo);
-        if (comm) comm->raycast(volume, cam[f], intr, cols, rows, points, normals, 0);
+        if (comm && row_bands) comm->raycastRowBands(volume, cam[f], intr, cols, rows, points, normals);
+        else if (comm) comm->raycast(volume, cam[f], intr, cols, rows, points, normals, 0);
         if (comm && !comm->ok()) { std::fprintf(stderr, "zslab_frame: %s\n", comm->lastError().c_str()); return 4; }
     }
     if (comm) { if (!comm->barrier()) { std::fprintf(stderr, "zslab_frame: %s\n", comm->lastError().c_str()); return 4; } } else cuda::waitAllDefaultStream();
 
+    if (comm && row_bands) {                                // every rank's band of the merged image: <out>.band<rank> = {row0, nrows, points, normals}
+        const std::string name = std::string(argv[9]) + ".band" + std::to_string(rank);
+        if (FILE* out = std::fopen(name.c_str(), "wb")) {
+            const int hdr[2] = {comm->bandRow0(rows), comm->bandRows(rows)};
+            std::vector<float> p((size_t)hdr[1] * cols * 4), n(p.size());
+            if (hdr[1] > 0) { points.download(p.data(), (size_t)cols * 16); normals.download(n.data(), (size_t)cols * 16); }
+            std::fwrite(hdr, 4, 2, out); std::fwrite(p.data(), 4, p.size(), out); std::fwrite(n.data(), 4, n.size(), out);
+            std::fclose(out);
+        }
+    }
     if (comm && rank > 0) {                                 // the other ranks leave their OWN planes beside rank 0's file (tests): <out>.r<rank>
         const std::string name = std::string(argv[9]) + ".r" + std::to_string(rank);
         if (FILE* out = std::fopen(name.c_str(), "wb")) {
@@ -145,7 +157,7 @@ int main(int argc, char** argv)
         FILE* out = std::fopen(argv[9], "wb");
         if (!out) { std::perror("out"); return 2; }
         std::vector<float> p((size_t)rows * cols * 4, 0.f), n(p.size(), 0.f);
-        if (comm) { points.download(p.data(), (size_t)cols * 16); normals.download(n.data(), (size_t)cols * 16); }
+        if (comm && !row_bands) { points.download(p.data(), (size_t)cols * 16); normals.download(n.data(), (size_t)cols * 16); }
         std::fwrite(p.data(), 4, p.size(), out);
         std::fwrite(n.data(), 4, n.size(), out);
         const size_t plane = (size_t)dims * dims;

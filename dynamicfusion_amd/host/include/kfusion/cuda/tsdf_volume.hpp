@@ -67,6 +67,9 @@ public:
     void raycastShadeNormals(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64, Normals& normals) const;
     void raycastPointsOfKeys(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64, const Normals& normals,
                              Cloud& points) const;
+    // the same for the band of pixel rows [row0, row0 + normals.rows()) of a cols x image_rows image (normals / points: the band's views)
+    void raycastPointsOfKeysRows(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64, int image_rows, int row0,
+                                 const Normals& normals, Cloud& points) const;
 
     // ---- fusion
     virtual void integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr);                        // rigid, tsdf_volume.cpp:110-122

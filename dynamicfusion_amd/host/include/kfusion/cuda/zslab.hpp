@@ -18,6 +18,7 @@
 // The same sequence, collective for collective, as dynamicfusion_amd/sharded.py (torch.distributed), which the world-size-2/3 gloo
 // tests and the one-GPU 8-slab emulation exercise; this file is what a C++ host (KinFu) links instead.
 #pragma once
+#include <algorithm>
 #include <string>
 #include <vector>
 #include <kfusion/types.hpp>
@@ -68,6 +69,14 @@ public:
     /// result on rank `dst`.  points / normals become dense cols x rows VIEWS of a buffer this object owns (valid until the next
     /// raycast); on the other ranks they hold that rank's partial image
     bool raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Intr& intr, int cols, int rows, Cloud& points, Normals& normals, int dst = 0);
+    /// The same cast with the second collective as ONE ncclReduceScatter of the normals by PIXEL ROWS (round 4): rank r receives the
+    /// summed normals of its band of rows -- bandRow0(rows), bandRows(rows) -- and makes the band's points itself; points / normals
+    /// become bandRows x cols views of the band.  1 / world of the image lands on a rank and none of them is a hot spot; the image
+    /// stays row-sharded for a row-sharded consumer.
+    bool raycastRowBands(TsdfVolume& slab, const Affine3f& camera_pose, const Intr& intr, int cols, int rows, Cloud& points, Normals& normals);
+    int bandRowsPerRank(int rows) const { return (rows + world_ - 1) / world_; }
+    int bandRow0(int rows) const { return std::min(rows, rank_ * bandRowsPerRank(rows)); }
+    int bandRows(int rows) const { return std::max(0, std::min(rows, (rank_ + 1) * bandRowsPerRank(rows)) - bandRow0(rows)); }
     bool barrier();
 private:
     bool fail(const std::string& what);

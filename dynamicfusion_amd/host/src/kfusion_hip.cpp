@@ -213,6 +213,15 @@ void TsdfVolume::raycastPointsOfKeys(const Affine3f& camera_pose, const Intr& in
                                          points.step(), points.cols(), points.rows(), nullptr));
 }
 
+void TsdfVolume::raycastPointsOfKeysRows(const Affine3f& camera_pose, const Intr& intr, const DeviceArray<unsigned long long>& merged_keys64, int image_rows,
+                                         int row0, const Normals& normals, Cloud& points) const
+{
+    float aff[12], Rinv[9], reproj[4];
+    raycast_args(pose_, camera_pose, intr, aff, Rinv, reproj);
+    KF_DF(dfusion_raycast_points_of_keys_rows(aff, Rinv, reproj, merged_keys64.ptr(), (const float*)normals.ptr(), normals.step(), (float*)points.ptr(),
+                                              points.step(), points.cols(), image_rows, row0, normals.rows(), nullptr));
+}
+
 void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr)   // :110-122
 {
     const Affine3f vol2cam = camera_pose.inv() * pose_;

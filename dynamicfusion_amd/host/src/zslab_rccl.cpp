@@ -284,6 +284,48 @@ bool ZSlabComm::raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Int
     return true;
 }
 
+bool ZSlabComm::raycastRowBands(TsdfVolume& slab, const Affine3f& camera_pose, const Intr& intr, int cols, int rows, Cloud& points, Normals& normals)
+{
+    if (!ok_) return false;
+    ncclComm_t c = (ncclComm_t)comm_; hipStream_t st = (hipStream_t)stream_;
+    const size_t px = (size_t)cols * rows;
+    const int per = bandRowsPerRank(rows), row0 = bandRow0(rows), nrows = bandRows(rows);
+    const size_t band_px = (size_t)per * cols, pad_px = band_px * (size_t)world_;
+    slab.raycastMarch(camera_pose, intr, cols, rows, (unsigned)rank_, keys64_);
+    if (world_ > 1 && backend_ == HOST_STAGED) {
+        if (px * 8 > slot_bytes_ || pad_px * 16 > slot_bytes_) return fail("ZSlabComm(host): image larger than a slot (DFUSION_ZSLAB_HOST_SLOT_MB)");
+        ZS_HIP(hipMemcpy(hostSlot(rank_), keys64_.ptr(), px * 8, hipMemcpyDeviceToHost));
+        if (!hostBarrier()) return false;
+        std::vector<long long> m((const long long*)hostSlot(0), (const long long*)hostSlot(0) + px);
+        for (int r = 1; r < world_; ++r) { const long long* o = (const long long*)hostSlot(r); for (size_t i = 0; i < px; ++i) m[i] = std::min(m[i], o[i]); }
+        if (!hostBarrier()) return false;
+        ZS_HIP(hipMemcpy(keys64_.ptr(), m.data(), px * 8, hipMemcpyHostToDevice));
+    } else if (world_ > 1) ZS_NCCL(ncclAllReduce(keys64_.ptr(), keys64_.ptr(), px, ncclInt64, ncclMin, c, st));
+    // out_: the padded normals every rank shades into (world * per rows; the rows past the image stay zero), this rank's band of
+    // the summed normals, this rank's band of points
+    out_.create(pad_px + 2 * band_px);
+    Normals shaded(rows, cols, out_.ptr(), (size_t)cols * sizeof(Normal));
+    if (pad_px > px) ZS_HIP(hipMemsetAsync(out_.ptr() + px, 0, (pad_px - px) * sizeof(Point), st));
+    slab.raycastShadeNormals(camera_pose, intr, keys64_, shaded);
+    Point* band_n = out_.ptr() + pad_px; Point* band_p = band_n + band_px;
+    if (world_ > 1 && backend_ == HOST_STAGED) {
+        ZS_HIP(hipMemcpy(hostSlot(rank_), out_.ptr(), pad_px * 16, hipMemcpyDeviceToHost));
+        if (!hostBarrier()) return false;
+        std::vector<int> sum(band_px * 4, 0);
+        for (int r = 0; r < world_; ++r) { const int* o = (const int*)hostSlot(r) + (size_t)rank_ * band_px * 4; for (size_t i = 0; i < band_px * 4; ++i) sum[i] = (int)((unsigned)sum[i] + (unsigned)o[i]); }
+        if (!hostBarrier()) return false;
+        ZS_HIP(hipMemcpy(band_n, sum.data(), band_px * 16, hipMemcpyHostToDevice));
+    } else if (world_ > 1) {
+        ZS_NCCL(ncclReduceScatter(out_.ptr(), band_n, band_px * 4, ncclInt32, ncclSum, c, st));
+    } else {
+        ZS_HIP(hipMemcpyAsync(band_n, out_.ptr(), band_px * 16, hipMemcpyDeviceToDevice, st));
+    }
+    normals = Normals(nrows, cols, band_n, (size_t)cols * sizeof(Normal));
+    points = Cloud(nrows, cols, band_p, (size_t)cols * sizeof(Point));
+    if (nrows > 0) slab.raycastPointsOfKeysRows(camera_pose, intr, keys64_, rows, row0, normals, points);
+    return true;
+}
+
 bool ZSlabComm::barrier()
 {
     if (!ok_) return false;

@@ -63,6 +63,26 @@ def coll_reduce(t, dst, op, group=None):
         dist.reduce(t, dst=dst, op=op, group=group)
 
 
+def row_bands(rows, world):
+    """Equal bands of pixel rows for the row-banded merge: rank r finishes rows [r * per, min((r + 1) * per, rows)); the normals buffer
+    that is reduce-scattered has world * per rows (the rows past the image stay zero)."""
+    per = (rows + world - 1) // world
+    return per, [(min(rows, r * per), max(0, min(rows, (r + 1) * per) - min(rows, r * per))) for r in range(world)]
+
+
+def coll_reduce_scatter_rows(full, out, group=None):
+    """out[per, ...] <- rank's band of the elementwise SUM over the ranks of full[world * per, ...] (int32 views).  RCCL: one
+    ncclReduceScatter.  gloo has no reduce-scatter (and host-staged runs go through gloo): all_reduce + slice there -- the same result."""
+    rank = dist.get_rank(group)
+    per = out.shape[0]
+    if dist.get_backend(group) == "nccl" and not _staged(full):
+        dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=group)
+    else:
+        c = full.cpu() if full.is_cuda else full.clone()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(c[rank * per:(rank + 1) * per])
+
+
 NO_EVENT = 0xFFFFFFFF                 # per-slab event key (step << 1 | hit): none
 KEY_NONE = 0x7FFFFFFFFFFFFFFF         # merge key: no event (include/dfusion.h DF_RC_KEY_NONE)
 MAX_RANKS = 128                       # the merge key carries the rank in 7 bits
@@ -248,24 +268,40 @@ def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, 
         r.wait()
 
 
-def raycast_sharded(march_fn, shade_fn, points_fn, rank, world, dst=0, group=None, collectives=None):
+def raycast_sharded(march_fn, shade_fn, points_fn, rank, world, dst=0, group=None, collectives=None, merge="root", band_out=None):
     """Sharded ray-cast (include/dfusion.h: dfusion_raycast_march / _shade / _points_of_keys).
 
     march_fn()                  -> keys64 int64 [rows, cols]: the merge keys of this slab (first event | rank | Ts bits)
-    shade_fn(keys64)            -> normals float32 [rows, cols, 4]; all-zero bits for pixels this slab does not resolve
+    shade_fn(keys64)            -> normals float32 [rows (+ padding), cols, 4]; all-zero bits for pixels this slab does not resolve
     points_fn(keys64, normals)  -> points float32 [rows, cols, 4], called on rank `dst` only, with the summed normals
     Returns (points, normals) of the merged cast on rank `dst`, (None, None) elsewhere.
 
-    TWO collectives per frame: all_reduce(MIN) of the int64 keys (2.4 MB at 640x480) -- which also delivers the winners' Ts -- and
-    reduce(SUM) of the NORMAL bits (4.9 MB; every summand but one is integer zero, so the sum is the owner's value, NaN fill
-    included).  The points cross no link: vertex = origin + direction * Ts from the pixel, and whether a hit stands is in the
-    normal's 4th component (round 2 exchanged vertices, 4.9 MB, and points, another 4.9 MB).  collectives: None = only when
-    world > 1; True = also with one rank (an RCCL dry run of the dtypes and ops)."""
+    merge = "root": TWO collectives per frame: all_reduce(MIN) of the int64 keys (2.4 MB at 640x480) -- which also delivers the
+    winners' Ts -- and reduce(SUM) of the NORMAL bits to rank `dst` (4.9 MB; every summand but one is integer zero, so the sum is the
+    owner's value, NaN fill included).  The points cross no link: vertex = origin + direction * Ts from the pixel, and whether a
+    hit stands is in the normal's 4th component (round 2 exchanged vertices, 4.9 MB, and points, another 4.9 MB).
+    merge = "rows" (round 4): the second collective is a reduce_scatter by PIXEL ROWS instead: rank r receives the summed normals of
+    its band of rows only (4.9 MB / world lands on a rank, none of them a hot spot) and finishes the band itself --
+    points_fn(keys64, normals_band, row0, nrows) -> points of the band; shade_fn must return a buffer of world * per rows (row_bands),
+    band_out an int32-viewable [per, cols, 4] float tensor.  Returns (points_band, normals_band, (row0, nrows)) on EVERY rank: the image
+    stays row-sharded for a row-sharded consumer (DESIGN.md section 5 says what that consumer is).
+    collectives: None = only when world > 1; True = also with one rank (an RCCL dry run of the dtypes and ops)."""
     on = world > 1 if collectives is None else collectives
     keys64 = march_fn()
     if on:
         coll_all_reduce(keys64, dist.ReduceOp.MIN, group=group)
     normals = shade_fn(keys64)
+    if merge == "rows":
+        rows = keys64.shape[0]
+        per, bands = row_bands(rows, world)
+        row0, nrows = bands[rank]
+        if on:
+            assert normals.shape[0] == world * per and band_out is not None and band_out.shape[0] == per
+            coll_reduce_scatter_rows(normals.view(torch.int32), band_out.view(torch.int32), group=group)
+            nb = band_out[:nrows]
+        else:
+            nb = normals[row0:row0 + nrows]
+        return points_fn(keys64, nb, row0, nrows), nb, (row0, nrows)
     if on:
         coll_reduce(normals.view(torch.int32), dst, dist.ReduceOp.SUM, group=group)
         if rank != dst:

@@ -264,12 +264,16 @@ class TsdfVolume:
                                                     _stream()), "dfusion_raycast_shade")
         return points, normals
 
-    def raycast_points_of_keys(self, camera_pose, intr, merged_keys64, normals, points):
-        """Stage 3 of the sharded cast, on the rank that wants the image: points from the merged keys (Ts) and the summed normals."""
+    def raycast_points_of_keys(self, camera_pose, intr, merged_keys64, normals, points, row0=0, nrows=None):
+        """Stage 3 of the sharded cast, on the rank that wants the image: points from the merged keys (Ts) and the summed normals.
+        row0 / nrows: only the band of pixel rows [row0, row0 + nrows) -- `normals` / `points` are then the BAND's tensors
+        ([nrows, cols, 4]), merged_keys64 the whole image's."""
         aff, Rinv = self._raycast_args(camera_pose)
         rows, cols = merged_keys64.shape
-        capi.check(capi.lib().dfusion_raycast_points_of_keys(aff, Rinv, intr.as_reproj(), _ptr(merged_keys64), _ptr(normals), cols * 16,
-                                                             _ptr(points), cols * 16, cols, rows, _stream()), "dfusion_raycast_points_of_keys")
+        nrows = rows - row0 if nrows is None else nrows
+        capi.check(capi.lib().dfusion_raycast_points_of_keys_rows(aff, Rinv, intr.as_reproj(), _ptr(merged_keys64), _ptr(normals), cols * 16,
+                                                                  _ptr(points), cols * 16, cols, rows, int(row0), int(nrows), _stream()),
+                   "dfusion_raycast_points_of_keys_rows")
         return points
 
     # ---- tsdf_volume.cpp:181-218 fetchCloud / fetchNormals (device tensors; count read back like the reference does)

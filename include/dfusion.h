@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 4   /* 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
+#define DFUSION_ABI_VERSION 4   /* 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
@@ -215,6 +215,13 @@ int dfusion_raycast_shade(DfVolume v, const DfSlab *slab, const float cam2vol[12
 int dfusion_raycast_points_of_keys(const float cam2vol[12], const float Rinv[9], const float reproj[4],
                                    const unsigned long long *merged_keys64_dev, const float *normals_dev, size_t normals_pitch,
                                    float *points_dev, size_t points_pitch, int cols, int rows, dfStream stream);
+/* The same for a BAND of pixel rows [row0, row0 + rows) of a cols x image_rows image: merged_keys64_dev is the whole image's (every
+ * rank holds it after the merge), normals_dev / points_dev point at the band's first row.  For the row-banded merge: the normals are
+ * reduce-scattered by pixel rows, every rank finishes its own band, and no rank receives the whole image (ABI 4).              */
+int dfusion_raycast_points_of_keys_rows(const float cam2vol[12], const float Rinv[9], const float reproj[4],
+                                        const unsigned long long *merged_keys64_dev, const float *normals_dev, size_t normals_pitch,
+                                        float *points_dev, size_t points_pitch, int cols, int image_rows, int row0, int rows,
+                                        dfStream stream);
 
 /* ---- surface extraction -------------------------------------------------------
  * device::extractCloud (internal.hpp:142; tsdf_volume.cu:511-710,798-817): zero crossings between every voxel and its

@@ -39,7 +39,7 @@ def _unsharded(sc):
     return vol, p, n
 
 
-def _worker(rank, world, port, recompute_halo, balanced=False):
+def _worker(rank, world, port, recompute_halo, balanced=False, merge="root"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -95,11 +95,31 @@ def _worker(rank, world, port, recompute_halo, balanced=False):
                 return torch.from_numpy(O.raycast_points_of_keys(synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.reproj, ts, merged, normals.numpy(),
                                                                  CFG.cols, CFG.rows))
 
-            pts, nrm = sharded.raycast_sharded(march, shade, points, rank, world)
+            if merge == "rows":
+                per, bands = sharded.row_bands(CFG.rows, world)
+
+                def shade_padded(k64):
+                    pad = torch.zeros((world * per, CFG.cols, 4), dtype=torch.float32)
+                    pad[:CFG.rows] = shade(k64)
+                    return pad
+
+                def points_band(k64, nb, r0, nr):                               # (the oracle takes whole images: embed the band, cut it out again)
+                    full = torch.zeros((CFG.rows, CFG.cols, 4), dtype=torch.float32)
+                    full[r0:r0 + nr] = nb
+                    return points(k64, full)[r0:r0 + nr]
+
+                pts, nrm, (r0, nr) = sharded.raycast_sharded(march, shade_padded, points_band, rank, world, merge="rows",
+                                                             band_out=torch.empty((per, CFG.cols, 4), dtype=torch.float32))
+            else:
+                pts, nrm = sharded.raycast_sharded(march, shade, points, rank, world)
         # every rank checks its slab (own + halo planes) against the unsharded volume; rank 0 checks the merged cast
         full, fp, fn = _unsharded(sc)
         assert np.array_equal(vol, full[lo:hi]), "rank %d: slab (incl. halos) differs from the unsharded volume" % rank
-        if rank == 0:
+        if merge == "rows":                                                     # every rank holds its band of the merged image
+            assert r0 == bands[rank][0] and nr == bands[rank][1] and sum(b[1] for b in bands) == CFG.rows
+            assert np.array_equal(pts.numpy().view(np.uint32), fp[r0:r0 + nr].view(np.uint32)), "rank %d: band of the merged vertices differs" % rank
+            assert np.array_equal(nrm.numpy().view(np.uint32), fn[r0:r0 + nr].view(np.uint32)), "rank %d: band of the merged normals differs" % rank
+        elif rank == 0:
             gp, gn = pts.numpy(), nrm.numpy()
             assert np.array_equal(gp.view(np.uint32), fp.view(np.uint32)), "merged ray-cast vertices differ"
             assert np.array_equal(gn.view(np.uint32), fn.view(np.uint32)), "merged ray-cast normals differ"
@@ -116,6 +136,24 @@ def test_zslab_pipeline_over_gloo(world, recompute_halo):
     """halo-recompute: every rank integrates its halo planes itself (the integrate is a pure function of the broadcast inputs, so
     the planes come out bit-identical with the neighbour's) -- no halo collective at all; what bench.py does."""
     mp.spawn(_worker, args=(world, _free_port(), recompute_halo), nprocs=world, join=True)
+
+
+def test_row_bands_cover_the_image_once():
+    for rows, world in ((480, 8), (480, 7), (96, 5), (5, 8), (1, 1)):
+        per, bands = sharded.row_bands(rows, world)
+        assert per * world >= rows and len(bands) == world
+        covered = []
+        for r0, n in bands:
+            assert 0 <= n <= per
+            covered += list(range(r0, r0 + n))
+        assert covered == list(range(rows))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_zslab_pipeline_row_banded_merge(world):
+    """The ray-cast's second collective as a reduce_scatter by pixel rows (bench.py's default, round 4): every rank ends with its band of
+    the merged image, bit-identical with the unsharded cast's rows."""
+    mp.spawn(_worker, args=(world, _free_port(), True, False, "rows"), nprocs=world, join=True)
 
 
 def test_zslab_pipeline_over_gloo_with_work_balanced_slabs():
