@@ -13,6 +13,7 @@
 // moves a voxel 2 m from its axis by 9 mm, the benchmark's warp amplitude moves the cull radii by up to 2 cm per frame: 5 cm is two to
 // five frames of lead, and widens the set that is ever built by a few per cent.
 #define DF_WARP_PREFETCH_MARGIN_M 0.05f
+#define DF_WARP_PREFETCH_CAP 1024u    // look-ahead table builds per frame at most: about one round of the resident build grid (50-80 us beside the sweep)
 
 #define DF_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (int)e__; } while (0)
 #define DF_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

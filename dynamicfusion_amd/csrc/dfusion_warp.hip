@@ -1109,6 +1109,8 @@ struct DfWarpedArgs {
     // verdict pass: look-ahead margin (metres; 0 = none).  Blocks that are not alive this frame but would be with every radius
     // widened by this much are "near": their tables / blend models are made off the critical path (dfusion_warp_blocks.h)
     float pf_margin;
+    unsigned pf_cap;               // look-ahead builds per frame at most (the list's counter may run past it)
+    unsigned work_cap;             // list-driven build: entries of the list at most (0 = all)
 };
 // A tile is ZERO-WEIGHT for a frame when tile_wmax * max_j |rot_j| < 2^-76: every component of every voxel's blend sum
 // sum_i w_i rot_i is then below 2^-75 in magnitude (the 2x margin covers the rounding of the sums), its square below 2^-150
@@ -1406,7 +1408,7 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
     __shared__ float s_key[DF_CAND_CHUNK];
     if (BUILD && a.work) {                                                 // on-demand build: the bricks of a work list, over a resident grid
         __shared__ uint32_t s_item;                                        // (drawn one at a time: a brick costs 20-80 us, unevenly)
-        const uint32_t n = *a.work_cnt;
+        const uint32_t n = a.work_cap ? min(*a.work_cnt, a.work_cap) : *a.work_cnt;
         for (uint32_t round = 0;; ++round) {
             uint32_t i = blockIdx.x;                                       // the first brick without an atomic (an empty list costs nothing)
             if (round) {
@@ -1685,6 +1687,9 @@ __device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<4>& r)
 // cnt[w] entries; the order inside a bin is whatever the atomics make it -- items are independent, the result does not depend on
 // it): the sweep takes the bins from w = 64 down, i.e. the items most work first, without a sorting pass.  `cnt_next` is the counter
 // set of the NEXT launch (the two sets alternate), zeroed here: nothing reads it any more once this kernel runs.
+#ifndef DF_SWEEP_BALANCE
+#define DF_SWEEP_BALANCE 1       // the pipelined sweep deals a workgroup's alive cells out evenly over its waves (0: one patch per wave)
+#endif
 #define DF_PLAN_BINS 65
 #define DF_PLAN_WG 1024          // 16 items per workgroup: neighbours in the volume, mostly of equal work, so their bin slots are taken with one atomic
 __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpedArgs a, int tiles_x, int tiles_y, unsigned n_items,
@@ -1762,6 +1767,55 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
 #ifdef DF_TRACE_WG
     unsigned n_layers = 0;
 #endif
+#if DF_SWEEP_BALANCE
+    // ---- the workgroup's work, dealt out evenly (round 4).  A workgroup takes SPW strip items = 4 SPW patches x <= 16 layers of alive
+    // (patch, layer) cells.  With one patch per wave the workgroup lasted as long as its fullest patch while the other waves' slots sat
+    // idle: a per-wave timeline showed the waves busy for 83 % of the time their workgroups held the slots.  Now the alive cells of all
+    // the workgroup's patches form ONE sequence (item, patch, layer, half-layer of 4 planes) and wave w takes the w-th of WGT / 64
+    // equal shares of it: a run of layers of one patch, or the tail of one patch and the head of the next -- SEGMENTS, each walked by
+    // the pipelined loop below as before.  Which voxel is updated by which wave changes; what is computed for it does not.
+    constexpr unsigned NW = WGT / 64;
+    unsigned items_s[SPW]; unsigned long long masks_s[SPW];
+    unsigned total2 = 0;
+#pragma unroll
+    for (unsigned s_ = 0; s_ < SPW; ++s_) {
+        const unsigned sidx = blockIdx.x * SPW + s_;
+        items_s[s_] = 0u; masks_s[s_] = 0ull;
+        if (sidx < n_alive) {
+            const int j = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(sidx < bin_end)) - 1;      // its bin: the first running total above sidx
+            const unsigned r = sidx - ((unsigned)__builtin_amdgcn_readlane((int)bin_end, j) - (unsigned)__builtin_amdgcn_readlane((int)bin_cnt, j));
+            items_s[s_] = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_PLAN_BINS - 1 - j) * a.plan_items + r]);
+            const unsigned long long m = a.plan_mask[items_s[s_]];
+            masks_s[s_] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32)) << 32) |
+                          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m);
+            total2 += 2u * (unsigned)__popcll(masks_s[s_]);
+        }
+    }
+    const unsigned c0 = total2 * (unsigned)wave / NW, c1 = total2 * ((unsigned)wave + 1u) / NW;      // this wave's half-layer cells [c0, c1)
+    unsigned pre = 0;
+#pragma unroll 1
+    for (unsigned q = 0; q < SPW * 4u; ++q) {
+    unsigned item = items_s[0]; unsigned long long m_item = masks_s[0];
+#pragma unroll
+    for (unsigned s_ = 1; s_ < SPW; ++s_) if ((q >> 2) == s_) { item = items_s[s_]; m_item = masks_s[s_]; }
+    const unsigned a16 = (unsigned)(m_item >> (16u * (q & 3u))) & 0xffffu;
+    const unsigned n2 = 2u * (unsigned)__popc(a16);
+    const unsigned seg_lo = max(c0, pre), seg_hi = min(c1, pre + n2);
+    const unsigned pre0 = pre;
+    pre += n2;
+    if (seg_lo >= seg_hi) continue;                                        // none of this patch's cells are this wave's
+    const unsigned lo = seg_lo - pre0, hi = seg_hi - pre0;                 // half-layer cells [lo, hi) of the patch's 2 popc(a16)
+    unsigned alive = a16;
+    for (unsigned i = 0; i < (lo >> 1); ++i) alive &= alive - 1u;          // drop the layers before the segment ...
+    {
+        unsigned keep = ((hi - 1u) >> 1) - (lo >> 1) + 1u, rest = alive, seg = 0u;
+        for (unsigned i = 0; i < keep; ++i) { const unsigned low = rest & (0u - rest); seg |= low; rest ^= low; }
+        alive = seg;                                                       // ... and those after it
+    }
+    int first_l = __ffs(alive) - 1, last_l = 31 - __clz(alive);
+    const int z_first_off = (int)(lo & 1u) * (DF_ROW_TZ / 2), z_last_off = ((int)((hi - 1u) & 1u) + 1) * (DF_ROW_TZ / 2);
+    const int wave_patch = (int)(q & 3u);
+#else
     const unsigned sidx = blockIdx.x * SPW + (unsigned)(wave >> 2);           // this wave's plan entry: 4 waves per strip item
     unsigned alive = 0, item = 0;
     if (sidx < n_alive) {
@@ -1772,19 +1826,29 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
         const unsigned mp = (wave & 2) ? (unsigned)(m >> 32) : (unsigned)m;
         alive = (unsigned)__builtin_amdgcn_readfirstlane((int)((wave & 1) ? mp >> 16 : mp & 0xffffu));
     }
+    const int wave_patch = wave & 3;
+#endif
     // item -> tile column, half, layer block; the wave's 8 x 8 patch is number wv of the 32 x 16 footprint (4 across, 2 down): a compact
     // footprint, so that the voxels of a wave fall on the same side of the frustum and of the observed surface more often
     const unsigned tcol = item >> 1;
     const int tx = (int)(tcol % (unsigned)tiles_x), ty = (int)((tcol / (unsigned)tiles_x) % (unsigned)a.plan_tiles_y);
-    const int wv = (int)(item & 1u) * 4 + (wave & 3);
+    const int wv = (int)(item & 1u) * 4 + wave_patch;
     const int x = tx * DF_ROW_TX + (wv & 3) * 8 + (ln & 7);
     const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (ln >> 3);
     const bool in_xy = x < a.X && y < a.Y;
     const int xc = min(x, a.X - 1), yc = min(y, a.Y - 1);                 // clamped: out-of-volume lanes read valid entries, write nothing
     const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
     const int lt0 = a.bz0 + (int)(tcol / ((unsigned)tiles_x * (unsigned)a.plan_tiles_y)) * a.zt;     // first tile layer of the item
+#if DF_SWEEP_BALANCE
+    // the segment's first / last layer start / end at a half-layer boundary; a layer the slab's own range cuts down to nothing is dropped
+    auto layer_zb = [&](int l) { const int z = max((lt0 + l) * DF_ROW_TZ, a.z_own0); return l == first_l ? max(z, (lt0 + l) * DF_ROW_TZ + z_first_off) : z; };
+    auto layer_ze = [&](int l) { const int z = min((lt0 + l + 1) * DF_ROW_TZ, own1); return l == last_l ? min(z, (lt0 + l) * DF_ROW_TZ + z_last_off) : z; };
+    if (alive && layer_zb(first_l) >= layer_ze(first_l)) { alive &= alive - 1u; first_l = alive ? __ffs(alive) - 1 : 0; }
+    if (alive && layer_zb(last_l) >= layer_ze(last_l)) { alive &= ~(1u << last_l); last_l = alive ? 31 - __clz(alive) : 0; }
+#else
     auto layer_zb = [&](int l) { return max((lt0 + l) * DF_ROW_TZ, a.z_own0); };
     auto layer_ze = [&](int l) { return min((lt0 + l + 1) * DF_ROW_TZ, own1); };
+#endif
     if (alive) {
         // batch sequence: U planes per batch inside a layer, then the first batch of the next alive layer; l < 0 = none
         auto advance = [&](int l, int z0, int* nl, int* nz0) {
@@ -1919,6 +1983,11 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
     }
 #ifdef DF_TRACE_WG
     n_layers += __popc(alive);
+#endif
+#if DF_SWEEP_BALANCE
+    }                                                                       // (the next segment of this wave)
+#endif
+#ifdef DF_TRACE_WG
     {
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -2035,6 +2104,7 @@ static int df_build_listed(DfWarpField* wf, const uint32_t* cnt, hipStream_t st,
 {
     DfWarpedArgs b = df_table_args(wf);
     b.work = wf->blk_work + (size_t)list * wf->blk_cap; b.work_cnt = cnt + (list ? 3 : 0); b.work_cursor = const_cast<uint32_t*>(cnt) + (list ? 4 : 2);
+    b.work_cap = list ? DF_WARP_PREFETCH_CAP : 0u;
     const DfWarpView W = df_view(wf);
     static unsigned grid[9] = {0};
     DF_DISPATCH_K(wf->tab_k, {
@@ -2098,7 +2168,10 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
     const bool quiet = !ahead && !(flags & (DF_WARP_NO_PREFETCH | DF_WARP_BLOCK_MODEL_NOW));      // a frame at rest: optional work waits for the next probe
     const int want_models_policy = want_models;
     const int want_models_now = quiet ? 0 : want_models_policy;
-    a.pf_margin = ahead && !wf->tab_complete ? DF_WARP_PREFETCH_MARGIN_M : 0.f;
+    // (not on the very first sweep over new tables: the urgent build of the whole alive set is the frame then, and a node set that
+    // changes every frame never pays for look-ahead work)
+    a.pf_margin = ahead && !wf->tab_complete && wf->tab_sweeps >= 1 ? DF_WARP_PREFETCH_MARGIN_M : 0.f;
+    a.pf_cap = DF_WARP_PREFETCH_CAP;
     uint32_t* cnt = wf->blk_cnt + 8 * wf->blk_phase;
     uint32_t* cnt_next = wf->blk_cnt + 8 * (wf->blk_phase ^ 1);
     uint32_t* list_urgent = wf->blk_work, *list_ahead = wf->blk_work + wf->blk_cap, *list_model = wf->blk_work + 2 * wf->blk_cap;

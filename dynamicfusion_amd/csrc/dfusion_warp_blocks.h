@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
         need_build = keep && build_on_demand && st == 0u;
         need_ahead = !keep && near && build_on_demand && st == 0u;
         need_model = (keep || near) && want_models && (st == 1u || (need_build && want_models > 1));
-        if (need_build || need_ahead) blk_state[blk] = 1;
+        if (need_build) blk_state[blk] = 1;                                // (look-ahead blocks: only those that get a slot below)
     }
     // one counter bump per wave and list
     const unsigned long long mb = __builtin_amdgcn_ballot_w64(need_build), ma = __builtin_amdgcn_ballot_w64(need_ahead), mm = __builtin_amdgcn_ballot_w64(need_model);
@@ -352,10 +352,14 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
         if (need_build) build_list[base + (unsigned)__popcll(mb & below)] = code;
     }
     if (ma) {
+        // at most a.pf_cap look-ahead builds per frame (the pass that makes them takes min(count, cap)): the shell around a NEW alive
+        // set is thousands of blocks, and built all at once the side stream would still be busy when the next frame has to wait for
+        // it.  A block that gets no slot stays unbuilt and is listed again next frame.
         unsigned base = 0;
         if ((threadIdx.x & 63) == 0) base = atomicAdd(&cnt[3], (unsigned)__popcll(ma));
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        if (need_ahead) ahead_list[base + (unsigned)__popcll(ma & below)] = code;
+        const unsigned slot = base + (unsigned)__popcll(ma & below);
+        if (need_ahead && slot < a.pf_cap) { ahead_list[slot] = code; blk_state[blk] = 1; }
     }
     if (mm) {
         unsigned base = 0;

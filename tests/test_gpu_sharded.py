@@ -56,6 +56,13 @@ def run_sharded(sc, world, frames, k=None, recompute_halo=False):
     vols[0].raycast_points_of_keys(sc.cam_poses[f], intr, merged, acc[1].view(torch.float32), p3)
     n_only = torch.empty_like(p3)
     vols[-1].raycast_shade(sc.cam_poses[f], intr, merged, None, n_only)          # (points_dev = NULL is accepted)
+    # the row-banded merge (round 4): a rank that holds only ITS band of the summed normals makes exactly its band of the points
+    per, bands = sharded.row_bands(cfg.rows, world)
+    for r0, nr in bands:
+        if nr:
+            pb = torch.empty((nr, cfg.cols, 4), dtype=torch.float32, device="cuda")
+            vols[0].raycast_points_of_keys(sc.cam_poses[f], intr, merged, acc[1][r0:r0 + nr].view(torch.float32).contiguous(), pb, r0, nr)
+            assert torch.equal(pb.view(torch.int32), acc[0][r0:r0 + nr])
     torch.cuda.synchronize()
     assert torch.equal(p3.view(torch.int32), acc[0])
     return vols, acc[0], acc[1], best

@@ -45,6 +45,6 @@ rm -rf gpurun_out/prof_nc
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_nc -o trace -- python $R/tools/nodes_changed.py 512 3 > $R/gpurun_out/${T}_nodes_changed.txt 2>&1)
 cp $(find gpurun_out/prof_nc -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_nodes_changed_kernel_stats.csv; grep "set_nodes" gpurun_out/${T}_nodes_changed.txt
 echo "== python bench.py --gpus 8 on ONE GPU: the launcher + the N = 8 code path (oversubscribed: gloo, host-staged collectives; not a timing)"
-(timeout 900 python bench.py --gpus 8 --steps 3 --warmup 1 --config 512 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-2500) > gpurun_out/${T}_bench_n8_one_gpu_smoke.txt; cut -c1-300 gpurun_out/${T}_bench_n8_one_gpu_smoke.txt
+(timeout 900 python bench.py --gpus 8 --steps 3 --warmup 1 --config 512 --no-extras --no-cpu-baseline 2>/dev/null | tail -1) > gpurun_out/${T}_bench_n8_one_gpu_smoke.txt; cut -c1-300 gpurun_out/${T}_bench_n8_one_gpu_smoke.txt
 echo "== hipMallocAsync repro"
 hipcc --offload-arch=gfx950 -O2 tools/async_scratch_repro.hip -o build/async_scratch_repro 2>/dev/null; timeout 300 build/async_scratch_repro 2000 > gpurun_out/${T}_async_scratch_repro.txt 2>&1; tail -1 gpurun_out/${T}_async_scratch_repro.txt
