@@ -270,3 +270,36 @@ def test_rigid_scratch_is_kept_per_stream_and_can_be_released():
     for o in outs[1:]:
         assert np.array_equal(outs[0], o)
     capi.check(capi.lib().dfusion_release_scratch())
+
+
+def test_rigid_scratch_cache_is_bounded_and_release_keeps_the_current_device():
+    """a host that makes a stream per frame must not accumulate one ~84 MB scratch per stream (the cache holds 8 (device,
+    stream) pairs, least recently used evicted), cached handles of DESTROYED streams must not be touched by the release, and the release
+    must leave the caller's current device as it was.  Twelve short-lived streams, the same volume from each."""
+    from dynamicfusion_amd import capi
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=0, k=4)
+    intr = Intr(*cfg.intr)
+    d = compute_dists(upload_u16(synth.depth_frame(cfg, 0)), intr)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    ref = None
+    for i in range(12):
+        s = torch.cuda.Stream()
+        v = TsdfVolume(cfg.dims); v.setSize([cfg.size] * 3); v.setTruncDist(cfg.trunc_dist); v.setMaxWeight(cfg.max_weight); v.setPose(cfg.volume_pose); v.clear()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            v.integrate(d, synth.camera_pose(cfg, 0), intr)
+        s.synchronize()
+        out = v.download()
+        ref = out if ref is None else ref
+        assert np.array_equal(out, ref)
+        del s, v                                             # the stream handle the cache remembers may now be gone
+    dev = torch.cuda.current_device()
+    capi.check(capi.lib().dfusion_release_scratch())
+    assert torch.cuda.current_device() == dev
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)              # nothing of the twelve scratches is left behind
+    v = TsdfVolume(cfg.dims); v.setSize([cfg.size] * 3); v.setTruncDist(cfg.trunc_dist); v.setMaxWeight(cfg.max_weight); v.setPose(cfg.volume_pose); v.clear()
+    v.integrate(d, synth.camera_pose(cfg, 0), intr)
+    assert np.array_equal(v.download(), ref)
+    capi.check(capi.lib().dfusion_release_scratch())
