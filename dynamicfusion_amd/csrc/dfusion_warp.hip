@@ -1813,7 +1813,7 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
         alive = seg;                                                       // ... and those after it
     }
     int first_l = __ffs(alive) - 1, last_l = 31 - __clz(alive);
-    const int z_first_off = (int)(lo & 1u) * (DF_ROW_TZ / 2), z_last_off = ((int)((hi - 1u) & 1u) + 1) * (DF_ROW_TZ / 2);
+    int z_first_off = (int)(lo & 1u) * (DF_ROW_TZ / 2), z_last_off = ((int)((hi - 1u) & 1u) + 1) * (DF_ROW_TZ / 2);
     const int wave_patch = (int)(q & 3u);
 #else
     const unsigned sidx = blockIdx.x * SPW + (unsigned)(wave >> 2);           // this wave's plan entry: 4 waves per strip item
@@ -1843,8 +1843,8 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
     // the segment's first / last layer start / end at a half-layer boundary; a layer the slab's own range cuts down to nothing is dropped
     auto layer_zb = [&](int l) { const int z = max((lt0 + l) * DF_ROW_TZ, a.z_own0); return l == first_l ? max(z, (lt0 + l) * DF_ROW_TZ + z_first_off) : z; };
     auto layer_ze = [&](int l) { const int z = min((lt0 + l + 1) * DF_ROW_TZ, own1); return l == last_l ? min(z, (lt0 + l) * DF_ROW_TZ + z_last_off) : z; };
-    if (alive && layer_zb(first_l) >= layer_ze(first_l)) { alive &= alive - 1u; first_l = alive ? __ffs(alive) - 1 : 0; }
-    if (alive && layer_zb(last_l) >= layer_ze(last_l)) { alive &= ~(1u << last_l); last_l = alive ? 31 - __clz(alive) : 0; }
+    if (alive && layer_zb(first_l) >= layer_ze(first_l)) { alive &= alive - 1u; first_l = alive ? __ffs(alive) - 1 : 0; z_first_off = 0; }   // (the next layer, if any, is taken whole)
+    if (alive && layer_zb(last_l) >= layer_ze(last_l)) { alive &= ~(1u << last_l); last_l = alive ? 31 - __clz(alive) : 0; z_last_off = DF_ROW_TZ; }
 #else
     auto layer_zb = [&](int l) { return max((lt0 + l) * DF_ROW_TZ, a.z_own0); };
     auto layer_ze = [&](int l) { return min((lt0 + l + 1) * DF_ROW_TZ, own1); };

@@ -186,3 +186,27 @@ def test_alive_block_profile_of_slabs_adds_up_to_the_unsharded_one():
     assert b[0] == 0 and b[2] == Z and b[1] % 8 == 0
     w = sharded.layer_weights_to_planes(full, Z)
     assert abs(w[:b[1]].sum() - w[b[1]:].sum()) <= abs(w[:Z // 2].sum() - w[Z // 2:].sum()) + 1e-9
+
+
+@pytest.mark.parametrize("cuts", [(0, 12, 37, 64), (0, 4, 60, 64), (0, 29, 35, 64)], ids=["12-37", "4-60", "29-35"])
+def test_slabs_that_cut_through_layers_equal_the_unsharded_sweep(cuts):
+    """Slab boundaries that are NOT multiples of 8 planes (the C-ABI takes any DfSlab): the pipelined sweep deals a workgroup's work out
+    in half-layer cells (round 4), so an own range that ends inside a layer, or inside its first half, clips the first / last cell of some
+    wave's segment -- every plane must still be swept exactly once, with and without the cull."""
+    sc = Scene(SMALL, n_frames=2)
+    intr = Intr(*SMALL.intr)
+    full = make_gpu_volume(sc)
+    wf = make_gpu_warp(sc)
+    for f in range(2):
+        wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+        full.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, wf)
+    for kw in (dict(), dict(cull=False)):
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            v = make_gpu_volume(sc, slab=(a, b - a, 0))
+            w2 = make_gpu_warp(sc)
+            n = torch.zeros(1, dtype=torch.int64, device="cuda")
+            for f in range(2):
+                w2.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+                v.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, w2, n_updated=n, **kw)
+            assert torch.equal(v.data(), full.data()[a:b]), (a, b, kw)
+            assert int(n.item()) == int(((v.data() >> 16) & 0xffff).sum().item())       # every update counted once (weights start at 0, 2 frames)
