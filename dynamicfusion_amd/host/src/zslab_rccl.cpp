@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <new>
 #include <thread>
 #include <vector>
 #include <fcntl.h>
