@@ -474,6 +474,9 @@ __device__ __forceinline__ bool ex_cross(uint32_t a, uint32_t b)
 //                    +z plane by 16-byte loads (L2 / Infinity Cache hits), 12 crossing tests per lane, __ballot /
 //                    popcount-prefix compaction into an LDS buffer flushed with ONE global atomicAdd per ~1000 points;
 //                    other workgroups are still streaming meanwhile, which hides the refine latency.
+#ifndef DF_EX_GRIDSTRIDE
+#define DF_EX_GRIDSTRIDE 0
+#endif
 #define DF_EX_CAP 1024          // points buffered per workgroup (16 KiB); a round that cannot fit goes straight to global
 
 template <int U>      // 16-byte loads in flight per lane
@@ -491,8 +494,12 @@ __global__ __launch_bounds__(256) void df_extract_kernel(const DfExtractArgs a, 
     const uint32_t* base = a.vol + (size_t)(a.z_own0 - a.z_store0) * plane;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    {   // ---- phase 1
-        const uint4* base4 = reinterpret_cast<const uint4*>(base);
+    {   // ---- phase 1: a workgroup streams CONTIGUOUS runs of 256 U lane-items (16 KiB at U = 4), U non-temporal 16-byte loads in flight
+        // per lane -- the form in which a plain copy reaches the part's rate (tools/copy_probe.hip: 5.7-6.3 TB/s against 4.4-5.6 for a
+        // grid-stride loop whose loads are a whole grid apart; round 3 scanned that way, 3.3 TB/s).  DF_EX_GRIDSTRIDE=1 restores it for A/B.
+        typedef unsigned int df_ex_u4 __attribute__((ext_vector_type(4)));
+        const df_ex_u4* base4 = reinterpret_cast<const df_ex_u4*>(base);
+#if DF_EX_GRIDSTRIDE
         const size_t stride = (size_t)gridDim.x * 256;
         const size_t first = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63);
         for (size_t w0 = first; w0 < n4; w0 += stride * U) {
@@ -500,7 +507,8 @@ __global__ __launch_bounds__(256) void df_extract_kernel(const DfExtractArgs a, 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const size_t i = w0 + u * stride + lane;
-                own[u] = i < n4 ? base4[i] : zero4;
+                const df_ex_u4 v = i < n4 ? base4[i] : df_ex_u4{0u, 0u, 0u, 0u};
+                own[u] = make_uint4(v.x, v.y, v.z, v.w);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -508,6 +516,23 @@ __global__ __launch_bounds__(256) void df_extract_kernel(const DfExtractArgs a, 
                 if (__any(ownv) && lane == 0) s_list[atomicAdd(&s_n, 1u)] = (unsigned int)((w0 + u * stride) >> 6);
             }
         }
+#else
+        const size_t chunk = (size_t)256 * U;
+        for (size_t c0 = (size_t)blockIdx.x * chunk; c0 < n4; c0 += (size_t)gridDim.x * chunk) {
+            uint4 own[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t i = c0 + (size_t)u * 256 + threadIdx.x;
+                const df_ex_u4 v = i < n4 ? __builtin_nontemporal_load(base4 + i) : df_ex_u4{0u, 0u, 0u, 0u};
+                own[u] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ownv = ex_valid(own[u].x) | ex_valid(own[u].y) | ex_valid(own[u].z) | ex_valid(own[u].w);
+                if (__any(ownv) && lane == 0) s_list[atomicAdd(&s_n, 1u)] = (unsigned int)((c0 + (size_t)u * 256 + (size_t)wave * 64) >> 6);
+            }
+        }
+#endif
     }
     __syncthreads();
 
