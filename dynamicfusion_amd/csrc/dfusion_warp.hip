@@ -2181,6 +2181,15 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
                        cnt, cnt_next);
     a.blk_cnt = cnt; a.host_report = (uint32_t*)wf->host_report; a.sweep_no = (uint32_t)wf->tab_sweeps;
     DF_LAUNCH_CHECK();
+#ifdef DF_TRACE_VERDICT
+    if (getenv("DF_TRACE_VERDICT_FILE")) {
+        DF_HIP(hipStreamSynchronize(st));
+        static unsigned long long h[8192 * 4];
+        DF_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_df_vtrace), sizeof(h)));
+        FILE* f = fopen(getenv("DF_TRACE_VERDICT_FILE"), "wb");
+        if (f) { fwrite(h, 8, 8192 * 4, f); fclose(f); }
+    }
+#endif
     wf->blk_phase ^= 1;
     // (every frame: running this pass only every 4th frame saved its 4.6 us launch and cost 3 % more swept voxels, 18 us, on a moving camera)
     auto launch_models = [&](hipStream_t s2) -> int {

@@ -285,6 +285,12 @@ __device__ __forceinline__ bool df_block_box_dead(const DfWarpedArgs& a, const f
 //          only serves from the next frame on).  With a.pf_margin == 0 list 1 stays empty and everything runs on the launch stream.
 // Builds are packed brick coordinates, models block indices.  Counter set `cnt`: [0] urgent builds, [1] models, [2] the urgent build
 // pass's cursor, [3] look-ahead builds, [4] their pass's cursor; this pass zeroes the other set, `cnt_next`.
+#ifdef DF_TRACE_VERDICT          // per-wave timeline of the verdict pass (tools/trace_verdict.py): start, after the ball test, after the box test, end
+__device__ unsigned long long g_df_vtrace[8192 * 4];
+#define DF_VT(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 8192) g_df_vtrace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define DF_VT(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArgs a, const float4* __restrict__ rot, const float4* __restrict__ node_t,
                                                                int nbx, int nby, int nbz, uint8_t* __restrict__ blk_state,
                                                                const float* __restrict__ blk_wmax, const float* __restrict__ brick_d1, int vbx, int vby, int zero_skip, int use_models, int want_models,
@@ -296,6 +302,7 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
 {
     const size_t nblk = (size_t)nbx * nby * nbz;
     const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
+    DF_VT(0);
     if (blockIdx.x == 0 && threadIdx.x < 8) cnt_next[threadIdx.x] = 0u;
     bool keep = false, near = false, need_build = false, need_ahead = false, need_model = false;
     int bx = 0, by = 0, bz = 0;
@@ -331,10 +338,12 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
                 } else keep = !df_tile_culled(a, c, wk);
             }
         }
+        DF_VT(1);
         if (keep && st == 2u && use_models) {
             const unsigned n = bm_cnt[blk];
             if (n != DF_BM_NONE && a.cull[1] <= 1.0f) keep = !df_block_box_dead(a, rot, node_t, nbx, nby, nblk, blk, n, bm_idx, bm_lam, bm_w);
         }
+        DF_VT(2);
         alive[blk] = keep ? 1 : 0;
         need_build = keep && build_on_demand && st == 0u;
         need_ahead = !keep && near && build_on_demand && st == 0u;
@@ -367,6 +376,7 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         if (need_model) model_list[base + (unsigned)__popcll(mm & below)] = (unsigned)blk;
     }
+    DF_VT(3);
 }
 
 // ---- every block whose tables are not built yet, onto the build list (completing on-demand tables for a sweep that has no verdicts)
