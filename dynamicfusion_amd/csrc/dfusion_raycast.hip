@@ -12,11 +12,15 @@
 //   * The zero-crossing march only RECORDS the event (step index, kind); the expensive refinement
 //     (2 + 6 trilinear interpolations = 64 gathers) runs after the loop, when the wave has
 //     reconverged, instead of stalling 63 marching lanes inside it.
+//   * The march is issue-bound, not memory-bound (4 steps' gathers are in flight together): its addresses are made in 32 bits with
+//     full-rate instructions (rc_march_addr) and the event search runs only for windows that hold a negative sample (rc_march).
 //   * Z-slab sharding: every GPU marches the same global step lattice t_k = tmin + k*time_step (the
 //     float accumulations `tcurr += time_step`, `next += vstep` are replayed identically) but only
 //     evaluates the steps whose `curr` sample lies in a plane it owns; the per-pixel event key
 //     (k<<1 | hit) is min-merged across GPUs by the host layer.
 #include "dfusion_internal.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 struct DfRayArgs {
     const uint32_t* vol; int X, Y, Z;
@@ -30,6 +34,7 @@ struct DfRayArgs {
     uint32_t* keys;
     int tiles_x, tiles_y;
     int row0;                     // points-of-keys over a band of pixel rows: image row of the band's first row (0 otherwise)
+    int addr32;                   // the march's 32-bit voxel index applies (rc_march_addr)
 };
 
 __device__ __forceinline__ const uint32_t* rc_vox_addr(const DfRayArgs& a, int x, int y, int z)
@@ -38,6 +43,26 @@ __device__ __forceinline__ const uint32_t* rc_vox_addr(const DfRayArgs& a, int x
     y = min(max(y, 0), a.Y - 1);
     int zl = min(max(z - a.z_store0, 0), a.z_store_n - 1);
     return a.vol + ((size_t)x + (size_t)y * a.X + (size_t)zl * a.X * a.Y);
+}
+// The march's form of the same address: it is most of the march's instructions (one per step and ray), so the clamps are one
+// v_med3_i32 each and the voxel index is made in 32 bits with 24-bit multiplies (full rate; v_mul_lo_u32 and the 64-bit
+// multiply-adds of the generic form are quarter rate).  Valid while z_store_n * Y <= 2^24, X < 2^24 and the slab holds <= 2^30
+// voxels (df_raycast_setup decides; larger slabs take the generic form).
+__device__ __forceinline__ int rc_med3(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+template <bool ADDR32>
+__device__ __forceinline__ const uint32_t* rc_march_addr(const DfRayArgs& a, int x, int y, int z)
+{
+    if (!ADDR32) return rc_vox_addr(a, x, y, z);
+    const unsigned xi = (unsigned)rc_med3(x, 0, a.X - 1), yi = (unsigned)rc_med3(y, 0, a.Y - 1), zi = (unsigned)rc_med3(z - a.z_store0, 0, a.z_store_n - 1);
+    unsigned row, idx;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(zi), "s"(a.Y), "v"(yi));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(idx) : "v"(row), "s"(a.X), "v"(xi));
+    return reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.vol) + (idx << 2));      // byte offset < 2^32
 }
 __device__ __forceinline__ float rc_vox(const DfRayArgs& a, int x, int y, int z)
 {   // device.hpp:17-18 ; clamped to the stored range (the reference reads unchecked, tsdf_volume.cu:262-270)
@@ -90,7 +115,7 @@ struct DfRayHit { uint32_t key; bool hit; float t_hit; f3 p_curr, p_next, org, d
 #define DF_RC_WINDOW 4
 #endif
 // :353-404 minus the refinement: first event on a step this slab owns.
-template <bool SLAB>
+template <bool SLAB, bool ADDR32>
 __device__ __forceinline__ DfRayHit rc_march(const DfRayArgs& a, int x, int y)
 {
     DfRayHit h;
@@ -121,7 +146,7 @@ __device__ __forceinline__ DfRayHit rc_march(const DfRayArgs& a, int x, int y)
     f3 next = add3(org, scale3(dir, tmin));
     // fetch_tsdf, :262-270 (__float2int_rn == rint, round-half-even)
     int zn = (int)rintf(next.z * a.vsiz);
-    float tsdf_next = rc_vox(a, (int)rintf(next.x * a.vsix), (int)rintf(next.y * a.vsiy), zn);   // :373
+    float tsdf_next = h2f_bits(*rc_march_addr<ADDR32>(a, (int)rintf(next.x * a.vsix), (int)rintf(next.y * a.vsiy), zn));   // :373
     // The march (:374-385) is one dependent nearest-voxel gather per step -- 50 to 170 L2 round trips one after the other, which is
     // most of the kernel's duration.  Sample positions do not depend on sample values, so the gathers of DF_RC_WINDOW consecutive
     // steps are issued together (clamped addresses: valid even past the last step, nothing branches around a load) and the events
@@ -141,7 +166,7 @@ __device__ __forceinline__ DfRayHit rc_march(const DfRayArgs& a, int x, int y)
                 pn[j] = add3(pc, vstep);
                 znn[j] = (int)rintf(pn[j].z * a.vsiz);
                 ownc[j] = zc >= a.z_own0 && zc < a.z_own1;
-                addr[j] = rc_vox_addr(a, (int)rintf(pn[j].x * a.vsix), (int)rintf(pn[j].y * a.vsiy), znn[j]);   // clamped: always a valid address
+                addr[j] = rc_march_addr<ADDR32>(a, (int)rintf(pn[j].x * a.vsix), (int)rintf(pn[j].y * a.vsiy), znn[j]);   // clamped: always a valid address
                 pc = pn[j]; zc = znn[j]; t += a.time_step;
             }
             tcurr = t;
@@ -162,8 +187,15 @@ __device__ __forceinline__ DfRayHit rc_march(const DfRayArgs& a, int x, int y)
 #pragma unroll
             for (int j = 0; j < DF_RC_WINDOW; ++j) tv[j] = 0.f;                        // (never looked at)
         }
+        // An event needs a NEGATIVE sample (:381 curr < 0, :384 next < 0).  A window with none -- free space, most of the march -- has
+        // no event, and a ray that ends inside it leaves the loop through `tcurr < tmax` above (tcurr is already past the window):
+        // the step-by-step search below, ~60 vector and ~180 scalar instructions of nested branches, is skipped.
+        bool any_neg = tsdf_next < 0.f;
+#pragma unroll
+        for (int j = 0; j < DF_RC_WINDOW; ++j) any_neg = any_neg || tv[j] < 0.f;
         float tsdf_curr = tsdf_next;
         f3 curr = next;
+        if (any_neg) {
 #pragma unroll
         for (int j = 0; j < DF_RC_WINDOW; ++j) {
             if (!finished) {
@@ -177,6 +209,7 @@ __device__ __forceinline__ DfRayHit rc_march(const DfRayArgs& a, int x, int y)
                 }
             }
             tsdf_curr = tv[j]; curr = pn[j];
+        }
         }
         next = pn[DF_RC_WINDOW - 1]; zn = znn[DF_RC_WINDOW - 1]; tsdf_next = tv[DF_RC_WINDOW - 1];
         k += DF_RC_WINDOW;
@@ -234,13 +267,21 @@ __device__ __forceinline__ bool rc_pixel(const DfRayArgs& a, int* px, int* py)
     return *px < a.cols && *py < a.rows;
 }
 
-template <int MODE /* 0 = Points (tsdf_volume.cu:340-405), 1 = Depth (:272-338) */>
+#ifdef DF_TRACE_RAYCAST           // per-wave timeline of the fused cast (tools/trace_raycast.py): start, march done, end; steps marched
+__device__ unsigned long long g_df_rtrace[8192 * 4];
+#define DF_RT(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 8192) g_df_rtrace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (i)] = (v); } while (0)
+#else
+#define DF_RT(i, v) do { } while (0)
+#endif
+template <int MODE /* 0 = Points (tsdf_volume.cu:340-405), 1 = Depth (:272-338) */, bool ADDR32>
 __global__ __launch_bounds__(256) void df_raycast_kernel(const DfRayArgs a)
 {
     int x, y;
+    DF_RT(0, wall_clock64());
     if (!rc_pixel(a, &x, &y)) return;
     const float qn = qnanf_();
-    const DfRayHit h = rc_march<false>(a, x, y);                                       // (launched on whole volumes; a slab's keys come from the march kernel)
+    const DfRayHit h = rc_march<false, ADDR32>(a, x, y);                                       // (launched on whole volumes; a slab's keys come from the march kernel)
+    DF_RT(1, wall_clock64());
     float4 out_p = make_float4(qn, qn, qn, qn), out_n = make_float4(qn, qn, qn, qn);   // :351
     uint16_t out_d = 0;                                                               // :283
     if (h.hit) rc_shade(a, rc_locate(a, h), &out_p, &out_n, &out_d);                   // refinement after the loop: wave reconverged
@@ -248,6 +289,7 @@ __global__ __launch_bounds__(256) void df_raycast_kernel(const DfRayArgs a)
     if (MODE == 0) *reinterpret_cast<float4*>((char*)a.pts + (size_t)y * a.ppitch + 16 * (size_t)x) = out_p;
     else *reinterpret_cast<uint16_t*>((char*)a.depth + (size_t)y * a.dpitch + 2 * (size_t)x) = out_d;
     if (a.keys) a.keys[(size_t)y * a.cols + x] = h.key;
+    DF_RT(2, wall_clock64());
 }
 
 // ---- sharded cast, stage 1: first event on owned steps, and for a hit its refined ray parameter Ts (:389).
@@ -255,11 +297,12 @@ __global__ __launch_bounds__(256) void df_raycast_kernel(const DfRayArgs a)
 // (ncclMin on int64; the top bit stays 0) picks the first event along the ray, names its owner AND delivers Ts -- the vertex is
 // org + dir * Ts, which every rank recomputes from the pixel exactly as the unsharded cast does (:390), so no vertex image has to
 // cross GPUs.  No event at all: 0x7fffffffffffffff, larger than every event.
+template <bool ADDR32>
 __global__ __launch_bounds__(256) void df_raycast_march_kernel(const DfRayArgs a, unsigned long long* __restrict__ keys64, unsigned int rank_tag)
 {
     int x, y;
     if (!rc_pixel(a, &x, &y)) return;
-    const DfRayHit h = rc_march<true>(a, x, y);
+    const DfRayHit h = rc_march<true, ADDR32>(a, x, y);
     unsigned long long k64 = 0x7fffffffffffffffull;
     if (h.key != 0xffffffffu) {
         const float ts = h.hit ? rc_locate_ts(a, h) : 0.f;
@@ -331,6 +374,9 @@ static int df_raycast_setup(DfRayArgs& a, const DfVolume& v, const DfSlab* slab,
     if (!df_slab_valid(v, s)) return DF_E_INVALID;
     a.vol = (const uint32_t*)v.data; a.X = v.dims[0]; a.Y = v.dims[1]; a.Z = v.dims[2];
     a.z_store0 = s.z_store0; a.z_store_n = s.z_store_n; a.z_own0 = s.z_own0; a.z_own1 = s.z_own0 + s.z_own_n;
+    a.row0 = 0;
+    a.addr32 = (unsigned long long)s.z_store_n * (unsigned long long)a.Y <= (1ull << 24) && a.X < (1 << 24) &&
+               (unsigned long long)s.z_store_n * (unsigned long long)a.Y * (unsigned long long)a.X <= (1ull << 30);
     a.vsx = v.voxel_size[0]; a.vsy = v.voxel_size[1]; a.vsz = v.voxel_size[2];
     a.sizex = a.vsx * (float)a.X; a.sizey = a.vsy * (float)a.Y; a.sizez = a.vsz * (float)a.Z;      // tsdf_volume.cu:464
     a.time_step = v.trunc_dist * step_factor;                                                      // :465
@@ -354,8 +400,18 @@ extern "C" int dfusion_raycast_points(DfVolume v, const DfSlab* slab, const floa
     int rc = df_raycast_setup(a, v, slab, cam2vol, Rinv, reproj, cols, rows, step_factor, delta_factor);
     if (rc) return rc;
     a.pts = points; a.ppitch = ppitch; a.nrm = normals; a.npitch = npitch; a.keys = keys;
-    hipLaunchKernelGGL(df_raycast_kernel<0>, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.addr32) hipLaunchKernelGGL((df_raycast_kernel<0, true>), dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((df_raycast_kernel<0, false>), dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a);
     DF_LAUNCH_CHECK();
+#ifdef DF_TRACE_RAYCAST
+    if (getenv("DF_TRACE_RAYCAST_FILE")) {
+        DF_HIP(hipStreamSynchronize((hipStream_t)stream));
+        static unsigned long long h[8192 * 4];
+        DF_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_df_rtrace), sizeof(h)));
+        FILE* f = fopen(getenv("DF_TRACE_RAYCAST_FILE"), "wb");
+        if (f) { fwrite(h, 8, 8192 * 4, f); fclose(f); }
+    }
+#endif
     return DF_OK;
 }
 
@@ -368,7 +424,8 @@ extern "C" int dfusion_raycast_depth(DfVolume v, const DfSlab* slab, const float
     int rc = df_raycast_setup(a, v, slab, cam2vol, Rinv, reproj, cols, rows, step_factor, delta_factor);
     if (rc) return rc;
     a.depth = depth; a.dpitch = dpitch; a.nrm = normals; a.npitch = npitch;
-    hipLaunchKernelGGL(df_raycast_kernel<1>, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.addr32) hipLaunchKernelGGL((df_raycast_kernel<1, true>), dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((df_raycast_kernel<1, false>), dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }
@@ -388,7 +445,8 @@ extern "C" int dfusion_raycast_march(DfVolume v, const DfSlab* slab, const float
         const double diag = sqrt((double)a.sizex * a.sizex + (double)a.sizey * a.sizey + (double)a.sizez * a.sizez);
         if (!(a.time_step > 0.f) || !(diag / (double)a.time_step < 8388608.0 - 4.0)) return DF_E_INVALID;
     }
-    hipLaunchKernelGGL(df_raycast_march_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, keys, rank_tag);
+    if (a.addr32) hipLaunchKernelGGL(df_raycast_march_kernel<true>, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, keys, rank_tag);
+    else hipLaunchKernelGGL(df_raycast_march_kernel<false>, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, (hipStream_t)stream, a, keys, rank_tag);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }

@@ -37,6 +37,8 @@ python tools/build_variant.py trace --only dfusion_volume.hip,dfusion_warp.hip -
 (timeout 300 python tools/trace_sweep.py 512 rigid 2>&1 | grep -v amdgpu.ids) > gpurun_out/${T}_trace_rigid_512.txt; head -1 gpurun_out/${T}_trace_rigid_512.txt
 python tools/build_variant.py vtrace --only dfusion_warp.hip -DDF_TRACE_VERDICT=1 > /dev/null
 (timeout 300 python tools/trace_verdict.py 512 2>&1 | grep -v amdgpu.ids) > gpurun_out/${T}_trace_verdict_512.txt; head -2 gpurun_out/${T}_trace_verdict_512.txt
+python tools/build_variant.py rtrace --only dfusion_raycast.hip -DDF_TRACE_RAYCAST=1 > /dev/null
+(timeout 300 python tools/trace_raycast.py 512 2>&1 | grep -v amdgpu.ids) > gpurun_out/${T}_trace_raycast_512.txt; head -3 gpurun_out/${T}_trace_raycast_512.txt
 echo "== predicted Z-slab scaling (measured per-slab kernels + collective model)"
 for kind in measured balanced uniform; do
   (timeout 600 python tools/scale_model.py 512 $kind 2>&1 | grep -v amdgpu.ids) | tee gpurun_out/${T}_scale_model_512_$kind.txt | head -7
