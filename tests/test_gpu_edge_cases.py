@@ -303,3 +303,59 @@ def test_rigid_scratch_cache_is_bounded_and_release_keeps_the_current_device():
     v.integrate(d, synth.camera_pose(cfg, 0), intr)
     assert np.array_equal(v.download(), ref)
     capi.check(capi.lib().dfusion_release_scratch())
+
+
+def test_march_addressing_generic_form_equals_the_32_bit_one_on_a_tall_volume():
+    """The march makes its voxel addresses in 32 bits where the stored planes allow it (z_store_n * Y <= 2^24 and <= 2^30 voxels:
+    dfusion_raycast.hip rc_march_addr) and in the generic 64-bit form elsewhere.  A 4 x 4096 x 8192 volume (512 MiB) is past the
+    first limit as a whole and inside it as four Z-slabs: the unsharded cast (generic form) and the slab casts merged the way the
+    collectives merge them (32-bit form) must agree bit for bit."""
+    from dynamicfusion_amd import sharded
+    dims = (4, 4096, 8192)
+    X, Y, Z = dims
+    cols, rows = 160, 120
+    intr = Intr(142.6, 142.6, 80.0, 60.0)
+
+    def mkvol(slab=None):
+        v = TsdfVolume(dims, slab=slab)
+        v.setSize([0.2, 2.0, 2.0]); v.setTruncDist(0.04); v.setMaxWeight(64)
+        pose = np.eye(4, dtype=np.float32); pose[:3, 3] = [-0.1, -1.0, 0.5]
+        v.setPose(pose)
+        return v
+    full = mkvol()
+    # a surface whose depth varies with y: +1 (weight 1) in front of plane Z/2 + 8 * (y % 64), -1 behind it
+    POS, NEG = (1 << 16) | 0x3c00, (1 << 16) | 0xbc00
+    zz = torch.arange(Z, device="cuda", dtype=torch.int32)[:, None, None]
+    yy = torch.arange(Y, device="cuda", dtype=torch.int32)[None, :, None]
+    data = full.data()
+    data.copy_(torch.where(zz >= Z // 2 + 8 * (yy % 64), torch.tensor(NEG, dtype=torch.int32, device="cuda"),
+                           torch.tensor(POS, dtype=torch.int32, device="cuda")).expand(Z, Y, X))
+    cam = np.eye(4, dtype=np.float32)
+    p0 = torch.empty((rows, cols, 4), dtype=torch.float32, device="cuda"); n0 = torch.empty_like(p0)
+    k0 = torch.empty((rows, cols), dtype=torch.int32, device="cuda")
+    full.raycast(cam, intr, p0, n0, keys=k0)
+    hits = int(((k0.view(torch.int32) != -1) & ((k0 & 1) == 1)).sum())
+    assert hits > 500, hits                                   # (the rays that stay inside the 0.2 m wide volume up to the surface)
+    world = 4
+    halo = sharded.halo_planes(full.getTruncDist(), full.getRaycastStepFactor(), full.getGradientDeltaFactor(), float(full.getVoxelSize()[2]))
+    slabs, k64s = [], []
+    for r in range(world):
+        z0, zn = sharded.slab_range(Z, r, world)
+        v = mkvol(slab=(z0, zn, halo))
+        assert (v.z_store_n * Y) <= (1 << 24) < Z * Y        # 32-bit form here, generic form on the whole volume
+        v.data().copy_(data[v.z_store0:v.z_store0 + v.z_store_n])
+        k64 = torch.empty((rows, cols), dtype=torch.int64, device="cuda")
+        v.raycast_march(cam, intr, k64, rank=r)
+        slabs.append(v); k64s.append(k64)
+    merged = torch.stack(k64s).min(0).values.contiguous()
+    ev = torch.where(merged == sharded.KEY_NONE, torch.full_like(merged, 0xFFFFFFFF), (merged >> 39) & 0xFFFFFF).to(torch.int32)
+    assert torch.equal(ev, k0), "first events differ"
+    acc = torch.zeros((rows, cols, 4), dtype=torch.int32, device="cuda")
+    for v in slabs:
+        n = torch.empty((rows, cols, 4), dtype=torch.float32, device="cuda")
+        v.raycast_shade(cam, intr, merged, None, n)
+        acc += n.view(torch.int32)
+    p1 = torch.empty_like(p0)
+    slabs[0].raycast_points_of_keys(cam, intr, merged, acc.view(torch.float32), p1)
+    assert torch.equal(acc, n0.view(torch.int32)), "normals differ"
+    assert torch.equal(p1.view(torch.int32), p0.view(torch.int32)), "points differ"
