@@ -818,7 +818,7 @@ def main():
             out["raycast"] = {"kernel": "df_raycast_kernel<0>", "ms": ms_ray, "algorithmic_bytes": rcb,
                               "steps": out["cpu_baseline"].pop("raycast_steps"), "hits": out["cpu_baseline"].pop("raycast_hits"),
                               "achieved_GBps": rcb / (ms_ray * 1e-3) / 1e9,
-                              "note": "gather-latency bound (one dependent 4-byte fetch per march step); reported, no roofline target (SURVEY 8d)"}
+                              "note": "issue-bound while every wave marches (19 VALU instructions + one 4-byte gather per step, 4 steps in flight), gather latency in its tail; reported, no roofline target (SURVEY 8d)"}
             try:
                 rw = reference_warp_baseline(cfg, pts, pos, sigma, dq_fr, wf)
                 if rw:
