@@ -303,6 +303,43 @@ def test_raycast_points_matches_oracle(cfg):
     assert np.abs(gn[m] - rn[m]).max() <= 1e-3
 
 
+def test_raycast_from_random_cameras_matches_oracle():
+    """Cameras the benchmark never takes: inside the volume, behind it, rolled, looking along an edge or past the volume altogether --
+    rays that never enter (tmin >= tmax), enter at t = 0, leave after a step or two, or cross the whole diagonal.  First events,
+    points and normals bit for bit (the march's event search only runs for windows with a negative sample, and its voxel addresses
+    are clamped: both have to hold for every one of these rays)."""
+    cfg = SMALL
+    sc = Scene(cfg, n_frames=2, with_nodes=False)
+    vol, ref = _filled(sc)
+    intr = Intr(*cfg.intr)
+    rng = np.random.RandomState(11)
+    centre = (sc.pose @ np.array([cfg.size / 2] * 3 + [1.0], np.float32))[:3]
+    n_hits = 0
+    for i in range(16):
+        axis = rng.randn(3); axis /= np.linalg.norm(axis)
+        ang = rng.uniform(0.0, [0.3, 1.2, 3.1][i % 3])
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        cam = np.eye(4, dtype=np.float32)
+        cam[:3, :3] = R.astype(np.float32)
+        # the eye: in front of the volume looking at its centre, or somewhere inside it, or off to a side
+        back = R @ np.array([0.0, 0.0, -1.0])
+        eye = centre + back * rng.uniform(0.0, 1.6) * cfg.size + (rng.randn(3) * 0.15 * cfg.size if i % 4 == 3 else 0.0)
+        cam[:3, 3] = eye.astype(np.float32)
+        cam2vol = synth.affine_mul(synth.affine_inv(sc.pose), cam)
+        rinv = np.linalg.inv(cam2vol[:3, :3].astype(np.float64)).astype(np.float32)
+        pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
+        keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int32, device="cuda")
+        vol.raycast(cam, intr, pts, nrm, keys=keys)
+        rp, rn, rk, stats = O.raycast_points(sc.ovol(ref), synth.aff12(cam2vol), rinv, sc.reproj, cfg.cols, cfg.rows,
+                                             cfg.raycast_step_factor, cfg.gradient_delta_factor, want_keys=True)
+        assert np.array_equal(keys.cpu().numpy().view(np.uint32), rk), "camera %d: first events differ" % i
+        assert np.array_equal(pts.cpu().numpy().view(np.uint32), rp.view(np.uint32)), "camera %d: points differ" % i
+        assert np.array_equal(nrm.cpu().numpy().view(np.uint32), rn.view(np.uint32)), "camera %d: normals differ" % i
+        n_hits += int(stats[1])
+    assert n_hits > 16 * 0.05 * cfg.cols * cfg.rows          # (the cameras do see the surface)
+
+
 def test_raycast_depth_matches_oracle():
     sc = Scene(SMALL, n_frames=2, with_nodes=False)
     vol, ref = _filled(sc)
