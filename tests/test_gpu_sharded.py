@@ -210,3 +210,52 @@ def test_slabs_that_cut_through_layers_equal_the_unsharded_sweep(cuts):
                 v.integrate_warped(upload_u16(sc.dists[f]), sc.cam_poses[f], intr, w2, n_updated=n, **kw)
             assert torch.equal(v.data(), full.data()[a:b]), (a, b, kw)
             assert int(n.item()) == int(((v.data() >> 16) & 0xffff).sum().item())       # every update counted once (weights start at 0, 2 frames)
+
+
+def test_slab_march_from_random_cameras_equals_the_unsharded_cast():
+    """Z-slab march + key merge + owner's shade from cameras that look across the slabs instead of along them (rolled, from the side,
+    from inside the volume): the first events, normals and points of the unsharded cast, bit for bit."""
+    from test_gpu_parity import _filled
+    cfg = SMALL
+    sc = Scene(cfg, n_frames=2, with_nodes=False)
+    full, ref = _filled(sc)
+    intr = Intr(*cfg.intr)
+    Z = cfg.dims[2]
+    world = 3
+    halo = sharded.halo_planes(sc.trunc, cfg.raycast_step_factor, cfg.gradient_delta_factor, float(sc.vs[2]))
+    slabs = []
+    for r in range(world):
+        z0, zn = sharded.slab_range(Z, r, world)
+        v = make_gpu_volume(sc, slab=(z0, zn, halo))
+        v.data().copy_(full.data()[v.z_store0:v.z_store0 + v.z_store_n])
+        slabs.append(v)
+    rng = np.random.RandomState(5)
+    centre = (sc.pose @ np.array([cfg.size / 2] * 3 + [1.0], np.float32))[:3]
+    for i in range(8):
+        axis = rng.randn(3); axis /= np.linalg.norm(axis)
+        ang = rng.uniform(0.2, 3.0)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        cam = np.eye(4, dtype=np.float32)
+        cam[:3, :3] = R.astype(np.float32)
+        cam[:3, 3] = (centre + (R @ np.array([0.0, 0.0, -1.0])) * rng.uniform(0.0, 1.5) * cfg.size).astype(np.float32)
+        p0 = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); n0 = torch.empty_like(p0)
+        k0 = torch.empty((cfg.rows, cfg.cols), dtype=torch.int32, device="cuda")
+        full.raycast(cam, intr, p0, n0, keys=k0)
+        k64s = []
+        for r, v in enumerate(slabs):
+            k64 = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device="cuda")
+            v.raycast_march(cam, intr, k64, rank=r)
+            k64s.append(k64)
+        merged = torch.stack(k64s).min(0).values.contiguous()
+        ev = torch.where(merged == sharded.KEY_NONE, torch.full_like(merged, 0xFFFFFFFF), (merged >> 39) & 0xFFFFFF).to(torch.int32)
+        assert torch.equal(ev, k0), "camera %d: first events differ" % i
+        acc = torch.zeros((cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
+        for v in slabs:
+            n = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda")
+            v.raycast_shade(cam, intr, merged, None, n)
+            acc += n.view(torch.int32)
+        p1 = torch.empty_like(p0)
+        slabs[0].raycast_points_of_keys(cam, intr, merged, acc.view(torch.float32), p1)
+        assert torch.equal(acc, n0.view(torch.int32)), "camera %d: normals differ" % i
+        assert torch.equal(p1.view(torch.int32), p0.view(torch.int32)), "camera %d: points differ" % i
