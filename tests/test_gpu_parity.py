@@ -8,6 +8,8 @@ Bar (BASELINE.json north_star / SURVEY.md 8d):
   * k-NN: identical index lists and distances; exact distance ties in nanoflann's tree order (tests/test_gpu_ties.py)
   * ray-cast: identical hit mask, vertex |delta| <= 1e-4 m, normal |delta| <= 1e-3
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -315,7 +317,7 @@ def test_raycast_from_random_cameras_matches_oracle():
     rng = np.random.RandomState(11)
     centre = (sc.pose @ np.array([cfg.size / 2] * 3 + [1.0], np.float32))[:3]
     n_hits = 0
-    for i in range(16):
+    for i in range(16 + int(os.environ.get("DFUSION_FUZZ_EXTRA", "0"))):          # (profiles/r04_cull_fuzz_extended.txt: one run with 2000 more)
         axis = rng.randn(3); axis /= np.linalg.norm(axis)
         ang = rng.uniform(0.0, [0.3, 1.2, 3.1][i % 3])
         K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
@@ -338,6 +340,7 @@ def test_raycast_from_random_cameras_matches_oracle():
         assert np.array_equal(nrm.cpu().numpy().view(np.uint32), rn.view(np.uint32)), "camera %d: normals differ" % i
         n_hits += int(stats[1])
     assert n_hits > 16 * 0.05 * cfg.cols * cfg.rows          # (the cameras do see the surface)
+    print("random cameras:", i + 1, "hits", n_hits)
 
 
 def test_raycast_depth_matches_oracle():
