@@ -37,6 +37,7 @@ DF_WARP_NO_DEPTH_PYRAMID = 64
 DF_WARP_NO_BLOCK_MODEL = 128
 DF_WARP_BLOCK_MODEL_NOW = 256
 DF_WARP_NO_PREFETCH = 512
+DF_WARP_STEADY_PREFETCH = 1024
 DF_RIGID_NO_DEPTH_CULL = 1
 DF_RIGID_NO_SHORT_FORMS = 2
 DF_RIGID_KEEP_ALL = 4

@@ -147,6 +147,34 @@ __device__ __forceinline__ quat q_normalize_near_unit(quat a, float s)
     const double e = (double)(n - 1.f);
     return q_scale_f64(__builtin_fma(e, e, 1.0 - e), a);
 }
+// ---- the FIRST normalisation, (float)((1.0 / (double)n) * (double)c) per component (quaternion.hpp:220-228), as an f32 division (round 5).
+// Claim: for f32 c, n with a NORMAL (or zero) f32 quotient, the reference's double-rounded value equals the correctly rounded f32
+// quotient RN32(c / n).  Proof.  inv = RN64(1 / n) = (1 / n)(1 + e1), p = RN64(inv * c) = (c / n)(1 + e), |e| < 2^-52 + 2^-105.  Write
+// c = C 2^a, n = N 2^b with integers 2^23 <= C, N < 2^24 and let the quotient Q = c / n lie in [2^k, 2^(k+1)).  An f32 rounding boundary
+// there is M 2^(k-24) with M odd, 2^24 < M < 2^25, and |Q - M 2^(k-24)| = 2^(k-24) |C 2^s - M N| / N with s = a - b - k + 24 in {24, 25}.
+// C 2^s = M N is impossible (M odd => 2^s | N, but N < 2^24), so the integer |C 2^s - M N| >= 1 and Q is more than 2^(k-48) away from
+// every boundary -- while |p - Q| < 2^(k+1) 2^-52 (1 + 2^-53) < 2^(k-50).  p and Q therefore round to the same f32, never on a tie.
+// (A zero component gives +-0 * inv = +-0 either way; the blend sums are never -0: they start at +0 and a sum is -0 only if both
+// terms are.)  RN32(c / n) itself is hipcc's division sequence minus v_div_scale / v_div_fixup (df_div_shared), which act on
+// numerators below 2^-103, on denominators and quotients near the ends of the exponent range: with 2^-100 <= |c| (or c = 0) and
+// 2^-48 <= n <= 2^20 -- q_div_f32_ok, tested wave-wide -- no operand, quotient (>= 2^-120) or residual (a multiple of 2^-147) comes
+// near them.  dfusion_selftest_exact_forms [8] compares the two on random and edge-of-domain inputs.
+__device__ __forceinline__ bool q_div_f32_ok(quat a, float s)       // s = q_sumsq(a)
+{
+    // every component zero or >= 2^-100 in magnitude: (bits << 1) - 1 maps +-0 to 0xffffffff and orders the rest by magnitude
+    const unsigned tw = (__float_as_uint(a.w) << 1) - 1u, tx = (__float_as_uint(a.x) << 1) - 1u;
+    const unsigned ty = (__float_as_uint(a.y) << 1) - 1u, tz = (__float_as_uint(a.z) << 1) - 1u;
+    return (min(min(tw, tx), min(ty, tz)) >= ((0x0d800000u << 1) - 1u)) & (s >= 0x1p-96f) & (s <= 0x1p40f);
+}
+__device__ __forceinline__ float df_rcp_refined(float d);
+__device__ __forceinline__ float df_div_shared(float n, float d, float r);
+__device__ __forceinline__ quat q_div_f32(quat a, float n)
+{
+    const float r = df_rcp_refined(n);
+    quat q;
+    q.w = df_div_shared(a.w, n, r); q.x = df_div_shared(a.x, n, r); q.y = df_div_shared(a.y, n, r); q.z = df_div_shared(a.z, n, r);
+    return q;
+}
 // ---- quaternion products on (w,x),(y,z) register pairs: 8 v_pk_mul_f32 + 6 v_pk_add_f32.  Every product and every sum of
 // q_mul above, in the same association -- ((p0 +- p1) +- p2) +- p3 per component -- with the operand halves picked by op_sel and
 // the signs by neg_lo / neg_hi (a sign flip of an operand: exact).  The compiler's own pairing of the scalar form needs 23

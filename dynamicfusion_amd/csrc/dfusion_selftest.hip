@@ -159,6 +159,62 @@ __global__ __launch_bounds__(256) void df_selftest_sample_kernel(unsigned long l
     for (int o = 32; o >= 1; o >>= 1) { bad += __shfl_xor(bad, o, 64); upd += __shfl_xor(upd, o, 64); }
     if ((threadIdx.x & 63) == 0) { if (bad) atomicAdd(&counts[6], bad); atomicAdd(&counts[7], upd); }
 }
+// [8] the first normalisation as an f32 division (q_div_f32) vs the reference's (float)((1.0 / (double)n) * (double)c), on every
+//     quaternion q_div_f32_ok accepts out of (i) random quaternions normalised the way the sweep does it (n = sqrtf(sumsq)), specials,
+//     zeros of both signs and denormal components included, (ii) components drawn at and around the domain's edges: |c| = 2^-100
+//     exactly and one ulp either side, n^2 at 2^-96 and 2^40, quotients down to 2^-120, components that are exact multiples of n
+//     (quotients with no rounding at all) and one ulp off them.   [9] = how many quaternions were compared.
+__global__ __launch_bounds__(256) void df_selftest_normdiv_kernel(unsigned long long n, unsigned long long* __restrict__ counts)
+{
+    unsigned long long bad = 0, seen = 0;
+    unsigned long long seed = 0x94d049bb133111ebull * (blockIdx.x * 256ull + threadIdx.x + 1ull);
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull) {
+        quat a;
+        const unsigned kind = st_rng(seed);
+        if ((kind & 3u) != 0u) {
+            a.w = st_float(seed); a.x = st_float(seed); a.y = st_float(seed); a.z = st_float(seed);
+            if ((kind & 12u) == 0u) {                                       // the scale of blend sums far from the nodes: 2^-47 .. 2^-2
+                const float sc = __uint_as_float((80u + (kind >> 8) % 46u) << 23);
+                a.w *= sc; a.x *= sc; a.y *= sc; a.z *= sc;
+            }
+        } else {
+            auto edge = [&]() {
+                const unsigned k = st_rng(seed), m = st_rng(seed);
+                float v;
+                switch (k & 7u) {
+                    case 0: v = 0x1p-100f; break;
+                    case 1: v = __uint_as_float(0x0d800000u - 1u); break;                                   // one ulp below the edge (must be refused)
+                    case 2: v = __uint_as_float(0x0d800000u + 1u); break;
+                    case 3: v = 0.f; break;
+                    case 4: v = __uint_as_float((m & 0x007fffffu) | ((27u + (k >> 8) % 8u) << 23)); break;  // 2^-100 .. 2^-93
+                    case 5: v = 0x1p-48f; break;                                                             // n^2 = 2^-96 when alone
+                    case 6: v = 0x1p20f * (1.f - (float)(m & 3u) * 0x1p-24f); break;                        // n^2 ~ 2^40
+                    default: v = __uint_as_float((m & 0x007fffffu) | ((100u + (k >> 8) % 40u) << 23)); break;
+                }
+                return (k & 0x80000000u) ? -v : v;
+            };
+            a.w = edge(); a.x = edge(); a.y = edge(); a.z = edge();
+            if ((kind & 0x30u) == 0u) {                                     // exact multiples of the norm: w = 3 t, x = 4 t => n = 5 t (and off by one ulp)
+                const float t = __uint_as_float((st_rng(seed) & 0x007fffffu) | ((110u + (kind >> 8) % 30u) << 23));
+                a.w = 3.f * t; a.x = 4.f * t; a.y = 0.f; a.z = (kind & 0x40u) ? 0.f : -0.f;
+                if (kind & 0x80u) a.x = __uint_as_float(__float_as_uint(a.x) + 1u);
+            }
+        }
+        // (-0 is outside the form's domain and cannot reach it in the sweep: the blend sums start at +0 and an IEEE sum is -0 only when
+        // both terms are -- q_div_f32's comment.  With a -0 component the two forms differ in the sign of that zero and nowhere else.)
+        if ((__float_as_uint(a.w) == 0x80000000u) | (__float_as_uint(a.x) == 0x80000000u) | (__float_as_uint(a.y) == 0x80000000u) |
+            (__float_as_uint(a.z) == 0x80000000u)) continue;
+        const float s = q_sumsq(a);
+        if (!q_div_f32_ok(a, s)) continue;
+        ++seen;
+        const float nrm = sqrtf(s);
+        const quat g = q_scale_f64(1.0 / (double)nrm, a), f = q_div_f32(a, nrm);
+        bad += !(st_same(g.w, f.w) && st_same(g.x, f.x) && st_same(g.y, f.y) && st_same(g.z, f.z));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { bad += __shfl_xor(bad, o, 64); seen += __shfl_xor(seen, o, 64); }
+    if ((threadIdx.x & 63) == 0) { if (bad) atomicAdd(&counts[8], bad); atomicAdd(&counts[9], seen); }
+}
 __global__ __launch_bounds__(256) void df_selftest_sample_image_kernel(uint16_t* __restrict__ img)
 {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
@@ -182,7 +238,7 @@ extern "C" int dfusion_selftest_exact_forms(unsigned long long n_random, unsigne
 {
     if (!counts_dev) return DF_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    DF_HIP(hipMemsetAsync(counts_dev, 0, 8 * sizeof(unsigned long long), st));
+    DF_HIP(hipMemsetAsync(counts_dev, 0, 10 * sizeof(unsigned long long), st));
     {
         uint16_t* img = nullptr;
         DF_HIP(hipMalloc((void**)&img, 64 * 48 * sizeof(uint16_t)));
@@ -197,6 +253,8 @@ extern "C" int dfusion_selftest_exact_forms(unsigned long long n_random, unsigne
     hipLaunchKernelGGL(df_selftest_quat_kernel, dim3(2048), dim3(256), 0, st, n_random, counts_dev);
     DF_LAUNCH_CHECK();
     hipLaunchKernelGGL(df_selftest_fuse_kernel, dim3(2048), dim3(256), 0, st, (unsigned)(n_random >> 21 ? n_random >> 21 : 1), counts_dev);
+    DF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(df_selftest_normdiv_kernel, dim3(2048), dim3(256), 0, st, n_random, counts_dev);
     DF_LAUNCH_CHECK();
     return DF_OK;
 }

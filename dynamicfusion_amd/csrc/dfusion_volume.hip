@@ -16,6 +16,7 @@
 #include "dfusion_internal.h"
 #include "dfusion_pyramid.h"
 #include <atomic>
+#include <list>
 #include <mutex>
 #include <vector>
 #include <math.h>
@@ -512,6 +513,26 @@ __device__ __forceinline__ void df_rigid_run_pipe(const DfRigidArgs& a, f3& vc, 
 #define DF_RIGID_ZC 32           // planes per chunk wanted (a multiple of DF_RIGID_SUB, <= DF_RIGID_SUB * DF_RIGID_MAX_SUBS)
 #endif
 #define DF_RIGID_BINS (DF_RIGID_STRIP * DF_RIGID_MAX_SUBS + 1)
+// Round 5: PAIRS.  Two x-adjacent 32 x 2 patches whose alive sub-chunks (nearly) coincide in a chunk are walked as two 64 x 1 ROWS instead:
+// the same voxels, but a wave then read-modify-writes ONE run of 256 contiguous bytes per plane instead of two of 128 -- the access
+// pattern tools/rmw_probe.hip measures at 6.3-6.6 TB/s against 4.4.  (Whole 64 x 1 patches everywhere were tried in round 3: a 64-wide
+// strip cuts the frustum's side planes more often, swept / updated 1.60 instead of 1.37, and the launch got slower.  Here the verdicts
+// stay those of the 32 x 2 patches; only pairs that would be swept together anyway change shape.)  A row item walks the UNION of the two
+// patches' masks; DF_RIGID_ROW_SLACK bounds what that may add: popc(a | b) * 2 - popc(a) - popc(b) half-patch sub-chunks.
+// MEASURED (round 5, same box, interleaved, volumes bit-identical; profiles/r05_ab_rigid_pairs.txt): 0.1123 ms with pairs against 0.1121
+// without, 0.1125 with slack 0, 0.1136 / 0.1143 with slack 2 / 4 -- the 256-byte runs buy nothing here, so the sweep is not bound by how
+// wide its row runs are after all (the probe's waves do nothing but read-modify-write; these wait for a dists gather per plane as
+// well).  Kept as a compile-time option, not the default.
+#ifndef DF_RIGID_PAIR
+#define DF_RIGID_PAIR 0
+#endif
+#ifndef DF_RIGID_ROW_SLACK
+#define DF_RIGID_ROW_SLACK 1
+#endif
+#define DF_RIGID_ROW_FLAG 0x100u
+#if DF_RIGID_PAIR && (DF_RIGID_STRIP != 1 || DF_RIGID_PX != 32 || !DF_RIGID_STARTS)
+#error "DF_RIGID_PAIR needs 32 x 2 patches, one patch per plan item and chunk starts from the plan kernel"
+#endif
 // Conservative, result-identical rejection of ALL the voxels of a 32 x 2 column patch on planes [zs, zs + n): the same two tests as
 // df_rigid_culled, on the box the patch's voxels span (its 8 corners; positions by multiplication, within the tests' margin of the
 // running sums the sweep carries): (a) all corners outside the same frustum side plane, (b) the box's least distance from the camera
@@ -598,7 +619,14 @@ __global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a
         const unsigned wg0 = blockIdx.x * 16u + (unsigned)(DF_RIGID_STRIP * q);      // the strip's first wave
         const int scg = (int)(wg0 / (unsigned)a.tiles), strip = (int)(wg0 % (unsigned)a.tiles) / DF_RIGID_STRIP;
         item = (unsigned)(scg * cpw + c) * (unsigned)(a.tiles / DF_RIGID_STRIP) + (unsigned)strip;
+#if DF_RIGID_PAIR
+        // the x-neighbour of the pair (a.tiles_x is even and a workgroup's first tile too: q ^ 1 is in this workgroup and in the same row)
+        const unsigned mb = (unsigned)(s_alive[q ^ 1] >> (c * subs)) & smask;
+        if (m && mb && 2 * __popc(m | mb) - __popc(m) - __popc(mb) <= DF_RIGID_ROW_SLACK) m = (m | mb) | DF_RIGID_ROW_FLAG;   // both threads of the pair decide alike
+        w = (unsigned)__popc(m & 0xffu);
+#else
         w = (unsigned)__popc(m);
+#endif
         if (m) slot = atomicAdd(&s_cnt[w], 1u);
     }
     __syncthreads();
@@ -647,13 +675,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
     const int j = __ffsll((unsigned long long)__ballot(lane < DF_RIGID_BINS - 1 && e < bin_end)) - 1;
     const unsigned r = e - ((unsigned)__builtin_amdgcn_readlane((int)bin_end, j) - (unsigned)__builtin_amdgcn_readlane((int)bin_cnt, j));
     const unsigned sitem = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_RIGID_BINS - 1 - j) * a.plan_items + r]);
+#if DF_RIGID_PAIR
+    const unsigned mword = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_mask[sitem]);
+    const unsigned mask = mword & 0xffu;
+    const bool row = (mword & DF_RIGID_ROW_FLAG) != 0u;                    // wave-uniform: this wave walks one 64 x 1 row of the pair
+#else
     const unsigned mask = ((unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_mask[sitem]) >> (8 * (wave % DF_RIGID_STRIP))) & 0xffu;
+#endif
     if (mask == 0u) return;                                                // nothing alive in this wave's patch
     const int strips = a.tiles / DF_RIGID_STRIP;
     const int chunk = (int)(sitem / (unsigned)strips), tile = (int)(sitem % (unsigned)strips) * DF_RIGID_STRIP + (wave % DF_RIGID_STRIP);
     const unsigned item = (unsigned)chunk * (unsigned)a.tiles + (unsigned)tile;     // (patch item: indexes plan_starts)
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+#if DF_RIGID_PAIR
+    // row item of patch tx: row (tx & 1) of the pair's two patches, lane l = column l of the 64
+    const int x = row ? (tx & ~1) * DF_RIGID_PX + lane : tx * DF_RIGID_PX + (lane & (DF_RIGID_PX - 1));
+    const int y = row ? ty * DF_RIGID_PY + (tx & 1) : ty * DF_RIGID_PY + (lane / DF_RIGID_PX);
+#else
     const int x = tx * DF_RIGID_PX + (lane & (DF_RIGID_PX - 1)), y = ty * DF_RIGID_PY + (lane / DF_RIGID_PX);
+#endif
     const bool active = x < a.X && y < a.Y;
     unsigned int my_upd = 0, my_swept = 0;
     const int zb = a.z_own0 + chunk * a.zc;
@@ -662,7 +702,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
     // the column's running position at plane zb: vol2cam * (x, y, 0) + zb additions of zstep (:71-75), made once per column by
     // the plan kernel
 #if DF_RIGID_STARTS
+#if DF_RIGID_PAIR
+    // (a row's columns are lanes 32 r ... 32 r + 31 of the two patches' start records: both patches are alive in this chunk, so both were written)
+    const float4 st4 = row ? a.plan_starts[((size_t)(item & ~1u) + (unsigned)(lane >> 5)) * 64 + (unsigned)((lane & 31) + 32 * (tx & 1))]
+                           : a.plan_starts[(size_t)item * 64 + lane];
+#else
     const float4 st4 = a.plan_starts[(size_t)item * 64 + lane];
+#endif
     f3 vc = mk3(st4.x, st4.y, st4.z);
 #else
     f3 vc = aff_mul(a.vol2cam, mk3((float)x * a.vsx, (float)y * a.vsy, 0.f));                  // :71-72
@@ -749,16 +795,21 @@ size_t df_pyramid_elems(int cols, int rows)
 }
 
 
-// The rigid integrate's scratch, cached per (device, stream) and kept until dfusion_release_scratch(): at most DF_SCRATCH_MAX entries,
-// the least recently used one is evicted (a host that makes a stream per frame would otherwise leave ~84 MB behind per stream at
-// 512^3).  A cached stream handle may have been destroyed by the host since: entries are freed after a DEVICE synchronise, never
-// through the stored handle.
+// The rigid integrate's scratch, cached per (device, stream) and kept until dfusion_release_scratch(): at most DF_SCRATCH_MAX entries PER
+// DEVICE, the least recently used idle one is evicted (a host that makes a stream per frame would otherwise leave ~84 MB behind per
+// stream at 512^3).  A cached stream handle may have been destroyed by the host since: entries are freed after a DEVICE synchronise,
+// never through the stored handle.
+// Round 5: an entry is HELD for the whole of the call that uses it -- `busy` is locked from the lookup until the call has
+// enqueued its last kernel -- so another host thread can neither evict nor regrow it in the window between the lookup and the launches
+// (a device synchronise sees nothing of kernels that are not enqueued yet).  Eviction only considers entries it can try_lock; when every
+// entry of the device is in use the cache grows past the cap instead.  Lock order: the table's mutex, then an entry's; nothing takes the
+// table's mutex while holding an entry.
 #define DF_SCRATCH_MAX 8
-struct DfScratchEntry { int device; hipStream_t stream; char* mem; size_t cap; unsigned long long used; };
+struct DfScratchEntry { int device; hipStream_t stream; char* mem; size_t cap; unsigned long long used; std::mutex busy; };
 static std::mutex g_df_scratch_mutex;
-static std::vector<DfScratchEntry> g_df_scratch;
+static std::list<DfScratchEntry> g_df_scratch;                            // (a list: entries never move while a call holds one)
 static unsigned long long g_df_scratch_clock = 0;
-static void df_scratch_free_entry(DfScratchEntry& c)
+static void df_scratch_free_entry(DfScratchEntry& c)                       // caller holds c.busy
 {
     if (!c.mem) return;
     int cur = 0;
@@ -768,36 +819,51 @@ static void df_scratch_free_entry(DfScratchEntry& c)
     if (have_cur) (void)hipSetDevice(cur);
     c.mem = nullptr; c.cap = 0;
 }
-static char* df_rigid_scratch(hipStream_t st, size_t bytes)
+// the entry of (current device, st), locked; nullptr on failure.  *mem_out = at least `bytes` of device memory.
+static DfScratchEntry* df_rigid_scratch_acquire(hipStream_t st, size_t bytes, char** mem_out)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(g_df_scratch_mutex);
     DfScratchEntry* e = nullptr;
-    for (DfScratchEntry& c : g_df_scratch) if (c.device == dev && c.stream == st) { e = &c; break; }
-    if (!e) {
-        if (g_df_scratch.size() >= DF_SCRATCH_MAX) {                       // evict the least recently used entry
-            size_t lru = 0;
-            for (size_t i = 1; i < g_df_scratch.size(); ++i) if (g_df_scratch[i].used < g_df_scratch[lru].used) lru = i;
-            df_scratch_free_entry(g_df_scratch[lru]);
-            g_df_scratch.erase(g_df_scratch.begin() + (long)lru);
+    {
+        std::lock_guard<std::mutex> lock(g_df_scratch_mutex);
+        for (DfScratchEntry& c : g_df_scratch) if (c.device == dev && c.stream == st) { e = &c; break; }
+        if (!e) {
+            size_t n_dev = 0;
+            for (const DfScratchEntry& c : g_df_scratch) n_dev += c.device == dev;
+            while (n_dev >= DF_SCRATCH_MAX) {                              // evict this device's least recently used IDLE entry
+                std::list<DfScratchEntry>::iterator lru = g_df_scratch.end();
+                for (auto it = g_df_scratch.begin(); it != g_df_scratch.end(); ++it)
+                    if (it->device == dev && (lru == g_df_scratch.end() || it->used < lru->used) && it->busy.try_lock()) {
+                        if (lru != g_df_scratch.end()) lru->busy.unlock();
+                        lru = it;
+                    }
+                if (lru == g_df_scratch.end()) break;                      // every entry is in use: grow past the cap
+                df_scratch_free_entry(*lru);
+                lru->busy.unlock();
+                g_df_scratch.erase(lru);
+                --n_dev;
+            }
+            g_df_scratch.emplace_back();
+            e = &g_df_scratch.back();
+            e->device = dev; e->stream = st; e->mem = nullptr; e->cap = 0; e->used = 0;
         }
-        g_df_scratch.push_back(DfScratchEntry{dev, st, nullptr, 0, 0});
-        e = &g_df_scratch.back();
+        e->used = ++g_df_scratch_clock;
+        e->busy.lock();                                                    // (a second thread on the SAME stream waits here for the first call's enqueue)
     }
-    e->used = ++g_df_scratch_clock;
     if (bytes > e->cap) {
         if (e->mem) { (void)hipStreamSynchronize(st); (void)hipFree(e->mem); e->mem = nullptr; e->cap = 0; }
         const size_t cap = bytes + bytes / 4;
-        if (hipMalloc((void**)&e->mem, cap) != hipSuccess) { (void)hipGetLastError(); e->mem = nullptr; return nullptr; }
+        if (hipMalloc((void**)&e->mem, cap) != hipSuccess) { (void)hipGetLastError(); e->mem = nullptr; e->busy.unlock(); return nullptr; }
         e->cap = cap;
     }
-    return e->mem;
+    *mem_out = e->mem;
+    return e;
 }
 extern "C" int dfusion_release_scratch(void)
 {
     std::lock_guard<std::mutex> lock(g_df_scratch_mutex);
-    for (DfScratchEntry& c : g_df_scratch) df_scratch_free_entry(c);      // (restores the caller's current device)
+    for (DfScratchEntry& c : g_df_scratch) { c.busy.lock(); df_scratch_free_entry(c); c.busy.unlock(); }      // (waits for calls in flight; restores the caller's device)
     g_df_scratch.clear();
     return DF_OK;
 }
@@ -844,7 +910,8 @@ extern "C" int dfusion_integrate_ex(const uint16_t* dists, size_t pitch, int col
         }
     }
     // column patches (one per wave), 4 side by side per strip (one per workgroup): the patch grid's x extent is padded to whole strips
-    const int tiles_x = ((a.X + DF_RIGID_PX - 1) / DF_RIGID_PX + DF_RIGID_STRIP - 1) / DF_RIGID_STRIP * DF_RIGID_STRIP;
+    constexpr int tx_pad = DF_RIGID_PAIR ? 2 : DF_RIGID_STRIP;             // (pairs: an even number of patches per row)
+    const int tiles_x = ((a.X + DF_RIGID_PX - 1) / DF_RIGID_PX + tx_pad - 1) / tx_pad * tx_pad;
     const int tiles = tiles_x * ((a.Y + DF_RIGID_PY - 1) / DF_RIGID_PY);
     // Z chunking: chunks of DF_RIGID_ZC planes -- 1, 2, 4 or 8 sub-chunks.  Short enough that the longest wave is a fraction of the
     // launch: a per-wave timeline (tools/trace_sweep.py, round 3) showed 64-plane items taking up to 93 us of a 115 us launch whose
@@ -870,12 +937,14 @@ extern "C" int dfusion_integrate_ex(const uint16_t* dists, size_t pitch, int col
     // hipMallocAsync / hipFreeAsync per call: in a process that also allocates and frees with hipMalloc / hipFree between the calls --
     // the host mirror's reference-shaped flow -- one integrate in ~30 then updated a different set of voxels from identical inputs;
     // with a plain or a kept allocation never, 200 runs each.)
-    char* scratch = df_rigid_scratch(st, bytes);
-    if (!scratch) return (int)hipErrorOutOfMemory;
+    char* scratch = nullptr;
+    DfScratchEntry* scratch_entry = df_rigid_scratch_acquire(st, bytes, &scratch);       // held until the last launch below is enqueued
+    if (!scratch_entry) return (int)hipErrorOutOfMemory;
+    struct ScratchHold { DfScratchEntry* e; ~ScratchHold() { e->busy.unlock(); } } scratch_hold{scratch_entry};
     // validation: the kept buffer still holds the previous call's plan -- exactly what would hide a read of plan data this call did
     // not write.  Poisoned (every byte 0xFF: NaN starts, out-of-range items, full masks), such a read cannot go unnoticed.
     if (flags & DF_RIGID_POISON_SCRATCH) DF_HIP(hipMemsetAsync(scratch, 0xFF, bytes, st));
-    auto release_scratch = [&]() {};
+    auto release_scratch = [&]() {};                                       // (scratch_hold's destructor: every return path)
     DfDistsPyramid Py;
     memset(&Py, 0, sizeof(Py));
     int rc = DF_OK;

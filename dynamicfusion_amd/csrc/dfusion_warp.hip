@@ -88,16 +88,26 @@ extern "C" int dfusion_warp_create(DfWarpField** out)
 static int df_side_init(DfWarpField* wf)
 {
     if (wf->side) return DF_OK;
-    DF_HIP(hipStreamCreateWithFlags(&wf->side, hipStreamNonBlocking));
-    DF_HIP(hipEventCreateWithFlags(&wf->ev_fork, hipEventDisableTiming));
-    DF_HIP(hipEventCreateWithFlags(&wf->ev_join, hipEventDisableTiming));
+    // every resource first, the handle last: a failure part-way leaves nothing behind that passes the test above
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; void* h = wf->host_report ? (void*)wf->host_report : nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+    if (e == hipSuccess && !h) e = hipHostMalloc(&h, 4 * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (side) (void)hipStreamDestroy(side);
+        if (h && !wf->host_report) (void)hipHostFree(h);
+        (void)hipGetLastError();
+        return (int)e;
+    }
     if (!wf->host_report) {
-        void* h = nullptr;
-        DF_HIP(hipHostMalloc(&h, 4 * sizeof(uint32_t), hipHostMallocDefault));
         wf->host_report = (volatile uint32_t*)h;
         wf->host_report[0] = wf->host_report[1] = wf->host_report[2] = 1u;       // nothing reported yet: assume work
         wf->host_report[3] = 0u;
     }
+    wf->ev_fork = ev_fork; wf->ev_join = ev_join; wf->side = side;
     return DF_OK;
 }
 static int df_side_join(DfWarpField* wf, hipStream_t st)
@@ -1432,6 +1442,21 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
 // re-ranking ~150 candidates (and 8 f32 divisions + 8 f64 exp) per voxel.  A workgroup owns a 32(x) x 8(y) x 8(z) tile:
 // a wave covers two 32-voxel rows, so every access is a run of >= 128 contiguous bytes (volume 4 B, k-NN 16 B, weights
 // 16 B per lane and plane); each lane walks the 8 planes of the tile.
+// ---- compile-time switches of the pipelined sweep (tools/build_variant.py builds the A/B variants)
+#ifndef DF_NORM_F32DIV
+#define DF_NORM_F32DIV 0         // the pipelined sweep's first normalisation as an f32 division (0: the f64 reciprocal and scaling).  Same bits
+                                 // (selftest [8]); measured round 5, same box: 0.644 against 0.640 ms -- not faster, so not the default
+#endif
+#ifndef DF_WARP_FUSE_SHORT
+#define DF_WARP_FUSE_SHORT 0     // the pipelined sweep's fuse division in its short form where a wave's stored values are finite (round 5:
+                                 // 0.644 against 0.642 ms without it -- the second code path costs what the shorter division saves)
+#endif
+#ifndef DF_TAB_ADDR_HOIST
+#define DF_TAB_ADDR_HOIST 1      // table record addresses from a per-segment base (0: the general df_tab_index arithmetic per load)
+#endif
+#ifndef DF_LDS_SPLIT
+#define DF_LDS_SPLIT 0           // experiment: rot and node_t in two 16-byte-strided LDS arrays (M <= 2048) instead of interleaved
+#endif
 #define DF_ROW_TX 32
 #define DF_ROW_TY 8
 #define DF_ROW_TZ 8
@@ -1619,16 +1644,23 @@ __device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<4>& r, int (&bi)[4
 }
 // Byte offset of node `word` (0 = low, 1 = high 16 bits of v) in the interleaved LDS node table: index * 32 in ONE instruction
 // (SDWA selects the 16-bit word as the shift's operand; and + shift / bfe + shift otherwise, two per index, 16 per voxel).
+#if DF_LDS_SPLIT
+#define DF_NODE_SHIFT "4"
+#define DF_NODE_T_OFF 2048       // (in 16-byte units: node_t[j] at byte 32768 + 16 j, inside the ds_read immediate offset)
+#else
+#define DF_NODE_SHIFT "5"
+#define DF_NODE_T_OFF 1
+#endif
 __device__ __forceinline__ unsigned df_node_off_lo(unsigned v)
 {
     unsigned r;
-    asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(v));
+    asm("v_lshlrev_b32_sdwa %0, " DF_NODE_SHIFT ", %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(v));
     return r;
 }
 __device__ __forceinline__ unsigned df_node_off_hi(unsigned v)
 {
     unsigned r;
-    asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(v));
+    asm("v_lshlrev_b32_sdwa %0, " DF_NODE_SHIFT ", %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(v));
     return r;
 }
 // The blend below addresses the nodes by byte offsets into the workgroup's LDS.  The node table is the kernel's only LDS object (the
@@ -1654,7 +1686,7 @@ __device__ __forceinline__ void df_blend_pair(DfBlendSums& S, unsigned idx2, df_
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         df_lds_cf4* nd = (df_lds_cf4*)(size_t)(h == 0 ? df_node_off_lo(idx2) : df_node_off_hi(idx2));
-        const df_v4f r4 = nd[0], t4 = nd[1];
+        const df_v4f r4 = nd[0], t4 = nd[DF_NODE_T_OFF];
         const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
         if (h == 0) {
             S.t01 = S.t01 + df_pk_mul_lo(wp, ta); S.t23 = S.t23 + df_pk_mul_lo(wp, tb);     // :211
@@ -1755,7 +1787,12 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
 #ifdef DF_TRACE_WG
     const unsigned long long t_start = wall_clock64();
 #endif
+#if DF_LDS_SPLIT
+    if (W.M > DF_NODE_T_OFF) __builtin_trap();
+    for (int j = threadIdx.x; j < W.M; j += WGT) { s_nodes[j] = W.rot[j]; s_nodes[DF_NODE_T_OFF + j] = W.node_t[j]; }
+#else
     for (int j = threadIdx.x; j < W.M; j += WGT) { s_nodes[2 * j] = W.rot[j]; s_nodes[2 * j + 1] = W.node_t[j]; }
+#endif
     if ((unsigned)(size_t)(df_lds_cf4*)s_nodes != 0u) __builtin_trap();  // the blend addresses the table from LDS address 0
     __syncthreads();
 
@@ -1868,6 +1905,22 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
         const unsigned lane_tab = (unsigned)((yc % DF_TAB_TY) * DF_TAB_TX + (xc % DF_TAB_TX));
         const size_t tile_col = (size_t)(yc / DF_TAB_TY) * a.tab_ntx + (size_t)(xc / DF_TAB_TX);      // == (ty, tx) of the workgroup: uniform
         const size_t tile_col_u = (size_t)__builtin_amdgcn_readfirstlane((int)tile_col);
+#if DF_TAB_ADDR_HOIST
+        // (round 5) the record index of plane z of tile layer lt0 + l is rec0 + l * rec_layer + (z mod 8) * 512: a tile layer of the sweep IS
+        // a tile layer of the tables (DF_ROW_TZ = DF_TAB_TZ, tab_z0 a multiple of 8), so the division, the remainder and the 64-bit
+        // products of the general form (39 scalar instructions per load, a fifth of the kernel's SALU work) are made once per segment
+        static_assert(DF_ROW_TZ == DF_TAB_TZ, "the sweep's layers are the tables' tile layers");
+        const size_t rec_layer = (size_t)a.tab_nty * (size_t)a.tab_ntx * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ);
+        const size_t rec0 = ((size_t)(lt0 - a.tab_z0 / DF_TAB_TZ) * a.tab_nty * a.tab_ntx + tile_col_u) * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ);
+        auto load_batch = [&](DfTabRaw<K> (&S)[U], int l, int z0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int zi = min(z0 + u, layer_ze(l) - 1) - (lt0 + l) * DF_ROW_TZ;         // plane inside the layer
+                const size_t rec = rec0 + (size_t)(unsigned)l * rec_layer + (size_t)(unsigned)(zi * (DF_TAB_TX * DF_TAB_TY));
+                tab_raw_load_at(a, rec, lane_tab, S[u]);
+            }
+        };
+#else
         auto load_batch = [&](DfTabRaw<K> (&S)[U], int l, int z0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1877,6 +1930,7 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
                 tab_raw_load_at(a, rec, lane_tab, S[u]);
             }
         };
+#endif
         int l = __ffs(alive) - 1, z0 = layer_zb(l);
         int l1, z1; advance(l, z0, &l1, &z1);
         DfTabRaw<K> S0[U], S1[U];
@@ -1890,6 +1944,28 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
 #pragma unroll
         for (int u = 0; u < U; ++u) { pend.vn[u] = 0.f; pend.dpb[u] = 0; pend.vox[u] = 0u; pend.z[u] = a.z_store0; pend.ok[u] = false; }
         auto finish_pending = [&]() {
+#if DF_WARP_FUSE_SHORT
+            // the fuse division in its short form (dfusion_device.h, tsdf_fuse_short: same bits for finite stored values) when every
+            // voxel the wave is about to fuse holds one
+            bool upd[U]; float sdf[U]; bool fin = true;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float Dp = h2f_bits(pend.dpb[u]);
+                sdf[u] = Dp - pend.vn[u];                                                     // :89
+                upd[u] = pend.ok[u] & (Dp != 0.f) & (sdf[u] >= -a.P.trunc);                   // :86, :91
+                fin = fin & (!upd[u] | tsdf_fuse_short_ok(pend.vox[u]));
+            }
+            fin = df_wave_all(fin);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (upd[u]) {
+                    df_global_ptr<uint32_t> vp = df_wave_uniform(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane) + lane_vox;
+                    const float ts = fminf(1.f, sdf[u] * a.P.trunc_inv);                      // :93
+                    *vp = fin ? tsdf_fuse_short(pend.vox[u], ts, a.P.max_weight) : tsdf_fuse(pend.vox[u], ts, a.P.max_weight);
+                    ++my_upd;
+                }
+            }
+#else
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float Dp = h2f_bits(pend.dpb[u]);
@@ -1901,6 +1977,7 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
                     ++my_upd;
                 }
             }
+#endif
         };
         // one batch: consumes S (tables of batch (l, z0)), then refills S with the tables of batch (l2, z2)
         auto step = [&](DfTabRaw<K> (&S)[U], int l, int z0, int l2, int z2) {
@@ -1931,9 +2008,17 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
                 half.wx = B.t01 * 0.5f; half.yz = B.t23 * 0.5f;
                 const float s1 = q_sumsq(rsum);
                 float n1;
+#if DF_NORM_F32DIV
+                // :214 as an f32 division where that has the reference's bits (dfusion_device.h, q_div_f32_ok: one wave-wide test for
+                // the short square root and the division together); the f64 form otherwise
+                quat rot;
+                if (__builtin_expect(df_wave_all(q_div_f32_ok(rsum, s1)), 1)) { n1 = df_sqrt_short(s1); rot = q_div_f32(rsum, n1); }
+                else { n1 = sqrtf(s1); rot = q_scale_f64(df_rcp_short((double)n1), rsum); }   // far from the nodes: tiny, denormal or zero sums
+#else
                 if (__builtin_expect(df_wave_all(df_sqrt_short_ok(s1)), 1)) n1 = df_sqrt_short(s1);
                 else n1 = sqrtf(s1);                             // far from the nodes: tiny, denormal or zero sums
                 const quat rot = q_scale_f64(df_rcp_short((double)n1), rsum);                 // :214 (see q_normalize_rcp_short)
+#endif
                 const quat2 dual = q_mul_pk(half, q_pairs(rot));                              // dual_quaternion.hpp:59-63
                 const float s2 = q_sumsq(rot);
                 if (__builtin_expect(df_wave_all(q_near_unit_ok(s2)), 1)) rn = q_normalize_near_unit(rot, s2);
@@ -2163,7 +2248,10 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
     // synchronisation, so it may be frames old; it only decides WHERE optional work runs.  On from the first sweeps over new tables,
     // while the last report listed anything, and every 8th sweep as a probe (a camera that starts to move is picked up by the urgent
     // list at once, by the look-ahead within the report's age).
-    if (ahead && wf->tab_sweeps >= 8 && (wf->tab_sweeps & 7) != 0 && wf->host_report &&
+    // (The unsynchronised read makes WHICH frame switches the side stream off depend on host / GPU timing -- never a result, but the
+    // swept-voxel counter and frame times of a run.  DF_WARP_STEADY_PREFETCH keeps the look-ahead on in every frame: what tests and
+    // measurements that compare such counters between runs pass -- ADVICE r4.)
+    if (ahead && !(flags & DF_WARP_STEADY_PREFETCH) && wf->tab_sweeps >= 8 && (wf->tab_sweeps & 7) != 0 && wf->host_report &&
         wf->host_report[0] == 0u && wf->host_report[1] == 0u && wf->host_report[2] == 0u) ahead = false;
     const bool quiet = !ahead && !(flags & (DF_WARP_NO_PREFETCH | DF_WARP_BLOCK_MODEL_NOW));      // a frame at rest: optional work waits for the next probe
     const int want_models_policy = want_models;
@@ -2209,10 +2297,14 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
         // does not read (near, not alive) or structures the sweep never reads (model records, state bytes)
         DF_HIP(hipEventRecord(wf->ev_fork, st));
         DF_HIP(hipStreamWaitEvent(wf->side, wf->ev_fork, 0));
-        if (!wf->tab_complete) { int rc = df_build_listed(wf, cnt, wf->side, 1); if (rc) return rc; }
-        if (want_models_now) { int rc = launch_models(wf->side); if (rc) return rc; }
-        DF_HIP(hipEventRecord(wf->ev_join, wf->side));
-        wf->side_pending = true;                                           // joined by the next call that touches the tables
+        // from here on the side stream may hold kernels that write tables, state bytes and model records: whatever fails below, the next
+        // call must not touch them before those kernels are done (an early return used to leave the fork unjoined)
+        int rc_side = DF_OK;
+        if (!wf->tab_complete) rc_side = df_build_listed(wf, cnt, wf->side, 1);
+        if (rc_side == DF_OK && want_models_now) rc_side = launch_models(wf->side);
+        if (hipEventRecord(wf->ev_join, wf->side) == hipSuccess) wf->side_pending = true;      // joined by the next call that touches the tables
+        else { (void)hipGetLastError(); df_side_drain(wf); if (rc_side == DF_OK) rc_side = (int)hipErrorUnknown; }
+        if (rc_side != DF_OK) return rc_side;
     }
     if (!wf->tab_complete) { int rc = df_build_listed(wf, cnt, st, 0); if (rc) return rc; }      // urgent: before this frame's sweep
     if (want_models_now && !ahead) { int rc = launch_models(st); if (rc) return rc; }
@@ -2261,6 +2353,13 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         a.tab_nvox = (size_t)a.tab_ntx * DF_TAB_TX * a.tab_nty * DF_TAB_TY * wf->tab_zn;
     }
     if (use_w) a.w_tab = wf->w_tab;
+    // the pipelined sweep's preconditions, decided ONCE: which pyramid is built below and which kernel is launched further down both
+    // follow from them (they used to be two hand-copied predicates).  LDS node table: 32 B per node, up to the whole 160 KiB
+    // of a CU; the pipelined kernel forms row * pitch with a 24-bit multiply and a 32-bit dists offset
+    const bool lds_ok = (size_t)wf->M * 32 <= 160 * 1024 && !(flags & DF_WARP_NO_LDS);
+    const bool pipe_form_ok = use_w && !(flags & DF_WARP_NO_PIPELINE) && pitch < (1u << 24) && rows < (1 << 24) &&
+                              (unsigned long long)rows * pitch < (1ull << 32);
+    const bool pipe_sweep = use_tab && lds_ok && pipe_form_ok && (k == 8 || k == 4);
 
     if (!(flags & DF_WARP_NO_CULL) && proj[0] > 0.f && proj[1] > 0.f) {
         if (!(flags & DF_WARP_NO_DEPTH_PYRAMID)) {
@@ -2272,8 +2371,10 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
             }
             // the pipelined sweep (the product path) reads the pyramid in its verdict pass only, and its plan kernel re-arms the
             // image-maximum word: levels 1..5 in ONE launch.  The other kernels take the full pyramid (two launches).
-            const bool pipe_path = use_w && (size_t)wf->M * 32 <= 160 * 1024 && !(flags & (DF_WARP_NO_LDS | DF_WARP_NO_PIPELINE)) && (k == 8 || k == 4) &&
-                                   pitch < (1u << 24) && rows < (1 << 24) && (unsigned long long)rows * pitch < (1ull << 32);
+            const bool pipe_path = pipe_sweep;
+            // (the image-maximum word is re-armed by the plan kernel after its readers; a call that returned early in between would leave
+            // the previous frame's maximum in it -- conservative, but a silently weaker cull: zeroed here as well)
+            if (pipe_path) DF_HIP(hipMemsetAsync(wf->bounds_dev + 6, 0, sizeof(float), st));
             int rc = df_build_dists_pyramid(dists, pitch, cols, rows, wf->pyr_mem, wf->pyr_cap, &a.py, st, pipe_path, nullptr,
                                             pipe_path ? (unsigned int*)(wf->bounds_dev + 6) : nullptr);
             if (rc) return rc;
@@ -2306,24 +2407,24 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
     }
 
     DfWarpView W = df_view(wf);
-    // LDS node table: 32 B per node, up to the whole 160 KiB of a CU (then one 512-thread workgroup per CU)
-    const bool lds_ok = (size_t)wf->M * 32 <= 160 * 1024 && !(flags & DF_WARP_NO_LDS);
     if (use_tab && lds_ok) {
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_LDS_TY - 1) / DF_LDS_TY;
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
         a.bz0 = zt_lo;
-        // the pipelined kernel forms row * pitch with a 24-bit multiply and a 32-bit dists offset
-        const bool pipe_ok = use_w && !(flags & DF_WARP_NO_PIPELINE) && pitch < (1u << 24) && rows < (1 << 24) &&
-                             (unsigned long long)rows * pitch < (1ull << 32);
+        const bool pipe_ok = pipe_form_ok;
         if (a.cull) a.tile_r = (float)(df_tile_radius(vol2world, pipe_ok && (k == 8 || k == 4) ? 8 : DF_ROW_TX, pipe_ok && (k == 8 || k == 4) ? 8 : DF_LDS_TY,
                                                       DF_ROW_TZ, v) * 1.001 + 1e-6);
+#if DF_LDS_SPLIT
+        const size_t lds = (size_t)(DF_NODE_T_OFF + wf->M) * 16;
+#else
         const size_t lds = (size_t)wf->M * 32;
+#endif
         typedef void (*lds_kernel_t)(const DfWarpedArgs, const DfWarpView, int);
         lds_kernel_t kern = nullptr;
         // tile layers per workgroup: long walks amortise the LDS fill and the pipeline ramp, short ones even out the last round of
         // workgroups on the 256 CUs (measured: 4 layers best at 256^3 = 1024 workgroups, 8 at 512^3, 16 at 1024^3 = 16384)
         const long long cols_layers = (long long)tiles_x * tiles_y * (zt_hi - zt_lo + 1);
-        const bool pipe = pipe_ok && (k == 8 || k == 4);        // df_warp_rows_lds_kernel always walks DF_LDS_ZT layers per workgroup
+        const bool pipe = pipe_sweep;                           // df_warp_rows_lds_kernel always walks DF_LDS_ZT layers per workgroup
         a.zt = !pipe ? DF_LDS_ZT : cols_layers <= 8192 ? 4 : cols_layers <= 65536 ? 8 : 16;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + a.zt - 1) / a.zt));
         const bool wide = pipe_ok && (k == 8 || k == 4) && lds > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads

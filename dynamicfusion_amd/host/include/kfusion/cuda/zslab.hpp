@@ -83,6 +83,7 @@ private:
     bool initRccl(const std::string& id_path);
     bool initHost(const std::string& id_path);
     bool hostBarrier();
+    int hostBarrierImpl(bool watch_magic);
     char* hostSlot(int rank) const;
     Backend backend_;
     void* seg_; size_t seg_bytes_, slot_bytes_;   // HOST_STAGED: the mapped segment {header, world slots}

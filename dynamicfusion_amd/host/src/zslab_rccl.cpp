@@ -92,6 +92,9 @@ bool ZSlabComm::initHost(const std::string& id_path)
     const size_t bytes = sizeof(SegHeader) + (size_t)world_ * slot;
     int fd = -1;
     if (rank_ == 0) {
+        // A segment left behind by a crashed run with the same nonce (0 by default) would pass the other ranks' header test: POISON it before
+        // removing the name -- a rank that has already mapped it sees its magic go and attaches again -- then publish ours.
+        { const int ofd = ::open(path.c_str(), O_RDWR); if (ofd >= 0) { const unsigned long long zero = 0; (void)!pwrite(ofd, &zero, sizeof(zero), 0); ::close(ofd); } }
         (void)std::remove(path.c_str());
         const std::string tmp = path + ".tmp." + std::to_string((long long)getpid());
         fd = ::open(tmp.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0600);
@@ -104,23 +107,32 @@ bool ZSlabComm::initHost(const std::string& id_path)
         seg_ = m; seg_bytes_ = bytes; slot_bytes_ = slot;
         if (std::rename(tmp.c_str(), path.c_str()) != 0) return fail("ZSlabComm(host): cannot publish " + path);
     } else {
-        for (int tries = 0;; ++tries) {
-            fd = ::open(path.c_str(), O_RDWR);
-            if (fd >= 0) {
-                struct stat sb;
-                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size == bytes) {
-                    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-                    ::close(fd);
-                    if (m != MAP_FAILED) {
-                        SegHeader* h = (SegHeader*)m;
-                        if (h->magic == SEG_MAGIC && h->nonce == nonce && h->slot_bytes == slot) { seg_ = m; seg_bytes_ = bytes; slot_bytes_ = slot; h->attached.fetch_add(1); break; }
-                        munmap(m, bytes);
-                    }
-                } else ::close(fd);
+        for (int attempt = 0;; ++attempt) {
+            for (int tries = 0;; ++tries) {
+                fd = ::open(path.c_str(), O_RDWR);
+                if (fd >= 0) {
+                    struct stat sb;
+                    if (fstat(fd, &sb) == 0 && (size_t)sb.st_size == bytes) {
+                        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                        ::close(fd);
+                        if (m != MAP_FAILED) {
+                            SegHeader* h = (SegHeader*)m;
+                            if (h->magic == SEG_MAGIC && h->nonce == nonce && h->slot_bytes == slot) { seg_ = m; seg_bytes_ = bytes; slot_bytes_ = slot; h->attached.fetch_add(1); break; }
+                            munmap(m, bytes);
+                        }
+                    } else ::close(fd);
+                }
+                if (tries > 6000) return fail("ZSlabComm(host): no segment for this run at " + path + " after 60 s");
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
             }
-            if (tries > 6000) return fail("ZSlabComm(host): no segment for this run at " + path + " after 60 s");
-            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            // the first barrier doubles as the check that this is THIS run's segment: rank 0 poisons a stale one's magic before it publishes
+            const int b = hostBarrierImpl(true);
+            if (b == 1) break;
+            if (b == 0) return false;
+            munmap(seg_, seg_bytes_); seg_ = nullptr;                          // stale segment: attach again
+            if (attempt > 100) return fail("ZSlabComm(host): only stale segments at " + path);
         }
+        return true;
     }
     if (!hostBarrier()) return false;
     if (rank_ == 0) (void)std::remove(path.c_str());                          // everybody has it mapped: the name has done its job
@@ -129,16 +141,19 @@ bool ZSlabComm::initHost(const std::string& id_path)
 
 char* ZSlabComm::hostSlot(int rank) const { return (char*)seg_ + sizeof(SegHeader) + (size_t)rank * slot_bytes_; }
 
-bool ZSlabComm::hostBarrier()
+bool ZSlabComm::hostBarrier() { return hostBarrierImpl(false) == 1; }
+// 1 = passed, 0 = failed (lastError set), -1 = (watch_magic only) the segment's magic was poisoned while waiting: a stale segment
+int ZSlabComm::hostBarrierImpl(bool watch_magic)
 {
     SegHeader* h = (SegHeader*)seg_;
     const unsigned g = h->gen.load();
-    if (h->arrive.fetch_add(1) + 1 == (unsigned)world_) { h->arrive.store(0); h->gen.store(g + 1); return true; }
+    if (h->arrive.fetch_add(1) + 1 == (unsigned)world_) { h->arrive.store(0); h->gen.store(g + 1); return 1; }
     for (long spins = 0; h->gen.load() == g; ++spins) {
-        if (spins > 1200000) return fail("ZSlabComm(host): barrier timed out after 120 s (a rank is gone)");
+        if (watch_magic && *(volatile unsigned long long*)&h->magic != SEG_MAGIC) return -1;
+        if (spins > 1200000) { fail("ZSlabComm(host): barrier timed out after 120 s (a rank is gone)"); return 0; }
         if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(100)); else std::this_thread::yield();
     }
-    return true;
+    return 1;
 }
 
 ZSlabComm::~ZSlabComm()

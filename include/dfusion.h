@@ -29,7 +29,10 @@
  *     the next call on the handle waits for it on the device -- invisible to the caller.)  dfusion_integrate keeps
  *     its pyramid and launch plan in a scratch buffer cached per (device, stream) -- calls on one
  *     stream are ordered, calls on different streams use different buffers; dfusion_release_scratch()
- *     frees them.  Validation switches and measurement counters are per call / per handle (ABI 4).
+ *     frees them.  At most 8 buffers are kept per device (the least recently used idle one goes); a
+ *     buffer is held for the whole of the call that uses it, so host threads may call on different
+ *     streams concurrently (two threads on the SAME stream are serialised for the enqueue).
+ *     Validation switches and measurement counters are per call / per handle (ABI 4).
  */
 #ifndef DFUSION_H
 #define DFUSION_H
@@ -41,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 4   /* 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
+#define DFUSION_ABI_VERSION 5   /* 5: dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
@@ -97,6 +100,11 @@ enum {
                                  (by default the tables / blend models of blocks NEAR the frame's alive set -- what a moving camera
                                  or a changing warp brings in over the next few frames -- are made beside the sweep, on a stream the
                                  handle owns, so that a block is usually built before it is first swept); validation switch     */
+#define DF_WARP_STEADY_PREFETCH 1024u /* keep the look-ahead side stream on in EVERY frame.  By default a handle whose last plan-kernel report
+                                 * listed nothing to build switches it off until the next probe (every 8th sweep); that report is read from
+                                 * pinned host memory WITHOUT a synchronisation, so which frame switches depends on host / GPU timing --
+                                 * never any result, but swept-voxel counters and frame times of a run.  For tests and measurements that
+                                 * compare such counters between runs (ABI 5).                                                         */
 /* flags for dfusion_warp_build_index */
 #define DF_INDEX_VOXEL_TABLE 1u /* also cache the exact k-NN of EVERY voxel of the slab in HBM:
                                    k * 2 bytes per voxel (2 GiB at 512^3, k = 8) -- the per-frame
@@ -271,12 +279,14 @@ int dfusion_warp_index_info(const DfWarpField *wf, unsigned long long *total_ent
 int dfusion_warp_set_point_tiling(DfWarpField *wf, int image_cols);
 
 /* Device self-test of the sweeps' short arithmetic forms (dfusion_device.h) against the generic ones they replace; no reference
- * counterpart, used by the parity tests.  counts_dev: EIGHT device entries (ABI 2; six in ABI 1), cleared by the call, receive
+ * counterpart, used by the parity tests.  counts_dev: TEN device entries (ABI 5; eight in ABI 2-4, six in ABI 1), cleared by the call, receive
  * mismatch counts: [0] short sqrtf over every f32 of its domain, [1] short f64 reciprocal over every positive normal f32, [2] packed
  * quaternion products on n_random random pairs (specials included), [3] near-unit normalisation on the normalised quaternions among
  * them, [4] how many of those there were, [5] the short fuse division on every finite stored half x 97 weights x (n_random >> 21)
  * tsdf values, [6] the projective sample -- tsdf_sample_fast and the two-stage saturation form of the rigid sweep -- against the
- * generic statements on n_random positions inside the forms' domain and on its edges, [7] how many of those samples updated.        */
+ * generic statements on n_random positions inside the forms' domain and on its edges, [7] how many of those samples updated,
+ * [8] the blend's first normalisation as an f32 division (q_div_f32) against (float)((1.0 / (double)n) * (double)c) on the quaternions
+ * its domain test accepts out of n_random random and edge-of-domain ones, [9] how many quaternions that were.                       */
 int dfusion_selftest_exact_forms(unsigned long long n_random, unsigned long long *counts_dev, dfStream stream);
 
 /* Measurement hook of dfusion_integrate_warped's cached sweep, per warp-field handle (NULL switches it off): while set, every

@@ -38,6 +38,14 @@ namespace cv
         T val[N];
         Vec() { for (int i = 0; i < N; ++i) val[i] = T(0); }
         Vec(T a, T b, T c) { static_assert(N == 3, "3-vector ctor"); val[0] = a; val[1] = b; val[2] = c; }
+        Vec(T a, T b, T c, T d) { static_assert(N == 4, "4-vector ctor"); val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+        // (names the reference's quaternion.hpp uses, tests/ref_host_bridge: plain T arithmetic, left to right)
+        T dot(const Vec& o) const { T s = T(0); for (int i = 0; i < N; ++i) s += val[i] * o.val[i]; return s; }
+        Vec cross(const Vec& o) const
+        {
+            static_assert(N == 3, "cross product of 3-vectors");
+            return Vec(val[1] * o.val[2] - val[2] * o.val[1], val[2] * o.val[0] - val[0] * o.val[2], val[0] * o.val[1] - val[1] * o.val[0]);
+        }
         template <typename U> Vec(const Vec<U, N>& o) { for (int i = 0; i < N; ++i) val[i] = (T)o.val[i]; }
         static Vec all(T v) { Vec r; for (int i = 0; i < N; ++i) r.val[i] = v; return r; }
         T& operator[](int i) { return val[i]; }
@@ -48,14 +56,22 @@ namespace cv
     template <typename T, int N> inline Vec<T, N> operator-(const Vec<T, N>& a, const Vec<T, N>& b) { Vec<T, N> r; for (int i = 0; i < N; ++i) r[i] = a[i] - b[i]; return r; }
     template <typename T, int N> inline Vec<T, N> operator*(const Vec<T, N>& a, T s) { Vec<T, N> r; for (int i = 0; i < N; ++i) r[i] = a[i] * s; return r; }
     typedef Vec<float, 3> Vec3f;
+    typedef Vec<float, 4> Vec4f;
     typedef Vec<double, 3> Vec3d;
     typedef Vec<int, 3> Vec3i;
+    template <typename T, int N> inline Vec<T, N> normalize(const Vec<T, N>& v)
+    {
+        double s = 0; for (int i = 0; i < N; ++i) s += (double)v[i] * v[i];
+        const double n = std::sqrt(s); Vec<T, N> r; for (int i = 0; i < N; ++i) r[i] = (T)(n > 0 ? v[i] / n : 0); return r;
+    }
+    struct Matx44f { float val[16]; Matx44f() { std::memset(val, 0, sizeof(val)); val[0] = val[5] = val[10] = val[15] = 1.f; } };
 
     template <typename T> struct Matx33
     {
         T val[9];                                        // row-major
         Matx33() { std::memset(val, 0, sizeof(val)); val[0] = val[4] = val[8] = T(1); }
         template <typename U> Matx33(const Matx33<U>& o) { for (int i = 0; i < 9; ++i) val[i] = (T)o.val[i]; }
+        Matx33(T a0, T a1, T a2, T a3, T a4, T a5, T a6, T a7, T a8) { const T v[9] = {a0, a1, a2, a3, a4, a5, a6, a7, a8}; std::memcpy(val, v, sizeof(val)); }
         T& operator()(int r, int c) { return val[3 * r + c]; }
         T operator()(int r, int c) const { return val[3 * r + c]; }
         Matx33 inv(int /*method*/ = DECOMP_LU) const     // adjugate in double (kfusion/types.hpp Mat3f::inv)
@@ -71,6 +87,11 @@ namespace cv
     };
     typedef Matx33<float> Matx33f;
     typedef Matx33<double> Matx33d;
+    template <typename T> inline Vec<T, 3> operator*(const Matx33<T>& m, const Vec<T, 3>& v)      // (Matx * Vec: in T, left to right)
+    {
+        return Vec<T, 3>(m(0, 0) * v[0] + m(0, 1) * v[1] + m(0, 2) * v[2], m(1, 0) * v[0] + m(1, 1) * v[1] + m(1, 2) * v[2],
+                         m(2, 0) * v[0] + m(2, 1) * v[1] + m(2, 2) * v[2]);
+    }
 
     // reference-counted owner (cv::Ptr<T>(new T) as demo.cpp:27 uses it)
     template <typename T> struct Ptr : std::shared_ptr<T>
@@ -117,6 +138,13 @@ namespace cv
     private:
         int type_;
         std::shared_ptr<std::vector<unsigned char>> buf_;
+    };
+
+    struct Mat3f
+    {
+        std::vector<Vec3f> rows_;
+        void push_back(const Vec3f& v) { rows_.push_back(v); }
+        template <typename T> T at(int r, int c) const { return (T)rows_[(size_t)r][c]; }
     };
 
     void glob(String pattern, std::vector<String>& result, bool recursive = false);   // every entry of the directory `pattern`

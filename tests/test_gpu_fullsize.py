@@ -85,6 +85,18 @@ def test_full_size_properties_and_sampled_oracle(name):
         assert s["bits_mismatch"] == 0, s
         n_checked += int(((ref >> 16) != 0).sum())
     assert n_checked > 0.05 * 2 * len(pairs) * X * Y                     # the sample lies in the fused part of the volume
+    # ---- 1024^3 (BASELINE config 5): ONE CONTIGUOUS band of 64 planes, both frames, through the reference's OWN classes (nanoflann +
+    # WarpField::DQB + DualQuaternion, oracle/_ref) -- 8 whole tile layers with everything between their boundaries (VERDICT r4 #4 ii;
+    # the full-volume comparisons stop at 512^3: a 1024^3 frame is 43 s of the host's 128 threads)
+    if name == "1024" and O.have_ref():
+        zb, nb = Z // 2 - 32, 64
+        band = np.zeros((nb, Y, X), np.uint32)
+        for f in range(2):
+            O.ref_integrate_warped(sc.dists[f], band, cfg.dims, sc.vs, sc.trunc, cfg.max_weight, synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)),
+                                   sc.intr, sc.pos, sc.dqs[f], sc.sigma, cfg.k, zb, zb, nb)
+        got = a.data()[zb:zb + nb].cpu().numpy().view(np.uint32)
+        assert ((band >> 16) != 0).sum() > 0.05 * band.size
+        assert np.array_equal(got, band), "%d of %d voxels of planes [%d, %d) differ" % (int((got != band).sum()), band.size, zb, zb + nb)
 
     # ---- slab-sharded (world = 8) integrate + raycast == unsharded
     world = 8
