@@ -47,18 +47,25 @@ def parse(argv=None):
                          "(a steady-state loop: every table and block model exists before the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rigid", action="store_true", help="(kept for old command lines; the extra kernels are timed by default)")
-    ap.add_argument("--halo", choices=["recompute", "exchange"], default="recompute",
+    ap.add_argument("--halo", choices=["recompute", "exchange", "both"], default="recompute",
                     help="N>1: how a rank gets its neighbours' boundary planes for the ray-cast -- recompute them (default: every rank "
                          "integrates its halo planes too, no collective) or exchange them after the integrate (paired isend/irecv over RCCL, "
-                         "the north star's wording; one more collective per frame, 2*H fewer planes to sweep)")
+                         "the north star's wording; one more collective per frame, 2*H fewer planes to sweep); `both` = `recompute` for the "
+                         "headline, and the exchange form timed as a variant in the same launch (scaling_detail.variants -- what N>1 runs do by default)")
     ap.add_argument("--slabs", choices=["balanced", "uniform", "measured"], default="measured",
                     help="N>1: Z-slab boundaries -- `balanced`: equal shares of an a-priori work model (planes weighted by how much of them lies "
                          "inside the frustum and in front of the first frame's surface); `measured` (default): start from `balanced`, then "
                          "re-cut once after the priming frames from the verdict pass's alive-block counts per plane (what the sweep really "
                          "visits), slabs re-allocated; `uniform`: equal plane counts")
-    ap.add_argument("--merge", choices=["rows", "root"], default="rows",
+    ap.add_argument("--merge", choices=["rows", "a2a", "root"], default="rows",
                     help="N>1: the ray-cast's second collective -- `rows` (default): reduce_scatter of the normals by pixel rows, every rank finishes "
-                         "its band (image stays row-sharded; 1/N of the bytes lands on a rank); `root`: reduce(SUM) to rank 0, which makes the whole image")
+                         "its band (image stays row-sharded; 1/N of the bytes lands on a rank); `a2a` (round 5): the same bands by ONE direct "
+                         "all-to-all of fixed-size pieces + a local sum (no ring, no count exchange); `root`: reduce(SUM) to rank 0, which makes "
+                         "the whole image.  N>1 runs time the other forms as variants after the timed region (scaling_detail.variants)")
+    ap.add_argument("--no-variants", action="store_true", help="N>1: skip the untimed variant passes (the other merges, the halo exchange)")
+    ap.add_argument("--long-frames", type=int, default=200,
+                    help="frame_stats.long_sweep: the sweep goes on (untimed by the wall clock, HIP events per frame) until this many consecutive frames "
+                         "have been measured -- the headline's 20 poses move +-6 %% with which poses they are (VERDICT r4 #7); 0 = off")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects (rigid_integrate, extract_cloud, kinfu_frame)")
     ap.add_argument("--no-kinfu", action="store_true", help="skip the kinfu_frame extra (it runs a child process; use under profilers)")
     ap.add_argument("--no-verify-cull", action="store_true",
@@ -133,6 +140,10 @@ def dry_run(args, rank, world):
             dist.broadcast(bundle, 0)
             dist.all_reduce(keys, op=dist.ReduceOp.MIN)
             dist.reduce(nrm.view(torch.int32), dst=0, op=dist.ReduceOp.SUM)
+            per, _ = sharded.row_bands(cfg.rows, world)           # the row-banded forms of the second collective (--merge rows / a2a)
+            pad = torch.zeros((world * per, cfg.cols, 4), dtype=torch.float32)
+            sharded.coll_reduce_scatter_rows(pad.view(torch.int32), torch.empty((per, cfg.cols, 4), dtype=torch.int32))
+            sharded.coll_all_to_all_rows(pad.view(torch.int32), torch.empty((world, per, cfg.cols, 4), dtype=torch.int32))
     if dist.is_initialized():
         dist.all_reduce(alive, op=dist.ReduceOp.SUM)       # the re-balance's per-plane alive counts
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
@@ -359,8 +370,9 @@ def main():
     # all consecutive poses of one sweep unless --frames F asks for F cycled poses
     n_extra = max(0, MIN_STAT_FRAMES - args.steps)
     n_seq = N_PRIME + args.warmup + args.steps + n_extra
-    F = args.frames if args.frames > 0 else n_seq
     monotone = args.frames <= 0
+    n_long = max(0, args.long_frames - args.steps - n_extra) if (monotone and args.config != "1024") else 0     # frames of the sweep past the percentile window
+    F = args.frames if args.frames > 0 else n_seq + n_long
 
     # ---- synthetic inputs, resident in HBM before the timed region (rank 0 owns the sensor and the solver output)
     cam_poses = [synth.camera_pose(cfg, f) for f in range(F)]
@@ -368,7 +380,10 @@ def main():
     dqs_np0 = synth.node_transforms(cfg, 0)
     depth0_np = synth.depth_frame(cfg, 0)
     if rank == 0 or not dist_on:
-        depths_np = [depth0_np] + [synth.depth_frame(cfg, f) for f in range(1, F)]
+        # (the synthetic sensor is numpy on one core, 0.4 s a frame: the sweep's frames are made on a thread pool)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(32, (os.cpu_count() or 8) // max(world, 1)))) as pool:
+            depths_np = [depth0_np] + list(pool.map(lambda f: synth.depth_frame(cfg, f), range(1, F)))
         depths = [upload_u16(d, dev) for d in depths_np]
         dqs = [torch.from_numpy(synth.node_transforms(cfg, f)).to(dev) for f in range(F)]
     else:
@@ -390,7 +405,7 @@ def main():
         v.clear()
         # N > 1: every rank also integrates its halo planes (a pure function of the broadcast inputs: bit-identical with the
         # neighbour's planes), so the frame has NO halo collective; `vi` is the same blob seen as owner of all its stored planes.
-        vi = v.owning_stored_planes() if (dist_on and args.halo == "recompute") else v
+        vi = v.owning_stored_planes() if (dist_on and args.halo in ("recompute", "both")) else v
         return v, vi
 
     def share_bounds(b):
@@ -425,50 +440,66 @@ def main():
     keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device=dev) if dist_on else None
     out2 = torch.empty((2, cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev)
     pts, nrm = out2[0], out2[1]
-    rows_merge = dist_on and args.merge == "rows"
+    rows_merge = dist_on          # (the band buffers exist whenever the frame is sharded: the variant passes use them too)
     if rows_merge:       # the normals buffer the reduce_scatter splits: world * per rows (rows past the image stay zero), + this rank's band
         per_rows, _ = sharded.row_bands(cfg.rows, world)
         nrm_pad = torch.zeros((world * per_rows, cfg.cols, 4), dtype=torch.float32, device=dev)
         nrm_band = torch.empty((per_rows, cfg.cols, 4), dtype=torch.float32, device=dev)
         pts_band = torch.empty((per_rows, cfg.cols, 4), dtype=torch.float32, device=dev)
+        a2a_recv = torch.empty((world, per_rows, cfg.cols, 4), dtype=torch.float32, device=dev)     # the direct merge's N pieces of this rank's band
     # frame inputs travel as ONE byte bundle (depth image + node transforms): one ncclBroadcast per frame
     n_depth = cfg.rows * cfg.cols * 2
     bundle = torch.empty(n_depth + cfg.nodes * 32, dtype=torch.uint8, device=dev)
     depth_in = bundle[:n_depth].view(torch.int16).view(cfg.rows, cfg.cols)
     dq_in = bundle[n_depth:].view(torch.float32).view(cfg.nodes, 8)
 
-    def step(i, ev=None):
+    halo_main = "recompute" if args.halo == "both" else args.halo
+
+    def step(i, ev=None, timer=None, merge=None, halo_mode=None):
+        """one frame.  timer: a sharded.StageTimer (the stages of this frame are marked); merge / halo_mode: a variant of the frame's
+        second collective / of how the halo planes are made (default: the command line's)."""
         f = i % F
+        merge = args.merge if merge is None else merge
+        halo_mode = halo_main if halo_mode is None else halo_mode
+        mark = timer.mark if timer is not None else (lambda name: None)
+        if timer is not None: timer.start()
         if dist_on:                                    # rank 0 owns the sensor frame and the solver output
             if rank == 0:
                 depth_in.copy_(depths[f]); dq_in.copy_(dqs[f])
             sharded.coll_broadcast(bundle, 0)
+            mark("broadcast")
             d_in, q_in = depth_in, dq_in
         else:
             d_in, q_in = depths[f], dqs[f]
         wf.set_transforms(q_in)
         compute_dists(d_in, intr, dists)
+        mark("set_transforms+compute_dists")
         if ev is not None: ev[0].record()
-        vol_int.integrate_warped(dists, cam_poses[f], intr, wf, sync=False, prefetch=not args.no_prefetch)
+        # (halo recompute: the integrate owns every stored plane; halo exchange: its own planes, the halos come from the neighbours)
+        (vol_int if halo_mode == "recompute" else vol).integrate_warped(dists, cam_poses[f], intr, wf, sync=False, prefetch=not args.no_prefetch)
+        mark("integrate_warped")
         if ev is not None: ev[1].record()
-        if dist_on and args.halo == "exchange":
+        if dist_on and halo_mode == "exchange":
             sharded.exchange_halos(vol.data(), vol.z_store0, vol.z_own0, vol.z_own_n, Z, halo, rank, world)
-        if rows_merge:
+            mark("halo_exchange")
+        if dist_on and merge in ("rows", "a2a"):
             def shade_padded(mk):
                 vol.raycast_shade(cam_poses[f], intr, mk, None, nrm_pad[:cfg.rows])
                 return nrm_pad
             out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, rank), shade_padded,
                                           lambda mk, nb, r0, nr: vol.raycast_points_of_keys(cam_poses[f], intr, mk, nb, pts_band[:nr], r0, nr),
-                                          rank, world, collectives=True, merge="rows", band_out=nrm_band)
+                                          rank, world, collectives=True, merge=merge, band_out=nrm_band, a2a_recv=a2a_recv, timer=timer)
         elif dist_on:
             out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, rank),
                                           lambda mk: vol.raycast_shade(cam_poses[f], intr, mk, None, nrm)[1],
                                           lambda mk, n: vol.raycast_points_of_keys(cam_poses[f], intr, mk, n, pts),
-                                          rank, world, collectives=True)
+                                          rank, world, collectives=True, timer=timer)
         else:
             vol.raycast(cam_poses[f], intr, pts, nrm)
+            mark("raycast")
             out = (pts, nrm)
         if ev is not None: ev[2].record()
+        if timer is not None: timer.end()
         return out
 
     def barrier():
@@ -527,10 +558,17 @@ def main():
     vol_end = vol.data().clone() if verify else None
     timed_frames = [(i0 + i) % F for i in range(args.steps)]
 
-    # ---- the sweep goes on (untimed by the wall clock, HIP events per frame) until the percentiles have MIN_STAT_FRAMES samples
+    # ---- the sweep goes on (untimed by the wall clock, HIP events per frame) until the percentiles have MIN_STAT_FRAMES samples; these
+    # frames also carry the per-stage events (sharded.StageTimer: every collective and kernel stage of the frame, per rank) -- not the
+    # timed ones, whose wall clock they would stretch by a dozen event records per frame
     ev_more = events(n_extra)
+    stage_timer = sharded.StageTimer()
     for i in range(n_extra):
-        step(i0 + args.steps + i, ev_more[i])
+        step(i0 + args.steps + i, ev_more[i], timer=stage_timer)
+    # ---- ... and on, to args.long_frames consecutive frames of the sweep (frame_stats.long_sweep)
+    ev_long = events(n_long)
+    for i in range(n_long):
+        step(i0 + args.steps + n_extra + i, ev_long[i])
     torch.cuda.synchronize()
     ms_int = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     ms_ray = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
@@ -545,6 +583,12 @@ def main():
                    "trajectory": ("monotone sweep, 0.25 deg per frame: %d priming + %d warm-up + %d timed + %d more frames, poses %d..%d timed"
                                   % (N_PRIME, args.warmup, args.steps, n_extra, i0, i0 + args.steps - 1)) if monotone else "%d poses cycled" % F,
                    "reference_shaped_ms": ms_int + 2.0 * ms_ray}
+    if n_long:
+        lf = np.array([e[0].elapsed_time(e[2]) for e in ev + ev_more + ev_long], np.float64)
+        frame_stats["long_sweep"] = {"frames": int(lf.size), "integrate+raycast_ms_mean": float(lf.mean()), "p10": float(np.percentile(lf, 10)),
+                                     "median": float(np.median(lf)), "p90": float(np.percentile(lf, 90)),
+                                     "what": "HIP-event integrate + ray-cast time of %d consecutive frames of the same sweep starting at the first timed pose "
+                                             "(the headline times the first %d of them; later poses look past the scene and sweep less)" % (lf.size, args.steps)}
     if monotone:
         # round 3's headline for comparison: the last four poses cycled -- every table and block model they need exists
         loop = [n_seq - 4 + j for j in range(4)]
@@ -590,6 +634,63 @@ def main():
         n_upd_total = n_upd_launch
     alg_bytes = 8.0 * n_upd_launch + 2.0 * cfg.cols * cfg.rows + 48.0 * cfg.nodes
     achieved = alg_bytes / (ms_int * 1e-3) / 1e9
+    frame_stats["timed_poses_mean_swept_voxels"] = n_swept_launch          # (this rank's planes; what roofline.traffic's profile is compared with)
+    frame_stats["timed_poses_mean_updated_voxels"] = n_upd_launch
+
+    # ---- per rank, per stage: HIP-event means over the n_extra frames after the timed region, gathered on rank 0; and,
+    # N > 1, the OTHER forms of the frame's collectives timed back to back in the same launch (wall clock between barriers + stages)
+    def gather(obj):
+        if not dist_on:
+            return [obj]
+        lst = [None] * world
+        dist.all_gather_object(lst, obj)
+        return lst
+
+    scaling_detail = None
+    if n_extra > 0:
+        per_rank = gather(stage_timer.means())
+        stages = list(per_rank[0].keys())
+        scaling_detail = {"stages": stages, "per_rank_ms": {k: [float(pr.get(k, float("nan"))) for pr in per_rank] for k in stages},
+                          "frames": n_extra, "how": "HIP events on each rank's launch stream around every stage, mean over the %d frames that follow the "
+                                                     "timed region (the same sweep; not the timed frames, which carry 3 events each)" % n_extra}
+    if dist_on and scaling_detail is not None:
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        sharded.coll_all_reduce(ones, dist.ReduceOp.SUM)
+        scaling_detail["rccl_ranks_seen"] = int(ones.item())
+        scaling_detail["backend"] = dist.get_backend()
+        scaling_detail["devices"] = gather("%s:%d" % (torch.cuda.get_device_name(dev), dev.index))
+        px = cfg.rows * cfg.cols
+        sizes = {"broadcast": px * 2 + cfg.nodes * 32, "all_reduce_min": px * 8, "reduce_scatter": px * 16, "all_to_all": px * 16, "reduce": px * 16,
+                 "halo_exchange": halo * X * Y * 4}
+        kinds = {"broadcast": "broadcast", "all_reduce_min": "all_reduce", "reduce_scatter": "reduce_scatter", "all_to_all": "all_to_all",
+                 "reduce": "reduce", "halo_exchange": "halo"}
+        scaling_detail["predicted_collective_ms"] = {k: 1e3 * sharded.collective_model_s(kinds[k], sizes[k], world) for k in sizes}
+        scaling_detail["predicted_how"] = ("tools/scale_model.py's stated model: %.0f us per call + %.0f us per ring step + bytes on the busiest link / %.0f GB/s "
+                                           "(rings: N - 1 steps, all_reduce 2 (N - 1); all_to_all and the halo exchange: one step)"
+                                           % (sharded.T_LAUNCH * 1e6, sharded.T_HOP * 1e6, sharded.LINK_GBPS))
+        if world > 1 and not args.no_variants:
+            variants = {}
+            n_var = max(4, min(10, args.steps))
+            base = i0 + args.steps                       # (the poses right after the timed ones, every variant the same ones)
+            todo = [("merge=%s" % m, dict(merge=m)) for m in ("rows", "a2a", "root")] + [("halo=exchange", dict(halo_mode="exchange"))]
+            for name, kw in todo:
+                tm = sharded.StageTimer()
+                for i in range(2):
+                    step(base + i, **kw)
+                barrier()
+                t1 = time.perf_counter()
+                for i in range(n_var):
+                    step(base + i, timer=tm, **kw)
+                barrier()
+                dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+                sharded.coll_all_reduce(dt, dist.ReduceOp.MAX)
+                pr = gather(tm.means())
+                variants[name] = {"ms_per_frame": 1e3 * float(dt.item()) / n_var, "frames": n_var,
+                                  "per_rank_ms": {k: [float(r.get(k, float("nan"))) for r in pr] for k in pr[0].keys()}}
+            scaling_detail["variants"] = variants
+            scaling_detail["variants_how"] = ("after the timed region, %d frames each (poses %d..%d, every variant the same; wall clock between barriers, "
+                                              "max over ranks, incl. the stage events): the headline's form is merge=%s, halo=%s"
+                                              % (n_var, base, base + n_var - 1, args.merge, halo_main))
 
     # ---- the launch plan's cull, verified on the timed frames themselves: the same frames from the same start volume with the cull
     # switched off (every voxel goes through the reference's own tests, tsdf_volume.cu:77-93) must leave the same bits
@@ -770,14 +871,17 @@ def main():
                        "depth": [cfg.cols, cfg.rows], "warp_nodes": cfg.nodes, "k": cfg.k,
                        "parallelism": "zslab%d" % world if dist_on else "single", "halo_planes": halo if dist_on else 0,
                        "slab_bounds": slab_bounds, "slabs": args.slabs if dist_on else None,
-                       "halo": (("integrated redundantly by every rank, no halo collective" if args.halo == "recompute" else
+                       "halo": (("integrated redundantly by every rank, no halo collective" if halo_main == "recompute" else
                                  "exchanged after the integrate (paired isend/irecv of %d planes per side)" % halo) if dist_on else None),
                        "raycast_merge": (("all_reduce(MIN) of the keys + reduce_scatter(SUM) of the normals by pixel rows: every rank finishes its band "
                                           "of %d rows, the image stays row-sharded" % sharded.row_bands(cfg.rows, world)[0]) if args.merge == "rows" else
+                                         ("all_reduce(MIN) of the keys + one direct all-to-all of the normals' row bands (fixed-size pieces, no counts) + a local "
+                                          "sum: every rank finishes its band of %d rows" % sharded.row_bands(cfg.rows, world)[0]) if args.merge == "a2a" else
                                          "all_reduce(MIN) of the keys + reduce(SUM) of the normals to rank 0") if dist_on else None,
                        "frame": "set_transforms + compute_dists + integrate_warped + raycast_points"},
             "kernel_ms": {"integrate_warped": ms_int, "raycast(+merge)": ms_ray, "index_build_once_s": t_index},
             "frame_stats": frame_stats,
+            "scaling_detail": scaling_detail,
             "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src, "compute": compute,

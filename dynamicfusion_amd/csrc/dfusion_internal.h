@@ -69,6 +69,7 @@ struct DfWarpField {
     float* tile_wmax; size_t tile_wmax_cap;             // per table tile: max over its voxels of the weight sum (with w_tab)
     // device scalars for the conservative brick cull: [0] max |t_i|, [1] max sin(theta_i/2), [2] max dists
     float* bounds_dev;
+    int max_phase;                    // which of bounds_dev[6], [7] this frame's capped pyramid leaves the image-wide maximum in
     uint16_t* pyr_mem; size_t pyr_cap;      // max-pyramid of the frame's dists image (warped sweep's depth cull), entries
     // scratch of dfusion_warp_solve_data_term (grown on demand)
     void* solver_ws; size_t solver_ws_cap;

@@ -1730,7 +1730,7 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
 {
     __shared__ unsigned int s_cnt[DF_PLAN_BINS], s_base[DF_PLAN_BINS];
     if (threadIdx.x < DF_PLAN_BINS) { s_cnt[threadIdx.x] = 0u; if (blockIdx.x == 0) cnt_next[threadIdx.x] = 0u; }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.py.capped) *const_cast<uint32_t*>(a.py.max_bits) = 0u;     // (its readers, the verdict pass, are done: 0 again for the next frame's pyramid)
+    if (blockIdx.x == 0 && threadIdx.x < 2 && a.py.capped && a.cull) ((uint32_t*)a.cull)[6 + threadIdx.x] = 0u;   // (both image-maximum words: this frame's -- its readers, the verdict pass, are done -- and the other one, see the launcher)
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.host_report && a.blk_cnt) {      // (the verdict pass is complete: this kernel follows it in the stream)
         a.host_report[0] = a.blk_cnt[0]; a.host_report[1] = a.blk_cnt[1]; a.host_report[2] = a.blk_cnt[3]; a.host_report[3] = a.sweep_no;
     }
@@ -2372,11 +2372,13 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
             // the pipelined sweep (the product path) reads the pyramid in its verdict pass only, and its plan kernel re-arms the
             // image-maximum word: levels 1..5 in ONE launch.  The other kernels take the full pyramid (two launches).
             const bool pipe_path = pipe_sweep;
-            // (the image-maximum word is re-armed by the plan kernel after its readers; a call that returned early in between would leave
-            // the previous frame's maximum in it -- conservative, but a silently weaker cull: zeroed here as well)
-            if (pipe_path) DF_HIP(hipMemsetAsync(wf->bounds_dev + 6, 0, sizeof(float), st));
+            // The image-maximum word: TWO of them ([6], [7]), used alternately; every plan kernel zeroes both once its readers are done.
+            // A call that returns early between its pyramid build and its plan kernel leaves ITS word dirty -- the next call uses the other
+            // one (zeroed by the plan kernel before), and that call's plan kernel cleans both (no memset node per frame).
+            wf->max_phase ^= 1;
+            unsigned int* max_word = (unsigned int*)(wf->bounds_dev + 6 + wf->max_phase);
             int rc = df_build_dists_pyramid(dists, pitch, cols, rows, wf->pyr_mem, wf->pyr_cap, &a.py, st, pipe_path, nullptr,
-                                            pipe_path ? (unsigned int*)(wf->bounds_dev + 6) : nullptr);
+                                            pipe_path ? max_word : nullptr);
             if (rc) return rc;
         }
         if (a.py.top == 0) {                                      // no pyramid (switched off, or an image under 32 px): the image-wide maximum alone

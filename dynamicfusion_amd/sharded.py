@@ -83,6 +83,97 @@ def coll_reduce_scatter_rows(full, out, group=None):
         out.copy_(c[rank * per:(rank + 1) * per])
 
 
+def coll_all_to_all_rows(full, recv, group=None):
+    """recv[s] <- rank s's copy of THIS rank's band: full is [world * per, ...] (band d = what goes to rank d), recv [world, per, ...].
+    RCCL: one ncclSend / ncclRecv group (all_to_all_single with equal splits) -- every byte crosses ONE xGMI link once, the seven links
+    of a rank in parallel, no ring.  gloo / host-staged runs: all_to_all_single where the backend has it, else paired isend / irecv."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = recv.shape[1]
+    assert full.shape[0] == world * per and recv.shape[0] == world
+    if dist.get_backend(group) == "nccl" and not _staged(full):
+        dist.all_to_all_single(recv.view(world * per, *recv.shape[2:]), full, group=group)
+        return
+    src = full.cpu() if full.is_cuda else full
+    dst = torch.empty((world * per,) + tuple(full.shape[1:]), dtype=full.dtype)
+    try:
+        dist.all_to_all_single(dst, src.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError):                    # (a gloo build without alltoall: the same exchange as point-to-point pairs)
+        ops = []
+        for r in range(world):
+            if r == rank:
+                dst[r * per:(r + 1) * per].copy_(src[r * per:(r + 1) * per])
+            else:
+                ops.append(dist.P2POp(dist.isend, src[r * per:(r + 1) * per].contiguous(), r, group))
+                ops.append(dist.P2POp(dist.irecv, dst[r * per:(r + 1) * per], r, group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    recv.copy_(dst.view(recv.shape))
+
+
+# ---- the collective model of tools/scale_model.py (DESIGN.md section 5), here so that bench.py can print the PREDICTED time of every
+# collective next to the one it measures: t = launches * T_LAUNCH + steps * T_HOP + bytes on the busiest link / LINK_GBPS
+T_LAUNCH, T_HOP, LINK_GBPS = 15e-6, 5e-6, 100.0
+
+
+def collective_model_s(kind, size, n):
+    """kind: broadcast | all_reduce | reduce | reduce_scatter (rings: N - 1 or 2 (N - 1) steps) | all_to_all (direct: one step, size / N
+    per link, all links of a rank in parallel) | halo (one paired send / receive of `size` bytes per side)."""
+    if n == 1:
+        return 0.0
+    if kind == "broadcast":
+        steps, b = n - 1, size
+    elif kind == "all_reduce":
+        steps, b = 2 * (n - 1), 2.0 * (n - 1) / n * size
+    elif kind == "reduce_scatter":
+        steps, b = n - 1, (n - 1.0) / n * size
+    elif kind == "all_to_all":
+        steps, b = 1, size / n
+    elif kind == "halo":
+        steps, b = 1, size
+    else:
+        steps, b = n - 1, size
+    return T_LAUNCH + steps * T_HOP + b / (LINK_GBPS * 1e9)
+
+
+class StageTimer:
+    """Per-stage times of a frame: mark(name) closes the stage `name` (everything enqueued on the current stream since the previous
+    mark).  HIP events on the launch stream -- torch.distributed's collectives make that stream wait for them before returning, so a
+    mark after a collective is after its completion -- or the host clock without a GPU.  means() -> {stage: mean ms}, in first-seen order."""
+
+    def __init__(self, cuda=None):
+        self.cuda = torch.cuda.is_available() if cuda is None else cuda
+        self.frames, self.cur = [], None
+
+    def _now(self):
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True); e.record(); return e
+        import time
+        return time.perf_counter()
+
+    def start(self):
+        self.cur = [("", self._now())]
+
+    def mark(self, name):
+        if self.cur is not None:
+            self.cur.append((name, self._now()))
+
+    def end(self):
+        if self.cur is not None:
+            self.frames.append(self.cur); self.cur = None
+
+    def means(self):
+        if self.cuda:
+            torch.cuda.synchronize()
+        acc, order = {}, []
+        for fr in self.frames:
+            for (_, a), (name, b) in zip(fr[:-1], fr[1:]):
+                ms = a.elapsed_time(b) if self.cuda else 1e3 * (b - a)
+                if name not in acc:
+                    acc[name] = []; order.append(name)
+                acc[name].append(ms)
+        return {k: float(np.mean(acc[k])) for k in order}
+
+
 NO_EVENT = 0xFFFFFFFF                 # per-slab event key (step << 1 | hit): none
 KEY_NONE = 0x7FFFFFFFFFFFFFFF         # merge key: no event (include/dfusion.h DF_RC_KEY_NONE)
 MAX_RANKS = 128                       # the merge key carries the rank in 7 bits
@@ -268,7 +359,8 @@ def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, 
         r.wait()
 
 
-def raycast_sharded(march_fn, shade_fn, points_fn, rank, world, dst=0, group=None, collectives=None, merge="root", band_out=None):
+def raycast_sharded(march_fn, shade_fn, points_fn, rank, world, dst=0, group=None, collectives=None, merge="root", band_out=None,
+                    a2a_recv=None, timer=None):
     """Sharded ray-cast (include/dfusion.h: dfusion_raycast_march / _shade / _points_of_keys).
 
     march_fn()                  -> keys64 int64 [rows, cols]: the merge keys of this slab (first event | rank | Ts bits)
@@ -285,25 +377,47 @@ def raycast_sharded(march_fn, shade_fn, points_fn, rank, world, dst=0, group=Non
     points_fn(keys64, normals_band, row0, nrows) -> points of the band; shade_fn must return a buffer of world * per rows (row_bands),
     band_out an int32-viewable [per, cols, 4] float tensor.  Returns (points_band, normals_band, (row0, nrows)) on EVERY rank: the image
     stays row-sharded for a row-sharded consumer (DESIGN.md section 5 says what that consumer is).
-    collectives: None = only when world > 1; True = also with one rank (an RCCL dry run of the dtypes and ops)."""
+    merge = "a2a" (round 5): the same row bands, but every pixel's normal travels DIRECTLY from the rank that made it to the rank that
+    finishes its row: one all-to-all of the band-sized pieces of the (padded) normals image -- each piece crosses one xGMI link once,
+    the seven links of a rank in parallel: N - 1 times fewer sequential steps than the ring behind reduce_scatter, the same bytes per
+    link -- and the receiver adds the N pieces of its band (integer adds; every summand but one is zero, so the sum is the owner's bits).
+    No counts are exchanged: the pieces have a fixed size.  a2a_recv: [world, per, cols, 4] float buffer for the pieces.
+    collectives: None = only when world > 1; True = also with one rank (an RCCL dry run of the dtypes and ops).
+    timer: a StageTimer; the stages march / all_reduce_min / shade / reduce_scatter | all_to_all | reduce / points are marked."""
     on = world > 1 if collectives is None else collectives
+    mark = timer.mark if timer is not None else (lambda name: None)
     keys64 = march_fn()
+    mark("march")
     if on:
         coll_all_reduce(keys64, dist.ReduceOp.MIN, group=group)
+        mark("all_reduce_min")
     normals = shade_fn(keys64)
-    if merge == "rows":
+    mark("shade")
+    if merge in ("rows", "a2a"):
         rows = keys64.shape[0]
         per, bands = row_bands(rows, world)
         row0, nrows = bands[rank]
         if on:
             assert normals.shape[0] == world * per and band_out is not None and band_out.shape[0] == per
-            coll_reduce_scatter_rows(normals.view(torch.int32), band_out.view(torch.int32), group=group)
+            if merge == "a2a":
+                assert a2a_recv is not None and a2a_recv.shape[0] == world and a2a_recv.shape[1] == per
+                coll_all_to_all_rows(normals.view(torch.int32), a2a_recv.view(torch.int32), group=group)
+                torch.sum(a2a_recv.view(torch.int32), dim=0, out=band_out.view(torch.int32))
+                mark("all_to_all")
+            else:
+                coll_reduce_scatter_rows(normals.view(torch.int32), band_out.view(torch.int32), group=group)
+                mark("reduce_scatter")
             nb = band_out[:nrows]
         else:
             nb = normals[row0:row0 + nrows]
-        return points_fn(keys64, nb, row0, nrows), nb, (row0, nrows)
+        out = points_fn(keys64, nb, row0, nrows)
+        mark("points")
+        return out, nb, (row0, nrows)
     if on:
         coll_reduce(normals.view(torch.int32), dst, dist.ReduceOp.SUM, group=group)
+        mark("reduce")
         if rank != dst:
             return None, None
-    return points_fn(keys64, normals), normals
+    out = points_fn(keys64, normals)
+    mark("points")
+    return out, normals

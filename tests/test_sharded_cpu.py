@@ -95,7 +95,7 @@ def _worker(rank, world, port, recompute_halo, balanced=False, merge="root"):
                 return torch.from_numpy(O.raycast_points_of_keys(synth.aff12(sc.cam2vol(f)), sc.rinv(f), sc.reproj, ts, merged, normals.numpy(),
                                                                  CFG.cols, CFG.rows))
 
-            if merge == "rows":
+            if merge in ("rows", "a2a"):
                 per, bands = sharded.row_bands(CFG.rows, world)
 
                 def shade_padded(k64):
@@ -108,14 +108,21 @@ def _worker(rank, world, port, recompute_halo, balanced=False, merge="root"):
                     full[r0:r0 + nr] = nb
                     return points(k64, full)[r0:r0 + nr]
 
-                pts, nrm, (r0, nr) = sharded.raycast_sharded(march, shade_padded, points_band, rank, world, merge="rows",
-                                                             band_out=torch.empty((per, CFG.cols, 4), dtype=torch.float32))
+                timer = sharded.StageTimer(cuda=False)
+                timer.start()
+                pts, nrm, (r0, nr) = sharded.raycast_sharded(march, shade_padded, points_band, rank, world, merge=merge,
+                                                             band_out=torch.empty((per, CFG.cols, 4), dtype=torch.float32),
+                                                             a2a_recv=torch.empty((world, per, CFG.cols, 4), dtype=torch.float32) if merge == "a2a" else None,
+                                                             timer=timer)
+                timer.end()
+                stages = list(timer.means())
+                assert stages == ["march", "all_reduce_min", "shade", "all_to_all" if merge == "a2a" else "reduce_scatter", "points"], stages
             else:
                 pts, nrm = sharded.raycast_sharded(march, shade, points, rank, world)
         # every rank checks its slab (own + halo planes) against the unsharded volume; rank 0 checks the merged cast
         full, fp, fn = _unsharded(sc)
         assert np.array_equal(vol, full[lo:hi]), "rank %d: slab (incl. halos) differs from the unsharded volume" % rank
-        if merge == "rows":                                                     # every rank holds its band of the merged image
+        if merge in ("rows", "a2a"):                                            # every rank holds its band of the merged image
             assert r0 == bands[rank][0] and nr == bands[rank][1] and sum(b[1] for b in bands) == CFG.rows
             assert np.array_equal(pts.numpy().view(np.uint32), fp[r0:r0 + nr].view(np.uint32)), "rank %d: band of the merged vertices differs" % rank
             assert np.array_equal(nrm.numpy().view(np.uint32), fn[r0:r0 + nr].view(np.uint32)), "rank %d: band of the merged normals differs" % rank
@@ -154,6 +161,22 @@ def test_zslab_pipeline_row_banded_merge(world):
     """The ray-cast's second collective as a reduce_scatter by pixel rows (bench.py's default, round 4): every rank ends with its band of
     the merged image, bit-identical with the unsharded cast's rows."""
     mp.spawn(_worker, args=(world, _free_port(), True, False, "rows"), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_zslab_pipeline_direct_all_to_all_merge(world):
+    """Round 5: the second collective without a ring -- every rank sends each other rank ITS band of the normals it made
+    (fixed-size pieces: no count exchange), the receiver adds the pieces of its band.  Same bits as the unsharded cast's rows."""
+    mp.spawn(_worker, args=(world, _free_port(), True, False, "a2a"), nprocs=world, join=True)
+
+
+def test_collective_model_orders_the_merges():
+    # the stated model (tools/scale_model.py): the direct all-to-all beats the ring reduce_scatter from 4 ranks on, both beat reduce-to-root
+    px16 = 640 * 480 * 16
+    for n in (4, 8):
+        a, rs, rd = (sharded.collective_model_s(k, px16, n) for k in ("all_to_all", "reduce_scatter", "reduce"))
+        assert a < rs < rd
+    assert sharded.collective_model_s("all_reduce", 1 << 20, 1) == 0.0
 
 
 def test_zslab_pipeline_over_gloo_with_work_balanced_slabs():

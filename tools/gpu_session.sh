@@ -2,7 +2,7 @@
 # Measurement session of a round: tests, bench, rocprofv3 kernel trace, PMC passes, probes.  Everything lands in gpurun_out/ under
 # names prefixed with the round tag (default r03); copy what is to be judged into profiles/.
 set -u
-T=${1:-r04}
+T=${1:-r05}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${T}_pytest_gpu.txt | tail -3
@@ -15,10 +15,10 @@ python tools/frame_trace.py $(find gpurun_out/prof -name "*kernel_trace.csv" | h
 # PMC: separate --pmc passes (MI355X_MICROARCH.md), --kernel-trace only beside them
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_GATE_EN1_sum" "TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_BUSY_sum TCC_EA0_WRREQ_STALL_sum"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/pmc/$tag -o p -- python $R/tools/pmc_run.py 512 3 tables > $R/gpurun_out/pmc_$tag.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/pmc/$tag -o p -- python $R/tools/pmc_run.py 512 20 bench > $R/gpurun_out/pmc_$tag.log 2>&1)
   tail -1 gpurun_out/pmc_$tag.log | cut -c1-120
 done
-python tools/pmc_summary.py gpurun_out/pmc --last 3 --json gpurun_out/pmc_latest.json --config 512 --tag "round ${T#r0}" > gpurun_out/${T}_pmc_512.txt 2>&1; tail -3 gpurun_out/${T}_pmc_512.txt
+python tools/pmc_summary.py gpurun_out/pmc --last 20 --json gpurun_out/pmc_latest.json --config 512 --tag "round ${T#r0}" > gpurun_out/${T}_pmc_512.txt 2>&1; tail -3 gpurun_out/${T}_pmc_512.txt
 cp gpurun_out/pmc_latest.json profiles/pmc_latest.json      # bench.py reads roofline.traffic from here (this run's counters, stamped with the source's sha256)
 echo "== bench 512 (the driver's command)"; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/${T}_bench_512.json; cut -c1-400 gpurun_out/${T}_bench_512.json
 echo "== A/B: look-ahead builds on / off, same box"; bash tools/ab_bench.sh ${T} "" "--no-prefetch" 2 > /dev/null; cat gpurun_out/${T}_ab_bench.txt

@@ -27,19 +27,8 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
 from dynamicfusion_amd import Intr, TsdfVolume, WarpField, compute_dists, sharded, synth, upload_u16  # noqa: E402
 
-T_LAUNCH, T_HOP, LINK_GBPS = 15e-6, 5e-6, 100.0
-
-
-def collective(kind, size, n):
-    if n == 1:
-        return 0.0
-    if kind == "broadcast":
-        steps, b = n - 1, size
-    elif kind == "all_reduce":
-        steps, b = 2 * (n - 1), 2.0 * (n - 1) / n * size
-    else:
-        steps, b = n - 1, size
-    return T_LAUNCH + steps * T_HOP + b / (LINK_GBPS * 1e9)
+T_LAUNCH, T_HOP, LINK_GBPS = sharded.T_LAUNCH, sharded.T_HOP, sharded.LINK_GBPS      # (the model lives in dynamicfusion_amd/sharded.py: bench.py prints it next to what it measures)
+collective = sharded.collective_model_s
 
 
 def timeit(fn, n=30):
@@ -107,8 +96,10 @@ def main():
             torch.cuda.empty_cache()
         comm = {k: collective(k, sizes[k], n) for k in sizes}
         t_frame = worst["sum"] + sum(comm.values())
+        comm["all_to_all"] = collective("all_to_all", sizes["reduce"], n)      # round 5: the direct form of the second collective (bench.py --merge a2a)
+        t_frame_a2a = t_frame - comm["reduce"] + comm["all_to_all"]
         rows.append({"n": n, "halo": halo if n > 1 else 0, "slabs": kind, "bounds": bounds, "kernels_ms": {k: 1e3 * v for k, v in worst.items()},
-                     "collectives_ms": {k: 1e3 * v for k, v in comm.items()}, "frame_ms": 1e3 * t_frame, "frames_per_s": 1.0 / t_frame,
+                     "collectives_ms": {k: 1e3 * v for k, v in comm.items()}, "frame_ms": 1e3 * t_frame, "frames_per_s": 1.0 / t_frame, "frame_ms_a2a": 1e3 * t_frame_a2a,
                      "per_rank_integrate_ms": [1e3 * p[0] for p in per_rank]})
     base = rows[0]["frames_per_s"]
     print("| N | planes swept by the slowest rank's kernels: integrate / march / shade (ms, measured on one GPU) | broadcast / all_reduce(MIN) / reduce(SUM) (ms, model) | frame (ms) | frames/s | speed-up |")
@@ -118,6 +109,8 @@ def main():
         print("| %d | %.3f / %.3f / %.3f | %.3f / %.3f / %.3f | %.3f | %.0f | %.2fx |" % (
             r["n"], k["integrate"], k["march"], k["shade"], c["broadcast"], c["all_reduce"], c["reduce"], r["frame_ms"], r["frames_per_s"],
             r["frames_per_s"] / base))
+    print("second collective as ONE direct all-to-all of the row bands (--merge a2a): " +
+          ", ".join("N = %d: %.3f ms -> frame %.3f ms (%.2fx)" % (r["n"], r["collectives_ms"]["all_to_all"], r["frame_ms_a2a"], rows[0]["frame_ms"] / r["frame_ms_a2a"]) for r in rows))
     for r in rows:
         print("N = %d (%s slabs %s) integrate per rank (ms):" % (r["n"], kind, r["bounds"]), " ".join("%.3f" % v for v in r["per_rank_integrate_ms"]))
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
