@@ -756,3 +756,33 @@ extern "C" int dfusion_extract_normals(DfVolume v, const DfSlab* slab, const flo
     DF_LAUNCH_CHECK();
     return DF_OK;
 }
+
+// ---- the direct row-band merge's local sum (include/dfusion.h dfusion_raycast_sum_pieces): out = the integer sum of n_pieces pieces of n words
+__global__ __launch_bounds__(256) void df_sum_pieces_kernel(const uint32_t* __restrict__ pieces, int n_pieces, unsigned long long n, uint32_t* __restrict__ out)
+{
+    for (unsigned long long i = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (unsigned long long)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            uint4 a = *reinterpret_cast<const uint4*>(pieces + i);
+            for (int p = 1; p < n_pieces; ++p) {
+                const uint4 b = *reinterpret_cast<const uint4*>(pieces + (unsigned long long)p * n + i);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            *reinterpret_cast<uint4*>(out + i) = a;
+        } else {
+            for (unsigned long long j = i; j < n; ++j) {
+                uint32_t a = pieces[j];
+                for (int p = 1; p < n_pieces; ++p) a += pieces[(unsigned long long)p * n + j];
+                out[j] = a;
+            }
+        }
+    }
+}
+extern "C" int dfusion_raycast_sum_pieces(const uint32_t* pieces, int n_pieces, unsigned long long n_words, uint32_t* out, dfStream stream)
+{
+    if (!pieces || !out || n_pieces < 1 || (n_words & 3ull) || ((size_t)pieces & 15) || ((size_t)out & 15)) return DF_E_INVALID;   // (float4 pixels: whole 16-byte words)
+    if (n_words == 0) return DF_OK;
+    const unsigned long long want = (n_words / 4 + 255) / 256;
+    hipLaunchKernelGGL(df_sum_pieces_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, pieces, n_pieces, n_words, out);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}

@@ -74,6 +74,13 @@ public:
     /// become bandRows x cols views of the band.  1 / world of the image lands on a rank and none of them is a hot spot; the image
     /// stays row-sharded for a row-sharded consumer.
     bool raycastRowBands(TsdfVolume& slab, const Affine3f& camera_pose, const Intr& intr, int cols, int rows, Cloud& points, Normals& normals);
+    /// How raycastRowBands moves the normals (round 5).  REDUCE_SCATTER: one ncclReduceScatter (a ring: N - 1 steps).  ALL_TO_ALL: every rank
+    /// sends each other rank ITS band of the normals it shaded -- fixed-size pieces, one ncclSend / ncclRecv group, each byte over one xGMI
+    /// link once, no count exchange -- and adds the N pieces of its own band (dfusion_raycast_sum_pieces).  Same bits either way.
+    /// Default: DFUSION_ZSLAB_MERGE=a2a selects ALL_TO_ALL, anything else REDUCE_SCATTER.
+    enum RowMerge { REDUCE_SCATTER = 0, ALL_TO_ALL = 1 };
+    void setRowMerge(RowMerge m) { row_merge_ = m; }
+    RowMerge rowMerge() const { return row_merge_; }
     int bandRowsPerRank(int rows) const { return (rows + world_ - 1) / world_; }
     int bandRow0(int rows) const { return std::min(rows, rank_ * bandRowsPerRank(rows)); }
     int bandRows(int rows) const { return std::max(0, std::min(rows, (rank_ + 1) * bandRowsPerRank(rows)) - bandRow0(rows)); }
@@ -95,6 +102,8 @@ private:
     DeviceArray<unsigned long long> keys64_;
     DeviceArray<Point> out_;     // normals (summed over the ranks), then the points (made from the merged keys on rank dst)
     DeviceArray<int> token_;
+    RowMerge row_merge_;
+    DeviceArray<Point> pieces_;  // ALL_TO_ALL: the world pieces of this rank's band
 };
 
 } }

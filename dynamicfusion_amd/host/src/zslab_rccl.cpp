@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <kfusion/cuda/zslab.hpp>
+#include "dfusion.h"
 
 using namespace kfusion;
 using namespace kfusion::cuda;
@@ -41,6 +42,7 @@ ZSlabComm::ZSlabComm(int rank, int world, const std::string& id_path, Backend ba
 {
     if (world < 1 || world > 128 || rank < 0 || rank >= world) { fail("ZSlabComm: rank " + std::to_string(rank) + " of " + std::to_string(world) + " (1..128 ranks: the merge key carries the rank in 7 bits)"); return; }
     if (backend_ == FROM_ENV) { const char* b = std::getenv("DFUSION_ZSLAB_BACKEND"); backend_ = (b && !std::strcmp(b, "host")) ? HOST_STAGED : RCCL; }
+    { const char* m = std::getenv("DFUSION_ZSLAB_MERGE"); row_merge_ = (m && !std::strcmp(m, "a2a")) ? ALL_TO_ALL : REDUCE_SCATTER; }
     if (backend_ == HOST_STAGED) initHost(id_path); else initRccl(id_path);
 }
 
@@ -324,7 +326,28 @@ bool ZSlabComm::raycastRowBands(TsdfVolume& slab, const Affine3f& camera_pose, c
     if (pad_px > px) ZS_HIP(hipMemsetAsync(out_.ptr() + px, 0, (pad_px - px) * sizeof(Point), st));
     slab.raycastShadeNormals(camera_pose, intr, keys64_, shaded);
     Point* band_n = out_.ptr() + pad_px; Point* band_p = band_n + band_px;
-    if (world_ > 1 && backend_ == HOST_STAGED) {
+    if (world_ > 1 && row_merge_ == ALL_TO_ALL) {
+        // the direct form: piece r of pieces_ = rank r's shading of MY band; then the pieces are added on the device
+        pieces_.create(pad_px);
+        if (backend_ == HOST_STAGED) {
+            ZS_HIP(hipMemcpy(hostSlot(rank_), out_.ptr(), pad_px * 16, hipMemcpyDeviceToHost));
+            if (!hostBarrier()) return false;
+            for (int r = 0; r < world_; ++r)
+                ZS_HIP(hipMemcpy(pieces_.ptr() + (size_t)r * band_px, hostSlot(r) + (size_t)rank_ * band_px * 16, band_px * 16, hipMemcpyHostToDevice));
+            if (!hostBarrier()) return false;
+        } else {
+            ZS_NCCL(ncclGroupStart());
+            bool sent = true;
+            for (int r = 0; r < world_ && sent; ++r) {
+                sent = ncclSend(out_.ptr() + (size_t)r * band_px, band_px * 4, ncclInt32, r, c, st) == ncclSuccess &&
+                       ncclRecv(pieces_.ptr() + (size_t)r * band_px, band_px * 4, ncclInt32, r, c, st) == ncclSuccess;
+            }
+            const bool closed = ncclGroupEnd() == ncclSuccess;               // (a failed send / receive must not leave the group open)
+            if (!sent || !closed) return fail("ZSlabComm: ncclSend / ncclRecv of the row-band pieces");
+        }
+        const int rc = dfusion_raycast_sum_pieces((const uint32_t*)pieces_.ptr(), world_, (unsigned long long)band_px * 4, (uint32_t*)band_n, stream_);
+        if (rc != 0) return fail(std::string("dfusion_raycast_sum_pieces: ") + dfusion_error_string(rc));
+    } else if (world_ > 1 && backend_ == HOST_STAGED) {
         ZS_HIP(hipMemcpy(hostSlot(rank_), out_.ptr(), pad_px * 16, hipMemcpyDeviceToHost));
         if (!hostBarrier()) return false;
         std::vector<int> sum(band_px * 4, 0);

@@ -402,7 +402,12 @@ def raycast_sharded(march_fn, shade_fn, points_fn, rank, world, dst=0, group=Non
             if merge == "a2a":
                 assert a2a_recv is not None and a2a_recv.shape[0] == world and a2a_recv.shape[1] == per
                 coll_all_to_all_rows(normals.view(torch.int32), a2a_recv.view(torch.int32), group=group)
-                torch.sum(a2a_recv.view(torch.int32), dim=0, out=band_out.view(torch.int32))
+                if a2a_recv.is_cuda:           # dfusion_raycast_sum_pieces: the N pieces of this rank's band added (integer adds: the owner's bits)
+                    from . import capi
+                    capi.check(capi.lib().dfusion_raycast_sum_pieces(a2a_recv.data_ptr(), world, a2a_recv[0].numel(), band_out.data_ptr(),
+                                                                     torch.cuda.current_stream().cuda_stream), "dfusion_raycast_sum_pieces")
+                else:
+                    torch.sum(a2a_recv.view(torch.int32), dim=0, out=band_out.view(torch.int32))
                 mark("all_to_all")
             else:
                 coll_reduce_scatter_rows(normals.view(torch.int32), band_out.view(torch.int32), group=group)

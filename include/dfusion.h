@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 5   /* 5: dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
+#define DFUSION_ABI_VERSION 5   /* 5: dfusion_raycast_sum_pieces (direct row-band merge), DF_WARP_STEADY_PREFETCH, dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
@@ -230,6 +230,12 @@ int dfusion_raycast_points_of_keys_rows(const float cam2vol[12], const float Rin
                                         const unsigned long long *merged_keys64_dev, const float *normals_dev, size_t normals_pitch,
                                         float *points_dev, size_t points_pitch, int cols, int image_rows, int row0, int rows,
                                         dfStream stream);
+
+/* The receiving end of the DIRECT form of the sharded cast's second collective (ABI 5): rank r gets, from every rank p, p's piece of r's row
+ * band of the normals image (fixed-size pieces: one all-to-all, no counts; every pixel's normal is non-zero in exactly one piece) and adds
+ * them: out[i] = sum over p < n_pieces of pieces[p * n_words + i], 32-bit integer adds on the bit patterns (all summands but one are zero, so
+ * the sum IS the owner's bits -- the same arithmetic a reduce_scatter(SUM) on the int32 view performs).  n_words: 32-bit words per piece.   */
+int dfusion_raycast_sum_pieces(const uint32_t *pieces_dev, int n_pieces, unsigned long long n_words, uint32_t *out_dev, dfStream stream);
 
 /* ---- surface extraction -------------------------------------------------------
  * device::extractCloud (internal.hpp:142; tsdf_volume.cu:511-710,798-817): zero crossings between every voxel and its

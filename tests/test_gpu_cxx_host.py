@@ -326,7 +326,8 @@ def test_cxx_zslab_rccl_path(tmp_path, with_nodes):
         assert planes.shape[0] == hi - lo and np.array_equal(planes, vol[lo:hi])
 
 
-@pytest.mark.parametrize("world,mode,rows", [(2, "exchange", False), (2, "recompute", False), (3, "recompute", False), (2, "recompute", True), (7, "recompute", True)])
+@pytest.mark.parametrize("world,mode,rows", [(2, "exchange", False), (2, "recompute", False), (3, "recompute", False), (2, "recompute", True), (7, "recompute", True),
+                                             (3, "recompute", "a2a"), (7, "recompute", "a2a")])
 def test_cxx_zslab_collectives_with_more_than_one_rank(tmp_path, world, mode, rows):
     """VERDICT r3 #6 iii: the C++ collective SEQUENCE (ZSlabComm: frame-input broadcasts, halo exchange or recompute, march ->
     all-reduce(MIN) of the keys -> shade -> reduce(SUM) of the normals -> points of the keys) with MORE THAN ONE rank.  RCCL refuses two
@@ -345,6 +346,7 @@ def test_cxx_zslab_collectives_with_more_than_one_rank(tmp_path, world, mode, ro
         if world == 7: cmd.append("bounds=0,16,24,32,40,48,56,64")         # (64 planes, halo 8: seven slabs of >= 8 planes)
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                               env=dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK="0", DFUSION_ZSLAB_BACKEND="host",
+                                       DFUSION_ZSLAB_MERGE="a2a" if rows == "a2a" else "rs",       # (round 5: the direct row-band merge -- pieces + dfusion_raycast_sum_pieces)
                                        DFUSION_ZSLAB_NONCE=str(os.getpid()), DFUSION_ZSLAB_HOST_SLOT_MB="16")) for r in range(world)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     import re
