@@ -57,10 +57,11 @@ def parse(argv=None):
                          "inside the frustum and in front of the first frame's surface); `measured` (default): start from `balanced`, then "
                          "re-cut once after the priming frames from the verdict pass's alive-block counts per plane (what the sweep really "
                          "visits), slabs re-allocated; `uniform`: equal plane counts")
-    ap.add_argument("--merge", choices=["rows", "a2a", "root"], default="rows",
-                    help="N>1: the ray-cast's second collective -- `rows` (default): reduce_scatter of the normals by pixel rows, every rank finishes "
-                         "its band (image stays row-sharded; 1/N of the bytes lands on a rank); `a2a` (round 5): the same bands by ONE direct "
-                         "all-to-all of fixed-size pieces + a local sum (no ring, no count exchange); `root`: reduce(SUM) to rank 0, which makes "
+    ap.add_argument("--merge", choices=["rows", "a2a", "root"], default="a2a",
+                    help="N>1: the ray-cast's second collective -- `a2a` (default since round 5): every rank finishes its band of pixel rows, the "
+                         "normals reach it by ONE direct all-to-all of fixed-size pieces + a local sum (no ring, no count exchange; the stated "
+                         "collective model puts it at 0.026 ms against 0.093 for the ring at N = 8); `rows` (round 4's default): the same bands by "
+                         "reduce_scatter (1/N of the bytes lands on a rank); `root`: reduce(SUM) to rank 0, which makes "
                          "the whole image.  N>1 runs time the other forms as variants after the timed region (scaling_detail.variants)")
     ap.add_argument("--no-variants", action="store_true", help="N>1: skip the untimed variant passes (the other merges, the halo exchange)")
     ap.add_argument("--long-frames", type=int, default=200,

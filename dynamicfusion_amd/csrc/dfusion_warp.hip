@@ -1134,11 +1134,27 @@ struct DfWarpedArgs {
 #define DF_TAB_TX 32
 #define DF_TAB_TY 16
 #define DF_TAB_TZ 8
+// Inside a tile plane (32 x 16 voxels): rows of 32 (DF_TAB_PATCH_MAJOR = 0, the product).  Round 5 measured the alternative -- PATCH-major:
+// the eight 8 x 8 column patches one after the other, so that the 64 records a wave of the pipelined sweep loads with one instruction are
+// ONE contiguous 1 KiB run instead of eight 128-byte pieces 512 bytes apart -- same box, interleaved: 0.691 against 0.686 ms at 512^3,
+// 0.153 / 0.156 at 256^3 (profiles/r05_ab_warp_variants.txt): the four waves of a strip fetch the pieces of a row's lines together anyway.
+#ifndef DF_TAB_PATCH_MAJOR
+#define DF_TAB_PATCH_MAJOR 0
+#endif
+__device__ __forceinline__ unsigned df_tab_in_plane(int x, int y)
+{
+    const unsigned xt = (unsigned)x % DF_TAB_TX, yt = (unsigned)y % DF_TAB_TY;
+#if DF_TAB_PATCH_MAJOR
+    return (((yt >> 3) * (DF_TAB_TX / 8) + (xt >> 3)) << 6) + ((yt & 7u) << 3) + (xt & 7u);
+#else
+    return yt * DF_TAB_TX + xt;
+#endif
+}
 __device__ __forceinline__ size_t df_tab_index(const DfWarpedArgs& a, int x, int y, int z)
 {
     const int zl = z - a.tab_z0;
     const size_t tile = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty + (y / DF_TAB_TY)) * a.tab_ntx + (x / DF_TAB_TX);
-    return tile * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ) + ((zl % DF_TAB_TZ) * DF_TAB_TY + (y % DF_TAB_TY)) * DF_TAB_TX + (x % DF_TAB_TX);
+    return tile * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ) + (size_t)(zl % DF_TAB_TZ) * (DF_TAB_TX * DF_TAB_TY) + df_tab_in_plane(x, y);
 }
 
 #define DF_CAND_CHUNK 256
@@ -1902,7 +1918,7 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
         // offset inside the tile plane): the uniform part stays in SGPRs and the loads take the saddr + voffset form instead of
         // a 64-bit VALU address per load
         const unsigned lane_vox = (unsigned)(yc * a.X + xc);
-        const unsigned lane_tab = (unsigned)((yc % DF_TAB_TY) * DF_TAB_TX + (xc % DF_TAB_TX));
+        const unsigned lane_tab = df_tab_in_plane(xc, yc);
         const size_t tile_col = (size_t)(yc / DF_TAB_TY) * a.tab_ntx + (size_t)(xc / DF_TAB_TX);      // == (ty, tx) of the workgroup: uniform
         const size_t tile_col_u = (size_t)__builtin_amdgcn_readfirstlane((int)tile_col);
 #if DF_TAB_ADDR_HOIST

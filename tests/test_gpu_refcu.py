@@ -117,32 +117,6 @@ def test_hip_equals_reference_kernels_live_512_full_volume():
     assert np.array_equal(key(cloud.cpu().numpy()), key(rc[:count]))
 
 
-@pytest.mark.skipif(not O.have_refcu() or os.environ.get("DFUSION_SLOW_TESTS") != "1",
-                    reason="3 minutes of host fibers: run with DFUSION_SLOW_TESTS=1 (log of the round's run: profiles/r04_fullscan6_512.txt)")
-def test_fetch_cloud_equals_reference_fullscan6_live_512():
-    """VERDICT r3 'missing' #4: the reference's FullScan6 extract_kernel + extract_normals_kernel (tsdf_volume.cu:511-795, compiled for
-    the host: a block's threads run as fibers, 3 minutes at this size) against dfusion_extract_cloud / _normals on the SAME 512^3 volume,
-    with no restatement in between: same count, same point set, same normals."""
-    cfg = synth.CONFIGS["512"]
-    from scene import Scene
-    sc = Scene(cfg, n_frames=2, with_nodes=False)
-    vol, intr = gpu_frames(sc, cfg, 2)
-    ref = vol.download()                                      # (HIP == the reference's integrate_kernel on this volume: the test above)
-    cloud = vol.fetchCloud()
-    normals = vol.fetchNormals(cloud)
-    torch.cuda.synchronize()
-    rc, count = O.refcu_extract_cloud(sc.ovol(ref), synth.aff12(sc.pose), 1 << 23)
-    assert count == cloud.shape[0] and count > 100000
-    key = lambda a: np.sort(np.ascontiguousarray(bits(a)[:, :3]).view([("x", "u4"), ("y", "u4"), ("z", "u4")]).reshape(-1), order=("x", "y", "z"))
-    c = cloud.cpu().numpy()
-    assert np.array_equal(key(c), key(rc[:count]))
-    rinv = np.linalg.inv(sc.pose[:3, :3].astype(np.float64)).astype(F32)
-    sub = c[::16]                                             # (the reference's normals kernel on every 16th point: 20 k points)
-    rn = O.refcu_extract_normals(sc.ovol(ref), synth.aff12(sc.pose), rinv, sub, cfg.gradient_delta_factor)
-    assert np.array_equal(bits(normals.cpu().numpy()[::16])[:, :3], bits(rn)[:, :3])
-    print("FullScan6 at 512^3: %d points, point set and normals identical with the reference's kernels" % count)
-
-
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref/libdfref.so did not travel")
 def test_warped_frame_equals_reference_classes_256_full_volume():
     """BASELINE config 1 (256^3 / 1 m, ~500 nodes, k = 4), EVERY voxel: the per-voxel composition driven by the reference's own
@@ -197,7 +171,7 @@ def test_warped_frame_equals_reference_classes_512_full_volume():
 def test_fetch_cloud_equals_reference_fullscan6_on_a_512x512x64_slab():
     """VERDICT r4 #4 iii: FullScan6 at the headline plane size inside the driver's run.  The reference's extract_kernel +
     extract_normals_kernel (tsdf_volume.cu:511-795, compiled for the host: a block's threads run as fibers -- 104 s for all of 512^3,
-    which is why test_fetch_cloud_equals_reference_fullscan6_live_512 stays behind DFUSION_SLOW_TESTS) run on the 64 planes of the fused
+    which is why the whole-volume run is tools/fullscan6_512.py, not a test) run on the 64 planes of the fused
     512^3 volume that hold the most surface, taken as a 512 x 512 x 64 volume in its own right (same voxel size, same pose) -- and so does
     dfusion_extract_cloud / _normals: same count, same point set, same normals.  13 s."""
     from dynamicfusion_amd import TsdfVolume

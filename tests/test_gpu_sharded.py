@@ -63,6 +63,18 @@ def run_sharded(sc, world, frames, k=None, recompute_halo=False):
             pb = torch.empty((nr, cfg.cols, 4), dtype=torch.float32, device="cuda")
             vols[0].raycast_points_of_keys(sc.cam_poses[f], intr, merged, acc[1][r0:r0 + nr].view(torch.float32).contiguous(), pb, r0, nr)
             assert torch.equal(pb.view(torch.int32), acc[0][r0:r0 + nr])
+    # the DIRECT row-band merge (round 5, --merge a2a): rank r receives every rank's piece of ITS band of the padded normals image and adds
+    # them on the device (dfusion_raycast_sum_pieces) -- the band of the summed normals, bit for bit
+    from dynamicfusion_amd import capi
+    shaded = torch.zeros((world, world * per, cfg.cols, 4), dtype=torch.float32, device="cuda")       # [source rank][padded image]
+    for s_, v in enumerate(vols):
+        v.raycast_shade(sc.cam_poses[f], intr, merged, None, shaded[s_, :cfg.rows])
+    for r, (r0, nr) in enumerate(bands):
+        pieces = shaded[:, r * per:(r + 1) * per].contiguous()                                        # what the all-to-all delivers to rank r
+        band = torch.empty((per, cfg.cols, 4), dtype=torch.float32, device="cuda")
+        capi.check(capi.lib().dfusion_raycast_sum_pieces(pieces.data_ptr(), world, pieces[0].numel(), band.data_ptr(), None), "dfusion_raycast_sum_pieces")
+        assert torch.equal(band[:nr].view(torch.int32), acc[1][r0:r0 + nr])
+        assert not band[nr:].view(torch.int32).any()                                                  # (rows past the image stay zero)
     torch.cuda.synchronize()
     assert torch.equal(p3.view(torch.int32), acc[0])
     return vols, acc[0], acc[1], best
@@ -154,6 +166,16 @@ def test_bench_gpus_n_launches_its_own_ranks():
             assert rb["to"][0] == 0 and rb["to"][-1] == 256 and sum(rb["alive_blocks_per_8_planes"]) > 0
         assert d["verify_cull"]["cull_bit_identical"] and d["verify_cull"]["updates_with_cull"] == d["verify_cull"]["updates_without_cull"] > 0
         assert d["value"] > 0
+        # round 5: what the first multi-GPU hardware run will be read from -- per rank, per stage; the ranks that took part;
+        # the model's predicted collective times; the other merges and the halo exchange timed in the same launch
+        sd = d["scaling_detail"]
+        assert sd["rccl_ranks_seen"] == n and len(sd["devices"]) == n
+        for st in ("broadcast", "integrate_warped", "march", "all_reduce_min", "shade", "points"):
+            assert st in sd["stages"] and len(sd["per_rank_ms"][st]) == n and all(v > 0 for v in sd["per_rank_ms"][st]), st
+        assert set(sd["variants"]) == {"merge=rows", "merge=a2a", "merge=root", "halo=exchange"}
+        assert "all_to_all" in sd["variants"]["merge=a2a"]["per_rank_ms"] and "halo_exchange" in sd["variants"]["halo=exchange"]["per_rank_ms"]
+        assert all(v["ms_per_frame"] > 0 for v in sd["variants"].values())
+        assert sd["predicted_collective_ms"]["all_to_all"] > 0 and sd["predicted_collective_ms"]["all_reduce_min"] > sd["predicted_collective_ms"]["broadcast"]
 
 
 def test_bench_force_dist_self_launch_is_one_real_rccl_rank():
