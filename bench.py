@@ -72,6 +72,14 @@ def parse(argv=None):
     ap.add_argument("--no-verify-cull", action="store_true",
                     help="skip the untimed pass that re-integrates every timed frame with the launch plan's cull switched off, from the same "
                          "start volume, and compares the volumes bit for bit (cull_bit_identical)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="N = 1: pipeline the frames over TWO streams (round 5): the part of the warped integrate that does not touch the volume "
+                         "-- set_transforms, compute_dists, dists pyramid, verdict pass, plan: dfusion_integrate_warped_prepare -- goes on a second "
+                         "stream, where it runs beside the PREVIOUS frame's sweep and ray-cast; the sweep (dfusion_integrate_warped_sweep) and the ray-cast stay "
+                         "on the first.  Same results, bit for bit (tests/test_gpu_parity.py).  Measured, same box, interleaved: +1 to +2.4 %% frames/s -- the "
+                         "prepare half's small kernels cost the sweep they run beside 30-80 us of workgroup slots, nearly what hiding them gains -- so it is "
+                         "NOT the default (profiles/r05_ab_pipeline.txt)")
+    ap.add_argument("--no-pipeline", action="store_true", help="(the default; kept for A/B command lines)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="A/B switch: DF_WARP_NO_PREFETCH on every warped integrate (no look-ahead table / model builds on the handle's side stream)")
     return ap.parse_args(argv)
@@ -438,6 +446,7 @@ def main():
     torch.cuda.synchronize()
 
     dists = torch.empty((cfg.rows, cfg.cols), dtype=torch.int16, device=dev)
+    dists2 = [dists, torch.empty_like(dists)]
     keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device=dev) if dist_on else None
     out2 = torch.empty((2, cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev)
     pts, nrm = out2[0], out2[1]
@@ -455,6 +464,19 @@ def main():
     dq_in = bundle[n_depth:].view(torch.float32).view(cfg.nodes, 8)
 
     halo_main = "recompute" if args.halo == "both" else args.halo
+    # frames pipelined across two streams (N = 1): see --no-pipeline
+    pipeline = (not dist_on) and args.pipeline and (not args.no_pipeline) and cfg.k in (4, 8) and cfg.nodes * 32 <= 160 * 1024
+    s_main = torch.cuda.current_stream()
+    s_prep = torch.cuda.Stream(device=dev) if pipeline else None
+    # the prepare half of frame n may run BESIDE the sweep of frame n - 1 (the library double-buffers what that sweep reads of the handle);
+    # what the caller owns of the sweep's inputs -- the dists image -- is double-buffered here: frame n uses dists2[n & 1], written once the
+    # sweep of frame n - 2 is done (ev_sweep[n & 1])
+    ev_sweep = [torch.cuda.Event(), torch.cuda.Event()] if pipeline else None
+    ev_prep = torch.cuda.Event() if pipeline else None       # this frame's prepare half is done
+    pipe_n = [0]
+    if pipeline:
+        s_prep.wait_stream(s_main)
+        ev_sweep[0].record(s_main); ev_sweep[1].record(s_main)
 
     def step(i, ev=None, timer=None, merge=None, halo_mode=None):
         """one frame.  timer: a sharded.StageTimer (the stages of this frame are marked); merge / halo_mode: a variant of the frame's
@@ -472,14 +494,36 @@ def main():
             d_in, q_in = depth_in, dq_in
         else:
             d_in, q_in = depths[f], dqs[f]
-        wf.set_transforms(q_in)
-        compute_dists(d_in, intr, dists)
-        mark("set_transforms+compute_dists")
-        if ev is not None: ev[0].record()
-        # (halo recompute: the integrate owns every stored plane; halo exchange: its own planes, the halos come from the neighbours)
-        (vol_int if halo_mode == "recompute" else vol).integrate_warped(dists, cam_poses[f], intr, wf, sync=False, prefetch=not args.no_prefetch)
-        mark("integrate_warped")
-        if ev is not None: ev[1].record()
+        if pipeline:
+            # the half of the frame that does not touch the volume, on the second stream: it runs beside the PREVIOUS frame's sweep and
+            # ray-cast (what that sweep still reads of the handle -- node arrays, launch plan -- is double-buffered inside the library)
+            # (the waits are made HERE, before the timing events, so that [3] -> [4] is the prepare half's own run time and [0] -> [1] the sweep
+            # kernel's; the library orders the same things itself -- dfusion.h -- and finds nothing left to wait for)
+            n = pipe_n[0]; pipe_n[0] += 1
+            dn = dists2[n & 1]
+            with torch.cuda.stream(s_prep):
+                s_prep.wait_event(ev_sweep[n & 1])
+                if ev is not None: ev[3].record()
+                wf.set_transforms(q_in)
+                compute_dists(d_in, intr, dn)
+                vol.integrate_warped_prepare(dn, cam_poses[f], intr, wf, prefetch=not args.no_prefetch)
+                if ev is not None: ev[4].record()
+                ev_prep.record()
+            s_main.wait_event(ev_prep)
+            if ev is not None: ev[0].record()
+            vol.integrate_warped_sweep(wf)
+            mark("integrate_sweep")
+            if ev is not None: ev[1].record()
+            ev_sweep[n & 1].record(s_main)
+        else:
+            wf.set_transforms(q_in)
+            compute_dists(d_in, intr, dists)
+            mark("set_transforms+compute_dists")
+            if ev is not None: ev[0].record()
+            # (halo recompute: the integrate owns every stored plane; halo exchange: its own planes, the halos come from the neighbours)
+            (vol_int if halo_mode == "recompute" else vol).integrate_warped(dists, cam_poses[f], intr, wf, sync=False, prefetch=not args.no_prefetch)
+            mark("integrate_warped")
+            if ev is not None: ev[1].record()
         if dist_on and halo_mode == "exchange":
             sharded.exchange_halos(vol.data(), vol.z_store0, vol.z_own0, vol.z_own_n, Z, halo, rank, world)
             mark("halo_exchange")
@@ -508,8 +552,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def events(n):
-        return [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(n)]
+    def events(n):          # per frame: [0] before the integrate (sweep), [1] after it, [2] after the ray-cast; pipelined: [3], [4] around the prepare half on its stream
+        return [tuple(torch.cuda.Event(enable_timing=True) for _ in range(5 if pipeline else 3)) for _ in range(n)]
+
+    def int_ms(e):          # the integrate of one frame: prepare (set_transforms + compute_dists + pyramid + verdict + plan, on its stream) + sweep
+        return e[0].elapsed_time(e[1]) + (e[3].elapsed_time(e[4]) if pipeline else 0.0)
 
     # The per-node-set work: with tables on demand (the mirrors' default) `ensure_index` above only builds the brick index; the tables,
     # then the blend models, of the blocks the launch plans find alive are made by the first sweeps.  N_PRIME untimed frames pay for
@@ -571,12 +618,13 @@ def main():
     for i in range(n_long):
         step(i0 + args.steps + n_extra + i, ev_long[i])
     torch.cuda.synchronize()
-    ms_int = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    ms_int = float(np.mean([int_ms(e) for e in ev]))
     ms_ray = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    ms_prep = float(np.mean([e[3].elapsed_time(e[4]) for e in ev])) if pipeline else None
     # per-frame spread (integrate + ray-cast between HIP events on the launch stream) and the reference-shaped frame
     # (KinFu::dynamicfusion integrates once and ray-casts twice)
-    per_frame = np.array([e[0].elapsed_time(e[2]) for e in ev + ev_more], np.float64)
-    per_int = np.array([e[0].elapsed_time(e[1]) for e in ev + ev_more], np.float64)
+    per_frame = np.array([int_ms(e) + e[1].elapsed_time(e[2]) for e in ev + ev_more], np.float64)
+    per_int = np.array([int_ms(e) for e in ev + ev_more], np.float64)
     frame_stats = {"integrate+raycast_ms": {"p10": float(np.percentile(per_frame, 10)), "median": float(np.median(per_frame)),
                                             "p90": float(np.percentile(per_frame, 90)), "max": float(per_frame.max()), "frames": int(per_frame.size)},
                    "integrate_warped_ms": {"p10": float(np.percentile(per_int, 10)), "median": float(np.median(per_int)),
@@ -585,7 +633,7 @@ def main():
                                   % (N_PRIME, args.warmup, args.steps, n_extra, i0, i0 + args.steps - 1)) if monotone else "%d poses cycled" % F,
                    "reference_shaped_ms": ms_int + 2.0 * ms_ray}
     if n_long:
-        lf = np.array([e[0].elapsed_time(e[2]) for e in ev + ev_more + ev_long], np.float64)
+        lf = np.array([int_ms(e) + e[1].elapsed_time(e[2]) for e in ev + ev_more + ev_long], np.float64)
         frame_stats["long_sweep"] = {"frames": int(lf.size), "integrate+raycast_ms_mean": float(lf.mean()), "p10": float(np.percentile(lf, 10)),
                                      "median": float(np.median(lf)), "p90": float(np.percentile(lf, 90)),
                                      "what": "HIP-event integrate + ray-cast time of %d consecutive frames of the same sweep starting at the first timed pose "
@@ -654,6 +702,10 @@ def main():
         scaling_detail = {"stages": stages, "per_rank_ms": {k: [float(pr.get(k, float("nan"))) for pr in per_rank] for k in stages},
                           "frames": n_extra, "how": "HIP events on each rank's launch stream around every stage, mean over the %d frames that follow the "
                                                      "timed region (the same sweep; not the timed frames, which carry 3 events each)" % n_extra}
+    if pipeline and scaling_detail is not None and n_extra > 0:
+        scaling_detail["per_rank_ms"]["prepare (second stream: set_transforms + compute_dists + pyramid + verdict pass + plan; beside the previous frame's ray-cast)"] = \
+            [float(np.mean([e[3].elapsed_time(e[4]) for e in ev_more]))]
+        scaling_detail["pipelined"] = True
     if dist_on and scaling_detail is not None:
         ones = torch.ones(1, dtype=torch.int64, device=dev)
         sharded.coll_all_reduce(ones, dist.ReduceOp.SUM)
@@ -879,8 +931,13 @@ def main():
                                          ("all_reduce(MIN) of the keys + one direct all-to-all of the normals' row bands (fixed-size pieces, no counts) + a local "
                                           "sum: every rank finishes its band of %d rows" % sharded.row_bands(cfg.rows, world)[0]) if args.merge == "a2a" else
                                          "all_reduce(MIN) of the keys + reduce(SUM) of the normals to rank 0") if dist_on else None,
-                       "frame": "set_transforms + compute_dists + integrate_warped + raycast_points"},
-            "kernel_ms": {"integrate_warped": ms_int, "raycast(+merge)": ms_ray, "index_build_once_s": t_index},
+                       "frame": "set_transforms + compute_dists + integrate_warped + raycast_points" +
+                                (" (frames pipelined over two streams: the volume-free half of frame f + 1 runs beside the sweep and ray-cast of frame f)" if pipeline else "")},
+            "kernel_ms": {"integrate_warped": ms_int, "raycast(+merge)": ms_ray, "index_build_once_s": t_index,
+                          "integrate_prepare_on_side_stream": ms_prep,
+                          "pipelined": ("set_transforms + compute_dists + dfusion_integrate_warped_prepare (pyramid, verdict pass, plan) on a second stream, beside the "
+                                        "previous frame's sweep and ray-cast; integrate_warped = that + the sweep, each between its own HIP events, so ms_per_step < "
+                                        "integrate_warped + raycast") if pipeline else None},
             "frame_stats": frame_stats,
             "scaling_detail": scaling_detail,
             "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved,

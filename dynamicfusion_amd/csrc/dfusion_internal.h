@@ -70,6 +70,19 @@ struct DfWarpField {
     // device scalars for the conservative brick cull: [0] max |t_i|, [1] max sin(theta_i/2), [2] max dists
     float* bounds_dev;
     int max_phase;                    // which of bounds_dev[6], [7] this frame's capped pyramid leaves the image-wide maximum in
+    // dfusion_integrate_warped_prepare / _sweep (round 5): the launch state a prepare call leaves for the sweep call (opaque here: the
+    // argument structs live in dfusion_warp.hip), and the two events that order the halves when they are issued on different streams
+    void* prep; bool prep_valid;
+    hipEvent_t ev_prep_done, ev_sweep_done[2]; bool split_events;
+    // What a sweep issued through the split API may still be READING when the next frame's set_transforms / prepare arrive on another
+    // stream is double-buffered, so that they can run BESIDE that sweep instead of after it: the node transform arrays (rot / dual / node_t
+    // and their alternates), the launch plan (two sets of mask + bins; FOUR counter sets, zeroed two frames ahead).  Sweeps are numbered;
+    // a buffer remembers the last sweep that reads it, the ring of two events holds the last two sweeps (all sweeps on one stream).
+    float4 *rot_alt, *dual_alt, *node_t_alt;
+    unsigned long long seq, recorded_seq;            // sweeps prepared / recorded so far
+    unsigned long long node_reader[2]; int nphase;  // [nphase] = the current node set's last reader, [nphase ^ 1] = the alternate's
+    unsigned long long plan_reader[2];
+    unsigned long long* plan_mask2[2]; unsigned int* plan_list2[2]; int pphase; unsigned hphase;
     uint16_t* pyr_mem; size_t pyr_cap;      // max-pyramid of the frame's dists image (warped sweep's depth cull), entries
     // scratch of dfusion_warp_solve_data_term (grown on demand)
     void* solver_ws; size_t solver_ws_cap;

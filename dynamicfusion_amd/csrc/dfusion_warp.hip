@@ -19,6 +19,7 @@
 #include "dfusion_internal.h"
 #include "dfusion_pyramid.h"
 #include <atomic>
+#include <utility>
 #include <stdlib.h>
 #include <stdio.h>
 #include <math.h>
@@ -123,11 +124,33 @@ static void df_side_drain(DfWarpField* wf)
     wf->side_pending = false;
 }
 
+static void df_prep_free(DfWarpField* wf);       // (defined with the sweep's argument structs below)
+// A sweep issued through dfusion_integrate_warped_sweep may still be reading the node arrays, the launch plan and the verdict bytes on ITS
+// stream when the next frame's set_transforms / prepare arrive on another one: they wait for it on the device.
+static int df_wait_split_sweep(DfWarpField* wf, hipStream_t st)            // every sweep recorded so far
+{
+    if (wf->recorded_seq) DF_HIP(hipStreamWaitEvent(st, wf->ev_sweep_done[wf->recorded_seq & 1], 0));
+    return DF_OK;
+}
+// ... or only the sweep (number `reader`) that last read a buffer about to be rewritten.  The ring holds the last two sweeps' events; all
+// sweeps are on one stream, so an older one is done when the second-to-last is.  A reader that was never recorded (a prepared plan that was
+// dropped) holds nothing.
+static int df_wait_reader(DfWarpField* wf, unsigned long long reader, hipStream_t st)
+{
+    if (reader == 0 || wf->recorded_seq == 0 || reader > wf->recorded_seq) return DF_OK;
+    const unsigned long long e = reader + 1 >= wf->recorded_seq ? reader : wf->recorded_seq - 1;
+    DF_HIP(hipStreamWaitEvent(st, wf->ev_sweep_done[e & 1], 0));
+    return DF_OK;
+}
 extern "C" int dfusion_warp_destroy(DfWarpField* wf)
 {
     if (!wf) return DF_OK;
     df_side_drain(wf);
     if (wf->side) { (void)hipEventDestroy(wf->ev_fork); (void)hipEventDestroy(wf->ev_join); (void)hipStreamDestroy(wf->side); }
+    if (wf->split_events) { (void)hipEventDestroy(wf->ev_prep_done); (void)hipEventDestroy(wf->ev_sweep_done[0]); (void)hipEventDestroy(wf->ev_sweep_done[1]); }
+    (void)hipFree(wf->rot_alt); (void)hipFree(wf->dual_alt); (void)hipFree(wf->node_t_alt);
+    (void)hipFree(wf->plan_mask2[1]); (void)hipFree(wf->plan_list2[1]);
+    df_prep_free(wf);
     if (wf->host_report) (void)hipHostFree((void*)wf->host_report);
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
@@ -141,16 +164,27 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     return DF_OK;
 }
 
+static int df_wait_all_sweeps_host(DfWarpField* wf)
+{
+    if (wf->recorded_seq) DF_HIP(hipEventSynchronize(wf->ev_sweep_done[wf->recorded_seq & 1]));
+    return DF_OK;
+}
 static int df_warp_reserve(DfWarpField* wf, int M)
 {
     if (M <= wf->cap) return DF_OK;
+    { int rc = df_wait_all_sweeps_host(wf); if (rc) return rc; }        // (a split sweep may still read what is freed here)
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
-    wf->pos_sigma = wf->rot = wf->dual = wf->node_t = nullptr; wf->cap = 0;
+    (void)hipFree(wf->rot_alt); (void)hipFree(wf->dual_alt); (void)hipFree(wf->node_t_alt);
+    wf->pos_sigma = wf->rot = wf->dual = wf->node_t = wf->rot_alt = wf->dual_alt = wf->node_t_alt = nullptr; wf->cap = 0;
     size_t bytes = (size_t)M * sizeof(float4);
     DF_HIP(hipMalloc((void**)&wf->pos_sigma, bytes));
     DF_HIP(hipMalloc((void**)&wf->rot, bytes));
     DF_HIP(hipMalloc((void**)&wf->dual, bytes));
     DF_HIP(hipMalloc((void**)&wf->node_t, bytes));
+    DF_HIP(hipMalloc((void**)&wf->rot_alt, bytes));                       // (the alternate set the next set_transforms writes)
+    DF_HIP(hipMalloc((void**)&wf->dual_alt, bytes));
+    DF_HIP(hipMalloc((void**)&wf->node_t_alt, bytes));
+    wf->node_reader[0] = wf->node_reader[1] = 0;
     if (!wf->bounds_dev) { DF_HIP(hipMalloc((void**)&wf->bounds_dev, 8 * sizeof(float))); DF_HIP(hipMemset(wf->bounds_dev, 0, 8 * sizeof(float))); }   // ([6]: the capped pyramid's image-wide maximum, 0 between frames)
     wf->cap = M;
     return DF_OK;
@@ -200,7 +234,21 @@ __global__ __launch_bounds__(1024) void df_pack_bounds_kernel(const float* __res
     }
 }
 
+static int df_warp_pack_current(DfWarpField* wf, const float* pos, const float* dq, const float* sigma, hipStream_t st);
+// The transforms go into the ALTERNATE node arrays, which then become the current ones: a sweep issued through the split API on another
+// stream may still be reading the set that was current when its plan was made.  What is waited for is the last sweep that read the
+// alternate set -- two set_transforms ago -- not the one running now.  (Positions -- set_nodes -- are not double-buffered: every
+// recorded sweep is waited for.)
 static int df_warp_pack(DfWarpField* wf, const float* pos, const float* dq, const float* sigma, hipStream_t st)
+{
+    if (pos) { int rc = df_wait_split_sweep(wf, st); if (rc) return rc; }
+    else { int rc = df_wait_reader(wf, wf->node_reader[wf->nphase ^ 1], st); if (rc) return rc; }
+    std::swap(wf->rot, wf->rot_alt); std::swap(wf->dual, wf->dual_alt); std::swap(wf->node_t, wf->node_t_alt);
+    wf->nphase ^= 1;
+    wf->node_reader[wf->nphase] = 0;                                       // (rewritten: nobody reads the old contents any more)
+    return df_warp_pack_current(wf, pos, dq, sigma, st);
+}
+static int df_warp_pack_current(DfWarpField* wf, const float* pos, const float* dq, const float* sigma, hipStream_t st)
 {
     if (wf->M <= 8192) {
         hipLaunchKernelGGL(df_pack_bounds_kernel, dim3(1), dim3(1024), 0, st, pos, dq, sigma, wf->M, wf->pos_sigma, wf->rot, wf->dual, wf->node_t,
@@ -2329,9 +2377,71 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
     return DF_OK;
 }
 
+// The launch state dfusion_integrate_warped_prepare leaves for dfusion_integrate_warped_sweep
+typedef void (*df_lds_kernel_t)(const DfWarpedArgs, const DfWarpView, int);
+struct DfPrepared { DfWarpedArgs a; DfWarpView W; df_lds_kernel_t kern; dim3 grid; unsigned threads; size_t lds; int tiles_x; DfVolume v; DfSlab s; unsigned long long seq; };
+static void df_prep_free(DfWarpField* wf) { delete (DfPrepared*)wf->prep; wf->prep = nullptr; wf->prep_valid = false; }
+enum { DF_MODE_WHOLE = 0, DF_MODE_PREPARE = 1 };
+
+static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
+                                    const float vol2world[12], const float world2cam[12], const float proj[4],
+                                    DfWarpField* wf, int k, unsigned flags, unsigned long long* n_updated, dfStream stream, int mode);
+
 extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
                                         const float vol2world[12], const float world2cam[12], const float proj[4],
                                         DfWarpField* wf, int k, unsigned flags, unsigned long long* n_updated, dfStream stream)
+{
+    return df_integrate_warped_impl(dists, pitch, cols, rows, v, slab, vol2world, world2cam, proj, wf, k, flags, n_updated, stream, DF_MODE_WHOLE);
+}
+
+// ---- the frame's warped integrate in two calls (include/dfusion.h): everything that does not touch the volume -- dists pyramid, verdict pass,
+// table builds, launch plan -- and the sweep.  The halves may be issued on different streams; the handle's events order them.
+extern "C" int dfusion_integrate_warped_prepare(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume geometry, const DfSlab* slab,
+                                                const float vol2world[12], const float world2cam[12], const float proj[4],
+                                                DfWarpField* wf, int k, unsigned flags, dfStream stream)
+{
+    if (!wf) return DF_E_INVALID;
+    if (!wf->split_events) {
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        for (int i = 0; i < 3; ++i)
+            if (hipEventCreateWithFlags(&e[i], hipEventDisableTiming) != hipSuccess) {
+                for (int j = 0; j < i; ++j) (void)hipEventDestroy(e[j]);
+                return (int)hipGetLastError();
+            }
+        wf->ev_prep_done = e[0]; wf->ev_sweep_done[0] = e[1]; wf->ev_sweep_done[1] = e[2]; wf->split_events = true;
+    }
+    wf->prep_valid = false;
+    if (!geometry.data) geometry.data = (void*)(size_t)16;          // (never dereferenced by the prepare half; df_volume_valid wants a pointer)
+    const int rc = df_integrate_warped_impl(dists, pitch, cols, rows, geometry, slab, vol2world, world2cam, proj, wf, k, flags, nullptr, stream, DF_MODE_PREPARE);
+    if (rc != DF_OK) return rc;
+    DF_HIP(hipEventRecord(wf->ev_prep_done, (hipStream_t)stream));
+    return DF_OK;
+}
+
+extern "C" int dfusion_integrate_warped_sweep(DfVolume v, const DfSlab* slab, DfWarpField* wf, unsigned long long* n_updated, dfStream stream)
+{
+    if (!wf || !df_volume_valid(v)) return DF_E_INVALID;
+    const DfSlab s = df_slab_or_full(v, slab);
+    if (!df_slab_valid(v, s)) return DF_E_INVALID;
+    if (s.z_own_n == 0) return DF_OK;                                // (as dfusion_integrate_warped: nothing to sweep, nothing was prepared)
+    DfPrepared* P = (DfPrepared*)wf->prep;
+    if (!P || !wf->prep_valid) return DF_E_INVALID;                  // no prepare call pending on this handle
+    if (memcmp(P->v.dims, v.dims, sizeof(v.dims)) || memcmp(P->v.voxel_size, v.voxel_size, sizeof(v.voxel_size)) || P->v.trunc_dist != v.trunc_dist ||
+        P->v.max_weight != v.max_weight || memcmp(&P->s, &s, sizeof(s))) return DF_E_INVALID;       // not the volume the plan was made for
+    hipStream_t st = (hipStream_t)stream;
+    wf->prep_valid = false;
+    DF_HIP(hipStreamWaitEvent(st, wf->ev_prep_done, 0));
+    P->a.vol = (uint32_t*)v.data; P->a.n_upd = n_updated;
+    P->kern<<<P->grid, dim3(P->threads), P->lds, st>>>(P->a, P->W, P->tiles_x);
+    DF_LAUNCH_CHECK();
+    DF_HIP(hipEventRecord(wf->ev_sweep_done[P->seq & 1], st));
+    wf->recorded_seq = P->seq;
+    return DF_OK;
+}
+
+static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int cols, int rows, DfVolume v, const DfSlab* slab,
+                                    const float vol2world[12], const float world2cam[12], const float proj[4],
+                                    DfWarpField* wf, int k, unsigned flags, unsigned long long* n_updated, dfStream stream, int mode)
 {
     if (!dists || !vol2world || !world2cam || !proj || !wf || cols <= 0 || rows <= 0 || !df_volume_valid(v)) return DF_E_INVALID;
     if (k < 1 || k > 8 || wf->M < k) return DF_E_INVALID;
@@ -2342,7 +2452,11 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         return DF_E_NO_INDEX;
     if (s.z_own_n == 0) return DF_OK;
     hipStream_t st = (hipStream_t)stream;
+    // (sweeps issued through the split API on another stream: the single call waits for all of them; a prepare only for the sweeps that
+    // still read what it rewrites -- see the plan sets below and df_warp_pack)
+    if (mode == DF_MODE_WHOLE) { int rc = df_wait_split_sweep(wf, st); if (rc) return rc; }
     { int rc = df_side_join(wf, st); if (rc) return rc; }     // the previous call's look-ahead builds (tables, models, state bytes)
+    wf->prep_valid = false;                                   // (a prepared plan that was never swept is void once the handle's scratch is rewritten)
 
     DfWarpedArgs a;
     memset(&a, 0, sizeof(a));
@@ -2462,27 +2576,41 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
             // 2 (4) plan entries.  The grid is sized for every strip -- nothing is read back -- and the workgroups past the plan's end
             // return at once.
             const unsigned n_zb = grid.y, n_items = (unsigned)tiles_x * (unsigned)tiles_y * 2u * n_zb;
+            // The plan lives in TWO sets of (masks, bins), used alternately, and its bin counters in FOUR, each plan kernel zeroing the set of
+            // the plan after next: a sweep issued through the split API may still be reading its plan while the next frame's is made.
             if (n_items > wf->plan_cap) {
-                (void)hipFree(wf->plan_mask); (void)hipFree(wf->plan_list); wf->plan_mask = nullptr; wf->plan_list = nullptr; wf->plan_cap = 0;
-                DF_HIP(hipMalloc((void**)&wf->plan_mask, (size_t)n_items * sizeof(unsigned long long)));
-                DF_HIP(hipMalloc((void**)&wf->plan_list, (size_t)n_items * DF_PLAN_BINS * sizeof(unsigned int)));      // the bins
-                wf->plan_cap = n_items;
+                { int rc = df_wait_all_sweeps_host(wf); if (rc) return rc; }
+                for (int i = 0; i < 2; ++i) {
+                    (void)hipFree(wf->plan_mask2[i]); (void)hipFree(wf->plan_list2[i]); wf->plan_mask2[i] = nullptr; wf->plan_list2[i] = nullptr;
+                }
+                wf->plan_cap = 0; wf->plan_mask = nullptr; wf->plan_list = nullptr;
+                for (int i = 0; i < 2; ++i) {
+                    DF_HIP(hipMalloc((void**)&wf->plan_mask2[i], (size_t)n_items * sizeof(unsigned long long)));
+                    DF_HIP(hipMalloc((void**)&wf->plan_list2[i], (size_t)n_items * DF_PLAN_BINS * sizeof(unsigned int)));      // the bins
+                }
+                wf->plan_mask = wf->plan_mask2[0]; wf->plan_list = wf->plan_list2[0];       // (the names the destructor frees)
+                wf->plan_cap = n_items; wf->plan_reader[0] = wf->plan_reader[1] = 0;
             }
-            if (!wf->plan_hist) {                                          // two counter sets, used alternately; each plan launch zeroes the other one
-                DF_HIP(hipMalloc((void**)&wf->plan_hist, 2 * 128 * sizeof(unsigned int)));
-                DF_HIP(hipMemsetAsync(wf->plan_hist, 0, 2 * 128 * sizeof(unsigned int), st));
-                wf->plan_phase = 0;
+            if (!wf->plan_hist) {
+                DF_HIP(hipMalloc((void**)&wf->plan_hist, 4 * 128 * sizeof(unsigned int)));
+                DF_HIP(hipMemsetAsync(wf->plan_hist, 0, 4 * 128 * sizeof(unsigned int), st));
+                wf->hphase = 0;
             }
+            wf->pphase ^= 1;
+            { int rc = df_wait_reader(wf, wf->plan_reader[wf->pphase], st); if (rc) return rc; }     // (the sweep two plans ago)
             if (a.cull) { int rc = df_block_verdicts(wf, a, k, flags, st); if (rc) return rc; }
             else { int rc = df_tables_complete(wf, st); if (rc) return rc; }
             ++wf->tab_sweeps;
-            unsigned int* cnt = wf->plan_hist + 128 * wf->plan_phase;
-            unsigned int* cnt_next = wf->plan_hist + 128 * (wf->plan_phase ^ 1);
-            hipLaunchKernelGGL(df_sweep_plan_kernel, dim3((n_items + DF_PLAN_WG / 64 - 1) / (DF_PLAN_WG / 64)), dim3(DF_PLAN_WG), 0, st, a, tiles_x, tiles_y, n_items, wf->plan_mask, cnt,
-                               wf->plan_list, cnt_next);
+            unsigned int* cnt = wf->plan_hist + 128 * (wf->hphase & 3u);
+            unsigned int* cnt_next = wf->plan_hist + 128 * ((wf->hphase + 2u) & 3u);       // (last read by the sweep two plans ago: waited for above)
+            unsigned long long* pmask = wf->plan_mask2[wf->pphase]; unsigned int* plist = wf->plan_list2[wf->pphase];
+            hipLaunchKernelGGL(df_sweep_plan_kernel, dim3((n_items + DF_PLAN_WG / 64 - 1) / (DF_PLAN_WG / 64)), dim3(DF_PLAN_WG), 0, st, a, tiles_x, tiles_y, n_items, pmask, cnt,
+                               plist, cnt_next);
             DF_LAUNCH_CHECK();
-            wf->plan_phase ^= 1;                                           // (only once the kernel that zeroes the other set is in the stream)
-            a.plan_mask = wf->plan_mask; a.plan_bins = wf->plan_list; a.plan_cnt = cnt; a.plan_items = n_items; a.plan_tiles_y = tiles_y;
+            ++wf->hphase;                                                  // (only once the kernel that zeroes the set after next is in the stream)
+            a.plan_mask = pmask; a.plan_bins = plist; a.plan_cnt = cnt; a.plan_items = n_items; a.plan_tiles_y = tiles_y;
+            // this plan's sweep: its number, and what it will read
+            wf->plan_reader[wf->pphase] = wf->node_reader[wf->nphase] = ++wf->seq;
             const unsigned spw = wide ? 4u : 2u;
             grid = dim3((n_items + spw - 1) / spw, 1);
 #ifdef DF_TRACE_WG
@@ -2504,8 +2632,23 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
             return DF_OK;
 #endif
         }
+        if (mode == DF_MODE_PREPARE) {
+            if (!pipe) return DF_E_INVALID;                                // (the split exists for the cached, pipelined sweep only)
+            if (!wf->prep) wf->prep = new DfPrepared();
+            DfPrepared* P = (DfPrepared*)wf->prep;
+            P->a = a; P->W = W; P->kern = kern; P->grid = grid; P->threads = wide ? 1024u : 512u; P->lds = lds; P->tiles_x = tiles_x; P->v = v; P->s = s;
+            P->seq = wf->seq;
+            wf->prep_valid = true;
+            return DF_OK;
+        }
         kern<<<grid, dim3(wide ? 1024 : 512), lds, st>>>(a, W, tiles_x);
+        if (pipe && wf->split_events) {                                   // (a handle that is also driven through the split API: this sweep counts)
+            DF_LAUNCH_CHECK();
+            DF_HIP(hipEventRecord(wf->ev_sweep_done[wf->seq & 1], st));
+            wf->recorded_seq = wf->seq;
+        }
     } else if (use_tab) {
+        if (mode == DF_MODE_PREPARE) return DF_E_INVALID;
         { int rc = df_tables_complete(wf, st); if (rc) return rc; }
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_ROW_TY - 1) / DF_ROW_TY;
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
@@ -2514,6 +2657,7 @@ extern "C" int dfusion_integrate_warped(const uint16_t* dists, size_t pitch, int
         if (use_w) { DF_DISPATCH_K(k, df_warp_rows_kernel<K, true, 4><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
         else { DF_DISPATCH_K(k, df_warp_rows_kernel<K, false, 4><<<grid, dim3(256), 0, st>>>(a, W, tiles_x)); }
     } else {
+        if (mode == DF_MODE_PREPARE) return DF_E_INVALID;
         const int bz_lo = s.z_own0 / DF_BRICK, bz_hi = (s.z_own0 + s.z_own_n - 1) / DF_BRICK;
         a.bz0 = bz_lo;
         dim3 grid((unsigned)(W.bx * W.by), (unsigned)(bz_hi - bz_lo + 1));

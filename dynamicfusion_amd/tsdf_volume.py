@@ -222,6 +222,27 @@ class TsdfVolume:
         if sync:
             torch.cuda.current_stream().synchronize()
 
+    # ---- the same frame in two calls (include/dfusion.h dfusion_integrate_warped_prepare / _sweep): `prepare` does everything that does
+    # not touch the volume and may run on another stream (beside the previous frame's ray-cast); `sweep` waits for it on the device
+    def integrate_warped_prepare(self, dists, camera_pose, intr, warp_field, k=None, prefetch=True, block_model=True):
+        k = warp_field.k if k is None else k
+        world2cam = affine_mul(affine_inv(np.asarray(camera_pose, F32)), warp_field.warp_to_live_)
+        warp_field.ensure_index(self, k)
+        rows, cols = dists.shape
+        capi.check(capi.lib().dfusion_integrate_warped_prepare(
+            _ptr(dists), cols * 2, cols, rows, self.c_volume(), self.c_slab(), capi.floats(aff12(self.pose_)),
+            capi.floats(aff12(world2cam)), intr.as_proj(), warp_field.handle, k,
+            (capi.DF_WARP_STEADY_PREFETCH if prefetch == "steady" else 0 if prefetch else capi.DF_WARP_NO_PREFETCH) |
+            (capi.DF_WARP_BLOCK_MODEL_NOW if block_model == "now" else 0 if block_model else capi.DF_WARP_NO_BLOCK_MODEL),
+            _stream()), "dfusion_integrate_warped_prepare")
+
+    def integrate_warped_sweep(self, warp_field, n_updated=None, sync=False):
+        capi.check(capi.lib().dfusion_integrate_warped_sweep(self.c_volume(), self.c_slab(), warp_field.handle,
+                                                             _ptr(n_updated) if n_updated is not None else None, _stream()),
+                   "dfusion_integrate_warped_sweep")
+        if sync:
+            torch.cuda.current_stream().synchronize()
+
     def _raycast_args(self, camera_pose):
         cam2vol = affine_mul(affine_inv(self.pose_), np.asarray(camera_pose, F32))      # tsdf_volume.cpp:162
         Rinv = np.linalg.inv(cam2vol[:3, :3].astype(np.float64)).astype(F32)            # :165 inv(DECOMP_SVD)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 5   /* 5: dfusion_raycast_sum_pieces (direct row-band merge), DF_WARP_STEADY_PREFETCH, dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
+#define DFUSION_ABI_VERSION 5   /* 5: dfusion_integrate_warped_prepare / _sweep (the frame's integrate in two calls, for cross-frame overlap), dfusion_raycast_sum_pieces (direct row-band merge), DF_WARP_STEADY_PREFETCH, dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
@@ -337,6 +337,24 @@ int dfusion_integrate_warped(const uint16_t *dists_dev, size_t dists_pitch, int 
                              const DfSlab *slab, const float vol2world[12], const float world2cam[12],
                              const float proj[4], DfWarpField *wf, int k, unsigned flags,
                              unsigned long long *n_updated_dev, dfStream stream);
+
+/* The same frame in TWO calls (ABI 5), for hosts that pipeline frames: everything of the warped integrate that does not touch the volume --
+ * the dists max-pyramid, the per-block verdict pass, on-demand table / model builds, the launch plan: ~70 us of small kernels at the
+ * headline size -- and the sweep.  `prepare` (and the dfusion_warp_set_transforms before it) may be issued on another stream than `sweep` and
+ * then runs BESIDE the previous frame's sweep and ray-cast: what a sweep reads of the handle -- the node transform arrays, the launch plan --
+ * is double-buffered, and the handle orders the rest itself (a sweep waits for its prepare on the device; set_transforms / prepare wait
+ * for the sweep TWO frames back, whose buffers they reuse).  The caller owns the dists image: give consecutive frames different buffers.
+ * All sweeps of a handle go on ONE stream; every other call on the handle must still be ordered by the caller, and a handle is driven
+ * either through these two calls or through dfusion_integrate_warped on one stream (mixing them is safe only on that one stream).
+ * Results are those of dfusion_integrate_warped, bit for bit.  Only the cached path has a plan to
+ * prepare: DF_E_INVALID without the per-voxel weight tables, with DF_WARP_NO_PIPELINE / NO_LDS / NO_TABLE, or k other than 4 / 8.
+ * geometry.data is not dereferenced by prepare (may be NULL); sweep wants the same dims / voxel size / slab.  A prepared plan is void
+ * after any other integrate on the handle.                                                                                              */
+int dfusion_integrate_warped_prepare(const uint16_t *dists_dev, size_t dists_pitch, int cols, int rows, DfVolume geometry,
+                                     const DfSlab *slab, const float vol2world[12], const float world2cam[12], const float proj[4],
+                                     DfWarpField *wf, int k, unsigned flags, dfStream stream);
+int dfusion_integrate_warped_sweep(DfVolume v, const DfSlab *slab, DfWarpField *wf, unsigned long long *n_updated_dev, dfStream stream);
+
 
 /* ---- depth front-end + projective ICP -----------------------------------------------------
  * All images are pitched device memory: depth u16 mm, points / normals float4.  `intr` = {fx, fy, cx, cy} of the

@@ -509,3 +509,60 @@ def test_block_models_shrink_the_swept_set_and_change_nothing():
         print("on demand %d: swept voxels / updated: ball test %.3f, with block models %.3f" % (on_demand, swept[0] / upd[0], swept[1] / upd[1]))
         assert torch.equal(vols[0], vols[1]) and upd[0] == upd[1] and upd[0] > 0
         assert swept[1] < 0.85 * swept[0] and swept[1] >= upd[1]
+
+
+def test_prepare_and_sweep_on_two_streams_equal_the_single_call():
+    """dfusion_integrate_warped_prepare / _sweep (round 5): the frame's warped integrate split into the part that does not touch the volume
+    (pyramid, verdict pass, table / model builds, plan) and the sweep, the former issued on ANOTHER stream beside the previous frame's
+    ray-cast -- the pipelining bench.py uses.  Twelve frames of a moving camera with changing transforms: volumes after every frame, update
+    counts and every ray-cast image must be the single call's, bit for bit; and the error paths of the split (no plan pending, a plan made
+    for another volume, a configuration without a plan) must say so."""
+    cfg = synth.Config(128, 1.0, cols=320, rows=240, nodes=300, k=8)
+    frames = 12
+    sc = Scene(cfg, n_frames=frames)
+    intr = Intr(*cfg.intr)
+    dists = [upload_u16(d) for d in sc.dists]
+    dqs = [torch.from_numpy(q).cuda() for q in sc.dqs]
+
+    def run(split):
+        v = make_gpu_volume(sc)
+        wf = make_gpu_warp(sc, k=cfg.k)
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
+        main, prep = torch.cuda.current_stream(), torch.cuda.Stream()
+        snaps, casts = [], []
+        for f in range(frames):
+            if split:
+                # nothing orders the prepare half of frame f against the sweep of frame f - 1 here but the library itself: they run side by side
+                if f == 0: prep.wait_stream(main)                   # (uploads and the volume's clear were enqueued on the main stream)
+                with torch.cuda.stream(prep):
+                    wf.set_transforms(dqs[f])
+                    v.integrate_warped_prepare(dists[f], sc.cam_poses[f], intr, wf, prefetch="steady")
+                v.integrate_warped_sweep(wf, n_updated=cnt)
+            else:
+                wf.set_transforms(dqs[f])
+                v.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, n_updated=cnt, sync=False, prefetch="steady")
+            v.raycast(sc.cam_poses[f], intr, pts, nrm)
+            snaps.append(v.data().clone()); casts.append(pts.clone())
+        torch.cuda.synchronize()
+        return snaps, casts, int(cnt.item()), v, wf
+
+    a_snaps, a_casts, a_n, _, _ = run(False)
+    b_snaps, b_casts, b_n, v, wf = run(True)
+    assert a_n == b_n > 0
+    for f in range(frames):
+        assert torch.equal(a_snaps[f], b_snaps[f]), "volume after frame %d differs" % f
+        assert torch.equal(a_casts[f].view(torch.int32), b_casts[f].view(torch.int32)), "ray-cast of frame %d differs" % f
+    # error paths: nothing prepared; a plan for another geometry; the lean configuration has no plan
+    with pytest.raises(capi.DfusionError):
+        v.integrate_warped_sweep(wf)
+    v.integrate_warped_prepare(dists[0], sc.cam_poses[0], intr, wf)
+    other = make_gpu_volume(Scene(synth.Config(64, 1.0, cols=320, rows=240, nodes=300, k=8), n_frames=1))
+    with pytest.raises(capi.DfusionError):
+        other.integrate_warped_sweep(wf)
+    v.integrate_warped_sweep(wf)                                  # (the pending plan is still good for ITS volume)
+    lean = WarpField(k=cfg.k, voxel_table=False)
+    lean.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
+    with pytest.raises(capi.DfusionError):
+        v.integrate_warped_prepare(dists[0], sc.cam_poses[0], intr, lean)
+    torch.cuda.synchronize()
