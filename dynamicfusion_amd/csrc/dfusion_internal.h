@@ -80,6 +80,7 @@ struct DfWarpField {
     // a buffer remembers the last sweep that reads it, the ring of two events holds the last two sweeps (all sweeps on one stream).
     float4 *rot_alt, *dual_alt, *node_t_alt;
     unsigned long long seq, recorded_seq;            // sweeps prepared / recorded so far
+    unsigned long long ring_seq[2];                  // the sweep whose completion ev_sweep_done[i] stands for (0: none)
     unsigned long long node_reader[2]; int nphase;  // [nphase] = the current node set's last reader, [nphase ^ 1] = the alternate's
     unsigned long long plan_reader[2];
     unsigned long long* plan_mask2[2]; unsigned int* plan_list2[2]; int pphase; unsigned hphase;

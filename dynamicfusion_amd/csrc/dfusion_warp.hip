@@ -138,8 +138,12 @@ static int df_wait_split_sweep(DfWarpField* wf, hipStream_t st)            // ev
 static int df_wait_reader(DfWarpField* wf, unsigned long long reader, hipStream_t st)
 {
     if (reader == 0 || wf->recorded_seq == 0 || reader > wf->recorded_seq) return DF_OK;
-    const unsigned long long e = reader + 1 >= wf->recorded_seq ? reader : wf->recorded_seq - 1;
-    DF_HIP(hipStreamWaitEvent(st, wf->ev_sweep_done[e & 1], 0));
+    // the earliest recorded sweep that is not older than `reader` (sweeps complete in order: its completion implies the reader's)
+    int pick = -1;
+    for (int i = 0; i < 2; ++i)
+        if (wf->ring_seq[i] >= reader && (pick < 0 || wf->ring_seq[i] < wf->ring_seq[pick])) pick = i;
+    if (pick < 0) return DF_OK;
+    DF_HIP(hipStreamWaitEvent(st, wf->ev_sweep_done[pick], 0));
     return DF_OK;
 }
 extern "C" int dfusion_warp_destroy(DfWarpField* wf)
@@ -2435,7 +2439,7 @@ extern "C" int dfusion_integrate_warped_sweep(DfVolume v, const DfSlab* slab, Df
     P->kern<<<P->grid, dim3(P->threads), P->lds, st>>>(P->a, P->W, P->tiles_x);
     DF_LAUNCH_CHECK();
     DF_HIP(hipEventRecord(wf->ev_sweep_done[P->seq & 1], st));
-    wf->recorded_seq = P->seq;
+    wf->recorded_seq = P->seq; wf->ring_seq[P->seq & 1] = P->seq;
     return DF_OK;
 }
 
@@ -2645,7 +2649,7 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
         if (pipe && wf->split_events) {                                   // (a handle that is also driven through the split API: this sweep counts)
             DF_LAUNCH_CHECK();
             DF_HIP(hipEventRecord(wf->ev_sweep_done[wf->seq & 1], st));
-            wf->recorded_seq = wf->seq;
+            wf->recorded_seq = wf->seq; wf->ring_seq[wf->seq & 1] = wf->seq;
         }
     } else if (use_tab) {
         if (mode == DF_MODE_PREPARE) return DF_E_INVALID;
