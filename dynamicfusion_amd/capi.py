@@ -38,6 +38,7 @@ DF_WARP_NO_BLOCK_MODEL = 128
 DF_WARP_BLOCK_MODEL_NOW = 256
 DF_WARP_NO_PREFETCH = 512
 DF_WARP_STEADY_PREFETCH = 1024
+DF_WARP_NO_CODES = 2048
 DF_RIGID_NO_DEPTH_CULL = 1
 DF_RIGID_NO_SHORT_FORMS = 2
 DF_RIGID_KEEP_ALL = 4
@@ -57,7 +58,7 @@ SYMBOLS = [
     "dfusion_bilateral_filter", "dfusion_truncate_depth", "dfusion_depth_pyramid", "dfusion_compute_normals_mask_depth",
     "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
     "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate", "dfusion_release_scratch", "dfusion_raycast_points_of_keys",
-    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_integrate_ex", "dfusion_warp_debug_counters", "dfusion_warp_alive_blocks", "dfusion_raycast_points_of_keys_rows", "dfusion_raycast_sum_pieces", "dfusion_integrate_warped_prepare", "dfusion_integrate_warped_sweep",
+    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_integrate_ex", "dfusion_warp_debug_counters", "dfusion_warp_alive_blocks", "dfusion_warp_coded_blocks", "dfusion_raycast_points_of_keys_rows", "dfusion_raycast_sum_pieces", "dfusion_integrate_warped_prepare", "dfusion_integrate_warped_sweep",
     "dfusion_render_image_points", "dfusion_render_image_depth", "dfusion_render_tangent_colors",
 ]
 
@@ -154,6 +155,7 @@ def load(path, strict=True):
     L.dfusion_integrate_ex.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, DfVolume, C.POINTER(DfSlab), fp, fp, C.c_uint, vp, vp, vp]
     L.dfusion_warp_debug_counters.argtypes = [vp, vp]
     L.dfusion_warp_alive_blocks.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    L.dfusion_warp_coded_blocks.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
     L.dfusion_copy_bandwidth_probe.argtypes = [vp, vp, C.c_size_t, vp]
     L.dfusion_read_bandwidth_probe.argtypes = [vp, C.c_size_t, vp, vp]
     for s in SYMBOLS:

@@ -84,6 +84,7 @@ struct DfWarpField {
     unsigned long long node_reader[2]; int nphase;  // [nphase] = the current node set's last reader, [nphase ^ 1] = the alternate's
     unsigned long long plan_reader[2];
     unsigned long long* plan_mask2[2]; unsigned int* plan_list2[2]; int pphase; unsigned hphase;
+    unsigned long long* plan_code2[2];               // per strip item: which of its (patch, layer) cells read 4-bit codes
     uint16_t* pyr_mem; size_t pyr_cap;      // max-pyramid of the frame's dists image (warped sweep's depth cull), entries
     // scratch of dfusion_warp_solve_data_term (grown on demand)
     void* solver_ws; size_t solver_ws_cap;
@@ -103,6 +104,9 @@ struct DfWarpField {
     // weights (allocated with the first model), bm_cnt entry counts
     uint8_t* blk_state; float* blk_wmax; uint8_t* blk_alive; uint32_t* blk_work; uint32_t* blk_cnt; size_t blk_cap; int blk_phase;
     uint16_t* bm_idx; uint32_t* bm_lam; uint32_t* bm_w; uint8_t* bm_cnt; size_t bm_cap;
+    // 4-bit neighbour codes (round 5): per voxel of a modelled block, its k neighbours as positions in the block's union list (bm_ids:
+    // [block][16] node ids, ascending); code_tab: one u32 per voxel, tile-major like the tables but PATCH-major inside a tile plane
+    uint32_t* code_tab; size_t code_cap; uint16_t* bm_ids;
     bool tab_complete;           // every block's tables are built
     int tab_sweeps;              // sweeps over the current tables so far (the models are made from the second one on)
     unsigned long long* dbg_swept;   // dfusion_warp_debug_counters: nullable device counter the sweeps through this handle add to

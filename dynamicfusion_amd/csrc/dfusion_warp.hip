@@ -153,13 +153,14 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     if (wf->side) { (void)hipEventDestroy(wf->ev_fork); (void)hipEventDestroy(wf->ev_join); (void)hipStreamDestroy(wf->side); }
     if (wf->split_events) { (void)hipEventDestroy(wf->ev_prep_done); (void)hipEventDestroy(wf->ev_sweep_done[0]); (void)hipEventDestroy(wf->ev_sweep_done[1]); }
     (void)hipFree(wf->rot_alt); (void)hipFree(wf->dual_alt); (void)hipFree(wf->node_t_alt);
-    (void)hipFree(wf->plan_mask2[1]); (void)hipFree(wf->plan_list2[1]);
+    (void)hipFree(wf->plan_mask2[1]); (void)hipFree(wf->plan_list2[1]); (void)hipFree(wf->plan_code2[0]); (void)hipFree(wf->plan_code2[1]);
     df_prep_free(wf);
     if (wf->host_report) (void)hipHostFree((void*)wf->host_report);
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
     (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids); (void)hipFree(wf->tile_wmax);
     (void)hipFree(wf->bm_idx); (void)hipFree(wf->bm_lam); (void)hipFree(wf->bm_w); (void)hipFree(wf->bm_cnt);
+    (void)hipFree(wf->code_tab); (void)hipFree(wf->bm_ids);
     (void)hipFree(wf->scan_tmp);
     (void)hipFree(wf->blk_state); (void)hipFree(wf->blk_wmax); (void)hipFree(wf->blk_alive); (void)hipFree(wf->blk_work); (void)hipFree(wf->blk_cnt);
     (void)hipFree(wf->nf_nodes); (void)hipFree(wf->nf_vpos); (void)hipFree(wf->pyr_mem);
@@ -1165,6 +1166,9 @@ struct DfWarpedArgs {
     // this frame's verdicts of the block blend models (dfusion_warp_blocks.h), one byte per 8 x 8 x 8 block of the table's planes,
     // x fastest; null = none.  bm_nbx / bm_nby: blocks per row / column (whole table tiles)
     const uint8_t* blk_alive; int bm_nbx, bm_nby;
+    // 4-bit neighbour codes of modelled blocks (DF_IDX_CODES; null = none): see df_code_index / df_block_model_kernel
+    uint32_t* code_tab; uint16_t* bm_ids;
+    const unsigned long long* plan_code;       // pipelined sweep: per strip item, bit 16 p + l: the cell's block has codes
     // table build (df_warp_brick_kernel<K, true>): per-block bound on sum_i w_i (same block grid), and -- when the build is driven by a
     // work list instead of the launch grid -- the list of packed brick coordinates (x | y << 10 | z << 20) and its length
     float* blk_wmax; const uint32_t* work; const uint32_t* work_cnt; uint32_t* work_cursor;
@@ -1207,6 +1211,25 @@ __device__ __forceinline__ size_t df_tab_index(const DfWarpedArgs& a, int x, int
     const int zl = z - a.tab_z0;
     const size_t tile = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty + (y / DF_TAB_TY)) * a.tab_ntx + (x / DF_TAB_TX);
     return tile * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ) + (size_t)(zl % DF_TAB_TZ) * (DF_TAB_TX * DF_TAB_TY) + df_tab_in_plane(x, y);
+}
+
+// entry of voxel (x, y, z) in the CODE table: the tables' tiles, but patch-major inside a tile plane (the eight 8 x 8 column patches one
+// after the other) -- the 64 codes a wave of the pipelined sweep loads for its 8 x 8 patch are ONE 256-byte run, two L2 requests.  (The
+// sweep is bound by the L2's request rate, TCC 86 % busy: measured, the same 4 bytes per voxel laid out in rows of 32 -- eight 32-byte
+// pieces per wave -- cost as much as the 16-byte index records they replace.)
+#ifndef DF_IDX_CODES
+#define DF_IDX_CODES 1
+#endif
+__device__ __forceinline__ unsigned df_code_in_plane(int x, int y)
+{
+    const unsigned xt = (unsigned)x % DF_TAB_TX, yt = (unsigned)y % DF_TAB_TY;
+    return (((yt >> 3) * (DF_TAB_TX / 8) + (xt >> 3)) << 6) + ((yt & 7u) << 3) + (xt & 7u);
+}
+__device__ __forceinline__ size_t df_code_index(const DfWarpedArgs& a, int x, int y, int z)
+{
+    const int zl = z - a.tab_z0;
+    const size_t tile = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty + (y / DF_TAB_TY)) * a.tab_ntx + (x / DF_TAB_TX);
+    return tile * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ) + (size_t)(zl % DF_TAB_TZ) * (DF_TAB_TX * DF_TAB_TY) + df_code_in_plane(x, y);
 }
 
 #define DF_CAND_CHUNK 256
@@ -1522,6 +1545,9 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
 #ifndef DF_TAB_ADDR_HOIST
 #define DF_TAB_ADDR_HOIST 1      // table record addresses from a per-segment base (0: the general df_tab_index arithmetic per load)
 #endif
+#ifndef DF_PIPE_ROWS
+#define DF_PIPE_ROWS 0           // experiment: the pipelined sweep's waves own 32 x 2 column patches (full 128-byte voxel rows) instead of 8 x 8
+#endif
 #ifndef DF_LDS_SPLIT
 #define DF_LDS_SPLIT 0           // experiment: rot and node_t in two 16-byte-strided LDS arrays (M <= 2048) instead of interleaved
 #endif
@@ -1655,7 +1681,11 @@ __global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArg
 // raw (still packed) table record of one voxel: kept packed while in flight, so that nothing consumes a prefetched
 // register before the next iteration (an unpack right after the load would make the compiler wait for it at once)
 template <int K> struct DfTabRaw;
+#if DF_IDX_CODES
+template <> struct DfTabRaw<8> { uint4 idx; float4 w0, w1; unsigned code; };
+#else
 template <> struct DfTabRaw<8> { uint4 idx; float4 w0, w1; };
+#endif
 template <> struct DfTabRaw<4> { uint2 idx; float4 w0; };
 __device__ __forceinline__ void tab_raw_load(const DfWarpedArgs& a, size_t tv, DfTabRaw<8>& r)
 {
@@ -1692,7 +1722,38 @@ __device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t re
     const df_v4f a4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec) + lane);
     const df_v4f b4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + a.tab_nvox + rec) + lane);
     r.idx = make_uint4(i4.x, i4.y, i4.z, i4.w); r.w0 = make_float4(a4.x, a4.y, a4.z, a4.w); r.w1 = make_float4(b4.x, b4.y, b4.z, b4.w);
+#if DF_IDX_CODES
+    r.code = 0u;
+#endif
 }
+#if DF_IDX_CODES
+// The same for a batch of a cell that may read 4-bit codes.  Branch-free (a branch around a load makes the compiler drain the prefetch
+// queue): BOTH the 16-byte index record and the 4-byte code are requested, the one the cell does not use from record 0 of its table -- a
+// place every wave hits in the L1 -- so it costs an instruction, no L2 request.  lane_c: the lane's offset in the patch-major code plane.
+#ifndef DF_CODES_LOAD_MODE
+#define DF_CODES_LOAD_MODE 0     // 0: one load per cell kind behind a wave-uniform branch (each arm issues exactly one load); 1: both loads, the unused one from record 0
+#endif
+__device__ __forceinline__ void tab_raw_load_coded(const DfWarpedArgs& a, size_t rec, bool coded, unsigned lane, unsigned lane_c, DfTabRaw<8>& r)
+{
+#if DF_CODES_LOAD_MODE == 0
+    r.idx = make_uint4(0u, 0u, 0u, 0u); r.code = 0u;
+    if (coded) {
+        r.code = DF_TAB_LD(df_wave_uniform(a.code_tab + rec) + lane_c);
+    } else {
+        const df_v4u i4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4u*>(a.knn_tab) + rec) + lane);
+        r.idx = make_uint4(i4.x, i4.y, i4.z, i4.w);
+    }
+#else
+    const size_t rec_i = coded ? (size_t)0 : rec, rec_c = coded ? rec : (size_t)0;
+    const df_v4u i4 = *(df_wave_uniform(reinterpret_cast<const df_v4u*>(a.knn_tab) + rec_i) + (coded ? (lane & 63u) : lane));
+    r.code = *(df_wave_uniform(a.code_tab + rec_c) + (coded ? lane_c : (lane_c & 63u)));
+    r.idx = make_uint4(i4.x, i4.y, i4.z, i4.w);
+#endif
+    const df_v4f a4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec) + lane);
+    const df_v4f b4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + a.tab_nvox + rec) + lane);
+    r.w0 = make_float4(a4.x, a4.y, a4.z, a4.w); r.w1 = make_float4(b4.x, b4.y, b4.z, b4.w);
+}
+#endif
 __device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<4>& r)
 {
     const df_v2u i2 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v2u*>(a.knn_tab) + rec) + lane);
@@ -1773,6 +1834,39 @@ __device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<8>& r)
     df_blend_pair(S, r.idx.z, df_v2f{r.w1.x, r.w1.y}); df_blend_pair(S, r.idx.w, df_v2f{r.w1.z, r.w1.w});
     return S;
 }
+#if DF_IDX_CODES
+// ... and from 4-bit codes: neighbour i = entry ((code >> 4 i) & 15) of the wave's LOCAL copy of its block's union (16 x 32 bytes at LDS
+// address lbase, a multiple of 512): a shift and an and-or per neighbour instead of one SDWA shift; the same nodes in the same order, so
+// the same sums.
+__device__ __forceinline__ void df_blend_pair_at(DfBlendSums& S, unsigned off_lo, unsigned off_hi, df_v2f wp)
+{
+    {
+        df_lds_cf4* nd = (df_lds_cf4*)(size_t)off_lo;
+        const df_v4f r4 = nd[0], t4 = nd[1];
+        const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
+        S.t01 = S.t01 + df_pk_mul_lo(wp, ta); S.t23 = S.t23 + df_pk_mul_lo(wp, tb);
+        S.r01 = S.r01 + df_pk_mul_lo(wp, ra); S.r23 = S.r23 + df_pk_mul_lo(wp, rb);
+    }
+    {
+        df_lds_cf4* nd = (df_lds_cf4*)(size_t)off_hi;
+        const df_v4f r4 = nd[0], t4 = nd[1];
+        const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
+        S.t01 = S.t01 + df_pk_mul_hi(wp, ta); S.t23 = S.t23 + df_pk_mul_hi(wp, tb);
+        S.r01 = S.r01 + df_pk_mul_hi(wp, ra); S.r23 = S.r23 + df_pk_mul_hi(wp, rb);
+    }
+}
+__device__ __forceinline__ DfBlendSums dqb_sums_codes(const DfTabRaw<8>& r, unsigned lbase)
+{
+    DfBlendSums S;
+    S.t01 = S.t23 = S.r01 = S.r23 = df_v2f{0.f, 0.f};
+    const unsigned c = r.code;
+#define DF_CODE_OFF(i) ((((i) == 0 ? (c << 5) : (i) == 1 ? (c << 1) : (c >> (4 * (i) - 5))) & 0x1e0u) | lbase)
+    df_blend_pair_at(S, DF_CODE_OFF(0), DF_CODE_OFF(1), df_v2f{r.w0.x, r.w0.y}); df_blend_pair_at(S, DF_CODE_OFF(2), DF_CODE_OFF(3), df_v2f{r.w0.z, r.w0.w});
+    df_blend_pair_at(S, DF_CODE_OFF(4), DF_CODE_OFF(5), df_v2f{r.w1.x, r.w1.y}); df_blend_pair_at(S, DF_CODE_OFF(6), DF_CODE_OFF(7), df_v2f{r.w1.z, r.w1.w});
+#undef DF_CODE_OFF
+    return S;
+}
+#endif
 __device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<4>& r)
 {
     DfBlendSums S;
@@ -1794,7 +1888,8 @@ __device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<4>& r)
 #define DF_PLAN_WG 1024          // 16 items per workgroup: neighbours in the volume, mostly of equal work, so their bin slots are taken with one atomic
 __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpedArgs a, int tiles_x, int tiles_y, unsigned n_items,
                                                                    unsigned long long* __restrict__ mask_out, unsigned int* __restrict__ cnt,
-                                                                   unsigned int* __restrict__ bins, unsigned int* __restrict__ cnt_next)
+                                                                   unsigned int* __restrict__ bins, unsigned int* __restrict__ cnt_next,
+                                                                   unsigned long long* __restrict__ code_out)
 {
     __shared__ unsigned int s_cnt[DF_PLAN_BINS], s_base[DF_PLAN_BINS];
     if (threadIdx.x < DF_PLAN_BINS) { s_cnt[threadIdx.x] = 0u; if (blockIdx.x == 0) cnt_next[threadIdx.x] = 0u; }
@@ -1812,12 +1907,32 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
         const int zb = (int)(tcol / ((unsigned)tiles_x * (unsigned)tiles_y));
         const int lt0 = a.bz0 + zb * a.zt;
         const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
+#if DF_PIPE_ROWS
+        // 32 x 2 patches (two full 128-byte voxel rows per wave and plane): patch p = rows 2p, 2p + 1 of the strip's 32 x 8 columns, which
+        // span the strip's FOUR 8 x 8 x 8 blocks of the layer -- alive when any of them is
+        const int x0 = tx * DF_ROW_TX, y0 = ty * DF_LDS_TY + (int)half * 8;
+        bool keep = l < a.zt && max((lt0 + l) * DF_ROW_TZ, a.z_own0) < min((lt0 + l + 1) * DF_ROW_TZ, own1) && x0 < a.X && y0 + 2 * p < a.Y;
+        if (keep && a.blk_alive) {
+            const uint8_t* row = a.blk_alive + ((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3);
+            keep = (row[0] | row[1] | row[2] | row[3]) != 0;               // (bm_nbx covers whole table tiles: the four bytes exist)
+        }
+#else
         const int x0 = tx * DF_ROW_TX + p * 8, y0 = ty * DF_LDS_TY + (int)half * 8;                  // first column of the patch
         bool keep = l < a.zt && max((lt0 + l) * DF_ROW_TZ, a.z_own0) < min((lt0 + l + 1) * DF_ROW_TZ, own1) && x0 < a.X && y0 < a.Y;
         // the verdict pass has judged the patch's 8 x 8 x 8 voxels of the layer (df_block_verdict_kernel: zero-weight, ball, blend-model box)
         if (keep && a.blk_alive)
             keep = a.blk_alive[((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3)] != 0;
+#endif
         m = __builtin_amdgcn_ballot_w64(keep);
+#if DF_IDX_CODES && !DF_PIPE_ROWS
+        if (code_out) {                                                    // (wave-uniform) which alive cells' blocks have 4-bit neighbour codes
+            bool coded = false;
+            if (keep && a.blk_alive)       // (bit 1 of the verdict byte: see df_block_verdict_kernel)
+                coded = (a.blk_alive[((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3)] & 2u) != 0;
+            const unsigned long long cm = __builtin_amdgcn_ballot_w64(coded);
+            if (ln == 0 && m) code_out[item] = cm;
+        }
+#endif
         if (a.n_swept) {                                                   // (measurement hook: what the sweep will put through the warp)
             unsigned v = keep ? (unsigned)(64 * (min((lt0 + l + 1) * DF_ROW_TZ, own1) - max((lt0 + l) * DF_ROW_TZ, a.z_own0))) : 0u;
 #pragma unroll
@@ -1881,11 +1996,17 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
     // the pipelined loop below as before.  Which voxel is updated by which wave changes; what is computed for it does not.
     constexpr unsigned NW = WGT / 64;
     unsigned items_s[SPW]; unsigned long long masks_s[SPW];
+#if DF_IDX_CODES
+    unsigned long long cmask_s[SPW];
+#endif
     unsigned total2 = 0;
 #pragma unroll
     for (unsigned s_ = 0; s_ < SPW; ++s_) {
         const unsigned sidx = blockIdx.x * SPW + s_;
         items_s[s_] = 0u; masks_s[s_] = 0ull;
+#if DF_IDX_CODES
+        cmask_s[s_] = 0ull;
+#endif
         if (sidx < n_alive) {
             const int j = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(sidx < bin_end)) - 1;      // its bin: the first running total above sidx
             const unsigned r = sidx - ((unsigned)__builtin_amdgcn_readlane((int)bin_end, j) - (unsigned)__builtin_amdgcn_readlane((int)bin_cnt, j));
@@ -1894,6 +2015,13 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
             masks_s[s_] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32)) << 32) |
                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m);
             total2 += 2u * (unsigned)__popcll(masks_s[s_]);
+#if DF_IDX_CODES
+            if (a.plan_code) {
+                const unsigned long long cm = a.plan_code[items_s[s_]];
+                cmask_s[s_] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cm >> 32)) << 32) |
+                              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cm);
+            }
+#endif
         }
     }
     const unsigned c0 = total2 * (unsigned)wave / NW, c1 = total2 * ((unsigned)wave + 1u) / NW;      // this wave's half-layer cells [c0, c1)
@@ -1904,6 +2032,12 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
 #pragma unroll
     for (unsigned s_ = 1; s_ < SPW; ++s_) if ((q >> 2) == s_) { item = items_s[s_]; m_item = masks_s[s_]; }
     const unsigned a16 = (unsigned)(m_item >> (16u * (q & 3u))) & 0xffffu;
+#if DF_IDX_CODES
+    unsigned long long c_item = cmask_s[0];
+#pragma unroll
+    for (unsigned s_ = 1; s_ < SPW; ++s_) if ((q >> 2) == s_) c_item = cmask_s[s_];
+    const unsigned cbits = (unsigned)(c_item >> (16u * (q & 3u))) & 0xffffu;       // layers of this patch whose block has 4-bit codes
+#endif
     const unsigned n2 = 2u * (unsigned)__popc(a16);
     const unsigned seg_lo = max(c0, pre), seg_hi = min(c1, pre + n2);
     const unsigned pre0 = pre;
@@ -1938,8 +2072,13 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
     const unsigned tcol = item >> 1;
     const int tx = (int)(tcol % (unsigned)tiles_x), ty = (int)((tcol / (unsigned)tiles_x) % (unsigned)a.plan_tiles_y);
     const int wv = (int)(item & 1u) * 4 + wave_patch;
+#if DF_PIPE_ROWS
+    const int x = tx * DF_ROW_TX + (ln & 31);
+    const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (wv & 3) * 2 + (ln >> 5);
+#else
     const int x = tx * DF_ROW_TX + (wv & 3) * 8 + (ln & 7);
     const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (ln >> 3);
+#endif
     const bool in_xy = x < a.X && y < a.Y;
     const int xc = min(x, a.X - 1), yc = min(y, a.Y - 1);                 // clamped: out-of-volume lanes read valid entries, write nothing
     const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
@@ -1980,12 +2119,34 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
         static_assert(DF_ROW_TZ == DF_TAB_TZ, "the sweep's layers are the tables' tile layers");
         const size_t rec_layer = (size_t)a.tab_nty * (size_t)a.tab_ntx * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ);
         const size_t rec0 = ((size_t)(lt0 - a.tab_z0 / DF_TAB_TZ) * a.tab_nty * a.tab_ntx + tile_col_u) * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ);
+#if DF_IDX_CODES
+        const unsigned lane_code = df_code_in_plane(xc, yc);
+        // the wave's copy of its block's union (16 nodes x {rot, node_t}): behind the node table, 512 bytes per wave, 512-aligned
+        const unsigned lbase = (((unsigned)W.M * 32u + 511u) & ~511u) + (unsigned)wave * 512u;
+        int loc_layer = -1;                                            // the layer whose union the copy holds
+        auto refill = [&](int l) {
+            const size_t blk = ((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y >> 3)) * a.bm_nbx + (unsigned)(x >> 3);
+            const size_t blk_u = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)blk) |
+                                 ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(blk >> 32)) << 32);
+            if (ln < DF_BM_NU) {
+                const unsigned id = a.bm_ids[blk_u * DF_BM_NU + (unsigned)ln];
+                float4* loc = (float4*)((char*)s_nodes + lbase);
+                loc[2 * ln] = s_nodes[2 * id]; loc[2 * ln + 1] = s_nodes[2 * id + 1];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the wave's own LDS writes, before its blends read them)
+        };
+#endif
         auto load_batch = [&](DfTabRaw<K> (&S)[U], int l, int z0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int zi = min(z0 + u, layer_ze(l) - 1) - (lt0 + l) * DF_ROW_TZ;         // plane inside the layer
                 const size_t rec = rec0 + (size_t)(unsigned)l * rec_layer + (size_t)(unsigned)(zi * (DF_TAB_TX * DF_TAB_TY));
+#if DF_IDX_CODES
+                if constexpr (K == 8) tab_raw_load_coded(a, rec, ((cbits >> l) & 1u) != 0u, lane_tab, lane_code, S[u]);
+                else tab_raw_load_at(a, rec, lane_tab, S[u]);
+#else
                 tab_raw_load_at(a, rec, lane_tab, S[u]);
+#endif
             }
         };
 #else
@@ -2061,6 +2222,10 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
             // square root take their short forms (dfusion_device.h: same bits on a restricted domain) when the whole wave is inside
             // the domain.
             f3 vc[U]; bool ok[U]; uint16_t dpb[U];
+#if DF_IDX_CODES
+            const bool coded = K == 8 && ((cbits >> l) & 1u) != 0u;       // wave-uniform
+            if (coded && l != loc_layer) { refill(l); loc_layer = l; }
+#endif
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 // canonical position.  With an axis-aligned volume (R = I exactly -- the reference's default pose is a pure
@@ -2070,7 +2235,13 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_ker
                 f3 q;
                 if constexpr (V2W_IDENTITY) q = add3(pv3, mk3(a.vol2world.t[0], a.vol2world.t[1], a.vol2world.t[2]));
                 else q = aff_mul(a.vol2world, pv3);
+#if DF_IDX_CODES
+                DfBlendSums B;
+                if constexpr (K == 8) { if (coded) B = dqb_sums_codes(S[u], lbase); else B = dqb_sums_lds_rec(S[u]); }
+                else B = dqb_sums_lds_rec(S[u]);
+#else
                 const DfBlendSums B = dqb_sums_lds_rec(S[u]);
+#endif
                 quat rsum, rn; quat2 half;
                 rsum.w = B.r01.x; rsum.x = B.r01.y; rsum.y = B.r23.x; rsum.z = B.r23.y;
                 half.wx = B.t01 * 0.5f; half.yz = B.t23 * 0.5f;
@@ -2193,22 +2364,22 @@ extern "C" int dfusion_warp_debug_counters(DfWarpField* wf, unsigned long long* 
 }
 
 // alive 8 x 8 x 8 blocks per 8-plane layer, from the verdict bytes of the last sweep: one workgroup per layer of the table
-__global__ __launch_bounds__(256) void df_alive_per_layer_kernel(const uint8_t* __restrict__ alive, unsigned per_layer, int layer0, int l_lo, int l_hi,
-                                                                 unsigned long long* __restrict__ out)
+__global__ __launch_bounds__(256) void df_alive_per_layer_kernel(const uint8_t* __restrict__ alive, unsigned mask, unsigned per_layer, int layer0, int l_lo,
+                                                                 int l_hi, unsigned long long* __restrict__ out)
 {
     __shared__ unsigned s[4];
     const int layer = layer0 + (int)blockIdx.x;
     if (layer < l_lo || layer >= l_hi) return;
     const uint8_t* a = alive + (size_t)blockIdx.x * per_layer;
     unsigned n = 0;
-    for (unsigned i = threadIdx.x; i < per_layer; i += 256) n += a[i] ? 1u : 0u;
+    for (unsigned i = threadIdx.x; i < per_layer; i += 256) n += (a[i] & mask) ? 1u : 0u;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = n;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&out[layer], (unsigned long long)(s[0] + s[1] + s[2] + s[3]));
 }
-extern "C" int dfusion_warp_alive_blocks(DfWarpField* wf, int z0, int zn, unsigned long long* per_layer_dev, int n_layers, dfStream stream)
+static int df_count_verdicts(DfWarpField* wf, unsigned mask, int z0, int zn, unsigned long long* per_layer_dev, int n_layers, dfStream stream)
 {
     if (!wf || !per_layer_dev || n_layers <= 0 || z0 < 0 || zn < 0) return DF_E_INVALID;
     if (!wf->tab_valid || !wf->alive_valid || !wf->blk_alive) return DF_E_NO_INDEX;
@@ -2217,10 +2388,19 @@ extern "C" int dfusion_warp_alive_blocks(DfWarpField* wf, int z0, int zn, unsign
     const int nbz = wf->tab_zn / 8, layer0 = wf->tab_z0 / 8;
     const int l_lo = (z0 + 7) / 8, l_hi = min((z0 + zn) / 8, n_layers);                 // layers entirely inside [z0, z0 + zn)
     if (nbz <= 0 || l_hi <= l_lo) return DF_OK;
-    hipLaunchKernelGGL(df_alive_per_layer_kernel, dim3((unsigned)nbz), dim3(256), 0, (hipStream_t)stream, wf->blk_alive, per_layer, layer0, l_lo, l_hi,
-                       per_layer_dev);
+    hipLaunchKernelGGL(df_alive_per_layer_kernel, dim3((unsigned)nbz), dim3(256), 0, (hipStream_t)stream, wf->blk_alive, mask, per_layer, layer0, l_lo,
+                       l_hi, per_layer_dev);
     DF_LAUNCH_CHECK();
     return DF_OK;
+}
+extern "C" int dfusion_warp_alive_blocks(DfWarpField* wf, int z0, int zn, unsigned long long* per_layer_dev, int n_layers, dfStream stream)
+{
+    return df_count_verdicts(wf, 0xffu, z0, zn, per_layer_dev, n_layers, stream);
+}
+// The kept blocks among them that the sweep served from 4-bit neighbour codes (verdict bit 1, dfusion_warp_blocks.h).
+extern "C" int dfusion_warp_coded_blocks(DfWarpField* wf, int z0, int zn, unsigned long long* per_layer_dev, int n_layers, dfStream stream)
+{
+    return df_count_verdicts(wf, 2u, z0, zn, per_layer_dev, n_layers, stream);
 }
 
 // The arguments of a table build over the current tables (geometry as dfusion_warp_build_index recorded it).
@@ -2240,6 +2420,7 @@ static DfWarpedArgs df_table_args(const DfWarpField* wf)
     a.tab_nvox = (size_t)ntx * DF_TAB_TX * nty * DF_TAB_TY * wf->tab_zn;
     a.bz0 = wf->tab_z0 / DF_BRICK;
     a.bm_nbx = ntx * (DF_TAB_TX / 8); a.bm_nby = nty * (DF_TAB_TY / 8);
+    a.code_tab = wf->code_tab; a.bm_ids = wf->bm_ids;
     return a;
 }
 // Workgroups of a list-driven pass: as many as are resident at once (workgroup i takes entries i, i + grid, ...: a second round of
@@ -2305,6 +2486,18 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
         DF_HIP(hipMalloc((void**)&wf->bm_lam, nblk * DF_BM_NU * sizeof(uint32_t)));
         DF_HIP(hipMalloc((void**)&wf->bm_w, nblk * DF_BM_NU * sizeof(uint32_t)));
         DF_HIP(hipMalloc((void**)&wf->bm_cnt, nblk));
+#if DF_IDX_CODES
+        (void)hipFree(wf->bm_ids); wf->bm_ids = nullptr;
+        DF_HIP(hipMalloc((void**)&wf->bm_ids, nblk * DF_BM_NU * sizeof(uint16_t)));
+        {
+            const size_t nvox = (size_t)a.tab_ntx * DF_TAB_TX * a.tab_nty * DF_TAB_TY * wf->tab_zn;
+            if (nvox > wf->code_cap) {
+                (void)hipFree(wf->code_tab); wf->code_tab = nullptr; wf->code_cap = 0;
+                DF_HIP(hipMalloc((void**)&wf->code_tab, nvox * sizeof(uint32_t)));
+                wf->code_cap = nvox;
+            }
+        }
+#endif
         wf->bm_cap = nblk;
     }
     // look-ahead: with on-demand tables or models still to make, blocks NEAR the alive set get theirs on the side
@@ -2552,6 +2745,11 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
                                                       DF_ROW_TZ, v) * 1.001 + 1e-6);
 #if DF_LDS_SPLIT
         const size_t lds = (size_t)(DF_NODE_T_OFF + wf->M) * 16;
+#elif DF_IDX_CODES
+        // (+ the pipelined sweep's per-wave copies of a block's union: 512 bytes per wave, behind the node table rounded up to 512)
+        const size_t lds_nodes = (size_t)wf->M * 32, lds_codes = ((lds_nodes + 511) & ~(size_t)511) + 16 * 512;
+        const bool codes_fit = k == 8 && lds_codes <= 160 * 1024;
+        const size_t lds = codes_fit ? lds_codes : lds_nodes;
 #else
         const size_t lds = (size_t)wf->M * 32;
 #endif
@@ -2586,11 +2784,13 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
                 { int rc = df_wait_all_sweeps_host(wf); if (rc) return rc; }
                 for (int i = 0; i < 2; ++i) {
                     (void)hipFree(wf->plan_mask2[i]); (void)hipFree(wf->plan_list2[i]); wf->plan_mask2[i] = nullptr; wf->plan_list2[i] = nullptr;
+                    (void)hipFree(wf->plan_code2[i]); wf->plan_code2[i] = nullptr;
                 }
                 wf->plan_cap = 0; wf->plan_mask = nullptr; wf->plan_list = nullptr;
                 for (int i = 0; i < 2; ++i) {
                     DF_HIP(hipMalloc((void**)&wf->plan_mask2[i], (size_t)n_items * sizeof(unsigned long long)));
                     DF_HIP(hipMalloc((void**)&wf->plan_list2[i], (size_t)n_items * DF_PLAN_BINS * sizeof(unsigned int)));      // the bins
+                    DF_HIP(hipMalloc((void**)&wf->plan_code2[i], (size_t)n_items * sizeof(unsigned long long)));
                 }
                 wf->plan_mask = wf->plan_mask2[0]; wf->plan_list = wf->plan_list2[0];       // (the names the destructor frees)
                 wf->plan_cap = n_items; wf->plan_reader[0] = wf->plan_reader[1] = 0;
@@ -2608,9 +2808,19 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
             unsigned int* cnt = wf->plan_hist + 128 * (wf->hphase & 3u);
             unsigned int* cnt_next = wf->plan_hist + 128 * ((wf->hphase + 2u) & 3u);       // (last read by the sweep two plans ago: waited for above)
             unsigned long long* pmask = wf->plan_mask2[wf->pphase]; unsigned int* plist = wf->plan_list2[wf->pphase];
+            // 4-bit neighbour codes: for the cells whose block has a model (and so a union list and codes), unless the models are switched off
+            unsigned long long* pcode = nullptr;
+#if DF_IDX_CODES && !DF_PIPE_ROWS
+            if (a.cull && a.blk_alive && wf->code_tab && wf->bm_ids && wf->bm_cap >= (size_t)a.bm_nbx * a.bm_nby * (wf->tab_zn / 8) &&
+                !(flags & (DF_WARP_NO_BLOCK_MODEL | DF_WARP_NO_CODES)) && codes_fit) {
+                pcode = wf->plan_code2[wf->pphase];
+                a.code_tab = wf->code_tab; a.bm_ids = wf->bm_ids;
+            }
+#endif
             hipLaunchKernelGGL(df_sweep_plan_kernel, dim3((n_items + DF_PLAN_WG / 64 - 1) / (DF_PLAN_WG / 64)), dim3(DF_PLAN_WG), 0, st, a, tiles_x, tiles_y, n_items, pmask, cnt,
-                               plist, cnt_next);
+                               plist, cnt_next, pcode);
             DF_LAUNCH_CHECK();
+            a.plan_code = pcode;
             ++wf->hphase;                                                  // (only once the kernel that zeroes the set after next is in the stream)
             a.plan_mask = pmask; a.plan_bins = plist; a.plan_cnt = cnt; a.plan_items = n_items; a.plan_tiles_y = tiles_y;
             // this plan's sweep: its number, and what it will read

@@ -167,6 +167,33 @@ __global__ __launch_bounds__(256) void df_block_model_kernel(const DfWarpedArgs 
         bm_lam[(size_t)dst * nblk + blk] = s_lam[wave][ln];
         bm_w[(size_t)dst * nblk + blk] = s_w[wave][ln];
     }
+#if DF_IDX_CODES
+    // 4-bit neighbour codes: every voxel's k neighbours as positions in the union list (ascending node order, s_idx[wave][0 .. n)), neighbour
+    // i in bits [4 i, 4 i + 4) -- the order of the table record, i.e. of the blend's sums -- and the list itself, block-major, for the
+    // sweep's per-cell copy of the union's transforms.  The sweep takes codes only from blocks whose state byte says "modelled" and whose
+    // count is not "none": both are written here, after the codes.
+    if (a.code_tab && a.bm_ids) {
+        unsigned uid[DF_BM_NU];
+#pragma unroll
+        for (int e = 0; e < DF_BM_NU; ++e) uid[e] = e < n ? s_idx[wave][e] : 0xffffffffu;
+        if (ln < DF_BM_NU) a.bm_ids[blk * DF_BM_NU + ln] = (uint16_t)(ln < n ? s_idx[wave][ln] : 0u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned code = 0u;
+            if (valid & (1u << j)) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    unsigned pos = 0u;
+#pragma unroll
+                    for (int e = 0; e < DF_BM_NU; ++e) pos = uid[e] == (unsigned)ids[j][i] ? (unsigned)e : pos;
+                    code |= pos << (4 * i);
+                }
+            }
+            if (col_in && z0 + j < a.Z) a.code_tab[df_code_index(a, x, y, z0 + j)] = code;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#endif
     if (ln == 0) bm_cnt[blk] = (uint8_t)n;
     __builtin_amdgcn_wave_barrier();                                       // (the next round reuses the wave's LDS rows)
     }
@@ -344,7 +371,10 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
             if (n != DF_BM_NONE && a.cull[1] <= 1.0f) keep = !df_block_box_dead(a, rot, node_t, nbx, nby, nblk, blk, n, bm_idx, bm_lam, bm_w);
         }
         DF_VT(2);
-        alive[blk] = keep ? 1 : 0;
+        // bit 1: the block has a model -- and so a union list and 4-bit neighbour codes -- that was COMPLETE before this pass started (the
+        // state byte was read above, after the previous frame's side-stream work was joined).  The plan kernel takes "coded" from here and
+        // not from the state bytes: it runs beside THIS frame's model builds, which set them before their codes are all written.
+        alive[blk] = keep ? (uint8_t)(1u | ((st == 2u && bm_cnt && bm_cnt[blk] != DF_BM_NONE) ? 2u : 0u)) : (uint8_t)0;
         need_build = keep && build_on_demand && st == 0u;
         need_ahead = !keep && near && build_on_demand && st == 0u;
         need_model = (keep || near) && want_models && (st == 1u || (need_build && want_models > 1));

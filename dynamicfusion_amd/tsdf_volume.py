@@ -201,11 +201,12 @@ class TsdfVolume:
     # ---- the north-star composition; no reference method of this name exists
     def integrate_warped(self, dists, camera_pose, intr, warp_field, k=None, n_updated=None, cull=True, sync=True,
                          use_table=True, use_weights=True, use_lds=True, pipelined=True, zero_skip=True, depth_pyramid=True, block_model=True,
-                         prefetch=True):
+                         prefetch=True, codes=True):
         """block_model: True = the library's policy (models built the second time a weight table is swept), "now" = at the first
         sweep, False = never (DF_WARP_NO_BLOCK_MODEL).  prefetch: True = the library's policy (look-ahead builds on the handle's side
         stream, switched off on a scene at rest from an unsynchronised report), False = DF_WARP_NO_PREFETCH, "steady" = on in every
-        frame (DF_WARP_STEADY_PREFETCH: reproducible swept-voxel counters)."""
+        frame (DF_WARP_STEADY_PREFETCH: reproducible swept-voxel counters).  codes: False = DF_WARP_NO_CODES (modelled blocks read the full
+        16-B neighbour record instead of their 4-bit codes)."""
         k = warp_field.k if k is None else k
         world2cam = affine_mul(affine_inv(np.asarray(camera_pose, F32)), warp_field.warp_to_live_)
         warp_field.ensure_index(self, k)
@@ -217,6 +218,7 @@ class TsdfVolume:
             (0 if use_weights else capi.DF_WARP_NO_WEIGHT_TABLE) | (0 if use_lds else capi.DF_WARP_NO_LDS) |
             (0 if pipelined else capi.DF_WARP_NO_PIPELINE) | (0 if zero_skip else capi.DF_WARP_NO_ZERO_SKIP) |
             (0 if depth_pyramid else capi.DF_WARP_NO_DEPTH_PYRAMID) | (capi.DF_WARP_STEADY_PREFETCH if prefetch == "steady" else 0 if prefetch else capi.DF_WARP_NO_PREFETCH) |
+            (0 if codes else capi.DF_WARP_NO_CODES) |
             (capi.DF_WARP_BLOCK_MODEL_NOW if block_model == "now" else 0 if block_model else capi.DF_WARP_NO_BLOCK_MODEL),
             _ptr(n_updated) if n_updated is not None else None, _stream()), "dfusion_integrate_warped")
         if sync:

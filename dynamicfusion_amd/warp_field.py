@@ -115,6 +115,11 @@ class WarpField:
                                                         int(layers_dev.numel()), _stream()), "dfusion_warp_alive_blocks")
         return layers_dev
 
+    def coded_blocks_per_layer(self, volume, layers_dev):
+        """The kept blocks among those that had 4-bit neighbour codes (include/dfusion.h dfusion_warp_coded_blocks)."""
+        capi.check(capi.lib().dfusion_warp_coded_blocks(self.handle, int(volume.z_own0), int(volume.z_own_n), _ptr(layers_dev),
+                                                        int(layers_dev.numel()), _stream()), "dfusion_warp_coded_blocks")
+
     def set_point_tiling(self, image_cols):
         """Locality hint (include/dfusion.h dfusion_warp_set_point_tiling): point queries are row-major images `image_cols` wide and are
         processed in 8x8 pixel tiles per wave; 0 = off.  Results do not change."""

@@ -100,6 +100,8 @@ enum {
                                  (by default the tables / blend models of blocks NEAR the frame's alive set -- what a moving camera
                                  or a changing warp brings in over the next few frames -- are made beside the sweep, on a stream the
                                  handle owns, so that a block is usually built before it is first swept); validation switch     */
+#define DF_WARP_NO_CODES 2048u /* the sweep reads the 16-byte neighbour-index record of every voxel (rounds 1-4) instead of the 4-bit codes of
+                                 * modelled blocks; validation / A/B switch (ABI 5)                                                     */
 #define DF_WARP_STEADY_PREFETCH 1024u /* keep the look-ahead side stream on in EVERY frame.  By default a handle whose last plan-kernel report
                                  * listed nothing to build switches it off until the next probe (every 8th sweep); that report is read from
                                  * pinned host memory WITHOUT a synchronisation, so which frame switches depends on host / GPU timing --
@@ -305,6 +307,10 @@ int dfusion_warp_debug_counters(DfWarpField *wf, unsigned long long *swept_dev);
  * entirely inside planes [z0, z0 + zn).  Z-slab re-balancing reads it (one all-reduce over the ranks gives the global profile of the
  * sweep's real work per plane).  DF_E_NO_INDEX when no sweep with verdicts has run since the index was built.                       */
 int dfusion_warp_alive_blocks(DfWarpField *wf, int z0, int zn, unsigned long long *per_layer_dev, int n_layers, dfStream stream);
+/* Same, counting only the kept blocks that had 4-bit neighbour codes for the sweep to read (blocks with a blend model made in an
+ * earlier frame; DF_WARP_NO_CODES makes a sweep ignore them, the count is of what was available).  A measurement hook: tests use it
+ * to see that the coded path engaged.                                                                                              */
+int dfusion_warp_coded_blocks(DfWarpField *wf, int z0, int zn, unsigned long long *per_layer_dev, int n_layers, dfStream stream);
 
 /* WarpField::KNN (warp_field.cpp:247-251) for N query points [N*3]: idx[N*k] int32, d2[N*k], ascending distance; exactly
  * equidistant nodes in the order the reference's nanoflann walk meets them (nanoflann.hpp:110-131,1200-1254).                    */

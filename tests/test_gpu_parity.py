@@ -511,6 +511,46 @@ def test_block_models_shrink_the_swept_set_and_change_nothing():
         assert swept[1] < 0.85 * swept[0] and swept[1] >= upd[1]
 
 
+@pytest.mark.parametrize("name, prefetch", [("256", "steady"), ("256", True), ("k8", "steady")])
+def test_neighbour_codes_engage_and_change_nothing(name, prefetch):
+    """DF_IDX_CODES (round 5): a block with a blend model stores each voxel's neighbours as 4-bit positions in the block's node union
+    (2 B a voxel at k = 4, 4 B at k = 8) and the sweep reads those instead of the 16-B record, resolving them through a 16-entry
+    per-wave LDS table.  Eight frames of a moving camera with changing transforms, codes on against DF_WARP_NO_CODES: the volume after
+    EVERY frame and the update count are identical bit for bit, and from the third frame on kept blocks do carry codes
+    (dfusion_warp_coded_blocks).  prefetch=True covers the look-ahead builds racing the plan (the model kernel runs on the side
+    stream while the plan kernel decides which blocks are coded: the decision must come from the verdict pass, before the fork)."""
+    cfg = synth.CONFIGS["256"] if name == "256" else synth.Config(128, 1.0, cols=320, rows=240, nodes=300, k=8)
+    frames = 8
+    sc = Scene(cfg, n_frames=frames)
+    intr = Intr(*cfg.intr)
+    dists = [upload_u16(d) for d in sc.dists]
+    nl = cfg.dims[2] // 8
+
+    def run(codes):
+        v = make_gpu_volume(sc)
+        wf = WarpField(k=cfg.k)
+        wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        snaps, coded, kept = [], [], []
+        for f in range(frames):
+            wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+            v.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, n_updated=cnt, prefetch=prefetch, codes=codes)
+            snaps.append(v.data().clone())
+            a = torch.zeros(nl, dtype=torch.int64, device="cuda"); c = torch.zeros_like(a)
+            wf.alive_blocks_per_layer(v, a); wf.coded_blocks_per_layer(v, c)
+            kept.append(int(a.sum().item())); coded.append(int(c.sum().item()))
+        return snaps, int(cnt.item()), kept, coded
+
+    a_snaps, a_n, kept, coded = run(True)
+    b_snaps, b_n, _, _ = run(False)
+    print("%s prefetch=%s: kept blocks %s, of them coded %s" % (name, prefetch, kept, coded))
+    assert a_n == b_n > 0
+    for f in range(frames):
+        assert torch.equal(a_snaps[f], b_snaps[f]), "volume after frame %d differs" % f
+    assert coded[0] == 0 and all(c <= k for c, k in zip(coded, kept))
+    assert coded[-1] > 0.5 * kept[-1]
+
+
 def test_prepare_and_sweep_on_two_streams_equal_the_single_call():
     """dfusion_integrate_warped_prepare / _sweep (round 5): the frame's warped integrate split into the part that does not touch the volume
     (pyramid, verdict pass, table / model builds, plan) and the sweep, the former issued on ANOTHER stream beside the previous frame's
