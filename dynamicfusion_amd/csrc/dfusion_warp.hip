@@ -1548,6 +1548,9 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
 #ifndef DF_PIPE_ROWS
 #define DF_PIPE_ROWS 0           // experiment: the pipelined sweep's waves own 32 x 2 column patches (full 128-byte voxel rows) instead of 8 x 8
 #endif
+#ifndef DF_LDS_PAD
+#define DF_LDS_PAD 0             // measurement: LDS bytes requested on top of what the sweep uses (fewer workgroups per CU: the occupancy series)
+#endif
 #ifndef DF_LDS_SPLIT
 #define DF_LDS_SPLIT 0           // experiment: rot and node_t in two 16-byte-strided LDS arrays (M <= 2048) instead of interleaved
 #endif
@@ -2749,7 +2752,7 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
         // (+ the pipelined sweep's per-wave copies of a block's union: 512 bytes per wave, behind the node table rounded up to 512)
         const size_t lds_nodes = (size_t)wf->M * 32, lds_codes = ((lds_nodes + 511) & ~(size_t)511) + 16 * 512;
         const bool codes_fit = k == 8 && lds_codes <= 160 * 1024;
-        const size_t lds = codes_fit ? lds_codes : lds_nodes;
+        const size_t lds = (codes_fit ? lds_codes : lds_nodes) + DF_LDS_PAD;
 #else
         const size_t lds = (size_t)wf->M * 32;
 #endif
@@ -2761,7 +2764,7 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
         const bool pipe = pipe_sweep;                           // df_warp_rows_lds_kernel always walks DF_LDS_ZT layers per workgroup
         a.zt = !pipe ? DF_LDS_ZT : cols_layers <= 8192 ? 4 : cols_layers <= 65536 ? 8 : 16;
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + a.zt - 1) / a.zt));
-        const bool wide = pipe_ok && (k == 8 || k == 4) && lds > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads
+        const bool wide = pipe_ok && (k == 8 || k == 4) && lds - DF_LDS_PAD > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads
         const bool vi = a.v2w_identity != 0;
         if (pipe_ok && k == 8)
             kern = wide ? (vi ? df_warp_rows_pipe_kernel<8, 2, 1024, true> : df_warp_rows_pipe_kernel<8, 2, 1024, false>)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 5   /* 5: dfusion_integrate_warped_prepare / _sweep (the frame's integrate in two calls, for cross-frame overlap), dfusion_raycast_sum_pieces (direct row-band merge), DF_WARP_STEADY_PREFETCH, dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
+#define DFUSION_ABI_VERSION 5   /* 5: dfusion_integrate_warped_prepare / _sweep (the frame's integrate in two calls, for cross-frame overlap), dfusion_raycast_sum_pieces (direct row-band merge), DF_WARP_STEADY_PREFETCH, dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation), DF_WARP_NO_CODES + dfusion_warp_coded_blocks (4-bit neighbour codes of modelled blocks); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
