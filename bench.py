@@ -862,7 +862,9 @@ def main():
     lds_ok = cfg.nodes * 32 <= 160 * 1024
     if lds_ok and cfg.k in (4, 8):
         axis_aligned = bool(np.array_equal(np.asarray(cfg.volume_pose, np.float32).reshape(4, 4)[:3, :3], np.eye(3, dtype=np.float32)))
-        kernel_name = "df_warp_rows_pipe_kernel<%d, 2, %d, %s>" % (cfg.k, 1024 if cfg.nodes * 32 > 80 * 1024 else 512, "true" if axis_aligned else "false")
+        wide = cfg.nodes * 32 > 80 * 1024          # (dfusion_warp.hip: one workgroup per CU -> 1024 threads; k = 8 otherwise 768 threads, one plane per batch)
+        kernel_name = "df_warp_rows_pipe_kernel<%d, %d, %d, %s>" % (cfg.k, 1 if cfg.k == 8 and not wide else 2, 1024 if wide else 768 if cfg.k == 8 else 512,
+                                                                    "true" if axis_aligned else "false")
     elif lds_ok:
         kernel_name = "df_warp_rows_lds_kernel<%d, true, 2>" % cfg.k
     else:

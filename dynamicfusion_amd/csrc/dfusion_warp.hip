@@ -1548,6 +1548,12 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
 #ifndef DF_PIPE_ROWS
 #define DF_PIPE_ROWS 0           // experiment: the pipelined sweep's waves own 32 x 2 column patches (full 128-byte voxel rows) instead of 8 x 8
 #endif
+#ifndef DF_PIPE_WGT
+#define DF_PIPE_WGT 768           // threads of a k = 8 sweep workgroup when two of them fit a CU's LDS (768: 12 waves dealing out 3 strip items; needs <= 80 VGPRs)
+#endif
+#ifndef DF_PIPE_U
+#define DF_PIPE_U 1               // planes per batch of that kernel (two batches' tables are in flight); the other forms of the sweep have 2
+#endif
 #ifndef DF_LDS_PAD
 #define DF_LDS_PAD 0             // measurement: LDS bytes requested on top of what the sweep uses (fewer workgroups per CU: the occupancy series)
 #endif
@@ -1958,7 +1964,7 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
 // One workgroup = WGT / 256 strip items of the plan (2 at WGT = 512: two workgroups per CU while the node table is <= 80 KiB, 2560
 // nodes; 4 at WGT = 1024, for the larger tables that leave room for only one workgroup per CU: 16 waves, 4 per SIMD, either way).
 template <int K, int U, int WGT, bool V2W_IDENTITY>
-__global__ __launch_bounds__(WGT, WGT == 512 ? 4 : 1) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
+__global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
     constexpr unsigned SPW = WGT / 256;                                    // strip items per workgroup
@@ -2766,12 +2772,19 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + a.zt - 1) / a.zt));
         const bool wide = pipe_ok && (k == 8 || k == 4) && lds - DF_LDS_PAD > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads
         const bool vi = a.v2w_identity != 0;
-        if (pipe_ok && k == 8)
+        // workgroup geometry: K = 8 with room for two workgroups per CU runs 768 threads, one plane per batch (77 VGPRs: 6 waves / SIMD;
+        // round 5: -2 to -4 % against 512 threads, two planes, 4 waves); k = 4 (+4 % that way at 256^3) and the one-workgroup tables (+2 %
+        // at 1024^3) keep two planes per batch
+        unsigned wg_threads = 512u;
+        if (pipe_ok && k == 8) {
             kern = wide ? (vi ? df_warp_rows_pipe_kernel<8, 2, 1024, true> : df_warp_rows_pipe_kernel<8, 2, 1024, false>)
-                        : (vi ? df_warp_rows_pipe_kernel<8, 2, 512, true> : df_warp_rows_pipe_kernel<8, 2, 512, false>);
-        else if (pipe_ok && k == 4)
+                        : (vi ? df_warp_rows_pipe_kernel<8, DF_PIPE_U, DF_PIPE_WGT, true> : df_warp_rows_pipe_kernel<8, DF_PIPE_U, DF_PIPE_WGT, false>);
+            wg_threads = wide ? 1024u : (unsigned)DF_PIPE_WGT;
+        } else if (pipe_ok && k == 4) {
             kern = wide ? (vi ? df_warp_rows_pipe_kernel<4, 2, 1024, true> : df_warp_rows_pipe_kernel<4, 2, 1024, false>)
                         : (vi ? df_warp_rows_pipe_kernel<4, 2, 512, true> : df_warp_rows_pipe_kernel<4, 2, 512, false>);
+            wg_threads = wide ? 1024u : 512u;
+        }
         else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
         else { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, false, 1>)); }
         DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2828,21 +2841,21 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
             a.plan_mask = pmask; a.plan_bins = plist; a.plan_cnt = cnt; a.plan_items = n_items; a.plan_tiles_y = tiles_y;
             // this plan's sweep: its number, and what it will read
             wf->plan_reader[wf->pphase] = wf->node_reader[wf->nphase] = ++wf->seq;
-            const unsigned spw = wide ? 4u : 2u;
+            const unsigned spw = wg_threads / 256u;
             grid = dim3((n_items + spw - 1) / spw, 1);
 #ifdef DF_TRACE_WG
             static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;
-            const size_t trace_n = (size_t)grid.x * (wide ? 16 : 8) * 4;
+            const size_t trace_n = (size_t)grid.x * (wg_threads / 64u) * 4;
             if (trace_n > trace_cap) { (void)hipFree(trace_dev); DF_HIP(hipMalloc((void**)&trace_dev, trace_n * 8)); trace_cap = trace_n; }
             DF_HIP(hipMemsetAsync(trace_dev, 0, trace_n * 8, st));
             a.trace = trace_dev;
-            kern<<<grid, dim3(wide ? 1024 : 512), lds, st>>>(a, W, tiles_x);
+            kern<<<grid, dim3(wg_threads), lds, st>>>(a, W, tiles_x);
             if (getenv("DF_TRACE_FILE")) {
                 DF_HIP(hipStreamSynchronize(st));
                 unsigned long long* h = (unsigned long long*)malloc(trace_n * 8);
                 DF_HIP(hipMemcpy(h, trace_dev, trace_n * 8, hipMemcpyDeviceToHost));
                 FILE* f = fopen(getenv("DF_TRACE_FILE"), "wb");
-                if (f) { unsigned long long hdr[4] = {grid.x, 1, (unsigned long long)(wide ? 16 : 8), 0}; fwrite(hdr, 8, 4, f); fwrite(h, 8, trace_n, f); fclose(f); }
+                if (f) { unsigned long long hdr[4] = {grid.x, 1, (unsigned long long)(wg_threads / 64u), 0}; fwrite(hdr, 8, 4, f); fwrite(h, 8, trace_n, f); fclose(f); }
                 free(h);
             }
             DF_LAUNCH_CHECK();
@@ -2853,12 +2866,12 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
             if (!pipe) return DF_E_INVALID;                                // (the split exists for the cached, pipelined sweep only)
             if (!wf->prep) wf->prep = new DfPrepared();
             DfPrepared* P = (DfPrepared*)wf->prep;
-            P->a = a; P->W = W; P->kern = kern; P->grid = grid; P->threads = wide ? 1024u : 512u; P->lds = lds; P->tiles_x = tiles_x; P->v = v; P->s = s;
+            P->a = a; P->W = W; P->kern = kern; P->grid = grid; P->threads = wg_threads; P->lds = lds; P->tiles_x = tiles_x; P->v = v; P->s = s;
             P->seq = wf->seq;
             wf->prep_valid = true;
             return DF_OK;
         }
-        kern<<<grid, dim3(wide ? 1024 : 512), lds, st>>>(a, W, tiles_x);
+        kern<<<grid, dim3(wg_threads), lds, st>>>(a, W, tiles_x);
         if (pipe && wf->split_events) {                                   // (a handle that is also driven through the split API: this sweep counts)
             DF_LAUNCH_CHECK();
             DF_HIP(hipEventRecord(wf->ev_sweep_done[wf->seq & 1], st));
