@@ -1548,6 +1548,9 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
 #ifndef DF_PIPE_ROWS
 #define DF_PIPE_ROWS 0           // experiment: the pipelined sweep's waves own 32 x 2 column patches (full 128-byte voxel rows) instead of 8 x 8
 #endif
+#ifndef DF_BM_WG_PER_CU_CAP
+#define DF_BM_WG_PER_CU_CAP 0
+#endif
 #ifndef DF_PIPE_WGT
 #define DF_PIPE_WGT 768           // threads of a k = 8 sweep workgroup when two of them fit a CU's LDS (768: 12 waves dealing out 3 strip items; needs <= 80 VGPRs)
 #endif
@@ -2553,7 +2556,16 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
     auto launch_models = [&](hipStream_t s2) -> int {
         const DfWarpedArgs b = df_table_args(wf);
         static unsigned g8 = 0, g4 = 0;
-        if (!g8) { g8 = df_work_grid((const void*)df_block_model_kernel<8>); g4 = df_work_grid((const void*)df_block_model_kernel<4>); }
+        if (!g8) {
+            g8 = df_work_grid((const void*)df_block_model_kernel<8>); g4 = df_work_grid((const void*)df_block_model_kernel<4>);
+#if DF_BM_WG_PER_CU_CAP
+            // (measurement: the model pass beside the sweep takes at most this many workgroups per CU)
+            int dev = 0; hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
+                g8 = min(g8, (unsigned)(DF_BM_WG_PER_CU_CAP * prop.multiProcessorCount)); g4 = min(g4, (unsigned)(DF_BM_WG_PER_CU_CAP * prop.multiProcessorCount));
+            }
+#endif
+        }
         if (k == 8) hipLaunchKernelGGL(df_block_model_kernel<8>, dim3(g8), dim3(256), 0, s2, b, nbx, nby, nbz, list_model, cnt + 1,
                                        wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_state);
         else hipLaunchKernelGGL(df_block_model_kernel<4>, dim3(g4), dim3(256), 0, s2, b, nbx, nby, nbz, list_model, cnt + 1,

@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t df_bm_pack(float lo, float hi)          // {
 // The union of the neighbour sets comes out in ascending node order: each round takes the smallest id above the last one over all
 // 512 x K table entries (a wave minimum), then the range of that node's lambda and w over the voxels.
 template <int K>
-__global__ __launch_bounds__(256) void df_block_model_kernel(const DfWarpedArgs a, int nbx, int nby, int nbz, const uint32_t* __restrict__ list,
+__global__ __launch_bounds__(256, K == 8 ? 3 : 4) void df_block_model_kernel(const DfWarpedArgs a, int nbx, int nby, int nbz, const uint32_t* __restrict__ list,
                                                              const uint32_t* __restrict__ count, uint16_t* __restrict__ bm_idx,
                                                              uint32_t* __restrict__ bm_lam, uint32_t* __restrict__ bm_w,
                                                              uint8_t* __restrict__ bm_cnt, uint8_t* __restrict__ blk_state)
@@ -96,6 +96,14 @@ __global__ __launch_bounds__(256) void df_block_model_kernel(const DfWarpedArgs 
     float wv[8][K], inv[8];
     bool bad = false;
     unsigned valid = 0;
+#if DF_IDX_CODES
+    // 4-bit neighbour codes: every voxel's k neighbours as positions in the union list (ascending node order), neighbour i in bits
+    // [4 i, 4 i + 4) -- the order of the table record, i.e. of the blend's sums.  Collected while the union is: entry n's node is neighbour i
+    // of voxel j where ids[j][i] == cand, the comparison the lambda range makes anyway.
+    unsigned code[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) code[j] = 0u;
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const bool in = col_in && z0 + j < a.Z;
@@ -131,8 +139,15 @@ __global__ __launch_bounds__(256) void df_block_model_kernel(const DfWarpedArgs 
             for (int j = 0; j < 8; ++j)
                 if (valid & (1u << j)) {
                     float w = 0.f;
+#if DF_IDX_CODES
+                    unsigned hit = 0u;
+#pragma unroll
+                    for (int i = 0; i < K; ++i) { const bool eq = ids[j][i] == cand; w = eq ? wv[j][i] : w; hit = eq ? (unsigned)n << (4 * i) : hit; }
+                    code[j] |= hit;
+#else
 #pragma unroll
                     for (int i = 0; i < K; ++i) w = ids[j][i] == cand ? wv[j][i] : w;
+#endif
                     const float lam = w * inv[j];
                     lmin = fminf(lmin, lam); lmax = fmaxf(lmax, lam); wmin = fminf(wmin, w); wmax = fmaxf(wmax, w);
                 }
@@ -168,29 +183,14 @@ __global__ __launch_bounds__(256) void df_block_model_kernel(const DfWarpedArgs 
         bm_w[(size_t)dst * nblk + blk] = s_w[wave][ln];
     }
 #if DF_IDX_CODES
-    // 4-bit neighbour codes: every voxel's k neighbours as positions in the union list (ascending node order, s_idx[wave][0 .. n)), neighbour
-    // i in bits [4 i, 4 i + 4) -- the order of the table record, i.e. of the blend's sums -- and the list itself, block-major, for the
-    // sweep's per-cell copy of the union's transforms.  The sweep takes codes only from blocks whose state byte says "modelled" and whose
-    // count is not "none": both are written here, after the codes.
+    // the codes and the union list itself (block-major, for the sweep's per-cell copy of the union's transforms).  The sweep takes codes only
+    // from blocks whose verdict byte says so, which the verdict pass derives from the state byte and the count: both are written here, after
+    // the codes.
     if (a.code_tab && a.bm_ids) {
-        unsigned uid[DF_BM_NU];
-#pragma unroll
-        for (int e = 0; e < DF_BM_NU; ++e) uid[e] = e < n ? s_idx[wave][e] : 0xffffffffu;
         if (ln < DF_BM_NU) a.bm_ids[blk * DF_BM_NU + ln] = (uint16_t)(ln < n ? s_idx[wave][ln] : 0u);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            unsigned code = 0u;
-            if (valid & (1u << j)) {
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    unsigned pos = 0u;
-#pragma unroll
-                    for (int e = 0; e < DF_BM_NU; ++e) pos = uid[e] == (unsigned)ids[j][i] ? (unsigned)e : pos;
-                    code |= pos << (4 * i);
-                }
-            }
-            if (col_in && z0 + j < a.Z) a.code_tab[df_code_index(a, x, y, z0 + j)] = code;
-        }
+        for (int j = 0; j < 8; ++j)
+            if (col_in && z0 + j < a.Z) a.code_tab[df_code_index(a, x, y, z0 + j)] = code[j];
     }
     __builtin_amdgcn_wave_barrier();
 #endif

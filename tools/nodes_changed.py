@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
 """The frame after a node-set change, for profiling (bench.py's frame_nodes_changed_ms): set_nodes + index + the frame (which, with
-on-demand tables, builds the tables of the blocks its launch plan finds alive).  Usage: tools/nodes_changed.py [CONFIG] [REPEATS] [eager]"""
+on-demand tables, builds the tables of the blocks its launch plan finds alive), then the next two frames timed back to back with
+events on the caller's stream (no device-wide synchronisation in between: the third frame's wait for the side stream's model builds is
+inside its time, as in a running pipeline).  Usage: tools/nodes_changed.py [CONFIG] [REPEATS] [eager] [--lib TAG]
+(TAG: build/libdfusion_hip_TAG.so, tools/build_variant.py)"""
 import os, sys, time
 import numpy as np
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
-from dynamicfusion_amd import Intr, TsdfVolume, WarpField, compute_dists, synth, upload_u16  # noqa: E402
+from dynamicfusion_amd import Intr, TsdfVolume, WarpField, capi, compute_dists, synth, upload_u16  # noqa: E402
+if "--lib" in sys.argv:
+    i = sys.argv.index("--lib"); tag = sys.argv[i + 1]; del sys.argv[i:i + 2]
+    capi._lib = capi.load(os.path.join(REPO, "build", "libdfusion_hip_%s.so" % tag), strict=False)
 
 name = sys.argv[1] if len(sys.argv) > 1 else "512"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -30,8 +36,12 @@ for _ in range(reps):
     vol.raycast(cam, intr, pts, nrm)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     ms.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3))
-    for _ in range(2):                                    # the next frames: models for the alive blocks, then the steady state
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        vol.integrate_warped(dists, cam, intr, wf, sync=True)
-        ms.append((0.0, (time.perf_counter() - t0) * 1e3))
+    # the next frames: models for the alive blocks (side stream, beside the second frame's sweep), then the steady state
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    for f in range(2):
+        vol.integrate_warped(dists, cam, intr, wf, sync=False)
+        ev[f + 1].record()
+    torch.cuda.synchronize()
+    ms.append((0.0, ev[0].elapsed_time(ev[1]))); ms.append((0.0, ev[1].elapsed_time(ev[2])))
 print("set_nodes + index / frame (ms):", " ".join("%.2f/%.2f" % m for m in ms))
