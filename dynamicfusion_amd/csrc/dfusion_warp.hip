@@ -2498,20 +2498,17 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
         DF_HIP(hipMalloc((void**)&wf->bm_lam, nblk * DF_BM_NU * sizeof(uint32_t)));
         DF_HIP(hipMalloc((void**)&wf->bm_w, nblk * DF_BM_NU * sizeof(uint32_t)));
         DF_HIP(hipMalloc((void**)&wf->bm_cnt, nblk));
-#if DF_IDX_CODES
-        (void)hipFree(wf->bm_ids); wf->bm_ids = nullptr;
-        DF_HIP(hipMalloc((void**)&wf->bm_ids, nblk * DF_BM_NU * sizeof(uint16_t)));
-        {
-            const size_t nvox = (size_t)a.tab_ntx * DF_TAB_TX * a.tab_nty * DF_TAB_TY * wf->tab_zn;
-            if (nvox > wf->code_cap) {
-                (void)hipFree(wf->code_tab); wf->code_tab = nullptr; wf->code_cap = 0;
-                DF_HIP(hipMalloc((void**)&wf->code_tab, nvox * sizeof(uint32_t)));
-                wf->code_cap = nvox;
-            }
-        }
-#endif
         wf->bm_cap = nblk;
     }
+#if DF_IDX_CODES
+    // 4-bit neighbour codes + the blocks' union lists (the sweep reads them at k = 8 only: no 4 bytes a voxel for the others)
+    if (want_models && k == 8 && (nblk * 512 > wf->code_cap || !wf->bm_ids || !wf->code_tab)) {
+        (void)hipFree(wf->bm_ids); (void)hipFree(wf->code_tab); wf->bm_ids = nullptr; wf->code_tab = nullptr; wf->code_cap = 0;
+        DF_HIP(hipMalloc((void**)&wf->bm_ids, nblk * DF_BM_NU * sizeof(uint16_t)));
+        DF_HIP(hipMalloc((void**)&wf->code_tab, nblk * 512 * sizeof(uint32_t)));
+        wf->code_cap = nblk * 512;
+    }
+#endif
     // look-ahead: with on-demand tables or models still to make, blocks NEAR the alive set get theirs on the side
     // stream while the sweep runs -- unless the caller wants models made at once (then everything stays on the launch stream, in order)
     bool ahead = !(flags & (DF_WARP_NO_PREFETCH | DF_WARP_BLOCK_MODEL_NOW));
@@ -2537,7 +2534,9 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
     uint32_t* cnt_next = wf->blk_cnt + 8 * (wf->blk_phase ^ 1);
     uint32_t* list_urgent = wf->blk_work, *list_ahead = wf->blk_work + wf->blk_cap, *list_model = wf->blk_work + 2 * wf->blk_cap;
     hipLaunchKernelGGL(df_block_verdict_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, a, wf->rot, wf->node_t, nbx, nby, nbz,
-                       wf->blk_state, wf->blk_wmax, wf->brick_thr + wf->off_cap, wf->bx, wf->by, a.tile_wmax != nullptr ? 1 : 0, use_models && wf->bm_cap >= nblk ? 1 : 0, want_models_now,
+                       wf->blk_state, wf->blk_wmax, wf->brick_thr + wf->off_cap, wf->bx, wf->by, a.tile_wmax != nullptr ? 1 : 0,
+                       (use_models && wf->bm_cap >= nblk ? 1 : 0) | (k == 8 && wf->bm_cnt && wf->code_tab && wf->bm_ids && wf->code_cap >= nblk * 512 ? 2 : 0),     // (bit 1: the blocks' codes exist)
+                       want_models_now,
                        wf->tab_complete ? 0 : 1, wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_alive, list_urgent, list_ahead, list_model,
                        cnt, cnt_next);
     a.blk_cnt = cnt; a.host_report = (uint32_t*)wf->host_report; a.sweep_no = (uint32_t)wf->tab_sweeps;

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
             }
         }
         DF_VT(1);
-        if (keep && st == 2u && use_models) {
+        if (keep && st == 2u && (use_models & 1)) {
             const unsigned n = bm_cnt[blk];
             if (n != DF_BM_NONE && a.cull[1] <= 1.0f) keep = !df_block_box_dead(a, rot, node_t, nbx, nby, nblk, blk, n, bm_idx, bm_lam, bm_w);
         }
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
         // bit 1: the block has a model -- and so a union list and 4-bit neighbour codes -- that was COMPLETE before this pass started (the
         // state byte was read above, after the previous frame's side-stream work was joined).  The plan kernel takes "coded" from here and
         // not from the state bytes: it runs beside THIS frame's model builds, which set them before their codes are all written.
-        alive[blk] = keep ? (uint8_t)(1u | ((st == 2u && bm_cnt && bm_cnt[blk] != DF_BM_NONE) ? 2u : 0u)) : (uint8_t)0;
+        alive[blk] = keep ? (uint8_t)(1u | ((st == 2u && (use_models & 2) && bm_cnt[blk] != DF_BM_NONE) ? 2u : 0u)) : (uint8_t)0;
         need_build = keep && build_on_demand && st == 0u;
         need_ahead = !keep && near && build_on_demand && st == 0u;
         need_model = (keep || near) && want_models && (st == 1u || (need_build && want_models > 1));

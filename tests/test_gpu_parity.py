@@ -511,15 +511,17 @@ def test_block_models_shrink_the_swept_set_and_change_nothing():
         assert swept[1] < 0.85 * swept[0] and swept[1] >= upd[1]
 
 
-@pytest.mark.parametrize("name, prefetch", [("256", "steady"), ("256", True), ("k8", "steady")])
+@pytest.mark.parametrize("name, prefetch", [("k8", "steady"), ("k8", True), ("k8-256", True), ("256", "steady")])
 def test_neighbour_codes_engage_and_change_nothing(name, prefetch):
     """DF_IDX_CODES (round 5): a block with a blend model stores each voxel's neighbours as 4-bit positions in the block's node union
     (2 B a voxel at k = 4, 4 B at k = 8) and the sweep reads those instead of the 16-B record, resolving them through a 16-entry
     per-wave LDS table.  Eight frames of a moving camera with changing transforms, codes on against DF_WARP_NO_CODES: the volume after
     EVERY frame and the update count are identical bit for bit, and from the third frame on kept blocks do carry codes
     (dfusion_warp_coded_blocks).  prefetch=True covers the look-ahead builds racing the plan (the model kernel runs on the side
-    stream while the plan kernel decides which blocks are coded: the decision must come from the verdict pass, before the fork)."""
-    cfg = synth.CONFIGS["256"] if name == "256" else synth.Config(128, 1.0, cols=320, rows=240, nodes=300, k=8)
+    stream while the plan kernel decides which blocks are coded: the decision must come from the verdict pass, before the fork).
+    k = 4 (BASELINE config 1) has no coded path: no block may claim codes, and the flag changes nothing."""
+    cfg = (synth.CONFIGS["256"] if name == "256" else synth.Config(256, 1.5, nodes=700, k=8) if name == "k8-256"
+           else synth.Config(128, 1.0, cols=320, rows=240, nodes=300, k=8))
     frames = 8
     sc = Scene(cfg, n_frames=frames)
     intr = Intr(*cfg.intr)
@@ -548,7 +550,8 @@ def test_neighbour_codes_engage_and_change_nothing(name, prefetch):
     for f in range(frames):
         assert torch.equal(a_snaps[f], b_snaps[f]), "volume after frame %d differs" % f
     assert coded[0] == 0 and all(c <= k for c, k in zip(coded, kept))
-    assert coded[-1] > 0.5 * kept[-1]
+    if cfg.k == 8: assert coded[-1] > 0.5 * kept[-1]
+    else: assert not any(coded)
 
 
 def test_prepare_and_sweep_on_two_streams_equal_the_single_call():
