@@ -1563,6 +1563,9 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
 #ifndef DF_LDS_SPLIT
 #define DF_LDS_SPLIT 0           // experiment: rot and node_t in two 16-byte-strided LDS arrays (M <= 2048) instead of interleaved
 #endif
+#if DF_IDX_CODES && (DF_LDS_SPLIT || !DF_TAB_ADDR_HOIST)
+#error "the coded sweep assumes interleaved LDS node records and per-segment table addresses: build the DF_LDS_SPLIT=1 / DF_TAB_ADDR_HOIST=0 measurement variants with -DDF_IDX_CODES=0"
+#endif
 #define DF_ROW_TX 32
 #define DF_ROW_TY 8
 #define DF_ROW_TZ 8
@@ -2779,7 +2782,11 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
         // workgroups on the 256 CUs (measured: 4 layers best at 256^3 = 1024 workgroups, 8 at 512^3, 16 at 1024^3 = 16384)
         const long long cols_layers = (long long)tiles_x * tiles_y * (zt_hi - zt_lo + 1);
         const bool pipe = pipe_sweep;                           // df_warp_rows_lds_kernel always walks DF_LDS_ZT layers per workgroup
+#ifdef DF_PIPE_ZT
+        a.zt = !pipe ? DF_LDS_ZT : DF_PIPE_ZT;                                 // (measurement)
+#else
         a.zt = !pipe ? DF_LDS_ZT : cols_layers <= 8192 ? 4 : cols_layers <= 65536 ? 8 : 16;
+#endif
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + a.zt - 1) / a.zt));
         const bool wide = pipe_ok && (k == 8 || k == 4) && lds - DF_LDS_PAD > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads
         const bool vi = a.v2w_identity != 0;
