@@ -554,6 +554,42 @@ def test_neighbour_codes_engage_and_change_nothing(name, prefetch):
     else: assert not any(coded)
 
 
+def test_one_handle_switching_k_keeps_its_codes_right():
+    """The code tables are allocated the first time a k = 8 sweep wants models -- whatever the handle swept before.  One warp field used
+    with k = 4 (tables, models, no codes), then k = 8 on the same geometry (index rebuilt; models AND codes), then k = 4 again and back:
+    every k = 8 frame must equal the same frame from a handle that never saw k = 4, and codes must engage in both k = 8 phases."""
+    cfg = synth.Config(128, 1.0, cols=320, rows=240, nodes=300, k=8)
+    frames = 16
+    sc = Scene(cfg, n_frames=frames)
+    intr = Intr(*cfg.intr)
+    dists = [upload_u16(d) for d in sc.dists]
+    ks = [4] * 3 + [8] * 5 + [4] * 3 + [8] * 5
+    nl = cfg.dims[2] // 8
+
+    def run(only8):
+        v = make_gpu_volume(sc)
+        wf = WarpField(k=8)
+        wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])
+        snaps, coded = {}, {}
+        for f in range(frames):
+            if only8 and ks[f] != 8: continue
+            wf.set_transforms(torch.from_numpy(sc.dqs[f]).cuda())
+            # (every frame starts from an empty volume: the two runs integrate different frame sets)
+            v.clear()
+            v.integrate_warped(dists[f], sc.cam_poses[f], intr, wf, k=ks[f], prefetch="steady")
+            if ks[f] == 8:
+                snaps[f] = v.data().clone()
+                c = torch.zeros(nl, dtype=torch.int64, device="cuda"); wf.coded_blocks_per_layer(v, c); coded[f] = int(c.sum().item())
+        return snaps, coded
+
+    a, ca = run(False)
+    b, cb = run(True)
+    print("coded blocks per k = 8 frame, handle that switches k: %s; k = 8 only: %s" % (ca, cb))
+    for f in a:
+        assert torch.equal(a[f], b[f]), "frame %d differs" % f
+    assert ca[7] > 0 and ca[15] > 0 and ca[3] == 0 and ca[11] == 0     # (a rebuilt index starts without models)
+
+
 def test_prepare_and_sweep_on_two_streams_equal_the_single_call():
     """dfusion_integrate_warped_prepare / _sweep (round 5): the frame's warped integrate split into the part that does not touch the volume
     (pyramid, verdict pass, table / model builds, plan) and the sweep, the former issued on ANOTHER stream beside the previous frame's
