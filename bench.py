@@ -685,6 +685,15 @@ def main():
     achieved = alg_bytes / (ms_int * 1e-3) / 1e9
     frame_stats["timed_poses_mean_swept_voxels"] = n_swept_launch          # (this rank's planes; what roofline.traffic's profile is compared with)
     frame_stats["timed_poses_mean_updated_voxels"] = n_upd_launch
+    try:        # how many of the blocks the last replayed pose kept were read as 4-bit neighbour codes (dfusion_warp_coded_blocks; this rank's planes)
+        if Z % 8 == 0:
+            kept_l = torch.zeros(Z // 8, dtype=torch.int64, device=dev); coded_l = torch.zeros_like(kept_l)
+            wf.alive_blocks_per_layer(vol, kept_l); wf.coded_blocks_per_layer(vol, coded_l)
+            kept_n, coded_n = int(kept_l.sum().item()), int(coded_l.sum().item())
+            frame_stats["last_pose_kept_blocks"] = kept_n
+            frame_stats["last_pose_coded_blocks"] = coded_n
+    except Exception as e:      # (a measurement extra never fails the bench line)
+        frame_stats["last_pose_coded_blocks_error"] = str(e)[:120]
 
     # ---- per rank, per stage: HIP-event means over the n_extra frames after the timed region, gathered on rank 0; and,
     # N > 1, the OTHER forms of the frame's collectives timed back to back in the same launch (wall clock between barriers + stages)
