@@ -172,7 +172,7 @@ for bz in layers:
             un = np.unique(bi); have = len(un) <= NU_MAX
             n["blocks"] += 1; n["ideal"] += u8.any(); n["ball"] += ball
             if not ball: continue
-            keys = ("model", "exactNT", "mu_eT", "eu_mT", "mu_sT", "lpu_sT", "lpu_lpsT", "lpu_eT")
+            keys = ("model", "exactNT", "mu_eT", "eu_mT", "mu_sT", "lpu_sT", "lpu_lpsT", "lpu_eT", "pca1", "pca2", "pca3", "pca4")
             if not have:
                 for k_ in keys: n[k_] += 1
                 continue
@@ -212,10 +212,31 @@ for bz in layers:
                     lo[c], hi[c] = min(cands), max(cands)
                 return lo, hi
             sT0 = sT(False); sT1 = sT(True); lu = lpu()
+            # PCA model of lambda over the block's voxels: lambda(q) = m + sum_j c_j(q) E_j + R(q); ranges of c_j, max |R_i|
+            wr = np.zeros((512, len(un_)))
+            for k_, node in enumerate(un_): wr[:, k_] = np.where(Bi == node, Bw, 0).max(1)
+            L = wr / wr.sum(1, keepdims=True); m_ = L.mean(0); Uu, Ss, Vt = np.linalg.svd(L - m_, full_matrices=False)
+            for rr in (1, 2, 3, 4):
+                E = Vt[:rr].astype(np.float16).astype(np.float64); E -= E.mean(1, keepdims=True)           # (rows sum to 0, kept exactly after rounding)
+                mm = m_.astype(np.float16).astype(np.float64); mm += (1 - mm.sum()) / len(mm)
+                Cc = (L - mm) @ np.linalg.pinv(E); Rr = (L - mm) - Cc @ E
+                clo, chi = Cc.min(0) - 1e-6, Cc.max(0) + 1e-6; res = np.abs(Rr).max(0) * 1.004 + 1e-7
+                e0r = np.argmax(res)
+                def rng(a):
+                    base = (mm * a).sum(); lo = hi = base
+                    for j in range(rr):
+                        g = (E[j] * a).sum(); x, y = clo[j] * g, chi[j] * g; lo += min(x, y); hi += max(x, y)
+                    e = (res * np.abs(a - a[e0r])).sum()
+                    return lo - e, hi + e
+                d_lo, d_hi = rng(r[un_, 0]); d_lo = max(d_lo, r[un_, 0].min()); d_hi = min(d_hi, r[un_, 0].max())
+                plo = np.zeros(3); phi = np.zeros(3)
+                for c in range(3):
+                    n_lo, n_hi = rng(r[un_, 1 + c]); cands = [n_lo / d_lo, n_lo / d_hi, n_hi / d_lo, n_hi / d_hi]; plo[c], phi[c] = min(cands), max(cands)
+                n["pca%d" % rr] += not box_dead(qlo, qhi, plo, phi, Tlo, Thi)
             n["mu_sT"] += not box_dead(qlo, qhi, ulo, uhi, sT0[0], sT0[1])
             n["lpu_sT"] += not box_dead(qlo, qhi, lu[0], lu[1], sT0[0], sT0[1])
             n["lpu_lpsT"] += not box_dead(qlo, qhi, lu[0], lu[1], sT1[0], sT1[1])
             n["lpu_eT"] += not box_dead(qlo, qhi, lu[0], lu[1], eT[0], eT[1])
     b = n["blocks"]
-    print("layer %2d (%.0f s) %5d blocks alive: ideal %.3f exactNT %.3f | model %.3f | model-u+exact-T %.3f exact-u+model-T %.3f | model-u + s*lam T %.3f | LP-u + s*lam T %.3f | LP-u + s*LP T %.3f | LP-u + exact T %.3f | ball %.3f" % (
-        bz, time.time() - t0, b, n["ideal"] / b, n["exactNT"] / b, n["model"] / b, n["mu_eT"] / b, n["eu_mT"] / b, n["mu_sT"] / b, n["lpu_sT"] / b, n["lpu_lpsT"] / b, n["lpu_eT"] / b, n["ball"] / b), flush=True)
+    print("layer %2d (%.0f s) %5d blocks alive: ideal %.3f exactNT %.3f | model %.3f | model-u+exact-T %.3f exact-u+model-T %.3f | model-u + s*lam T %.3f | LP-u + s*lam T %.3f | LP-u + s*LP T %.3f | LP-u + exact T %.3f | PCA-u r=1..4 + model T %.3f %.3f %.3f %.3f | ball %.3f" % (
+        bz, time.time() - t0, b, n["ideal"] / b, n["exactNT"] / b, n["model"] / b, n["mu_eT"] / b, n["eu_mT"] / b, n["mu_sT"] / b, n["lpu_sT"] / b, n["lpu_lpsT"] / b, n["lpu_eT"] / b, n["pca1"] / b, n["pca2"] / b, n["pca3"] / b, n["pca4"] / b, n["ball"] / b), flush=True)
