@@ -226,7 +226,7 @@ class TsdfVolume:
 
     # ---- the same frame in two calls (include/dfusion.h dfusion_integrate_warped_prepare / _sweep): `prepare` does everything that does
     # not touch the volume and may run on another stream (beside the previous frame's ray-cast); `sweep` waits for it on the device
-    def integrate_warped_prepare(self, dists, camera_pose, intr, warp_field, k=None, prefetch=True, block_model=True):
+    def integrate_warped_prepare(self, dists, camera_pose, intr, warp_field, k=None, prefetch=True, block_model=True, codes=True):
         k = warp_field.k if k is None else k
         world2cam = affine_mul(affine_inv(np.asarray(camera_pose, F32)), warp_field.warp_to_live_)
         warp_field.ensure_index(self, k)
@@ -235,6 +235,7 @@ class TsdfVolume:
             _ptr(dists), cols * 2, cols, rows, self.c_volume(), self.c_slab(), capi.floats(aff12(self.pose_)),
             capi.floats(aff12(world2cam)), intr.as_proj(), warp_field.handle, k,
             (capi.DF_WARP_STEADY_PREFETCH if prefetch == "steady" else 0 if prefetch else capi.DF_WARP_NO_PREFETCH) |
+            (0 if codes else capi.DF_WARP_NO_CODES) |
             (capi.DF_WARP_BLOCK_MODEL_NOW if block_model == "now" else 0 if block_model else capi.DF_WARP_NO_BLOCK_MODEL),
             _stream()), "dfusion_integrate_warped_prepare")
 
