@@ -2805,7 +2805,10 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
         }
         else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
         else { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, false, 1>)); }
-        DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // (the CU's whole LDS, whatever THIS launch asks for: the attribute belongs to the kernel, not to the launch, and two host threads
+        // sweeping warp fields of different sizes would otherwise lower it under each other's launches)
+        DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (lds > 160 * 1024) return DF_E_INVALID;
         if (!pipe) { int rc = df_tables_complete(wf, st); if (rc) return rc; }
         if (pipe) {
             // the launch plan: verdict masks of all strip items (one wave each), the alive ones sorted by work; then one workgroup per
