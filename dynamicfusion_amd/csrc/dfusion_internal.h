@@ -41,6 +41,7 @@ struct DfWarpView {
     const float4* rot;         // [M] rotation_ (w,x,y,z)
     const float4* dual;        // [M] translation_ (w,x,y,z)
     const float4* node_t;      // [M] getTranslation() of the node (w,x,y,z), dual_quaternion.hpp:120-125
+    const float4* rt;          // [2M] rot_j, node_t_j interleaved (32 bytes a node: what the sweep's union refills and uncoded cells gather)
     int M;
     // brick index
     const uint32_t* brick_off; // [nb+1]
@@ -79,6 +80,7 @@ struct DfWarpField {
     // and their alternates), the launch plan (two sets of mask + bins; FOUR counter sets, zeroed two frames ahead).  Sweeps are numbered;
     // a buffer remembers the last sweep that reads it, the ring of two events holds the last two sweeps (all sweeps on one stream).
     float4 *rot_alt, *dual_alt, *node_t_alt;
+    float4 *rt, *rt_alt;                             // {rot, node_t} interleaved, and its alternate (see DfWarpView)
     unsigned long long seq, recorded_seq;            // sweeps prepared / recorded so far
     unsigned long long ring_seq[2];                  // the sweep whose completion ev_sweep_done[i] stands for (0: none)
     unsigned long long node_reader[2]; int nphase;  // [nphase] = the current node set's last reader, [nphase ^ 1] = the alternate's
@@ -104,9 +106,13 @@ struct DfWarpField {
     // weights (allocated with the first model), bm_cnt entry counts
     uint8_t* blk_state; float* blk_wmax; uint8_t* blk_alive; uint32_t* blk_work; uint32_t* blk_cnt; size_t blk_cap; int blk_phase;
     uint16_t* bm_idx; uint32_t* bm_lam; uint32_t* bm_w; uint8_t* bm_cnt; size_t bm_cap;
-    // 4-bit neighbour codes (round 5): per voxel of a modelled block, its k neighbours as positions in the block's union list (bm_ids:
-    // [block][16] node ids, ascending); code_tab: one u32 per voxel, tile-major like the tables but PATCH-major inside a tile plane
-    uint32_t* code_tab; size_t code_cap; uint16_t* bm_ids;
+    // 4-bit neighbour codes (round 5; round 6: per 4 x 4 x 4 SUB-block, so that they exist at any node density): per voxel of a block
+    // the model pass has visited, its k neighbours as positions in the union list of its sub-block (ascending node ids, <= 16).
+    //   bm_ids   [block][64] u32: entry q * 16 + e = union entry e of column quadrant q (x >> 2 & 1 | (y >> 2 & 1) << 1), low half
+    //            word for planes 0-3 of the block, high half word for planes 4-7 -- the dword a sweep lane loads to refill its wave's copies
+    //   bm_coded [block] 1 = every sub-block's union fits 16 entries and the codes are written
+    //   code_tab one u32 per voxel, tile-major like the tables but PATCH-major inside a tile plane
+    uint32_t* code_tab; size_t code_cap; uint32_t* bm_ids; uint8_t* bm_coded;
     bool tab_complete;           // every block's tables are built
     int tab_sweeps;              // sweeps over the current tables so far (the models are made from the second one on)
     unsigned long long* dbg_swept;   // dfusion_warp_debug_counters: nullable device counter the sweeps through this handle add to

@@ -28,7 +28,7 @@
 __global__ __launch_bounds__(256) void df_pack_nodes_kernel(const float* __restrict__ pos, const float* __restrict__ dq,
                                                             const float* __restrict__ sigma, int M,
                                                             float4* __restrict__ pos_sigma, float4* __restrict__ rot,
-                                                            float4* __restrict__ dual, float4* __restrict__ node_t)
+                                                            float4* __restrict__ dual, float4* __restrict__ node_t, float4* __restrict__ rt)
 {
     int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= M) return;
@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void df_pack_nodes_kernel(const float* __restr
     rot[j] = make_float4(r.w, r.x, r.y, r.z);
     dual[j] = make_float4(d.w, d.x, d.y, d.z);
     node_t[j] = make_float4(t.w, t.x, t.y, t.z);
+    rt[2 * j] = rot[j]; rt[2 * j + 1] = node_t[j];
 }
 
 // Conservative per-node displacement ingredients for brick culling: max |t_i| and max sin(theta_i/2)
@@ -152,7 +153,7 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     df_side_drain(wf);
     if (wf->side) { (void)hipEventDestroy(wf->ev_fork); (void)hipEventDestroy(wf->ev_join); (void)hipStreamDestroy(wf->side); }
     if (wf->split_events) { (void)hipEventDestroy(wf->ev_prep_done); (void)hipEventDestroy(wf->ev_sweep_done[0]); (void)hipEventDestroy(wf->ev_sweep_done[1]); }
-    (void)hipFree(wf->rot_alt); (void)hipFree(wf->dual_alt); (void)hipFree(wf->node_t_alt);
+    (void)hipFree(wf->rot_alt); (void)hipFree(wf->dual_alt); (void)hipFree(wf->node_t_alt); (void)hipFree(wf->rt); (void)hipFree(wf->rt_alt);
     (void)hipFree(wf->plan_mask2[1]); (void)hipFree(wf->plan_list2[1]); (void)hipFree(wf->plan_code2[0]); (void)hipFree(wf->plan_code2[1]);
     df_prep_free(wf);
     if (wf->host_report) (void)hipHostFree((void*)wf->host_report);
@@ -160,7 +161,7 @@ extern "C" int dfusion_warp_destroy(DfWarpField* wf)
     (void)hipFree(wf->brick_off); (void)hipFree(wf->brick_cnt); (void)hipFree(wf->brick_list); (void)hipFree(wf->bounds_dev); (void)hipFree(wf->brick_thr);
     (void)hipFree(wf->knn_tab); (void)hipFree(wf->w_tab); (void)hipFree(wf->solver_ws); (void)hipFree(wf->pt_ids); (void)hipFree(wf->tile_wmax);
     (void)hipFree(wf->bm_idx); (void)hipFree(wf->bm_lam); (void)hipFree(wf->bm_w); (void)hipFree(wf->bm_cnt);
-    (void)hipFree(wf->code_tab); (void)hipFree(wf->bm_ids);
+    (void)hipFree(wf->code_tab); (void)hipFree(wf->bm_ids); (void)hipFree(wf->bm_coded);
     (void)hipFree(wf->scan_tmp);
     (void)hipFree(wf->blk_state); (void)hipFree(wf->blk_wmax); (void)hipFree(wf->blk_alive); (void)hipFree(wf->blk_work); (void)hipFree(wf->blk_cnt);
     (void)hipFree(wf->nf_nodes); (void)hipFree(wf->nf_vpos); (void)hipFree(wf->pyr_mem);
@@ -179,8 +180,9 @@ static int df_warp_reserve(DfWarpField* wf, int M)
     if (M <= wf->cap) return DF_OK;
     { int rc = df_wait_all_sweeps_host(wf); if (rc) return rc; }        // (a split sweep may still read what is freed here)
     (void)hipFree(wf->pos_sigma); (void)hipFree(wf->rot); (void)hipFree(wf->dual); (void)hipFree(wf->node_t);
-    (void)hipFree(wf->rot_alt); (void)hipFree(wf->dual_alt); (void)hipFree(wf->node_t_alt);
-    wf->pos_sigma = wf->rot = wf->dual = wf->node_t = wf->rot_alt = wf->dual_alt = wf->node_t_alt = nullptr; wf->cap = 0;
+    (void)hipFree(wf->rot_alt); (void)hipFree(wf->dual_alt); (void)hipFree(wf->node_t_alt); (void)hipFree(wf->rt); (void)hipFree(wf->rt_alt);
+    wf->pos_sigma = wf->rot = wf->dual = wf->node_t = wf->rot_alt = wf->dual_alt = wf->node_t_alt = wf->rt = wf->rt_alt = nullptr; wf->cap = 0;
+    wf->prep_valid = false;                                               // (a prepared plan points into the arrays freed here)
     size_t bytes = (size_t)M * sizeof(float4);
     DF_HIP(hipMalloc((void**)&wf->pos_sigma, bytes));
     DF_HIP(hipMalloc((void**)&wf->rot, bytes));
@@ -189,6 +191,8 @@ static int df_warp_reserve(DfWarpField* wf, int M)
     DF_HIP(hipMalloc((void**)&wf->rot_alt, bytes));                       // (the alternate set the next set_transforms writes)
     DF_HIP(hipMalloc((void**)&wf->dual_alt, bytes));
     DF_HIP(hipMalloc((void**)&wf->node_t_alt, bytes));
+    DF_HIP(hipMalloc((void**)&wf->rt, 2 * bytes));
+    DF_HIP(hipMalloc((void**)&wf->rt_alt, 2 * bytes));
     wf->node_reader[0] = wf->node_reader[1] = 0;
     if (!wf->bounds_dev) { DF_HIP(hipMalloc((void**)&wf->bounds_dev, 8 * sizeof(float))); DF_HIP(hipMemset(wf->bounds_dev, 0, 8 * sizeof(float))); }   // ([6]: the capped pyramid's image-wide maximum, 0 between frames)
     wf->cap = M;
@@ -199,7 +203,8 @@ static int df_warp_reserve(DfWarpField* wf, int M)
 // set_transforms was three launches of ~4.5 us each).
 __global__ __launch_bounds__(1024) void df_pack_bounds_kernel(const float* __restrict__ pos, const float* __restrict__ dq, const float* __restrict__ sigma,
                                                               int M, float4* __restrict__ pos_sigma, float4* __restrict__ rot,
-                                                              float4* __restrict__ dual, float4* __restrict__ node_t, float* __restrict__ bounds)
+                                                              float4* __restrict__ dual, float4* __restrict__ node_t, float4* __restrict__ rt,
+                                                              float* __restrict__ bounds)
 {
     __shared__ float s_red[4][16];
     float tn = 0.f, sh = 0.f, rn = 0.f, sg = 0.f;
@@ -215,6 +220,7 @@ __global__ __launch_bounds__(1024) void df_pack_bounds_kernel(const float* __res
         rot[j] = make_float4(r.w, r.x, r.y, r.z);
         dual[j] = make_float4(d.w, d.x, d.y, d.z);
         node_t[j] = make_float4(t.w, t.x, t.y, t.z);
+        rt[2 * j] = make_float4(r.w, r.x, r.y, r.z); rt[2 * j + 1] = make_float4(t.w, t.x, t.y, t.z);
         // (the bounds exactly as df_node_bounds_kernel takes them from the packed arrays)
         float tj = sqrtf(t.x * t.x + t.y * t.y + t.z * t.z);
         const float n = sqrtf(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z);
@@ -248,7 +254,7 @@ static int df_warp_pack(DfWarpField* wf, const float* pos, const float* dq, cons
 {
     if (pos) { int rc = df_wait_split_sweep(wf, st); if (rc) return rc; }
     else { int rc = df_wait_reader(wf, wf->node_reader[wf->nphase ^ 1], st); if (rc) return rc; }
-    std::swap(wf->rot, wf->rot_alt); std::swap(wf->dual, wf->dual_alt); std::swap(wf->node_t, wf->node_t_alt);
+    std::swap(wf->rot, wf->rot_alt); std::swap(wf->dual, wf->dual_alt); std::swap(wf->node_t, wf->node_t_alt); std::swap(wf->rt, wf->rt_alt);
     wf->nphase ^= 1;
     wf->node_reader[wf->nphase] = 0;                                       // (rewritten: nobody reads the old contents any more)
     return df_warp_pack_current(wf, pos, dq, sigma, st);
@@ -257,12 +263,12 @@ static int df_warp_pack_current(DfWarpField* wf, const float* pos, const float* 
 {
     if (wf->M <= 8192) {
         hipLaunchKernelGGL(df_pack_bounds_kernel, dim3(1), dim3(1024), 0, st, pos, dq, sigma, wf->M, wf->pos_sigma, wf->rot, wf->dual, wf->node_t,
-                           wf->bounds_dev);
+                           wf->rt, wf->bounds_dev);
         DF_LAUNCH_CHECK();
         return DF_OK;
     }
     hipLaunchKernelGGL(df_pack_nodes_kernel, dim3((wf->M + 255) / 256), dim3(256), 0, st, pos, dq, sigma, wf->M,
-                       wf->pos_sigma, wf->rot, wf->dual, wf->node_t);
+                       wf->pos_sigma, wf->rot, wf->dual, wf->node_t, wf->rt);
     DF_LAUNCH_CHECK();
     DF_HIP(hipMemsetAsync(wf->bounds_dev, 0, 4 * sizeof(float), st));     // [2] (max dists) is rewritten by every integrate
     if (pos) { const float unknown = 3.0e38f; DF_HIP(hipMemcpyAsync(wf->bounds_dev + 4, &unknown, sizeof(float), hipMemcpyHostToDevice, st)); }   // (no sigma bound on this path)
@@ -705,7 +711,7 @@ __global__ __launch_bounds__(256) void df_points_wave_kernel(DfWarpView W, const
 static DfWarpView df_view(const DfWarpField* wf)
 {
     DfWarpView W;
-    W.pos_sigma = wf->pos_sigma; W.rot = wf->rot; W.dual = wf->dual; W.node_t = wf->node_t; W.M = wf->M;
+    W.pos_sigma = wf->pos_sigma; W.rot = wf->rot; W.dual = wf->dual; W.node_t = wf->node_t; W.rt = wf->rt; W.M = wf->M;
     W.brick_off = wf->brick_off; W.brick_list = wf->brick_list; W.brick_thr = wf->brick_thr; W.bx = wf->bx; W.by = wf->by; W.bz = wf->bz;
     W.nf.nodes = wf->nf_ok ? wf->nf_nodes : nullptr; W.nf.vpos = wf->nf_vpos;
     return W;
@@ -1166,8 +1172,8 @@ struct DfWarpedArgs {
     // this frame's verdicts of the block blend models (dfusion_warp_blocks.h), one byte per 8 x 8 x 8 block of the table's planes,
     // x fastest; null = none.  bm_nbx / bm_nby: blocks per row / column (whole table tiles)
     const uint8_t* blk_alive; int bm_nbx, bm_nby;
-    // 4-bit neighbour codes of modelled blocks (DF_IDX_CODES; null = none): see df_code_index / df_block_model_kernel
-    uint32_t* code_tab; uint16_t* bm_ids;
+    // 4-bit neighbour codes (null = none): see df_code_index / df_block_model_kernel
+    uint32_t* code_tab; uint32_t* bm_ids; uint8_t* bm_coded;
     const unsigned long long* plan_code;       // pipelined sweep: per strip item, bit 16 p + l: the cell's block has codes
     // table build (df_warp_brick_kernel<K, true>): per-block bound on sum_i w_i (same block grid), and -- when the build is driven by a
     // work list instead of the launch grid -- the list of packed brick coordinates (x | y << 10 | z << 20) and its length
@@ -1190,21 +1196,13 @@ struct DfWarpedArgs {
 #define DF_TAB_TX 32
 #define DF_TAB_TY 16
 #define DF_TAB_TZ 8
-// Inside a tile plane (32 x 16 voxels): rows of 32 (DF_TAB_PATCH_MAJOR = 0, the product).  Round 5 measured the alternative -- PATCH-major:
-// the eight 8 x 8 column patches one after the other, so that the 64 records a wave of the pipelined sweep loads with one instruction are
-// ONE contiguous 1 KiB run instead of eight 128-byte pieces 512 bytes apart -- same box, interleaved: 0.691 against 0.686 ms at 512^3,
-// 0.153 / 0.156 at 256^3 (profiles/r05_ab_warp_variants.txt): the four waves of a strip fetch the pieces of a row's lines together anyway.
-#ifndef DF_TAB_PATCH_MAJOR
-#define DF_TAB_PATCH_MAJOR 0
-#endif
+// Inside a tile plane (32 x 16 voxels): rows of 32.  (Round 5 measured the alternative -- the eight 8 x 8 column patches one after the
+// other, a wave's 64 records as ONE 1 KiB run -- same box, interleaved: 0.691 against 0.686 ms at 512^3, profiles/r05_ab_warp_variants.txt:
+// the four waves of a strip fetch the pieces of a row's lines together anyway.)
 __device__ __forceinline__ unsigned df_tab_in_plane(int x, int y)
 {
     const unsigned xt = (unsigned)x % DF_TAB_TX, yt = (unsigned)y % DF_TAB_TY;
-#if DF_TAB_PATCH_MAJOR
-    return (((yt >> 3) * (DF_TAB_TX / 8) + (xt >> 3)) << 6) + ((yt & 7u) << 3) + (xt & 7u);
-#else
     return yt * DF_TAB_TX + xt;
-#endif
 }
 __device__ __forceinline__ size_t df_tab_index(const DfWarpedArgs& a, int x, int y, int z)
 {
@@ -1217,9 +1215,6 @@ __device__ __forceinline__ size_t df_tab_index(const DfWarpedArgs& a, int x, int
 // after the other) -- the 64 codes a wave of the pipelined sweep loads for its 8 x 8 patch are ONE 256-byte run, two L2 requests.  (The
 // sweep is bound by the L2's request rate, TCC 86 % busy: measured, the same 4 bytes per voxel laid out in rows of 32 -- eight 32-byte
 // pieces per wave -- cost as much as the 16-byte index records they replace.)
-#ifndef DF_IDX_CODES
-#define DF_IDX_CODES 1
-#endif
 __device__ __forceinline__ unsigned df_code_in_plane(int x, int y)
 {
     const unsigned xt = (unsigned)x % DF_TAB_TX, yt = (unsigned)y % DF_TAB_TY;
@@ -1533,39 +1528,10 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
 // re-ranking ~150 candidates (and 8 f32 divisions + 8 f64 exp) per voxel.  A workgroup owns a 32(x) x 8(y) x 8(z) tile:
 // a wave covers two 32-voxel rows, so every access is a run of >= 128 contiguous bytes (volume 4 B, k-NN 16 B, weights
 // 16 B per lane and plane); each lane walks the 8 planes of the tile.
-// ---- compile-time switches of the pipelined sweep (tools/build_variant.py builds the A/B variants)
-#ifndef DF_NORM_F32DIV
-#define DF_NORM_F32DIV 0         // the pipelined sweep's first normalisation as an f32 division (0: the f64 reciprocal and scaling).  Same bits
-                                 // (selftest [8]); measured round 5, same box: 0.644 against 0.640 ms -- not faster, so not the default
-#endif
-#ifndef DF_WARP_FUSE_SHORT
-#define DF_WARP_FUSE_SHORT 0     // the pipelined sweep's fuse division in its short form where a wave's stored values are finite (round 5:
-                                 // 0.644 against 0.642 ms without it -- the second code path costs what the shorter division saves)
-#endif
-#ifndef DF_TAB_ADDR_HOIST
-#define DF_TAB_ADDR_HOIST 1      // table record addresses from a per-segment base (0: the general df_tab_index arithmetic per load)
-#endif
-#ifndef DF_PIPE_ROWS
-#define DF_PIPE_ROWS 0           // experiment: the pipelined sweep's waves own 32 x 2 column patches (full 128-byte voxel rows) instead of 8 x 8
-#endif
-#ifndef DF_BM_WG_PER_CU_CAP
-#define DF_BM_WG_PER_CU_CAP 0
-#endif
-#ifndef DF_PIPE_WGT
-#define DF_PIPE_WGT 768           // threads of a k = 8 sweep workgroup when two of them fit a CU's LDS (768: 12 waves dealing out 3 strip items; needs <= 80 VGPRs)
-#endif
-#ifndef DF_PIPE_U
-#define DF_PIPE_U 1               // planes per batch of that kernel (two batches' tables are in flight); the other forms of the sweep have 2
-#endif
-#ifndef DF_LDS_PAD
-#define DF_LDS_PAD 0             // measurement: LDS bytes requested on top of what the sweep uses (fewer workgroups per CU: the occupancy series)
-#endif
-#ifndef DF_LDS_SPLIT
-#define DF_LDS_SPLIT 0           // experiment: rot and node_t in two 16-byte-strided LDS arrays (M <= 2048) instead of interleaved
-#endif
-#if DF_IDX_CODES && (DF_LDS_SPLIT || !DF_TAB_ADDR_HOIST)
-#error "the coded sweep assumes interleaved LDS node records and per-segment table addresses: build the DF_LDS_SPLIT=1 / DF_TAB_ADDR_HOIST=0 measurement variants with -DDF_IDX_CODES=0"
-#endif
+// ---- geometry of the pipelined sweep.  (Rounds 4-5 measured, and dropped, a series of compile-time variants of it -- 32 x 2 patches, an
+// f32-division normalisation, a short fuse division, split LDS node arrays, patch-major tables, both-loads code records: profiles/NOTES.md
+// and profiles/r05_ab_warp_variants.txt hold the numbers; the source keeps only what runs.)
+#define DF_PIPE_WGT 768           // threads of a k = 8 sweep workgroup: 12 waves dealing out 3 strip items; needs <= 80 VGPRs for two workgroups per CU
 #define DF_ROW_TX 32
 #define DF_ROW_TY 8
 #define DF_ROW_TZ 8
@@ -1686,7 +1652,7 @@ __global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArg
 }
 
 // ---- software-pipelined form of the kernel above (the default).  PMC on the batched kernel: waves spend ~45 % of their
-// cycles parked on the table loads and raising occupancy is not possible (LDS node table: 2 workgroups per CU; ~100 VGPRs),
+// cycles parked on the table loads and raising occupancy is not possible (~100 VGPRs),
 // so the loads of batch b+1 are issued in the middle of batch b.  Vector-memory results return IN ORDER (vmcnt), hence the
 // order inside a batch matters:  volume words + dists gathers of batch b (needed now)  ->  table loads of batch b+1 (needed
 // next iteration)  ->  wait only for the former (vmcnt leaves the 6 prefetches in flight)  ->  sqrt / fuse / store, then the
@@ -1696,11 +1662,7 @@ __global__ __launch_bounds__(512) void df_warp_rows_lds_kernel(const DfWarpedArg
 // raw (still packed) table record of one voxel: kept packed while in flight, so that nothing consumes a prefetched
 // register before the next iteration (an unpack right after the load would make the compiler wait for it at once)
 template <int K> struct DfTabRaw;
-#if DF_IDX_CODES
 template <> struct DfTabRaw<8> { uint4 idx; float4 w0, w1; unsigned code; };
-#else
-template <> struct DfTabRaw<8> { uint4 idx; float4 w0, w1; };
-#endif
 template <> struct DfTabRaw<4> { uint2 idx; float4 w0; };
 __device__ __forceinline__ void tab_raw_load(const DfWarpedArgs& a, size_t tv, DfTabRaw<8>& r)
 {
@@ -1730,46 +1692,23 @@ __device__ __forceinline__ df_global_ptr<T> df_wave_uniform(T* p)
 }
 // the per-voxel tables are read once per frame and never again before 5 GB of other data have gone by: non-temporal loads (`nt`)
 #define DF_TAB_LD(p) __builtin_nontemporal_load(p)
-// the same with the record index split into a wave-uniform base and a 32-bit lane offset
-__device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<8>& r)
+// the record index split into a wave-uniform base and a 32-bit lane offset.  k = 8: a cell whose block has 4-bit neighbour codes loads
+// the 4-byte code (record rec_c + lane_c of the patch-major code plane) INSTEAD of the 16-byte index record, behind a wave-uniform
+// branch whose arms issue exactly one load each (the prefetch queue's vmcnt stays exact)
+__device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, size_t rec_c, bool coded, unsigned lane, unsigned lane_c, DfTabRaw<8>& r)
 {
-    const df_v4u i4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4u*>(a.knn_tab) + rec) + lane);
-    const df_v4f a4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec) + lane);
-    const df_v4f b4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + a.tab_nvox + rec) + lane);
-    r.idx = make_uint4(i4.x, i4.y, i4.z, i4.w); r.w0 = make_float4(a4.x, a4.y, a4.z, a4.w); r.w1 = make_float4(b4.x, b4.y, b4.z, b4.w);
-#if DF_IDX_CODES
-    r.code = 0u;
-#endif
-}
-#if DF_IDX_CODES
-// The same for a batch of a cell that may read 4-bit codes.  Branch-free (a branch around a load makes the compiler drain the prefetch
-// queue): BOTH the 16-byte index record and the 4-byte code are requested, the one the cell does not use from record 0 of its table -- a
-// place every wave hits in the L1 -- so it costs an instruction, no L2 request.  lane_c: the lane's offset in the patch-major code plane.
-#ifndef DF_CODES_LOAD_MODE
-#define DF_CODES_LOAD_MODE 0     // 0: one load per cell kind behind a wave-uniform branch (each arm issues exactly one load); 1: both loads, the unused one from record 0
-#endif
-__device__ __forceinline__ void tab_raw_load_coded(const DfWarpedArgs& a, size_t rec, bool coded, unsigned lane, unsigned lane_c, DfTabRaw<8>& r)
-{
-#if DF_CODES_LOAD_MODE == 0
     r.idx = make_uint4(0u, 0u, 0u, 0u); r.code = 0u;
     if (coded) {
-        r.code = DF_TAB_LD(df_wave_uniform(a.code_tab + rec) + lane_c);
+        r.code = DF_TAB_LD(df_wave_uniform(a.code_tab + rec_c) + lane_c);
     } else {
         const df_v4u i4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4u*>(a.knn_tab) + rec) + lane);
         r.idx = make_uint4(i4.x, i4.y, i4.z, i4.w);
     }
-#else
-    const size_t rec_i = coded ? (size_t)0 : rec, rec_c = coded ? rec : (size_t)0;
-    const df_v4u i4 = *(df_wave_uniform(reinterpret_cast<const df_v4u*>(a.knn_tab) + rec_i) + (coded ? (lane & 63u) : lane));
-    r.code = *(df_wave_uniform(a.code_tab + rec_c) + (coded ? lane_c : (lane_c & 63u)));
-    r.idx = make_uint4(i4.x, i4.y, i4.z, i4.w);
-#endif
     const df_v4f a4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec) + lane);
     const df_v4f b4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + a.tab_nvox + rec) + lane);
     r.w0 = make_float4(a4.x, a4.y, a4.z, a4.w); r.w1 = make_float4(b4.x, b4.y, b4.z, b4.w);
 }
-#endif
-__device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, unsigned lane, DfTabRaw<4>& r)
+__device__ __forceinline__ void tab_raw_load_at(const DfWarpedArgs& a, size_t rec, size_t, bool, unsigned lane, unsigned, DfTabRaw<4>& r)
 {
     const df_v2u i2 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v2u*>(a.knn_tab) + rec) + lane);
     const df_v4f a4 = DF_TAB_LD(df_wave_uniform(reinterpret_cast<const df_v4f*>(a.w_tab) + rec) + lane);
@@ -1786,29 +1725,22 @@ __device__ __forceinline__ void tab_raw_unpack(const DfTabRaw<4>& r, int (&bi)[4
     bi[0] = r.idx.x & 0xffff; bi[1] = r.idx.x >> 16; bi[2] = r.idx.y & 0xffff; bi[3] = r.idx.y >> 16;
     wt[0] = r.w0.x; wt[1] = r.w0.y; wt[2] = r.w0.z; wt[3] = r.w0.w;
 }
-// Byte offset of node `word` (0 = low, 1 = high 16 bits of v) in the interleaved LDS node table: index * 32 in ONE instruction
+// Byte offset of node `word` (0 = low, 1 = high 16 bits of v) in an interleaved {rot, node_t} node table: index * 32 in ONE instruction
 // (SDWA selects the 16-bit word as the shift's operand; and + shift / bfe + shift otherwise, two per index, 16 per voxel).
-#if DF_LDS_SPLIT
-#define DF_NODE_SHIFT "4"
-#define DF_NODE_T_OFF 2048       // (in 16-byte units: node_t[j] at byte 32768 + 16 j, inside the ds_read immediate offset)
-#else
-#define DF_NODE_SHIFT "5"
-#define DF_NODE_T_OFF 1
-#endif
 __device__ __forceinline__ unsigned df_node_off_lo(unsigned v)
 {
     unsigned r;
-    asm("v_lshlrev_b32_sdwa %0, " DF_NODE_SHIFT ", %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(v));
+    asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(v));
     return r;
 }
 __device__ __forceinline__ unsigned df_node_off_hi(unsigned v)
 {
     unsigned r;
-    asm("v_lshlrev_b32_sdwa %0, " DF_NODE_SHIFT ", %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(v));
+    asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(v));
     return r;
 }
-// The blend below addresses the nodes by byte offsets into the workgroup's LDS.  The node table is the kernel's only LDS object (the
-// dynamic array), so it starts at LDS address 0 and the offset IS the address -- df_warp_rows_pipe_kernel checks that.
+// The LDS forms of the blend address the nodes by byte offsets into the workgroup's LDS.  The dynamic array is the kernel's only LDS
+// object, so it starts at LDS address 0 and the offset IS the address -- df_warp_rows_pipe_kernel checks that.
 typedef const __attribute__((address_space(3))) df_v4f df_lds_cf4;
 // w.lo * q and w.hi * q on both halves of q: the weight is picked out of its register PAIR by op_sel (the table record delivers the
 // weights two to a pair), instead of being copied into a {w, w} pair first -- 12 v_mov per voxel at k = 8.
@@ -1824,52 +1756,63 @@ __device__ __forceinline__ df_v2f df_pk_mul_hi(df_v2f w, df_v2f q)
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "v"(q));
     return r;
 }
-// the blend sums straight from a packed table record: node offsets and weights are taken out of the loaded registers where they are used
-__device__ __forceinline__ void df_blend_pair(DfBlendSums& S, unsigned idx2, df_v2f wp)
-{
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        df_lds_cf4* nd = (df_lds_cf4*)(size_t)(h == 0 ? df_node_off_lo(idx2) : df_node_off_hi(idx2));
-        const df_v4f r4 = nd[0], t4 = nd[DF_NODE_T_OFF];
-        const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
-        if (h == 0) {
-            S.t01 = S.t01 + df_pk_mul_lo(wp, ta); S.t23 = S.t23 + df_pk_mul_lo(wp, tb);     // :211
-            S.r01 = S.r01 + df_pk_mul_lo(wp, ra); S.r23 = S.r23 + df_pk_mul_lo(wp, rb);     // :212
-        } else {
-            S.t01 = S.t01 + df_pk_mul_hi(wp, ta); S.t23 = S.t23 + df_pk_mul_hi(wp, tb);
-            S.r01 = S.r01 + df_pk_mul_hi(wp, ra); S.r23 = S.r23 + df_pk_mul_hi(wp, rb);
-        }
-    }
-}
-__device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<8>& r)
-{
-    DfBlendSums S;
-    S.t01 = S.t23 = S.r01 = S.r23 = df_v2f{0.f, 0.f};
-    df_blend_pair(S, r.idx.x, df_v2f{r.w0.x, r.w0.y}); df_blend_pair(S, r.idx.y, df_v2f{r.w0.z, r.w0.w});
-    df_blend_pair(S, r.idx.z, df_v2f{r.w1.x, r.w1.y}); df_blend_pair(S, r.idx.w, df_v2f{r.w1.z, r.w1.w});
-    return S;
-}
-#if DF_IDX_CODES
-// ... and from 4-bit codes: neighbour i = entry ((code >> 4 i) & 15) of the wave's LOCAL copy of its block's union (16 x 32 bytes at LDS
-// address lbase, a multiple of 512): a shift and an and-or per neighbour instead of one SDWA shift; the same nodes in the same order, so
-// the same sums.
-__device__ __forceinline__ void df_blend_pair_at(DfBlendSums& S, unsigned off_lo, unsigned off_hi, df_v2f wp)
+// One pair of neighbours added to the blend sums (element-wise IEEE mul then add, the scalar sequence of warp_field.cpp:211-212), given
+// their {rot, node_t} records
+__device__ __forceinline__ void df_blend_acc(DfBlendSums& S, df_v2f wp, df_v4f r_lo, df_v4f t_lo, df_v4f r_hi, df_v4f t_hi)
 {
     {
-        df_lds_cf4* nd = (df_lds_cf4*)(size_t)off_lo;
-        const df_v4f r4 = nd[0], t4 = nd[1];
-        const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
-        S.t01 = S.t01 + df_pk_mul_lo(wp, ta); S.t23 = S.t23 + df_pk_mul_lo(wp, tb);
-        S.r01 = S.r01 + df_pk_mul_lo(wp, ra); S.r23 = S.r23 + df_pk_mul_lo(wp, rb);
+        const df_v2f ta = {t_lo.x, t_lo.y}, tb = {t_lo.z, t_lo.w}, ra = {r_lo.x, r_lo.y}, rb = {r_lo.z, r_lo.w};
+        S.t01 = S.t01 + df_pk_mul_lo(wp, ta); S.t23 = S.t23 + df_pk_mul_lo(wp, tb);     // :211
+        S.r01 = S.r01 + df_pk_mul_lo(wp, ra); S.r23 = S.r23 + df_pk_mul_lo(wp, rb);     // :212
     }
     {
-        df_lds_cf4* nd = (df_lds_cf4*)(size_t)off_hi;
-        const df_v4f r4 = nd[0], t4 = nd[1];
-        const df_v2f ta = {t4.x, t4.y}, tb = {t4.z, t4.w}, ra = {r4.x, r4.y}, rb = {r4.z, r4.w};
+        const df_v2f ta = {t_hi.x, t_hi.y}, tb = {t_hi.z, t_hi.w}, ra = {r_hi.x, r_hi.y}, rb = {r_hi.z, r_hi.w};
         S.t01 = S.t01 + df_pk_mul_hi(wp, ta); S.t23 = S.t23 + df_pk_mul_hi(wp, tb);
         S.r01 = S.r01 + df_pk_mul_hi(wp, ra); S.r23 = S.r23 + df_pk_mul_hi(wp, rb);
     }
 }
+// ... the two records read from LDS byte addresses
+__device__ __forceinline__ void df_blend_pair_at(DfBlendSums& S, unsigned off_lo, unsigned off_hi, df_v2f wp)
+{
+    df_lds_cf4* nl = (df_lds_cf4*)(size_t)off_lo; df_lds_cf4* nh = (df_lds_cf4*)(size_t)off_hi;
+    df_blend_acc(S, wp, nl[0], nl[1], nh[0], nh[1]);
+}
+// the blend sums straight from a packed table record: node offsets and weights are taken out of the loaded registers where they are used.
+// (i) node table in LDS at address 0 (k = 4)
+__device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<4>& r)
+{
+    DfBlendSums S;
+    S.t01 = S.t23 = S.r01 = S.r23 = df_v2f{0.f, 0.f};
+    df_blend_pair_at(S, df_node_off_lo(r.idx.x), df_node_off_hi(r.idx.x), df_v2f{r.w0.x, r.w0.y});
+    df_blend_pair_at(S, df_node_off_lo(r.idx.y), df_node_off_hi(r.idx.y), df_v2f{r.w0.z, r.w0.w});
+    return S;
+}
+// (ii) node table in global memory (the L2): W.rt, 32 bytes a node -- the cells without codes of the k = 8 sweep, and k = 4 node sets too
+// large for the LDS
+__device__ __forceinline__ void df_blend_pair_global(DfBlendSums& S, df_global_ptr<const char> rt, unsigned idx2, df_v2f wp)
+{
+    const df_global_ptr<const df_v4f> nl = (df_global_ptr<const df_v4f>)(rt + df_node_off_lo(idx2));
+    const df_global_ptr<const df_v4f> nh = (df_global_ptr<const df_v4f>)(rt + df_node_off_hi(idx2));
+    df_blend_acc(S, wp, nl[0], nl[1], nh[0], nh[1]);
+}
+__device__ __forceinline__ DfBlendSums dqb_sums_global_rec(const DfTabRaw<8>& r, df_global_ptr<const char> rt)
+{
+    DfBlendSums S;
+    S.t01 = S.t23 = S.r01 = S.r23 = df_v2f{0.f, 0.f};
+    df_blend_pair_global(S, rt, r.idx.x, df_v2f{r.w0.x, r.w0.y}); df_blend_pair_global(S, rt, r.idx.y, df_v2f{r.w0.z, r.w0.w});
+    df_blend_pair_global(S, rt, r.idx.z, df_v2f{r.w1.x, r.w1.y}); df_blend_pair_global(S, rt, r.idx.w, df_v2f{r.w1.z, r.w1.w});
+    return S;
+}
+__device__ __forceinline__ DfBlendSums dqb_sums_global_rec(const DfTabRaw<4>& r, df_global_ptr<const char> rt)
+{
+    DfBlendSums S;
+    S.t01 = S.t23 = S.r01 = S.r23 = df_v2f{0.f, 0.f};
+    df_blend_pair_global(S, rt, r.idx.x, df_v2f{r.w0.x, r.w0.y}); df_blend_pair_global(S, rt, r.idx.y, df_v2f{r.w0.z, r.w0.w});
+    return S;
+}
+// (iii) from 4-bit codes: neighbour i = entry ((code >> 4 i) & 15) of the wave's LOCAL copy of the voxel's sub-block union (16 x 32 bytes at
+// LDS address lbase, a multiple of 512, per lane: the four column quadrants of a wave's patch have a union each): a shift and an and-or per
+// neighbour; the same nodes in the same order as the index record names, so the same sums.
 __device__ __forceinline__ DfBlendSums dqb_sums_codes(const DfTabRaw<8>& r, unsigned lbase)
 {
     DfBlendSums S;
@@ -1881,14 +1824,6 @@ __device__ __forceinline__ DfBlendSums dqb_sums_codes(const DfTabRaw<8>& r, unsi
 #undef DF_CODE_OFF
     return S;
 }
-#endif
-__device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<4>& r)
-{
-    DfBlendSums S;
-    S.t01 = S.t23 = S.r01 = S.r23 = df_v2f{0.f, 0.f};
-    df_blend_pair(S, r.idx.x, df_v2f{r.w0.x, r.w0.y}); df_blend_pair(S, r.idx.y, df_v2f{r.w0.z, r.w0.w});
-    return S;
-}
 
 // The launch plan of the pipelined sweep.  One wave per strip item: lane = (patch p = lane / 16, layer l = lane % 16) judges the
 // 8 x 8 x 8 voxels of its patch and layer (the verdict costs ~200 instructions; in the sweep itself it held a workgroup's LDS while
@@ -1896,9 +1831,6 @@ __device__ __forceinline__ DfBlendSums dqb_sums_lds_rec(const DfTabRaw<4>& r)
 // cnt[w] entries; the order inside a bin is whatever the atomics make it -- items are independent, the result does not depend on
 // it): the sweep takes the bins from w = 64 down, i.e. the items most work first, without a sorting pass.  `cnt_next` is the counter
 // set of the NEXT launch (the two sets alternate), zeroed here: nothing reads it any more once this kernel runs.
-#ifndef DF_SWEEP_BALANCE
-#define DF_SWEEP_BALANCE 1       // the pipelined sweep deals a workgroup's alive cells out evenly over its waves (0: one patch per wave)
-#endif
 #define DF_PLAN_BINS 65
 #define DF_PLAN_WG 1024          // 16 items per workgroup: neighbours in the volume, mostly of equal work, so their bin slots are taken with one atomic
 __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpedArgs a, int tiles_x, int tiles_y, unsigned n_items,
@@ -1922,32 +1854,20 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
         const int zb = (int)(tcol / ((unsigned)tiles_x * (unsigned)tiles_y));
         const int lt0 = a.bz0 + zb * a.zt;
         const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
-#if DF_PIPE_ROWS
-        // 32 x 2 patches (two full 128-byte voxel rows per wave and plane): patch p = rows 2p, 2p + 1 of the strip's 32 x 8 columns, which
-        // span the strip's FOUR 8 x 8 x 8 blocks of the layer -- alive when any of them is
-        const int x0 = tx * DF_ROW_TX, y0 = ty * DF_LDS_TY + (int)half * 8;
-        bool keep = l < a.zt && max((lt0 + l) * DF_ROW_TZ, a.z_own0) < min((lt0 + l + 1) * DF_ROW_TZ, own1) && x0 < a.X && y0 + 2 * p < a.Y;
-        if (keep && a.blk_alive) {
-            const uint8_t* row = a.blk_alive + ((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3);
-            keep = (row[0] | row[1] | row[2] | row[3]) != 0;               // (bm_nbx covers whole table tiles: the four bytes exist)
-        }
-#else
         const int x0 = tx * DF_ROW_TX + p * 8, y0 = ty * DF_LDS_TY + (int)half * 8;                  // first column of the patch
         bool keep = l < a.zt && max((lt0 + l) * DF_ROW_TZ, a.z_own0) < min((lt0 + l + 1) * DF_ROW_TZ, own1) && x0 < a.X && y0 < a.Y;
         // the verdict pass has judged the patch's 8 x 8 x 8 voxels of the layer (df_block_verdict_kernel: zero-weight, ball, blend-model box)
-        if (keep && a.blk_alive)
-            keep = a.blk_alive[((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3)] != 0;
-#endif
+        unsigned verdict = 1u;
+        if (keep && a.blk_alive) {
+            verdict = a.blk_alive[((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3)];
+            keep = verdict != 0u;
+        }
         m = __builtin_amdgcn_ballot_w64(keep);
-#if DF_IDX_CODES && !DF_PIPE_ROWS
         if (code_out) {                                                    // (wave-uniform) which alive cells' blocks have 4-bit neighbour codes
-            bool coded = false;
-            if (keep && a.blk_alive)       // (bit 1 of the verdict byte: see df_block_verdict_kernel)
-                coded = (a.blk_alive[((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y0 >> 3)) * a.bm_nbx + (unsigned)(x0 >> 3)] & 2u) != 0;
+            const bool coded = keep && a.blk_alive && (verdict & 2u) != 0u;                          // (bit 1 of the verdict byte: see df_block_verdict_kernel)
             const unsigned long long cm = __builtin_amdgcn_ballot_w64(coded);
             if (ln == 0 && m) code_out[item] = cm;
         }
-#endif
         if (a.n_swept) {                                                   // (measurement hook: what the sweep will put through the warp)
             unsigned v = keep ? (unsigned)(64 * (min((lt0 + l + 1) * DF_ROW_TZ, own1) - max((lt0 + l) * DF_ROW_TZ, a.z_own0))) : 0u;
 #pragma unroll
@@ -1967,12 +1887,21 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
     }
 }
 
-// One workgroup = WGT / 256 strip items of the plan (2 at WGT = 512: two workgroups per CU while the node table is <= 80 KiB, 2560
-// nodes; 4 at WGT = 1024, for the larger tables that leave room for only one workgroup per CU: 16 waves, 4 per SIMD, either way).
-template <int K, int U, int WGT, bool V2W_IDENTITY>
+// The sweep.  One workgroup = WGT / 256 strip items of the plan; its waves are independent of each other once the plan is read.
+//   LDSN = false (k = 8, every node count; k = 4 where the node table is too large for the LDS): NO node table in LDS.  A cell whose block
+//     has 4-bit neighbour codes (the model pass has been over it: all but the blocks new this frame) blends out of the wave's own copies
+//     of its sub-block unions -- 8 sub-blocks x 16 x {rot, node_t} = 4 KiB per wave, refilled once per (patch, layer) cell from W.rt in the
+//     L2 through the union lists (bm_ids: one dword per lane, prefetched a layer ahead); the others gather their neighbours from W.rt.
+//     48 KiB of LDS per 768-thread workgroup whatever M is: the occupancy (two workgroups per CU, 6 waves / SIMD at <= 80 VGPRs) and the
+//     codes no longer depend on the node count.  (Rounds 1-5 kept rot / node_t of ALL nodes in LDS: 32 bytes a node, one workgroup per CU
+//     from 2560 nodes on, no room for the union copies -- so no codes -- from 4864, no pipelined sweep at all from 5120.)
+//   LDSN = true (k = 4, M <= 5120): rot / node_t of all nodes in LDS, gathers by ds_read_b128 (k = 4 has no codes: measured +2 %, NOTES r5).
+template <int K, int U, int WGT, bool V2W_IDENTITY, bool LDSN>
 __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 s_nodes[];     // [2M]: rot_j, node_t_j interleaved
+    extern __shared__ __attribute__((aligned(16))) float4 s_lds[];      // LDSN: [2M] rot_j, node_t_j interleaved; else [waves][8][16][2] union copies
+    constexpr bool CODES = !LDSN && K == 8;
+    static_assert(!CODES || U == 1, "a coded batch lies in one half layer");
     constexpr unsigned SPW = WGT / 256;                                    // strip items per workgroup
     // entry e of the plan = the e-th item counting the bins from the fullest down: lane j holds the count of bin 64 - j and the
     // running total up to and including it
@@ -1985,24 +1914,21 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
 #ifdef DF_TRACE_WG
     const unsigned long long t_start = wall_clock64();
 #endif
-#if DF_LDS_SPLIT
-    if (W.M > DF_NODE_T_OFF) __builtin_trap();
-    for (int j = threadIdx.x; j < W.M; j += WGT) { s_nodes[j] = W.rot[j]; s_nodes[DF_NODE_T_OFF + j] = W.node_t[j]; }
-#else
-    for (int j = threadIdx.x; j < W.M; j += WGT) { s_nodes[2 * j] = W.rot[j]; s_nodes[2 * j + 1] = W.node_t[j]; }
-#endif
-    if ((unsigned)(size_t)(df_lds_cf4*)s_nodes != 0u) __builtin_trap();  // the blend addresses the table from LDS address 0
-    __syncthreads();
+    if ((unsigned)(size_t)(df_lds_cf4*)s_lds != 0u) __builtin_trap();    // the blend addresses the LDS from address 0
+    if constexpr (LDSN) {
+        for (int j = threadIdx.x; j < W.M; j += WGT) { s_lds[2 * j] = W.rot[j]; s_lds[2 * j + 1] = W.node_t[j]; }
+        __syncthreads();
+    }
+    const df_global_ptr<const char> rt_g = (df_global_ptr<const char>)df_wave_uniform(reinterpret_cast<const char*>(W.rt));
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), ln = threadIdx.x & 63;    // in an SGPR: what follows from it stays scalar
     const size_t plane = (size_t)a.X * a.Y;
     const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
     const unsigned pitch24 = (unsigned)a.P.pitch;                          // rows, pitch < 2^24 (checked by the launcher): 24-bit multiply
-    unsigned int my_upd = 0;
+    unsigned int wave_upd = 0;                                             // (a wave-level count: ballots, no lane register)
 #ifdef DF_TRACE_WG
     unsigned n_layers = 0;
 #endif
-#if DF_SWEEP_BALANCE
     // ---- the workgroup's work, dealt out evenly (round 4).  A workgroup takes SPW strip items = 4 SPW patches x <= 16 layers of alive
     // (patch, layer) cells.  With one patch per wave the workgroup lasted as long as its fullest patch while the other waves' slots sat
     // idle: a per-wave timeline showed the waves busy for 83 % of the time their workgroups held the slots.  Now the alive cells of all
@@ -2011,17 +1937,13 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
     // the pipelined loop below as before.  Which voxel is updated by which wave changes; what is computed for it does not.
     constexpr unsigned NW = WGT / 64;
     unsigned items_s[SPW]; unsigned long long masks_s[SPW];
-#if DF_IDX_CODES
     unsigned long long cmask_s[SPW];
-#endif
     unsigned total2 = 0;
 #pragma unroll
     for (unsigned s_ = 0; s_ < SPW; ++s_) {
         const unsigned sidx = blockIdx.x * SPW + s_;
         items_s[s_] = 0u; masks_s[s_] = 0ull;
-#if DF_IDX_CODES
         cmask_s[s_] = 0ull;
-#endif
         if (sidx < n_alive) {
             const int j = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(sidx < bin_end)) - 1;      // its bin: the first running total above sidx
             const unsigned r = sidx - ((unsigned)__builtin_amdgcn_readlane((int)bin_end, j) - (unsigned)__builtin_amdgcn_readlane((int)bin_cnt, j));
@@ -2030,13 +1952,11 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
             masks_s[s_] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32)) << 32) |
                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m);
             total2 += 2u * (unsigned)__popcll(masks_s[s_]);
-#if DF_IDX_CODES
-            if (a.plan_code) {
+            if (CODES && a.plan_code) {
                 const unsigned long long cm = a.plan_code[items_s[s_]];
                 cmask_s[s_] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cm >> 32)) << 32) |
                               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cm);
             }
-#endif
         }
     }
     const unsigned c0 = total2 * (unsigned)wave / NW, c1 = total2 * ((unsigned)wave + 1u) / NW;      // this wave's half-layer cells [c0, c1)
@@ -2047,12 +1967,10 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
 #pragma unroll
     for (unsigned s_ = 1; s_ < SPW; ++s_) if ((q >> 2) == s_) { item = items_s[s_]; m_item = masks_s[s_]; }
     const unsigned a16 = (unsigned)(m_item >> (16u * (q & 3u))) & 0xffffu;
-#if DF_IDX_CODES
     unsigned long long c_item = cmask_s[0];
 #pragma unroll
     for (unsigned s_ = 1; s_ < SPW; ++s_) if ((q >> 2) == s_) c_item = cmask_s[s_];
-    const unsigned cbits = (unsigned)(c_item >> (16u * (q & 3u))) & 0xffffu;       // layers of this patch whose block has 4-bit codes
-#endif
+    const unsigned cbits = CODES ? (unsigned)(c_item >> (16u * (q & 3u))) & 0xffffu : 0u;      // layers of this patch whose block has 4-bit codes
     const unsigned n2 = 2u * (unsigned)__popc(a16);
     const unsigned seg_lo = max(c0, pre), seg_hi = min(c1, pre + n2);
     const unsigned pre0 = pre;
@@ -2069,45 +1987,22 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
     int first_l = __ffs(alive) - 1, last_l = 31 - __clz(alive);
     int z_first_off = (int)(lo & 1u) * (DF_ROW_TZ / 2), z_last_off = ((int)((hi - 1u) & 1u) + 1) * (DF_ROW_TZ / 2);
     const int wave_patch = (int)(q & 3u);
-#else
-    const unsigned sidx = blockIdx.x * SPW + (unsigned)(wave >> 2);           // this wave's plan entry: 4 waves per strip item
-    unsigned alive = 0, item = 0;
-    if (sidx < n_alive) {
-        const int j = __ffsll((unsigned long long)__builtin_amdgcn_ballot_w64(sidx < bin_end)) - 1;      // its bin: the first running total above sidx
-        const unsigned r = sidx - ((unsigned)__builtin_amdgcn_readlane((int)bin_end, j) - (unsigned)__builtin_amdgcn_readlane((int)bin_cnt, j));
-        item = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_PLAN_BINS - 1 - j) * a.plan_items + r]);
-        const unsigned long long m = a.plan_mask[item];
-        const unsigned mp = (wave & 2) ? (unsigned)(m >> 32) : (unsigned)m;
-        alive = (unsigned)__builtin_amdgcn_readfirstlane((int)((wave & 1) ? mp >> 16 : mp & 0xffffu));
-    }
-    const int wave_patch = wave & 3;
-#endif
     // item -> tile column, half, layer block; the wave's 8 x 8 patch is number wv of the 32 x 16 footprint (4 across, 2 down): a compact
     // footprint, so that the voxels of a wave fall on the same side of the frustum and of the observed surface more often
     const unsigned tcol = item >> 1;
     const int tx = (int)(tcol % (unsigned)tiles_x), ty = (int)((tcol / (unsigned)tiles_x) % (unsigned)a.plan_tiles_y);
     const int wv = (int)(item & 1u) * 4 + wave_patch;
-#if DF_PIPE_ROWS
-    const int x = tx * DF_ROW_TX + (ln & 31);
-    const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (wv & 3) * 2 + (ln >> 5);
-#else
     const int x = tx * DF_ROW_TX + (wv & 3) * 8 + (ln & 7);
     const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (ln >> 3);
-#endif
     const bool in_xy = x < a.X && y < a.Y;
     const int xc = min(x, a.X - 1), yc = min(y, a.Y - 1);                 // clamped: out-of-volume lanes read valid entries, write nothing
     const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
     const int lt0 = a.bz0 + (int)(tcol / ((unsigned)tiles_x * (unsigned)a.plan_tiles_y)) * a.zt;     // first tile layer of the item
-#if DF_SWEEP_BALANCE
     // the segment's first / last layer start / end at a half-layer boundary; a layer the slab's own range cuts down to nothing is dropped
     auto layer_zb = [&](int l) { const int z = max((lt0 + l) * DF_ROW_TZ, a.z_own0); return l == first_l ? max(z, (lt0 + l) * DF_ROW_TZ + z_first_off) : z; };
     auto layer_ze = [&](int l) { const int z = min((lt0 + l + 1) * DF_ROW_TZ, own1); return l == last_l ? min(z, (lt0 + l) * DF_ROW_TZ + z_last_off) : z; };
     if (alive && layer_zb(first_l) >= layer_ze(first_l)) { alive &= alive - 1u; first_l = alive ? __ffs(alive) - 1 : 0; z_first_off = 0; }   // (the next layer, if any, is taken whole)
     if (alive && layer_zb(last_l) >= layer_ze(last_l)) { alive &= ~(1u << last_l); last_l = alive ? 31 - __clz(alive) : 0; z_last_off = DF_ROW_TZ; }
-#else
-    auto layer_zb = [&](int l) { return max((lt0 + l) * DF_ROW_TZ, a.z_own0); };
-    auto layer_ze = [&](int l) { return min((lt0 + l + 1) * DF_ROW_TZ, own1); };
-#endif
     if (alive) {
         // batch sequence: U planes per batch inside a layer, then the first batch of the next alive layer; l < 0 = none
         auto advance = [&](int l, int z0, int* nl, int* nz0) {
@@ -2127,54 +2022,55 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
         const unsigned lane_tab = df_tab_in_plane(xc, yc);
         const size_t tile_col = (size_t)(yc / DF_TAB_TY) * a.tab_ntx + (size_t)(xc / DF_TAB_TX);      // == (ty, tx) of the workgroup: uniform
         const size_t tile_col_u = (size_t)__builtin_amdgcn_readfirstlane((int)tile_col);
-#if DF_TAB_ADDR_HOIST
         // (round 5) the record index of plane z of tile layer lt0 + l is rec0 + l * rec_layer + (z mod 8) * 512: a tile layer of the sweep IS
         // a tile layer of the tables (DF_ROW_TZ = DF_TAB_TZ, tab_z0 a multiple of 8), so the division, the remainder and the 64-bit
         // products of the general form (39 scalar instructions per load, a fifth of the kernel's SALU work) are made once per segment
         static_assert(DF_ROW_TZ == DF_TAB_TZ, "the sweep's layers are the tables' tile layers");
         const size_t rec_layer = (size_t)a.tab_nty * (size_t)a.tab_ntx * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ);
         const size_t rec0 = ((size_t)(lt0 - a.tab_z0 / DF_TAB_TZ) * a.tab_nty * a.tab_ntx + tile_col_u) * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ);
-#if DF_IDX_CODES
-        const unsigned lane_code = df_code_in_plane(xc, yc);
-        // the wave's copy of its block's union (16 nodes x {rot, node_t}): behind the node table, 512 bytes per wave, 512-aligned
-        const unsigned lbase = (((unsigned)W.M * 32u + 511u) & ~511u) + (unsigned)wave * 512u;
-        int loc_layer = -1;                                            // the layer whose union the copy holds
+        // (the code plane is patch-major: the wave's 64 codes are entries [64 * patch, + 64) of the tile plane, lane ln's at + ln -- formed
+        // from the lane id where it is used instead of living in a register across the loop; a lane past the volume's edge reads the
+        // padding's code, some 4-bit positions in the copies the wave holds, and stores nothing)
+        const unsigned code_patch = ((unsigned)wv << 6);
+        // ---- the wave's copies of the sub-block unions of the cell it is in (CODES): LDS bytes [wave * 4096, + 4096) = [h][q][16] x {rot,
+        // node_t}; a lane's voxel of plane z reads the copy of (h = z >> 2 & 1, q = its column quadrant).  The union lists of the segment's
+        // coded layers are fetched one layer ahead (ids_nxt: the dword of lane = q * 16 + e holds entry e of quadrant q, low half word
+        // h = 0, high half word h = 1), the 2 x 64 records they name gathered from W.rt at the cell's first batch.
+        const unsigned lds_wave = (unsigned)wave * 4096u;
+        const unsigned lq_base = lds_wave + ((((unsigned)xc >> 2) & 1u) | ((((unsigned)yc >> 2) & 1u) << 1)) * 512u;
+        int loc_layer = -1;                                            // the layer whose unions the copies hold
+        unsigned ids_nxt = 0u;
+        const unsigned coded_alive = CODES ? (alive & cbits) : 0u;
+        // (the block of the wave's patch in layer l, from scalars: tile column, patch number)
+        const unsigned blk_x = (unsigned)tx * (DF_ROW_TX / 8) + ((unsigned)wv & 3u), blk_y = (unsigned)ty * (DF_LDS_TY / 8) + ((unsigned)wv >> 2);
+        auto lane_id = [&]() -> unsigned { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };   // (recomputed where used: no register held across the loop)
+        auto ids_load = [&](int l) -> unsigned {
+            const size_t blk = ((size_t)(unsigned)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * (unsigned)a.bm_nby + blk_y) * (unsigned)a.bm_nbx + blk_x;
+            return *((df_global_ptr<const uint32_t>)(a.bm_ids + blk * 64) + lane_id());
+        };
         auto refill = [&](int l) {
-            const size_t blk = ((size_t)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * a.bm_nby + (unsigned)(y >> 3)) * a.bm_nbx + (unsigned)(x >> 3);
-            const size_t blk_u = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)blk) |
-                                 ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(blk >> 32)) << 32);
-            if (ln < DF_BM_NU) {
-                const unsigned id = a.bm_ids[blk_u * DF_BM_NU + (unsigned)ln];
-                float4* loc = (float4*)((char*)s_nodes + lbase);
-                loc[2 * ln] = s_nodes[2 * id]; loc[2 * ln + 1] = s_nodes[2 * id + 1];
-            }
+            const unsigned ids = ids_nxt;                                  // (of layer l: refills come in the order of the coded layers)
+            const df_global_ptr<const df_v4f> n0 = (df_global_ptr<const df_v4f>)(rt_g + df_node_off_lo(ids));
+            const df_global_ptr<const df_v4f> n1 = (df_global_ptr<const df_v4f>)(rt_g + df_node_off_hi(ids));
+            const df_v4f r0 = n0[0], t0 = n0[1], r1 = n1[0], t1 = n1[1];
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned rem = coded_alive >> (l + 1);                   // the next coded layer's list: in flight until its refill
+            ids_nxt = ids_load(rem ? l + 1 + (__ffs(rem) - 1) : l);
+            __builtin_amdgcn_sched_barrier(0);
+            df_v4f* loc = (df_v4f*)((char*)s_lds + lds_wave + lane_id() * 32u);
+            loc[0] = r0; loc[1] = t0; loc[128] = r1; loc[129] = t1;        // (h = 1: 2048 bytes on)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the wave's own LDS writes, before its blends read them)
         };
-#endif
+        if (coded_alive) ids_nxt = ids_load(__ffs(coded_alive) - 1);
         auto load_batch = [&](DfTabRaw<K> (&S)[U], int l, int z0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int zi = min(z0 + u, layer_ze(l) - 1) - (lt0 + l) * DF_ROW_TZ;         // plane inside the layer
                 const size_t rec = rec0 + (size_t)(unsigned)l * rec_layer + (size_t)(unsigned)(zi * (DF_TAB_TX * DF_TAB_TY));
-#if DF_IDX_CODES
-                if constexpr (K == 8) tab_raw_load_coded(a, rec, ((cbits >> l) & 1u) != 0u, lane_tab, lane_code, S[u]);
-                else tab_raw_load_at(a, rec, lane_tab, S[u]);
-#else
-                tab_raw_load_at(a, rec, lane_tab, S[u]);
-#endif
+                const bool coded_l = CODES && ((cbits >> l) & 1u) != 0u;
+                tab_raw_load_at(a, rec, rec + code_patch, coded_l, lane_tab, lane_id(), S[u]);
             }
         };
-#else
-        auto load_batch = [&](DfTabRaw<K> (&S)[U], int l, int z0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int zl = min(z0 + u, layer_ze(l) - 1) - a.tab_z0;
-                const size_t rec = ((size_t)(zl / DF_TAB_TZ) * a.tab_nty * a.tab_ntx + tile_col_u) * (DF_TAB_TX * DF_TAB_TY * DF_TAB_TZ) +
-                                   (size_t)(zl % DF_TAB_TZ) * (DF_TAB_TX * DF_TAB_TY);
-                tab_raw_load_at(a, rec, lane_tab, S[u]);
-            }
-        };
-#endif
         int l = __ffs(alive) - 1, z0 = layer_zb(l);
         int l1, z1; advance(l, z0, &l1, &z1);
         DfTabRaw<K> S0[U], S1[U];
@@ -2188,40 +2084,17 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
 #pragma unroll
         for (int u = 0; u < U; ++u) { pend.vn[u] = 0.f; pend.dpb[u] = 0; pend.vox[u] = 0u; pend.z[u] = a.z_store0; pend.ok[u] = false; }
         auto finish_pending = [&]() {
-#if DF_WARP_FUSE_SHORT
-            // the fuse division in its short form (dfusion_device.h, tsdf_fuse_short: same bits for finite stored values) when every
-            // voxel the wave is about to fuse holds one
-            bool upd[U]; float sdf[U]; bool fin = true;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float Dp = h2f_bits(pend.dpb[u]);
-                sdf[u] = Dp - pend.vn[u];                                                     // :89
-                upd[u] = pend.ok[u] & (Dp != 0.f) & (sdf[u] >= -a.P.trunc);                   // :86, :91
-                fin = fin & (!upd[u] | tsdf_fuse_short_ok(pend.vox[u]));
-            }
-            fin = df_wave_all(fin);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (upd[u]) {
-                    df_global_ptr<uint32_t> vp = df_wave_uniform(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane) + lane_vox;
-                    const float ts = fminf(1.f, sdf[u] * a.P.trunc_inv);                      // :93
-                    *vp = fin ? tsdf_fuse_short(pend.vox[u], ts, a.P.max_weight) : tsdf_fuse(pend.vox[u], ts, a.P.max_weight);
-                    ++my_upd;
-                }
-            }
-#else
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float Dp = h2f_bits(pend.dpb[u]);
                 const float sdf = Dp - pend.vn[u];                                            // :89
                 const bool upd = pend.ok[u] & (Dp != 0.f) & (sdf >= -a.P.trunc);              // :86, :91
+                wave_upd += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(upd));
                 if (upd) {
                     df_global_ptr<uint32_t> vp = df_wave_uniform(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane) + lane_vox;
                     *vp = tsdf_fuse(pend.vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight);   // :93
-                    ++my_upd;
                 }
             }
-#endif
         };
         // one batch: consumes S (tables of batch (l, z0)), then refills S with the tables of batch (l2, z2)
         auto step = [&](DfTabRaw<K> (&S)[U], int l, int z0, int l2, int z2) {
@@ -2237,10 +2110,8 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
             // square root take their short forms (dfusion_device.h: same bits on a restricted domain) when the whole wave is inside
             // the domain.
             f3 vc[U]; bool ok[U]; uint16_t dpb[U];
-#if DF_IDX_CODES
-            const bool coded = K == 8 && ((cbits >> l) & 1u) != 0u;       // wave-uniform
-            if (coded && l != loc_layer) { refill(l); loc_layer = l; }
-#endif
+            const bool coded = CODES && ((cbits >> l) & 1u) != 0u;        // wave-uniform
+            if (CODES && coded && l != loc_layer) { refill(l); loc_layer = l; }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 // canonical position.  With an axis-aligned volume (R = I exactly -- the reference's default pose is a pure
@@ -2250,29 +2121,20 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
                 f3 q;
                 if constexpr (V2W_IDENTITY) q = add3(pv3, mk3(a.vol2world.t[0], a.vol2world.t[1], a.vol2world.t[2]));
                 else q = aff_mul(a.vol2world, pv3);
-#if DF_IDX_CODES
                 DfBlendSums B;
-                if constexpr (K == 8) { if (coded) B = dqb_sums_codes(S[u], lbase); else B = dqb_sums_lds_rec(S[u]); }
-                else B = dqb_sums_lds_rec(S[u]);
-#else
-                const DfBlendSums B = dqb_sums_lds_rec(S[u]);
-#endif
+                if constexpr (LDSN) B = dqb_sums_lds_rec(S[u]);
+                else if constexpr (CODES) {
+                    if (coded) B = dqb_sums_codes(S[u], lq_base | (((unsigned)(z0 + u) & 4u) << 9));        // (h = plane 4-7 of the layer: + 2048)
+                    else B = dqb_sums_global_rec(S[u], rt_g);
+                } else B = dqb_sums_global_rec(S[u], rt_g);
                 quat rsum, rn; quat2 half;
                 rsum.w = B.r01.x; rsum.x = B.r01.y; rsum.y = B.r23.x; rsum.z = B.r23.y;
                 half.wx = B.t01 * 0.5f; half.yz = B.t23 * 0.5f;
                 const float s1 = q_sumsq(rsum);
                 float n1;
-#if DF_NORM_F32DIV
-                // :214 as an f32 division where that has the reference's bits (dfusion_device.h, q_div_f32_ok: one wave-wide test for
-                // the short square root and the division together); the f64 form otherwise
-                quat rot;
-                if (__builtin_expect(df_wave_all(q_div_f32_ok(rsum, s1)), 1)) { n1 = df_sqrt_short(s1); rot = q_div_f32(rsum, n1); }
-                else { n1 = sqrtf(s1); rot = q_scale_f64(df_rcp_short((double)n1), rsum); }   // far from the nodes: tiny, denormal or zero sums
-#else
                 if (__builtin_expect(df_wave_all(df_sqrt_short_ok(s1)), 1)) n1 = df_sqrt_short(s1);
                 else n1 = sqrtf(s1);                             // far from the nodes: tiny, denormal or zero sums
                 const quat rot = q_scale_f64(df_rcp_short((double)n1), rsum);                 // :214 (see q_normalize_rcp_short)
-#endif
                 const quat2 dual = q_mul_pk(half, q_pairs(rot));                              // dual_quaternion.hpp:59-63
                 const float s2 = q_sumsq(rot);
                 if (__builtin_expect(df_wave_all(q_near_unit_ok(s2)), 1)) rn = q_normalize_near_unit(rot, s2);
@@ -2323,9 +2185,7 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
 #ifdef DF_TRACE_WG
     n_layers += __popc(alive);
 #endif
-#if DF_SWEEP_BALANCE
     }                                                                       // (the next segment of this wave)
-#endif
 #ifdef DF_TRACE_WG
     {
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -2336,7 +2196,7 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
         }
     }
 #endif
-    df_count_updates(a, my_upd);
+    if (a.n_upd && ln == 0 && wave_upd) atomicAdd(a.n_upd, (unsigned long long)wave_upd);
 }
 
 // max dists value over the image (for the cull's depth test); `out` zeroed on the stream first.
@@ -2435,9 +2295,26 @@ static DfWarpedArgs df_table_args(const DfWarpField* wf)
     a.tab_nvox = (size_t)ntx * DF_TAB_TX * nty * DF_TAB_TY * wf->tab_zn;
     a.bz0 = wf->tab_z0 / DF_BRICK;
     a.bm_nbx = ntx * (DF_TAB_TX / 8); a.bm_nby = nty * (DF_TAB_TY / 8);
-    a.code_tab = wf->code_tab; a.bm_ids = wf->bm_ids;
+    a.code_tab = wf->code_tab; a.bm_ids = wf->bm_ids; a.bm_coded = wf->bm_coded;
     return a;
 }
+// LDS a workgroup may ask for on this device (160 KiB on gfx950), what the node-table kernels' "fits" is decided against (the
+// dynamic-LDS attribute used to be a fixed 160 KiB, which fails on a part with less whatever the launch needs)
+static size_t df_lds_limit()
+{
+    static std::atomic<size_t> cached{0};
+    size_t v = cached.load();
+    if (v) return v;
+    int dev = 0, bytes = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || bytes < 64 * 1024) {
+        (void)hipGetLastError();
+        bytes = 64 * 1024;
+    }
+    v = (size_t)bytes < (size_t)160 * 1024 ? (size_t)bytes : (size_t)160 * 1024;
+    cached.store(v);
+    return v;
+}
+
 // Workgroups of a list-driven pass: as many as are resident at once (workgroup i takes entries i, i + grid, ...: a second round of
 // workgroups would start when the first has finished its whole share).  An empty list costs their launch.
 static unsigned df_work_grid(const void* kernel)
@@ -2503,15 +2380,16 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
         DF_HIP(hipMalloc((void**)&wf->bm_cnt, nblk));
         wf->bm_cap = nblk;
     }
-#if DF_IDX_CODES
-    // 4-bit neighbour codes + the blocks' union lists (the sweep reads them at k = 8 only: no 4 bytes a voxel for the others)
-    if (want_models && k == 8 && (nblk * 512 > wf->code_cap || !wf->bm_ids || !wf->code_tab)) {
-        (void)hipFree(wf->bm_ids); (void)hipFree(wf->code_tab); wf->bm_ids = nullptr; wf->code_tab = nullptr; wf->code_cap = 0;
-        DF_HIP(hipMalloc((void**)&wf->bm_ids, nblk * DF_BM_NU * sizeof(uint16_t)));
+    // 4-bit neighbour codes + the sub-blocks' union lists (the sweep reads them at k = 8 only: no 4 bytes a voxel for the others)
+    if (want_models && k == 8 && (nblk * 512 > wf->code_cap || !wf->bm_ids || !wf->code_tab || !wf->bm_coded)) {
+        (void)hipFree(wf->bm_ids); (void)hipFree(wf->code_tab); (void)hipFree(wf->bm_coded);
+        wf->bm_ids = nullptr; wf->code_tab = nullptr; wf->bm_coded = nullptr; wf->code_cap = 0;
+        DF_HIP(hipMalloc((void**)&wf->bm_ids, nblk * 64 * sizeof(uint32_t)));
         DF_HIP(hipMalloc((void**)&wf->code_tab, nblk * 512 * sizeof(uint32_t)));
+        DF_HIP(hipMalloc((void**)&wf->bm_coded, nblk));
+        DF_HIP(hipMemsetAsync(wf->bm_coded, 0, nblk, st));
         wf->code_cap = nblk * 512;
     }
-#endif
     // look-ahead: with on-demand tables or models still to make, blocks NEAR the alive set get theirs on the side
     // stream while the sweep runs -- unless the caller wants models made at once (then everything stays on the launch stream, in order)
     bool ahead = !(flags & (DF_WARP_NO_PREFETCH | DF_WARP_BLOCK_MODEL_NOW));
@@ -2538,9 +2416,9 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
     uint32_t* list_urgent = wf->blk_work, *list_ahead = wf->blk_work + wf->blk_cap, *list_model = wf->blk_work + 2 * wf->blk_cap;
     hipLaunchKernelGGL(df_block_verdict_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, a, wf->rot, wf->node_t, nbx, nby, nbz,
                        wf->blk_state, wf->blk_wmax, wf->brick_thr + wf->off_cap, wf->bx, wf->by, a.tile_wmax != nullptr ? 1 : 0,
-                       (use_models && wf->bm_cap >= nblk ? 1 : 0) | (k == 8 && wf->bm_cnt && wf->code_tab && wf->bm_ids && wf->code_cap >= nblk * 512 ? 2 : 0),     // (bit 1: the blocks' codes exist)
+                       (use_models && wf->bm_cap >= nblk ? 1 : 0) | (k == 8 && wf->bm_cnt && wf->code_tab && wf->bm_ids && wf->bm_coded && wf->code_cap >= nblk * 512 ? 2 : 0),     // (bit 1: the blocks' codes exist)
                        want_models_now,
-                       wf->tab_complete ? 0 : 1, wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_alive, list_urgent, list_ahead, list_model,
+                       wf->tab_complete ? 0 : 1, wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->bm_coded, wf->blk_alive, list_urgent, list_ahead, list_model,
                        cnt, cnt_next);
     a.blk_cnt = cnt; a.host_report = (uint32_t*)wf->host_report; a.sweep_no = (uint32_t)wf->tab_sweeps;
     DF_LAUNCH_CHECK();
@@ -2560,13 +2438,6 @@ static int df_block_verdicts(DfWarpField* wf, DfWarpedArgs& a, int k, unsigned f
         static unsigned g8 = 0, g4 = 0;
         if (!g8) {
             g8 = df_work_grid((const void*)df_block_model_kernel<8>); g4 = df_work_grid((const void*)df_block_model_kernel<4>);
-#if DF_BM_WG_PER_CU_CAP
-            // (measurement: the model pass beside the sweep takes at most this many workgroups per CU)
-            int dev = 0; hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
-                g8 = min(g8, (unsigned)(DF_BM_WG_PER_CU_CAP * prop.multiProcessorCount)); g4 = min(g4, (unsigned)(DF_BM_WG_PER_CU_CAP * prop.multiProcessorCount));
-            }
-#endif
         }
         if (k == 8) hipLaunchKernelGGL(df_block_model_kernel<8>, dim3(g8), dim3(256), 0, s2, b, nbx, nby, nbz, list_model, cnt + 1,
                                        wf->bm_idx, wf->bm_lam, wf->bm_w, wf->bm_cnt, wf->blk_state);
@@ -2704,12 +2575,16 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
     }
     if (use_w) a.w_tab = wf->w_tab;
     // the pipelined sweep's preconditions, decided ONCE: which pyramid is built below and which kernel is launched further down both
-    // follow from them (they used to be two hand-copied predicates).  LDS node table: 32 B per node, up to the whole 160 KiB
-    // of a CU; the pipelined kernel forms row * pitch with a 24-bit multiply and a 32-bit dists offset
-    const bool lds_ok = (size_t)wf->M * 32 <= 160 * 1024 && !(flags & DF_WARP_NO_LDS);
+    // follow from them (they used to be two hand-copied predicates).  The pipelined kernel forms row * pitch with a 24-bit
+    // multiply and a 32-bit dists offset.  It needs no LDS node table (round 6): k = 8 blends out of per-wave union copies or gathers from
+    // the L2, for ANY node count; k = 4 keeps the table (32 B per node) where it fits the CU's LDS.  DF_WARP_NO_LDS asks for the plain
+    // gather kernel (df_warp_rows_kernel: no plan, no verdicts).
+    const size_t lds_limit = df_lds_limit();
+    const bool no_lds = (flags & DF_WARP_NO_LDS) != 0;
+    const bool lds_fits = (size_t)wf->M * 32 <= lds_limit;
     const bool pipe_form_ok = use_w && !(flags & DF_WARP_NO_PIPELINE) && pitch < (1u << 24) && rows < (1 << 24) &&
                               (unsigned long long)rows * pitch < (1ull << 32);
-    const bool pipe_sweep = use_tab && lds_ok && pipe_form_ok && (k == 8 || k == 4);
+    const bool pipe_sweep = use_tab && !no_lds && pipe_form_ok && (k == 8 || k == 4);
 
     if (!(flags & DF_WARP_NO_CULL) && proj[0] > 0.f && proj[1] > 0.f) {
         if (!(flags & DF_WARP_NO_DEPTH_PYRAMID)) {
@@ -2759,56 +2634,45 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
     }
 
     DfWarpView W = df_view(wf);
-    if (use_tab && lds_ok) {
+    if (use_tab && !no_lds && (pipe_sweep || lds_fits)) {
         const int tiles_x = (a.X + DF_ROW_TX - 1) / DF_ROW_TX, tiles_y = (a.Y + DF_LDS_TY - 1) / DF_LDS_TY;
         const int zt_lo = s.z_own0 / DF_ROW_TZ, zt_hi = (s.z_own0 + s.z_own_n - 1) / DF_ROW_TZ;
         a.bz0 = zt_lo;
-        const bool pipe_ok = pipe_form_ok;
-        if (a.cull) a.tile_r = (float)(df_tile_radius(vol2world, pipe_ok && (k == 8 || k == 4) ? 8 : DF_ROW_TX, pipe_ok && (k == 8 || k == 4) ? 8 : DF_LDS_TY,
-                                                      DF_ROW_TZ, v) * 1.001 + 1e-6);
-#if DF_LDS_SPLIT
-        const size_t lds = (size_t)(DF_NODE_T_OFF + wf->M) * 16;
-#elif DF_IDX_CODES
-        // (+ the pipelined sweep's per-wave copies of a block's union: 512 bytes per wave, behind the node table rounded up to 512)
-        const size_t lds_nodes = (size_t)wf->M * 32, lds_codes = ((lds_nodes + 511) & ~(size_t)511) + 16 * 512;
-        const bool codes_fit = k == 8 && lds_codes <= 160 * 1024;
-        const size_t lds = (codes_fit ? lds_codes : lds_nodes) + DF_LDS_PAD;
-#else
-        const size_t lds = (size_t)wf->M * 32;
-#endif
+        const bool pipe_ok = pipe_sweep;
+        if (a.cull) a.tile_r = (float)(df_tile_radius(vol2world, pipe_ok ? 8 : DF_ROW_TX, pipe_ok ? 8 : DF_LDS_TY, DF_ROW_TZ, v) * 1.001 + 1e-6);
+        // LDS of a launch: the node table (32 B a node) for the kernels that keep one -- k = 4's pipelined sweep where it fits, the batched
+        // kernel of the other k --, 4 KiB of union copies per wave for k = 8's, nothing for k = 4 without a table
+        const bool k4_table = pipe_ok && k == 4 && lds_fits;
+        const size_t lds = !pipe_ok || k4_table ? (size_t)wf->M * 32 : k == 8 ? (size_t)(DF_PIPE_WGT / 64) * 4096 : 0;
         typedef void (*lds_kernel_t)(const DfWarpedArgs, const DfWarpView, int);
         lds_kernel_t kern = nullptr;
         // tile layers per workgroup: long walks amortise the LDS fill and the pipeline ramp, short ones even out the last round of
         // workgroups on the 256 CUs (measured: 4 layers best at 256^3 = 1024 workgroups, 8 at 512^3, 16 at 1024^3 = 16384)
         const long long cols_layers = (long long)tiles_x * tiles_y * (zt_hi - zt_lo + 1);
         const bool pipe = pipe_sweep;                           // df_warp_rows_lds_kernel always walks DF_LDS_ZT layers per workgroup
-#ifdef DF_PIPE_ZT
-        a.zt = !pipe ? DF_LDS_ZT : DF_PIPE_ZT;                                 // (measurement)
-#else
         a.zt = !pipe ? DF_LDS_ZT : cols_layers <= 8192 ? 4 : cols_layers <= 65536 ? 8 : 16;
-#endif
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + a.zt - 1) / a.zt));
-        const bool wide = pipe_ok && (k == 8 || k == 4) && lds - DF_LDS_PAD > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads
+        const bool wide = k4_table && lds > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads
         const bool vi = a.v2w_identity != 0;
-        // workgroup geometry: K = 8 with room for two workgroups per CU runs 768 threads, one plane per batch (77 VGPRs: 6 waves / SIMD;
-        // round 5: -2 to -4 % against 512 threads, two planes, 4 waves); k = 4 (+4 % that way at 256^3) and the one-workgroup tables (+2 %
-        // at 1024^3) keep two planes per batch
+        // workgroup geometry: k = 8 runs 768 threads, one plane per batch (<= 80 VGPRs: two workgroups per CU, 6 waves / SIMD; round 5: -2 to
+        // -4 % against 512 threads, two planes, 4 waves); k = 4 keeps two planes per batch (+4 % that way at 256^3)
         unsigned wg_threads = 512u;
         if (pipe_ok && k == 8) {
-            kern = wide ? (vi ? df_warp_rows_pipe_kernel<8, 2, 1024, true> : df_warp_rows_pipe_kernel<8, 2, 1024, false>)
-                        : (vi ? df_warp_rows_pipe_kernel<8, DF_PIPE_U, DF_PIPE_WGT, true> : df_warp_rows_pipe_kernel<8, DF_PIPE_U, DF_PIPE_WGT, false>);
-            wg_threads = wide ? 1024u : (unsigned)DF_PIPE_WGT;
-        } else if (pipe_ok && k == 4) {
-            kern = wide ? (vi ? df_warp_rows_pipe_kernel<4, 2, 1024, true> : df_warp_rows_pipe_kernel<4, 2, 1024, false>)
-                        : (vi ? df_warp_rows_pipe_kernel<4, 2, 512, true> : df_warp_rows_pipe_kernel<4, 2, 512, false>);
+            kern = vi ? df_warp_rows_pipe_kernel<8, 1, DF_PIPE_WGT, true, false> : df_warp_rows_pipe_kernel<8, 1, DF_PIPE_WGT, false, false>;
+            wg_threads = (unsigned)DF_PIPE_WGT;
+        } else if (pipe_ok && k4_table) {
+            kern = wide ? (vi ? df_warp_rows_pipe_kernel<4, 2, 1024, true, true> : df_warp_rows_pipe_kernel<4, 2, 1024, false, true>)
+                        : (vi ? df_warp_rows_pipe_kernel<4, 2, 512, true, true> : df_warp_rows_pipe_kernel<4, 2, 512, false, true>);
             wg_threads = wide ? 1024u : 512u;
+        } else if (pipe_ok) {
+            kern = vi ? df_warp_rows_pipe_kernel<4, 2, 512, true, false> : df_warp_rows_pipe_kernel<4, 2, 512, false, false>;
         }
         else if (use_w) { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, true, 2>)); }
         else { DF_DISPATCH_K(k, kern = (df_warp_rows_lds_kernel<K, false, 1>)); }
         // (the CU's whole LDS, whatever THIS launch asks for: the attribute belongs to the kernel, not to the launch, and two host threads
         // sweeping warp fields of different sizes would otherwise lower it under each other's launches)
-        DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (lds > 160 * 1024) return DF_E_INVALID;
+        if (lds > lds_limit) return DF_E_INVALID;
+        DF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
         if (!pipe) { int rc = df_tables_complete(wf, st); if (rc) return rc; }
         if (pipe) {
             // the launch plan: verdict masks of all strip items (one wave each), the alive ones sorted by work; then one workgroup per
@@ -2845,15 +2709,13 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
             unsigned int* cnt = wf->plan_hist + 128 * (wf->hphase & 3u);
             unsigned int* cnt_next = wf->plan_hist + 128 * ((wf->hphase + 2u) & 3u);       // (last read by the sweep two plans ago: waited for above)
             unsigned long long* pmask = wf->plan_mask2[wf->pphase]; unsigned int* plist = wf->plan_list2[wf->pphase];
-            // 4-bit neighbour codes: for the cells whose block has a model (and so a union list and codes), unless the models are switched off
+            // 4-bit neighbour codes (k = 8): for the cells whose block the model pass has been over, unless the models are switched off
             unsigned long long* pcode = nullptr;
-#if DF_IDX_CODES && !DF_PIPE_ROWS
-            if (a.cull && a.blk_alive && wf->code_tab && wf->bm_ids && wf->bm_cap >= (size_t)a.bm_nbx * a.bm_nby * (wf->tab_zn / 8) &&
-                !(flags & (DF_WARP_NO_BLOCK_MODEL | DF_WARP_NO_CODES)) && codes_fit) {
+            if (k == 8 && a.cull && a.blk_alive && wf->code_tab && wf->bm_ids && wf->bm_coded && wf->bm_cap >= (size_t)a.bm_nbx * a.bm_nby * (wf->tab_zn / 8) &&
+                !(flags & (DF_WARP_NO_BLOCK_MODEL | DF_WARP_NO_CODES))) {
                 pcode = wf->plan_code2[wf->pphase];
-                a.code_tab = wf->code_tab; a.bm_ids = wf->bm_ids;
+                a.code_tab = wf->code_tab; a.bm_ids = wf->bm_ids; a.bm_coded = wf->bm_coded;
             }
-#endif
             hipLaunchKernelGGL(df_sweep_plan_kernel, dim3((n_items + DF_PLAN_WG / 64 - 1) / (DF_PLAN_WG / 64)), dim3(DF_PLAN_WG), 0, st, a, tiles_x, tiles_y, n_items, pmask, cnt,
                                plist, cnt_next, pcode);
             DF_LAUNCH_CHECK();

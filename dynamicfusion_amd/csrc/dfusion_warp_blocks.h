@@ -96,14 +96,6 @@ __global__ __launch_bounds__(256, K == 8 ? 3 : 4) void df_block_model_kernel(con
     float wv[8][K], inv[8];
     bool bad = false;
     unsigned valid = 0;
-#if DF_IDX_CODES
-    // 4-bit neighbour codes: every voxel's k neighbours as positions in the union list (ascending node order), neighbour i in bits
-    // [4 i, 4 i + 4) -- the order of the table record, i.e. of the blend's sums.  Collected while the union is: entry n's node is neighbour i
-    // of voxel j where ids[j][i] == cand, the comparison the lambda range makes anyway.
-    unsigned code[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) code[j] = 0u;
-#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const bool in = col_in && z0 + j < a.Z;
@@ -139,15 +131,8 @@ __global__ __launch_bounds__(256, K == 8 ? 3 : 4) void df_block_model_kernel(con
             for (int j = 0; j < 8; ++j)
                 if (valid & (1u << j)) {
                     float w = 0.f;
-#if DF_IDX_CODES
-                    unsigned hit = 0u;
-#pragma unroll
-                    for (int i = 0; i < K; ++i) { const bool eq = ids[j][i] == cand; w = eq ? wv[j][i] : w; hit = eq ? (unsigned)n << (4 * i) : hit; }
-                    code[j] |= hit;
-#else
 #pragma unroll
                     for (int i = 0; i < K; ++i) w = ids[j][i] == cand ? wv[j][i] : w;
-#endif
                     const float lam = w * inv[j];
                     lmin = fminf(lmin, lam); lmax = fmaxf(lmax, lam); wmin = fminf(wmin, w); wmax = fmaxf(wmax, w);
                 }
@@ -166,6 +151,67 @@ __global__ __launch_bounds__(256, K == 8 ? 3 : 4) void df_block_model_kernel(con
         }
     }
     __builtin_amdgcn_wave_barrier();
+    // ---- 4-bit neighbour codes (k = 8; round 6: per 4 x 4 x 4 SUB-block).  A voxel's k neighbours as positions in the union of the
+    // neighbour sets of its sub-block (ascending node ids; <= 16 of them: 99 % of the sub-blocks at four times the headline's node
+    // density, where a whole block's union fits 16 for one block in four), neighbour i in bits [4 i, 4 i + 4) -- the order of the table
+    // record, i.e. of the blend's sums.  Sub-block (h, q): planes 4 h .. 4 h + 3 of column quadrant q = (x >> 2 & 1) | (y >> 2 & 1) << 1,
+    // i.e. the 16 lanes that agree in lane bits 2 and 5.  Every round each sub-block takes its smallest id above its last one (a minimum
+    // over its 16 lanes: xor 1, 2, 8, 16); a sub-block's e-th round is its union's entry e.  The union lists go out as the dword a sweep lane
+    // loads (dfusion_internal.h: bm_ids) -- padded with node 0, which exists.  Independent of the blend model: a block without one (union
+    // of the whole block above 16, weights too small to normalise) still gets codes.
+    if constexpr (K == 8) {
+        if (a.code_tab && a.bm_ids && !any_valid) { if (ln == 0) a.bm_coded[blk] = 0; }
+        if (a.code_tab && a.bm_ids && any_valid) {
+            unsigned code[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) code[j] = 0u;
+            int last_h[2] = {-1, -1};
+            bool sub_over = false;
+            const bool writer = (ln & 0x1b) == 0;                              // one lane per quadrant: lanes 0, 4, 32, 36
+            const unsigned qd = ((unsigned)(ln >> 2) & 1u) | (((unsigned)(ln >> 5) & 1u) << 1);
+            uint32_t* ids_out = a.bm_ids + blk * 64;
+            ids_out[ln] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            for (int e = 0;; ++e) {
+                int cand_h[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int c = 0x7fffffff;
+#pragma unroll
+                    for (int j = 4 * h; j < 4 * h + 4; ++j)
+                        if (valid & (1u << j)) {
+#pragma unroll
+                            for (int i = 0; i < K; ++i) { const int id = ids[j][i]; c = (id > last_h[h] && id < c) ? id : c; }
+                        }
+                    c = min(c, __shfl_xor(c, 1, 64)); c = min(c, __shfl_xor(c, 2, 64)); c = min(c, __shfl_xor(c, 8, 64)); c = min(c, __shfl_xor(c, 16, 64));
+                    cand_h[h] = c;
+                }
+                if (__builtin_amdgcn_ballot_w64(cand_h[0] != 0x7fffffff || cand_h[1] != 0x7fffffff) == 0ull) break;
+                if (e == DF_BM_NU) { sub_over = true; break; }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (cand_h[h] == 0x7fffffff) continue;
+#pragma unroll
+                    for (int j = 4 * h; j < 4 * h + 4; ++j)
+                        if (valid & (1u << j)) {
+                            unsigned hit = 0u;
+#pragma unroll
+                            for (int i = 0; i < K; ++i) hit = ids[j][i] == cand_h[h] ? (unsigned)e << (4 * i) : hit;
+                            code[j] |= hit;
+                        }
+                    if (writer) ((uint16_t*)(ids_out + qd * 16 + (unsigned)e))[h] = (uint16_t)cand_h[h];
+                    last_h[h] = cand_h[h];
+                }
+            }
+            if (!sub_over) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (col_in && z0 + j < a.Z) a.code_tab[df_code_index(a, x, y, z0 + j)] = code[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (ln == 0) a.bm_coded[blk] = sub_over ? (uint8_t)0 : (uint8_t)1;
+        }
+    }
     if (ln == 0) blk_state[blk] = 2;                                       // a model record exists (possibly "none")
     if (bad || overflow || n == 0) { if (ln == 0) bm_cnt[blk] = DF_BM_NONE; continue; }
     // entry 0 = the node with the widest lambda interval: its value is the reference v* of the verdict, its own error term vanishes
@@ -182,18 +228,6 @@ __global__ __launch_bounds__(256, K == 8 ? 3 : 4) void df_block_model_kernel(con
         bm_lam[(size_t)dst * nblk + blk] = s_lam[wave][ln];
         bm_w[(size_t)dst * nblk + blk] = s_w[wave][ln];
     }
-#if DF_IDX_CODES
-    // the codes and the union list itself (block-major, for the sweep's per-cell copy of the union's transforms).  The sweep takes codes only
-    // from blocks whose verdict byte says so, which the verdict pass derives from the state byte and the count: both are written here, after
-    // the codes.
-    if (a.code_tab && a.bm_ids) {
-        if (ln < DF_BM_NU) a.bm_ids[blk * DF_BM_NU + ln] = (uint16_t)(ln < n ? s_idx[wave][ln] : 0u);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (col_in && z0 + j < a.Z) a.code_tab[df_code_index(a, x, y, z0 + j)] = code[j];
-    }
-    __builtin_amdgcn_wave_barrier();
-#endif
     if (ln == 0) bm_cnt[blk] = (uint8_t)n;
     __builtin_amdgcn_wave_barrier();                                       // (the next round reuses the wave's LDS rows)
     }
@@ -323,7 +357,7 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
                                                                const float* __restrict__ blk_wmax, const float* __restrict__ brick_d1, int vbx, int vby, int zero_skip, int use_models, int want_models,
                                                                int build_on_demand, const uint16_t* __restrict__ bm_idx,
                                                                const uint32_t* __restrict__ bm_lam, const uint32_t* __restrict__ bm_w,
-                                                               const uint8_t* __restrict__ bm_cnt, uint8_t* __restrict__ alive,
+                                                               const uint8_t* __restrict__ bm_cnt, const uint8_t* __restrict__ bm_coded, uint8_t* __restrict__ alive,
                                                                uint32_t* __restrict__ build_list, uint32_t* __restrict__ ahead_list, uint32_t* __restrict__ model_list,
                                                                uint32_t* __restrict__ cnt, uint32_t* __restrict__ cnt_next)
 {
@@ -371,10 +405,10 @@ __global__ __launch_bounds__(256) void df_block_verdict_kernel(const DfWarpedArg
             if (n != DF_BM_NONE && a.cull[1] <= 1.0f) keep = !df_block_box_dead(a, rot, node_t, nbx, nby, nblk, blk, n, bm_idx, bm_lam, bm_w);
         }
         DF_VT(2);
-        // bit 1: the block has a model -- and so a union list and 4-bit neighbour codes -- that was COMPLETE before this pass started (the
-        // state byte was read above, after the previous frame's side-stream work was joined).  The plan kernel takes "coded" from here and
-        // not from the state bytes: it runs beside THIS frame's model builds, which set them before their codes are all written.
-        alive[blk] = keep ? (uint8_t)(1u | ((st == 2u && (use_models & 2) && bm_cnt[blk] != DF_BM_NONE) ? 2u : 0u)) : (uint8_t)0;
+        // bit 1: the model pass has been over the block -- it has union lists and 4-bit neighbour codes -- and was COMPLETE before this pass
+        // started (the state byte was read above, after the previous frame's side-stream work was joined).  The plan kernel takes "coded"
+        // from here and not from the state bytes: it runs beside THIS frame's model builds, which set them before their codes are all written.
+        alive[blk] = keep ? (uint8_t)(1u | ((st == 2u && (use_models & 2) && bm_coded[blk] != 0) ? 2u : 0u)) : (uint8_t)0;
         need_build = keep && build_on_demand && st == 0u;
         need_ahead = !keep && near && build_on_demand && st == 0u;
         need_model = (keep || near) && want_models && (st == 1u || (need_build && want_models > 1));
