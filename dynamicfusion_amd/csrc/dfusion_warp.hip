@@ -2018,7 +2018,9 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
         // table address = (workgroup-uniform record index: tile column + tile layer + plane in tile) + (loop-invariant 32-bit lane
         // offset inside the tile plane): the uniform part stays in SGPRs and the loads take the saddr + voffset form instead of
         // a 64-bit VALU address per load
-        const unsigned lane_vox = (unsigned)(yc * a.X + xc);
+        // (the lane's BYTE offset in a volume plane, 32 bits: scalar plane base + zero-extended lane offset is then the load's / store's
+        // saddr form -- an element index would be scaled after the extension, a 64-bit VALU address per access and a register pair)
+        const unsigned lane_vox4 = (unsigned)(yc * a.X + xc) * 4u;
         const unsigned lane_tab = df_tab_in_plane(xc, yc);
         const size_t tile_col = (size_t)(yc / DF_TAB_TY) * a.tab_ntx + (size_t)(xc / DF_TAB_TX);      // == (ty, tx) of the workgroup: uniform
         const size_t tile_col_u = (size_t)__builtin_amdgcn_readfirstlane((int)tile_col);
@@ -2091,8 +2093,8 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
                 const bool upd = pend.ok[u] & (Dp != 0.f) & (sdf >= -a.P.trunc);              // :86, :91
                 wave_upd += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(upd));
                 if (upd) {
-                    df_global_ptr<uint32_t> vp = df_wave_uniform(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane) + lane_vox;
-                    *vp = tsdf_fuse(pend.vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight);   // :93
+                    df_global_ptr<char> vp = (df_global_ptr<char>)df_wave_uniform(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane) + lane_vox4;
+                    *(df_global_ptr<uint32_t>)vp = tsdf_fuse(pend.vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight);   // :93
                 }
             }
         };
@@ -2165,7 +2167,7 @@ __global__ __launch_bounds__(WGT, WGT == 512 ? 4 : WGT == 768 ? 6 : 1) void df_w
                 // the voxel word is only needed if the voxel projects into the image (the finish is a batch away: time enough), and
                 // whole 32-byte runs of lanes that do not are not fetched at all
                 uint32_t vw = 0u;
-                if (ok[u]) vw = *(df_wave_uniform(a.vol + (size_t)(zv[u] - a.z_store0) * plane) + lane_vox);   // uniform plane base + lane offset
+                if (ok[u]) vw = *(df_global_ptr<const uint32_t>)((df_global_ptr<const char>)df_wave_uniform(a.vol + (size_t)(zv[u] - a.z_store0) * plane) + lane_vox4);   // uniform plane base + lane offset
                 pend.vn[u] = vn; pend.dpb[u] = dpb[u]; pend.vox[u] = vw; pend.z[u] = zv[u]; pend.ok[u] = ok[u];
             }
         };
