@@ -253,7 +253,14 @@ static int df_warp_pack_current(DfWarpField* wf, const float* pos, const float* 
 static int df_warp_pack(DfWarpField* wf, const float* pos, const float* dq, const float* sigma, hipStream_t st)
 {
     if (pos) { int rc = df_wait_split_sweep(wf, st); if (rc) return rc; }
-    else { int rc = df_wait_reader(wf, wf->node_reader[wf->nphase ^ 1], st); if (rc) return rc; }
+    else {
+        // The alternate set is about to be rewritten.  Its last reader may be a plan that was PREPARED and not yet swept (host order
+        // prepare(t), set_transforms, set_transforms, sweep(t)): nothing on the device orders this write after a sweep that has not been
+        // issued, and the sweep would blend with the wrong transforms without an error.  Such a plan is void from here on -- its sweep
+        // call returns DF_E_INVALID.
+        if (wf->prep_valid && wf->node_reader[wf->nphase ^ 1] == wf->seq && wf->seq > wf->recorded_seq) wf->prep_valid = false;
+        int rc = df_wait_reader(wf, wf->node_reader[wf->nphase ^ 1], st); if (rc) return rc;
+    }
     std::swap(wf->rot, wf->rot_alt); std::swap(wf->dual, wf->dual_alt); std::swap(wf->node_t, wf->node_t_alt); std::swap(wf->rt, wf->rt_alt);
     wf->nphase ^= 1;
     wf->node_reader[wf->nphase] = 0;                                       // (rewritten: nobody reads the old contents any more)
@@ -316,6 +323,7 @@ extern "C" int dfusion_warp_set_nodes(DfWarpField* wf, const float* pos, const f
 {
     if (!wf || !pos || !dq || !sigma || M <= 0 || M > 65535) return DF_E_INVALID;
     df_side_drain(wf);                                         // (look-ahead builds read the node arrays)
+    wf->prep_valid = false;                                    // (a prepared plan was made for the old node set: ADVICE r5)
     int rc = df_warp_reserve(wf, M);
     if (rc) return rc;
     wf->M = M;
@@ -1032,6 +1040,7 @@ extern "C" int dfusion_warp_build_index(DfWarpField* wf, DfVolume v, const DfSla
     if (sl.z_own_n < 0 || sl.z_own0 < 0 || sl.z_own0 + sl.z_own_n > v.dims[2]) return DF_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     df_side_drain(wf);                                         // (look-ahead builds of the tables about to be re-made)
+    wf->prep_valid = false;                                    // (a prepared plan points into the index and tables re-made here: ADVICE r5)
     DfIndexGeom g;
     g.X = v.dims[0]; g.Y = v.dims[1]; g.Z = v.dims[2];
     g.bx = (g.X + DF_BRICK - 1) / DF_BRICK; g.by = (g.Y + DF_BRICK - 1) / DF_BRICK; g.bz = (g.Z + DF_BRICK - 1) / DF_BRICK;

@@ -9,6 +9,8 @@
 #include <new>
 #include <thread>
 #include <vector>
+#include <cerrno>
+#include <csignal>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -82,7 +84,11 @@ bool ZSlabComm::initRccl(const std::string& id_path)
 // ---- HOST_STAGED: a file-backed shared segment {header, one slot per rank}.  Rank 0 creates it (a stale one removed first) and
 // publishes it by rename, with the run's nonce in the header; the others map it once magic and nonce match.  The barrier is a
 // sense-reversing counter in the header (lock-free atomics on MAP_SHARED memory are process-shared on this platform).
-namespace { struct SegHeader { unsigned long long magic, nonce; unsigned long long slot_bytes; std::atomic<unsigned> arrive, gen, attached; char pad[24]; }; const unsigned long long SEG_MAGIC = 0x44465a53484d3031ull; }
+// owner_pid: the process that made the segment (rank 0 of ITS run).  A segment whose maker is gone is a crashed run's, whatever its
+// barrier counters say (a stale header with arrive == world - 1 let a new rank's first barrier pass at once, before this run's
+// rank 0 had poisoned it; the nonce, 0 by default, does not separate runs).
+namespace { struct SegHeader { unsigned long long magic, nonce; unsigned long long slot_bytes; std::atomic<unsigned> arrive, gen, attached; long long owner_pid; char pad[16]; }; const unsigned long long SEG_MAGIC = 0x44465a53484d3032ull; }
+static bool df_pid_alive(long long pid) { return pid > 0 && (::kill((pid_t)pid, 0) == 0 || errno == EPERM); }
 
 bool ZSlabComm::initHost(const std::string& id_path)
 {
@@ -105,7 +111,7 @@ bool ZSlabComm::initHost(const std::string& id_path)
         ::close(fd);
         if (m == MAP_FAILED) return fail("ZSlabComm(host): mmap");
         SegHeader* h = new (m) SegHeader();
-        h->magic = SEG_MAGIC; h->nonce = nonce; h->slot_bytes = slot; h->arrive = 0; h->gen = 0; h->attached = 1;
+        h->magic = SEG_MAGIC; h->nonce = nonce; h->slot_bytes = slot; h->arrive = 0; h->gen = 0; h->attached = 1; h->owner_pid = (long long)getpid();
         seg_ = m; seg_bytes_ = bytes; slot_bytes_ = slot;
         if (std::rename(tmp.c_str(), path.c_str()) != 0) return fail("ZSlabComm(host): cannot publish " + path);
     } else {
@@ -119,7 +125,7 @@ bool ZSlabComm::initHost(const std::string& id_path)
                         ::close(fd);
                         if (m != MAP_FAILED) {
                             SegHeader* h = (SegHeader*)m;
-                            if (h->magic == SEG_MAGIC && h->nonce == nonce && h->slot_bytes == slot) { seg_ = m; seg_bytes_ = bytes; slot_bytes_ = slot; h->attached.fetch_add(1); break; }
+                            if (h->magic == SEG_MAGIC && h->nonce == nonce && h->slot_bytes == slot && df_pid_alive(h->owner_pid)) { seg_ = m; seg_bytes_ = bytes; slot_bytes_ = slot; h->attached.fetch_add(1); break; }
                             munmap(m, bytes);
                         }
                     } else ::close(fd);
@@ -129,7 +135,10 @@ bool ZSlabComm::initHost(const std::string& id_path)
             }
             // the first barrier doubles as the check that this is THIS run's segment: rank 0 poisons a stale one's magic before it publishes
             const int b = hostBarrierImpl(true);
-            if (b == 1) break;
+            // (passed: once more -- a barrier a stale header completed at once returns before the poison lands; this run's rank 0 is alive
+            // and never poisons its own segment)
+            if (b == 1 && *(volatile unsigned long long*)&((SegHeader*)seg_)->magic == SEG_MAGIC && df_pid_alive(((SegHeader*)seg_)->owner_pid)) break;
+            if (b == 1) { munmap(seg_, seg_bytes_); seg_ = nullptr; if (attempt > 100) return fail("ZSlabComm(host): only stale segments at " + path); continue; }
             if (b == 0) return false;
             munmap(seg_, seg_bytes_); seg_ = nullptr;                          // stale segment: attach again
             if (attempt > 100) return fail("ZSlabComm(host): only stale segments at " + path);

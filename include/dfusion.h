@@ -83,8 +83,10 @@ enum {
 #define DF_WARP_NO_CULL 1u   /* disable the (result-identical) conservative brick culling     */
 #define DF_WARP_NO_TABLE 2u  /* ignore the per-voxel k-NN table even if built (re-rank per frame) */
 #define DF_WARP_NO_WEIGHT_TABLE 4u /* ignore the per-voxel weight table (recompute exp per frame)   */
-#define DF_WARP_NO_LDS 8u    /* gather node transforms from global memory (the path taken when the
-                                node table exceeds the 160 KiB LDS, M > 5120); validation switch  */
+#define DF_WARP_NO_LDS 8u    /* the plain gather kernel: node transforms from global memory per neighbour, no launch
+                                plan, no verdict pass, no codes, no prepare / sweep split; validation switch.  (Until
+                                round 6 this was also the path of node sets whose table exceeds the 160 KiB LDS,
+                                M > 5120; the planned sweep now needs no LDS node table and takes every node count.) */
 #define DF_WARP_NO_PIPELINE 16u /* batched instead of software-pipelined table loads; validation switch */
 #define DF_WARP_NO_ZERO_SKIP 32u /* also sweep tiles whose blend weights are all so small that the reference's
                                  normalisation divides by zero (they cannot update); validation switch  */
@@ -100,8 +102,9 @@ enum {
                                  (by default the tables / blend models of blocks NEAR the frame's alive set -- what a moving camera
                                  or a changing warp brings in over the next few frames -- are made beside the sweep, on a stream the
                                  handle owns, so that a block is usually built before it is first swept); validation switch     */
-#define DF_WARP_NO_CODES 2048u /* the sweep reads the 16-byte neighbour-index record of every voxel (rounds 1-4) instead of the 4-bit codes of
-                                 * modelled blocks; validation / A/B switch (ABI 5)                                                     */
+#define DF_WARP_NO_CODES 2048u /* the sweep reads the 16-byte neighbour-index record of every voxel and gathers its neighbours' transforms
+                                 * from global memory, instead of the 4-bit codes into the per-wave copies of the 4 x 4 x 4 sub-block unions
+                                 * (k = 8; every block the model pass has visited); validation / A/B switch (ABI 5)                      */
 #define DF_WARP_STEADY_PREFETCH 1024u /* keep the look-ahead side stream on in EVERY frame.  By default a handle whose last plan-kernel report
                                  * listed nothing to build switches it off until the next probe (every 8th sweep); that report is read from
                                  * pinned host memory WITHOUT a synchronisation, so which frame switches depends on host / GPU timing --
@@ -355,7 +358,9 @@ int dfusion_integrate_warped(const uint16_t *dists_dev, size_t dists_pitch, int 
  * Results are those of dfusion_integrate_warped, bit for bit.  Only the cached path has a plan to
  * prepare: DF_E_INVALID without the per-voxel weight tables, with DF_WARP_NO_PIPELINE / NO_LDS / NO_TABLE, or k other than 4 / 8.
  * geometry.data is not dereferenced by prepare (may be NULL); sweep wants the same dims / voxel size / slab.  A prepared plan is void
- * after any other integrate on the handle.                                                                                              */
+ * -- its sweep call returns DF_E_INVALID -- after any other integrate on the handle, after dfusion_warp_set_nodes or
+ * dfusion_warp_build_index (they free or re-make what the plan points at), and after a SECOND dfusion_warp_set_transforms since the
+ * prepare (the first writes the alternate node set; the second would rewrite the one the plan reads).                                 */
 int dfusion_integrate_warped_prepare(const uint16_t *dists_dev, size_t dists_pitch, int cols, int rows, DfVolume geometry,
                                      const DfSlab *slab, const float vol2world[12], const float world2cam[12], const float proj[4],
                                      DfWarpField *wf, int k, unsigned flags, dfStream stream);

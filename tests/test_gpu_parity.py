@@ -694,3 +694,21 @@ def test_prepare_and_sweep_on_two_streams_equal_the_single_call():
     with pytest.raises(capi.DfusionError):
         v.integrate_warped_prepare(dists[0], sc.cam_poses[0], intr, lean)
     torch.cuda.synchronize()
+    # what voids a pending plan: ONE set_transforms after the prepare is the pipelined order and leaves it good -- it writes the
+    # alternate node set --; a SECOND would rewrite the set the plan reads, so the sweep must refuse instead of blending with frame t + 2's
+    # transforms; set_nodes and a rebuilt index free or re-make what the plan points at
+    dq = [torch.from_numpy(sc.dqs[f]).cuda() for f in range(3)]
+    wf.set_transforms(dq[0])
+    v.integrate_warped_prepare(dists[0], sc.cam_poses[0], intr, wf)
+    wf.set_transforms(dq[1])
+    v.integrate_warped_sweep(wf, sync=True)                       # still the plan's transforms: accepted
+    v.integrate_warped_prepare(dists[1], sc.cam_poses[1], intr, wf)
+    wf.set_transforms(dq[2]); wf.set_transforms(dq[0])
+    with pytest.raises(capi.DfusionError):
+        v.integrate_warped_sweep(wf)
+    wf.set_transforms(dq[1])
+    v.integrate_warped_prepare(dists[1], sc.cam_poses[1], intr, wf)
+    wf.init(sc.pos, sigma=sc.sigma, transforms=sc.dqs[0])       # dfusion_warp_set_nodes
+    with pytest.raises(capi.DfusionError):
+        v.integrate_warped_sweep(wf)
+    torch.cuda.synchronize()

@@ -8,7 +8,12 @@ C-ABI of libdfusion_hip.so.  That is the patch a maintainer of the reference wou
     TsdfVolume from the REFERENCE's tsdf_volume.cpp, not from this repository's mirror;
   * GPU: the binary (built in the container, travelled with the snapshot) runs kfusion::cuda::TsdfVolume::{clear, integrate, raycast x2,
     compute_points, compute_normals} and cuda::computeDists of the reference on the MI355X, and every output equals the oracle's bit for
-    bit (kfusion/src/tsdf_volume.cpp:89-174,184-220,312-324; kinfu.cpp:226,248,297,398-399)."""
+    bit (kfusion/src/tsdf_volume.cpp:89-174,184-220,312-324; kinfu.cpp:226,248,297,398-399);
+  * round 6: ALL 19 forwards of the bridge run -- the front-end through the reference's own imgproc.cpp wrappers
+    (depthBilateralFilter, depthTruncation, depthBuildPyramid, computeNormalsAndMaskDepth, computePointNormals, resizeDepthNormals,
+    resizePointsNormals, renderImage x 2, renderTangentColors) with NON-SQUARE intrinsics, TsdfVolume::psdf (tsdf_volume.cpp:266-292) ->
+    device::project_and_remove, and the overload nothing in the reference calls, directly -- each output equal to the oracle's bit for
+    bit; the binary reports which forwards ran and the test asserts 19 of 19."""
 import os
 import subprocess
 import sys
@@ -60,8 +65,15 @@ def test_reference_tsdf_volume_class_on_the_gpu_matches_oracle(tmp_path):
         for i in range(frames):
             f.write(sc.depths[i].tobytes())
             f.write(synth.aff12(sc.cam_poses[i]).tobytes())
+        intr2 = np.array([cfg.intr[0] * 1.0625, cfg.intr[1] * 0.9375, cfg.intr[2] + 1.5, cfg.intr[3] - 2.25], F32)     # fx != fy: both axes of focal_of()
+        f.write(intr2.tobytes())
     r = subprocess.run([app, str(cfg.dims[0]), str(cfg.size), str(cfg.cols), str(cfg.rows), str(frames), fin, fout], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ref_host_frame ok" in r.stdout, r.stdout + r.stderr
+    rep_line = [ln for ln in r.stdout.splitlines() if ln.startswith("hip_bridge forwards ")]
+    assert rep_line, r.stdout
+    print(rep_line[-1])
+    assert rep_line[-1].split()[2] == "19/19:", rep_line[-1]                 # every kfusion::device::* forward of the bridge ran
+    assert "=0" not in rep_line[-1]
     raw = np.fromfile(fout, np.uint8)
     nv, npx = int(np.prod(cfg.dims)), cfg.rows * cfg.cols
     o = 0
@@ -75,6 +87,15 @@ def test_reference_tsdf_volume_class_on_the_gpu_matches_oracle(tmp_path):
     cnt = int(take(8, np.uint64, (1,))[0])
     cloud = take(16 * cnt, F32, (cnt, 4)); cloud_n = take(16 * cnt, F32, (cnt, 4))
     vol_cleared = take(4 * nv, np.uint32, (nv,))
+    H, W, h, w = cfg.rows, cfg.cols, cfg.rows // 2, cfg.cols // 2
+    bil = take(2 * npx, np.uint16, (H, W)); trunc = take(2 * npx, np.uint16, (H, W)); pyr = take(2 * h * w, np.uint16, (h, w))
+    md = take(2 * npx, np.uint16, (H, W)); mn = take(16 * npx, F32, (H, W, 4))
+    pc = take(16 * npx, F32, (H, W, 4)); pn = take(16 * npx, F32, (H, W, 4))
+    dh = take(2 * h * w, np.uint16, (h, w)); nh = take(16 * h * w, F32, (h, w, 4))
+    ph = take(16 * h * w, F32, (h, w, 4)); pnh = take(16 * h * w, F32, (h, w, 4))
+    im1 = take(4 * npx, np.uint8, (H, W, 4)); im2 = take(4 * npx, np.uint8, (H, W, 4)); im3 = take(4 * npx, np.uint8, (H, W, 4))
+    ro = take(4 * npx, F32, (npx,)); d2_after = take(2 * npx, np.uint16, (H, W))
+    p4 = take(16 * npx, F32, (npx, 4)); d3_after = take(2 * npx, np.uint16, (H, W))
     assert o == len(raw)
 
     # the oracle on the same inputs, with the host arithmetic of the OpenCV stand-in (= the mirror's: cxx_inv / cxx_mul) for
@@ -99,3 +120,34 @@ def test_reference_tsdf_volume_class_on_the_gpu_matches_oracle(tmp_path):
     rnrm = O.extract_normals(sc.ovol(ref), synth.aff12(sc.pose), cxx_inv(sc.pose)[:3, :3], cloud, cfg.gradient_delta_factor)
     assert np.array_equal(cloud_n.view(np.uint32), rnrm.view(np.uint32))       # compute_normals: fetchNormals -> device::extractNormals
     assert not vol_cleared.any()                                               # TsdfVolume::clear -> device::clear_volume
+
+    # ---- the front-end forwards, through the reference's imgproc.cpp wrappers (non-square intrinsics), vs the oracle, bit for bit
+    u = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    d_last = sc.depths[frames - 1]
+    o_bil = O.bilateral(d_last, 7, 4.5, 0.04)
+    assert np.array_equal(bil, o_bil) and (bil != d_last).any()                # cuda::depthBilateralFilter -> device::bilateralFilter
+    o_tr = O.truncate_depth(o_bil, 1.2)
+    assert np.array_equal(trunc, o_tr) and (o_tr != o_bil).any() and o_tr.any()                 # cuda::depthTruncation -> device::truncateDepth
+    assert np.array_equal(pyr, O.depth_pyramid(o_bil, 0.04)) and pyr.any()      # cuda::depthBuildPyramid -> device::depthPyr
+    o_md, o_mn = O.compute_normals_mask_depth(o_bil, intr2)
+    assert np.array_equal(md, o_md) and np.array_equal(u(mn), u(o_mn)) and np.isfinite(o_mn[..., 0]).sum() > 1000     # computeNormalsAndMaskDepth
+    o_pc, o_pn = O.compute_point_normals(o_bil, intr2)
+    assert np.array_equal(u(pc), u(o_pc)) and np.array_equal(u(pn), u(o_pn)) and np.isfinite(o_pn[..., 0]).sum() > 1000    # computePointNormals
+    # (square intrinsics give different bits: the bridge's focal_of() really reconstructs fx and fy separately)
+    assert not np.array_equal(u(O.compute_point_normals(o_bil, np.asarray(cfg.intr, F32))[0]), u(o_pc))
+    o_dh, o_nh = O.resize_depth_normals(o_md, o_mn)
+    assert np.array_equal(dh, o_dh) and np.array_equal(u(nh), u(o_nh))          # cuda::resizeDepthNormals
+    o_ph, o_pnh = O.resize_points_normals(o_pc, o_pn)
+    assert np.array_equal(u(ph), u(o_ph)) and np.array_equal(u(pnh), u(o_pnh))  # cuda::resizePointsNormals
+    light = np.array([0.3, -0.2, -0.5], F32)
+    assert np.array_equal(im1, O.render_depth(o_md, o_mn, intr2, light)) and im1[..., :3].any()     # renderImage(Depth, ...)
+    assert np.array_equal(im2, O.render_points(o_pc, o_pn, light)) and im2[..., :3].any()           # renderImage(Cloud, ...)
+    assert np.array_equal(im3, O.render_tangent_colors(o_pn)) and im3[..., :3].any()                # renderTangentColors
+    # ---- TsdfVolume::psdf -> device::project_and_remove(const PtrStepSz<ushort>&, ...): distances and the dists image after the removal
+    dists2 = O.compute_dists(d_last, intr2)
+    w4 = np.zeros((npx, 4), F32); w4[:, :3] = pts.reshape(-1, 4)[:, :3]
+    o_p4, o_after, o_ro, n_in = O.project_and_remove(dists2, w4, intr2)
+    assert n_in > 1000
+    assert np.array_equal(u(ro), u(o_ro)) and np.array_equal(d2_after, o_after) and (o_after != dists2).sum() > 1000
+    # ---- the non-const overload, called directly: the rewritten points and the same removal
+    assert np.array_equal(u(p4), u(o_p4)) and np.array_equal(d3_after, o_after)
