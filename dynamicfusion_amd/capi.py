@@ -59,7 +59,7 @@ SYMBOLS = [
     "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
     "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate", "dfusion_release_scratch", "dfusion_raycast_points_of_keys",
     "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_integrate_ex", "dfusion_warp_debug_counters", "dfusion_warp_alive_blocks", "dfusion_warp_coded_blocks", "dfusion_raycast_points_of_keys_rows", "dfusion_raycast_sum_pieces", "dfusion_integrate_warped_prepare", "dfusion_integrate_warped_sweep",
-    "dfusion_render_image_points", "dfusion_render_image_depth", "dfusion_render_tangent_colors",
+    "dfusion_render_image_points", "dfusion_render_image_depth", "dfusion_render_tangent_colors", "dfusion_cloud_to_depth",
 ]
 
 
@@ -132,6 +132,7 @@ def load(path, strict=True):
     sz = C.c_size_t
     L.dfusion_bilateral_filter.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]
     L.dfusion_truncate_depth.argtypes = [vp, sz, C.c_int, C.c_int, C.c_float, vp]
+    L.dfusion_cloud_to_depth.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, vp]
     L.dfusion_depth_pyramid.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, C.c_float, vp]
     L.dfusion_compute_normals_mask_depth.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, fp, vp]
     L.dfusion_compute_point_normals.argtypes = [vp, sz, vp, sz, vp, sz, C.c_int, C.c_int, fp, vp]

@@ -78,6 +78,26 @@ extern "C" int dfusion_truncate_depth(uint16_t* depth, size_t pitch, int cols, i
     return DF_OK;
 }
 
+// ------------------------------------------------------------------------------------------ cloud -> depth (imgproc.cu:273-282, 296-303)
+// depth(y, x) = cloud(y, x).z * 1000, converted float -> ushort as the reference's target converts (cvt.rzi.u16.f32: toward zero,
+// saturating, NaN -> 0 -- a ray-cast miss becomes "no depth").
+__global__ __launch_bounds__(256) void df_cloud_to_depth_kernel(const float* __restrict__ cloud, size_t cpitch, uint16_t* __restrict__ depth, size_t dpitch,
+                                                                int cols, int rows)
+{
+    FE_XY;
+    if (x >= cols || y >= rows) return;
+    const float mm = ((const float*)((const char*)cloud + (size_t)y * cpitch))[4 * x + 2] * 1000;      // :280
+    const unsigned v = mm >= 65535.f ? 65535u : (mm > 0.f ? (unsigned)mm : 0u);                        // (NaN fails both tests: 0)
+    st16(depth, dpitch, y, x, (uint16_t)v);
+}
+extern "C" int dfusion_cloud_to_depth(const float* cloud, size_t cloud_pitch, uint16_t* depth, size_t depth_pitch, int cols, int rows, dfStream stream)
+{
+    if (!cloud || !depth || cols <= 0 || rows <= 0) return DF_E_INVALID;
+    hipLaunchKernelGGL(df_cloud_to_depth_kernel, FE_GRID(cols, rows), dim3(256), 0, (hipStream_t)stream, cloud, cloud_pitch, depth, depth_pitch, cols, rows);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}
+
 // ------------------------------------------------------------------------------------------ pyramid (imgproc.cu:94-137)
 __global__ __launch_bounds__(256) void df_pyramid_kernel(const uint16_t* __restrict__ src, size_t spitch, int scols, int srows,
                                                          uint16_t* __restrict__ dst, size_t dpitch, int dcols, int drows, float thr)

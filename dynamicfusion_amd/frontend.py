@@ -43,6 +43,15 @@ def depthTruncation(depth, threshold):
     return depth
 
 
+def cloudToDepth(cloud, out=None):
+    """cuda::cloudToDepth (imgproc.cpp:98-103): depth mm = points.z * 1000 (a NaN point -- a ray-cast miss -- gives 0)."""
+    rows, cols = cloud.shape[:2]
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.int16, device=cloud.device)
+    capi.check(capi.lib().dfusion_cloud_to_depth(_ptr(cloud), cols * 16, _ptr(out), cols * 2, cols, rows, _stream()), "dfusion_cloud_to_depth")
+    return out
+
+
 def depthBuildPyramid(depth, sigma_depth, out=None):
     rows, cols = depth.shape
     if out is None:

@@ -5,6 +5,7 @@
 // suites go through WarpField::energy_data.)
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #include <kfusion/warp_field.hpp>
 
@@ -93,8 +94,54 @@ static bool WarpAndReverseTest()                                           // ce
     return true;
 }
 
-int main()
+// `warp_tests dqb in.bin out.bin` (round 6): WarpField::DQB / getWeightsAndUpdateKNN / weighting of the mirror, point by point, for
+// tests/test_gpu_cxx_host.py to compare with the reference's classes.  in.bin: M u32, N u32, k u32, positions f32[3M], transforms f32[8M]
+// {rotation_, translation_}, dg_w f32[M], points f32[3N]; out.bin: per point the blend f32[8] {rotation_, translation_}, then per point
+// the k weights f32[k] and the k neighbour ids u32[k].
+static int dqb_mode(const char* fin, const char* fout)
 {
+    FILE* f = std::fopen(fin, "rb");
+    if (!f) return 2;
+    unsigned hdr[3];
+    if (std::fread(hdr, 4, 3, f) != 3) return 2;
+    const unsigned M = hdr[0], N = hdr[1], k = hdr[2];
+    std::vector<float> pos(3 * (size_t)M), dq(8 * (size_t)M), sigma(M), pts(3 * (size_t)N);
+    if (std::fread(pos.data(), 4, pos.size(), f) != pos.size() || std::fread(dq.data(), 4, dq.size(), f) != dq.size() ||
+        std::fread(sigma.data(), 4, sigma.size(), f) != sigma.size() || std::fread(pts.data(), 4, pts.size(), f) != pts.size()) return 2;
+    std::fclose(f);
+    kfusion::WarpField wf((int)k);
+    std::vector<Vec3f> seeds(M);
+    for (unsigned i = 0; i < M; ++i) seeds[i] = Vec3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+    wf.init(seeds);
+    std::vector<kfusion::deformation_node>& nodes = *wf.getNodes();
+    if (nodes.size() != M) return 3;
+    for (unsigned i = 0; i < M; ++i) { std::memcpy((void*)nodes[i].transform.raw(), &dq[8 * i], 32); nodes[i].weight = sigma[i]; }
+    wf.commit(true);                                                       // (dg_w changed: set_nodes again)
+    FILE* o = std::fopen(fout, "wb");
+    if (!o) return 2;
+    std::vector<float> w_all((size_t)N * k); std::vector<unsigned> id_all((size_t)N * k);
+    for (unsigned i = 0; i < N; ++i) {
+        const Vec3f p(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+        const kfusion::utils::DualQuaternion<float> d = wf.DQB(p);
+        std::fwrite(d.raw(), 4, 8, o);
+        float w[KNN_NEIGHBOURS];
+        wf.getWeightsAndUpdateKNN(p, w);
+        for (unsigned j = 0; j < k; ++j) {
+            w_all[(size_t)i * k + j] = w[j]; id_all[(size_t)i * k + j] = (unsigned)(*wf.getRetIndex())[j];
+            if (w[j] != wf.weighting((*wf.getDistSquared())[j], sigma[id_all[(size_t)i * k + j]])) return 4;
+        }
+    }
+    std::fwrite(w_all.data(), 4, w_all.size(), o);
+    std::fwrite(id_all.data(), 4, id_all.size(), o);
+    std::fclose(o);
+    wf.clear();                                                            // (empty, as in the reference)
+    std::printf("warp_tests dqb ok: %u points, %u nodes, k = %u\n", N, M, k);
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc == 4 && !std::strcmp(argv[1], "dqb")) return dqb_mode(argv[2], argv[3]);
     struct { const char* name; bool (*fn)(); } tests[] = {
         {"EnergyDataSingleVertexTest", EnergyDataSingleVertexTest}, {"EnergyDataRigidTest", EnergyDataRigidTest},
         {"WarpAndReverseTest", WarpAndReverseTest}, {"MultipleNodesTest", MultipleNodesTest}, {"NonRigidTest", NonRigidTest}};

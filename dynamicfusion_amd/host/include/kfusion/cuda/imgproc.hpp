@@ -1,7 +1,7 @@
 // kfusion/cuda/imgproc.hpp -- the image operators KinFu::operator() calls, with the reference's names and argument order
 // (/root/reference/kfusion/include/kfusion/cuda/imgproc.hpp; host wrappers kfusion/src/imgproc.cpp).  Every function allocates its
 // outputs like the reference's wrapper does and enqueues one or two HIP kernels through the C-ABI (include/dfusion.h); nothing
-// synchronises except waitAllDefaultStream.  cloudToDepth / mergePointNormal (never called by KinFu or the demo) are out of scope.
+// synchronises except waitAllDefaultStream.
 //
 //   image types   Depth / Dists : DeviceArray2D<unsigned short>   (millimetres / IEEE-half bits of the ray length in metres)
 //                 Cloud / Normals: DeviceArray2D<Point>            (float4, invalid pixels are NaN)
@@ -17,6 +17,9 @@ void waitAllDefaultStream();
 // ---- per-frame inputs of the fusion
 // ray length per pixel for TsdfVolume::integrate: dists = half(depth_mm * sqrt(xl^2 + yl^2 + 1) / 1000)      imgproc.cpp:87-91
 void computeDists(const Depth& depth, Dists& dists, const Intr& intr);
+
+// points image -> depth image in millimetres (z * 1000; a NaN point gives 0)                                   imgproc.cpp:98-103
+void cloudToDepth(const Cloud& cloud, Depth& depth);
 
 // ---- depth pyramid of the tracker
 // edge-preserving smoothing, window ksz x ksz                                                                 imgproc.cpp:10-14

@@ -30,6 +30,10 @@ public:
     int getUsedLevelsNum() const;
     void setDeviceLoop(bool on) { device_loop_ = on; }      // default true; poses of the two flows agree to ~1e-5
 
+    // projective_icp.hpp:30: the Frame form.  The reference's body is CV_Assert(!"Not implemented") (projective_icp.cpp:110-123, its
+    // dispatch on the pyramids commented out); the same here: error(), never a transform.
+    virtual bool estimateTransform(Affine3f& affine, const Intr& intr, const Frame& curr, const Frame& prev);
+
     // curr -> prev rigid motion.  Depth variant: masked depth + normals pyramids ("if depth(y,x) is not zero, normals(y,x) is not
     // qnan"); points variant: float4 vertex + normal pyramids.  Returns false when a normal matrix is singular.
     virtual bool estimateTransform(Affine3f& affine, const Intr& intr, const DepthPyr& dcurr, const NormalsPyr ncurr, const DepthPyr dprev,

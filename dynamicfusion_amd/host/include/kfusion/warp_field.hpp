@@ -1,8 +1,10 @@
 // kfusion/warp_field.hpp -- WarpField with the reference's hot-path interface
 // (/root/reference/kfusion/include/kfusion/warp_field.hpp:41-88): host node store + GPU k-NN / DQB / warp through the
-// C-ABI.  energy_data is the GPU data-term solve; energy_reg is out of scope (no regularisation term is ever added to the
-// reference's problem either).
+// C-ABI.  energy_data is the GPU data-term solve; energy / energy_reg / clear exist with the reference's (empty) behaviour -- no
+// regularisation term is ever added to the reference's problem either.  tests/test_mirror_headers.py checks every public name of the
+// reference's header against this one.
 #pragma once
+#include <utility>
 #include <vector>
 #include <kfusion/types.hpp>
 #include <kfusion/utils/dual_quaternion.hpp>
@@ -33,6 +35,24 @@ namespace kfusion
         /// warp_field.cpp:68-88: one identity node per point, dg_w = 3 (NaN points skipped -- the reference
         /// leaves zero-position, zero-weight nodes in their place; fixed)
         void init(const std::vector<Vec3f>& first_frame);
+#ifdef KFUSION_USE_OPENCV
+        /// warp_field.cpp:41-63: every 50th point of every 50th row of a cloud image (KinFu passes the 1 x N extracted cloud,
+        /// kinfu.cpp:252: every 50th point); only the sampled, non-NaN points become nodes
+        void init(const cv::Mat& first_frame);
+#endif
+        /// warp_field.cpp:98-108: checks that the two images have the same size, nothing else (as in the reference)
+        void energy(const cuda::Cloud& frame, const cuda::Normals& normals, const Affine3f& pose, const cuda::TsdfVolume& tsdfVolume,
+                    const std::vector<std::pair<utils::DualQuaternion<float>, utils::DualQuaternion<float>>>& edges);
+        /// warp_field.cpp:168-172: empty in the reference, empty here
+        void energy_reg(const std::vector<std::pair<utils::DualQuaternion<float>, utils::DualQuaternion<float>>>& edges);
+        /// warp_field.cpp:203-217: the dual-quaternion blend at one vertex (k-NN on the GPU, sums on the host in the reference's order)
+        utils::DualQuaternion<float> DQB(const Vec3f& vertex) const;
+        /// warp_field.cpp:225-230: KNN(vertex), then weights[i] = weighting(dist_i^2, dg_w of neighbour i)
+        void getWeightsAndUpdateKNN(const Vec3f& vertex, float weights[KNN_NEIGHBOURS]) const;
+        /// warp_field.cpp:238-241: exp(-d^2 / (2 dg_w^2)), the exponential in double as the reference's overload resolves it
+        float weighting(float squared_dist, float weight) const;
+        /// warp_field.cpp:298-301: empty in the reference, empty here
+        void clear();
         /// the host node store; after a GPU solve (energy_data) the transforms are fetched from the device on the first access
         const std::vector<deformation_node>* getNodes() const { pullNodes(); return &nodes_; }
         std::vector<deformation_node>* getNodes() { pullNodes(); return &nodes_; }

@@ -425,6 +425,61 @@ void WarpField::init(const std::vector<Vec3f>& first_frame)
     commit(true);
 }
 
+#ifdef KFUSION_USE_OPENCV
+// warp_field.cpp:41-63: every 50th point of every 50th row of a cloud image.  (KinFu hands it the extracted cloud, 1 x N: every 50th
+// point, kinfu.cpp:252.)  The reference sizes its node array for EVERY pixel and fills only the sampled ones, leaving the rest
+// zero-positioned with weight 0; here only the sampled, non-NaN points become nodes (as in init(std::vector)).
+void WarpField::init(const cv::Mat& first_frame)
+{
+    std::vector<Vec3f> seeds;
+    const int step = 50;                                   // :49
+    for (int i = 0; i < first_frame.rows; i += step)
+        for (int j = 0; j < first_frame.cols; j += step) {
+            const Point point = first_frame.at<Point>(i, j);
+            if (!std::isnan(point.x)) seeds.push_back(Vec3f(point.x, point.y, point.z));
+        }
+    init(seeds);
+}
+#endif
+
+// warp_field.cpp:238-241
+// (the reference's unqualified exp(float) resolves to the C library's double exp -- oracle/ref_glue.cpp pins that with a static_assert --
+// so the argument, formed in float, is widened: std::exp(float) would pick expf and differ in the last bit for ~0.3 % of the weights)
+float WarpField::weighting(float squared_dist, float weight) const { return (float)std::exp((double)(-squared_dist / (2 * weight * weight))); }
+
+// warp_field.cpp:225-230: the k-NN on the GPU (KNN above), the weights on the host with the reference's expression; entries past k() are 0
+void WarpField::getWeightsAndUpdateKNN(const Vec3f& vertex, float weights[KNN_NEIGHBOURS]) const
+{
+    KNN(vertex);
+    for (int i = 0; i < KNN_NEIGHBOURS; ++i)
+        weights[i] = i < k_ ? weighting(out_dist_sqr_[i], nodes_[ret_index_[i]].weight) : 0.f;
+}
+
+// warp_field.cpp:203-217: the blend at ONE vertex -- the per-point form of what dfusion_warp_points / dfusion_integrate_warped do on the
+// device, operation for operation (sums in neighbour order, normalize, DualQuaternion(translation, rotation))
+utils::DualQuaternion<float> WarpField::DQB(const Vec3f& vertex) const
+{
+    float weights[KNN_NEIGHBOURS];
+    getWeightsAndUpdateKNN(vertex, weights);
+    pullNodes();
+    utils::Quaternion<float> translation_sum(0, 0, 0, 0), rotation_sum(0, 0, 0, 0);
+    for (int i = 0; i < k_; ++i) {
+        translation_sum = translation_sum + weights[i] * nodes_[ret_index_[i]].transform.getTranslation();     // :211
+        rotation_sum = rotation_sum + weights[i] * nodes_[ret_index_[i]].transform.getRotation();              // :212
+    }
+    rotation_sum.normalize();                                                                                  // :214
+    return utils::DualQuaternion<float>(translation_sum, rotation_sum);
+}
+
+// warp_field.cpp:98-108 (two asserts on the image sizes), :168-172 and :298-301 (empty bodies): nothing to do here either
+void WarpField::energy(const cuda::Cloud& frame, const cuda::Normals& normals, const Affine3f&, const cuda::TsdfVolume&,
+                       const std::vector<std::pair<utils::DualQuaternion<float>, utils::DualQuaternion<float>>>&)
+{
+    if (normals.cols() != frame.cols() || normals.rows() != frame.rows()) error("WarpField::energy: normals and frame differ in size", __FILE__, __LINE__, "");
+}
+void WarpField::energy_reg(const std::vector<std::pair<utils::DualQuaternion<float>, utils::DualQuaternion<float>>>&) {}
+void WarpField::clear() {}
+
 void WarpField::commit(bool positions_changed)
 {
     pullNodes();                                           // (edits were made through getNodes(), which had pulled already)
@@ -564,6 +619,11 @@ void kfusion::cuda::depthBilateralFilter(const Depth& in, Depth& out, int ksz, f
 {
     out.create(in.rows(), in.cols());
     KF_DF(dfusion_bilateral_filter(in.ptr(), in.step(), out.ptr(), out.step(), in.cols(), in.rows(), ksz, sigma_spatial, sigma_depth, nullptr));
+}
+void kfusion::cuda::cloudToDepth(const Cloud& cloud, Depth& depth)
+{
+    depth.create(cloud.rows(), cloud.cols());
+    KF_DF(dfusion_cloud_to_depth((const float*)cloud.ptr(), cloud.step(), depth.ptr(), depth.step(), cloud.cols(), cloud.rows(), nullptr));
 }
 void kfusion::cuda::depthTruncation(Depth& depth, float threshold)
 {
@@ -744,6 +804,11 @@ bool ProjectiveICP::iterate(Affine3f& affine, const Intr& intr, const void* cons
     return true;
 }
 
+bool ProjectiveICP::estimateTransform(Affine3f& /*affine*/, const Intr& /*intr*/, const Frame& /*curr*/, const Frame& /*prev*/)   // projective_icp.cpp:110-123
+{
+    error("Not implemented", __FILE__, __LINE__, "ProjectiveICP::estimateTransform(Frame)");
+    return false;
+}
 bool ProjectiveICP::estimateTransform(Affine3f& affine, const Intr& intr, const DepthPyr& dcurr, const NormalsPyr ncurr, const DepthPyr dprev,
                                       const NormalsPyr nprev)
 {

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 5   /* 5: dfusion_integrate_warped_prepare / _sweep (the frame's integrate in two calls, for cross-frame overlap), dfusion_raycast_sum_pieces (direct row-band merge), DF_WARP_STEADY_PREFETCH, dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation), DF_WARP_NO_CODES + dfusion_warp_coded_blocks (4-bit neighbour codes of modelled blocks); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
+#define DFUSION_ABI_VERSION 6   /* 6: dfusion_cloud_to_depth; the planned warped sweep takes every node count (no LDS node table: DF_WARP_NO_LDS now only selects the plain gather kernel), a prepared plan is also voided by set_nodes / build_index / a second set_transforms; 5: dfusion_integrate_warped_prepare / _sweep (the frame's integrate in two calls, for cross-frame overlap), dfusion_raycast_sum_pieces (direct row-band merge), DF_WARP_STEADY_PREFETCH, dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation), DF_WARP_NO_CODES + dfusion_warp_coded_blocks (4-bit neighbour codes of modelled blocks); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
@@ -378,6 +378,9 @@ int dfusion_bilateral_filter(const uint16_t *src_dev, size_t src_pitch, uint16_t
                              int kernel_size, float sigma_spatial, float sigma_depth, dfStream stream);
 /* device::truncateDepth (internal.hpp:127; imgproc.cu:66-85): depth > max_dist (metres) <- 0, in place.            */
 int dfusion_truncate_depth(uint16_t *depth_dev, size_t pitch, int cols, int rows, float max_dist, dfStream stream);
+/* device::cloud_to_depth (internal.hpp:125; imgproc.cu:273-282, 296-303), behind cuda::cloudToDepth (imgproc.cpp:98-103): depth (mm) =
+ * points.z (metres) * 1000, float -> ushort toward zero and saturating, NaN (a ray-cast miss) -> 0 (ABI 6).                          */
+int dfusion_cloud_to_depth(const float *points_dev, size_t points_pitch, uint16_t *depth_dev, size_t depth_pitch, int cols, int rows, dfStream stream);
 /* device::depthPyr (internal.hpp:129; imgproc.cu:94-137): dst is (src_rows/2) x (src_cols/2).                       */
 int dfusion_depth_pyramid(const uint16_t *src_dev, size_t src_pitch, int src_cols, int src_rows, uint16_t *dst_dev, size_t dst_pitch,
                           float sigma_depth, dfStream stream);

@@ -99,6 +99,18 @@ ORC_API void orc_truncate_depth(uint16_t *depth, size_t pitch, int cols, int row
             if (PIX16(depth, pitch, y, x) > md) PIX16(depth, pitch, y, x) = 0;
 }
 
+/* ---------------------------------------------------------------- cloud -> depth (imgproc.cu:273-282): depth = z * 1000 as ushort.  The
+ * conversion is the CUDA target's (cvt.rzi.u16.f32): toward zero, saturating, NaN -> 0; in C that range is spelled out (the plain cast is
+ * undefined outside [0, 65536) and for NaN). */
+ORC_API void orc_cloud_to_depth(const float *cloud, size_t cpitch, uint16_t *depth, size_t dpitch, int cols, int rows)
+{
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const float mm = ((const float *)((const char *)cloud + (size_t)y * cpitch))[4 * x + 2] * 1000;   /* :280 */
+            PIX16(depth, dpitch, y, x) = mm >= 65535.f ? (uint16_t)65535 : (mm > 0.f ? (uint16_t)mm : (uint16_t)0);
+        }
+}
+
 /* ---------------------------------------------------------------- pyramid (imgproc.cu:94-137); dst is (rows/2) x (cols/2) */
 ORC_API void orc_depth_pyramid(const uint16_t *src, size_t spitch, int scols, int srows, uint16_t *dst, size_t dpitch,
                                float sigma_depth /* metres */)

@@ -147,6 +147,15 @@ RCU_API void refcu_bilateral(const unsigned short* src, int rows, int cols, int 
     down(o, dst);
 }
 
+RCU_API void refcu_cloud_to_depth(const float* cloud, int rows, int cols, unsigned short* depth)
+{
+    Modes m(0, 1);
+    Points p; up(p, cloud, rows, cols);
+    Depth d(rows, cols);
+    cloud_to_depth(p, d);                                                                                // :296-303 (kernel :273-282)
+    down(d, depth);
+}
+
 RCU_API void refcu_truncate_depth(unsigned short* depth, int rows, int cols, float max_dist)
 {
     Modes m(0, 1);

@@ -126,6 +126,7 @@ namespace cv
         template <typename T> T& at(int i) { return ((T*)data)[i]; }                       // single-row / continuous matrices
         template <typename T> const T& at(int i) const { return ((const T*)data)[i]; }
         template <typename T> T& at(int r, int c) { return ptr<T>(r)[c]; }
+        template <typename T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }     // (as cv::Mat: warp_field.cpp:53 reads a const Mat)
         void convertTo(Mat& m, int rtype, double alpha = 1, double beta = 0) const         // u16 / u8 -> u8 only (demo.cpp:39)
         {
             m.create(rows, cols, CV_MAKETYPE(rtype & 7, channels()));

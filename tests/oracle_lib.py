@@ -104,6 +104,8 @@ def lib():
         L.orc_bilateral.argtypes = [u16p, sz, u16p, sz, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
         L.orc_truncate_depth.restype = None
         L.orc_truncate_depth.argtypes = [u16p, sz, C.c_int, C.c_int, C.c_float]
+        L.orc_cloud_to_depth.restype = None
+        L.orc_cloud_to_depth.argtypes = [f32p, sz, u16p, sz, C.c_int, C.c_int]
         L.orc_depth_pyramid.restype = None
         L.orc_depth_pyramid.argtypes = [u16p, sz, C.c_int, C.c_int, u16p, sz, C.c_float]
         L.orc_compute_normals_mask_depth.restype = None
@@ -220,6 +222,7 @@ def refcu():
         R.refcu_bilateral.argtypes = [u16p, i, i, i, f, f, u16p]
         R.refcu_truncate_depth.argtypes = [u16p, i, i, f]
         R.refcu_depth_pyramid.argtypes = [u16p, i, i, f, u16p]
+        R.refcu_cloud_to_depth.argtypes = [f32p, i, i, u16p]
         R.refcu_compute_normals_mask_depth.argtypes = [u16p, i, i, f32p, f32p]
         R.refcu_compute_point_normals.argtypes = [u16p, i, i, f32p, f32p, f32p]
         R.refcu_resize_depth_normals.argtypes = [u16p, f32p, i, i, u16p, f32p]
@@ -231,7 +234,7 @@ def refcu():
         for n in dir(R):
             pass
         for name in ("refcu_clear", "refcu_integrate", "refcu_raycast_points", "refcu_raycast_depth", "refcu_project_and_remove",
-                     "refcu_extract_normals", "refcu_compute_dists", "refcu_bilateral", "refcu_truncate_depth", "refcu_depth_pyramid",
+                     "refcu_extract_normals", "refcu_compute_dists", "refcu_bilateral", "refcu_truncate_depth", "refcu_depth_pyramid", "refcu_cloud_to_depth",
                      "refcu_compute_normals_mask_depth", "refcu_compute_point_normals", "refcu_resize_depth_normals",
                      "refcu_resize_points_normals", "refcu_render_points", "refcu_render_depth", "refcu_render_tangent_colors",
                      "refcu_icp_sums_points"):
@@ -457,6 +460,13 @@ def bilateral(depth, ksz, sigma_spatial, sigma_depth):
 def truncate_depth(depth, max_dist):
     out = _u16(depth).copy(); rows, cols = out.shape
     lib().orc_truncate_depth(out, cols * 2, cols, rows, max_dist)
+    return out
+
+
+def cloud_to_depth(cloud):
+    c = f32(cloud); rows, cols = c.shape[:2]
+    out = np.zeros((rows, cols), np.uint16)
+    lib().orc_cloud_to_depth(c.reshape(-1), cols * 16, out, cols * 2, cols, rows)
     return out
 
 

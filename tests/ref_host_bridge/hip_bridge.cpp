@@ -7,8 +7,8 @@
 // device_memory}.cpp (read where they lie under /root/reference) into tests/ref_host_bridge/_build/libkfusion_refhost.so, and
 // tests/test_gpu_ref_host_bridge.py drives the REFERENCE's kfusion::cuda::TsdfVolume on the MI355X through it.
 //
-// Not bridged (nothing compiled here calls them on the hot path): device::project (tsdf_volume.cu:180, no caller in the reference),
-// device::cloud_to_depth (imgproc.cu:296, only behind cuda::cloudToDepth), device::mergePointNormal, device::ComputeIcpHelper
+// Not bridged (nothing compiled here calls them): device::project (tsdf_volume.cu:180, no caller in the reference),
+// device::mergePointNormal, device::ComputeIcpHelper
 // (proj_icp.cu; the C-ABI's dfusion_icp_* are its counterpart, bound by the mirror's ProjectiveICP).
 #include "precomp.hpp"           // the reference's: device::TsdfVolume, Aff3f, Projector, Reprojector, Dists, Points, Normals, Depth, Image
 #include "dfusion.h"
@@ -34,19 +34,19 @@ static void chk(int rc, const char* file, int line) { if (rc) kfusion::cuda::err
 #define DF_CHK(expr) chk((expr), __FILE__, __LINE__)
 
 // Which forwards have run (a test hook, nothing a maintainer needs): tests/ref_host_bridge/ref_host_frame.cpp prints the report and
-// tests/test_gpu_ref_host_bridge.py asserts that every one of the 19 did.
-static const char* const g_forward_names[19] = {
+// tests/test_gpu_ref_host_bridge.py asserts that every one of the 20 did.
+static const char* const g_forward_names[20] = {
     "clear_volume", "integrate", "raycast(Points)", "raycast(Depth)", "project_and_remove(PtrStepSz&)", "project_and_remove(const PtrStepSz&)",
     "extractCloud", "extractNormals", "compute_dists", "truncateDepth", "bilateralFilter", "depthPyr", "resizeDepthNormals", "resizePointsNormals",
-    "computeNormalsAndMaskDepth", "computePointNormals", "renderImage(Depth)", "renderImage(Points)", "renderTangentColors"};
-static unsigned g_forward_calls[19];
+    "computeNormalsAndMaskDepth", "computePointNormals", "renderImage(Depth)", "renderImage(Points)", "renderTangentColors", "cloud_to_depth"};
+static unsigned g_forward_calls[20];
 #define DF_FORWARD(i) (++g_forward_calls[i])
-extern "C" int hip_bridge_forward_report(char* buf, int cap)       // "ran/19: name=count ..." ; returns the number of forwards that ran
+extern "C" int hip_bridge_forward_report(char* buf, int cap)       // "ran/20: name=count ..." ; returns the number of forwards that ran
 {
     int ran = 0, o = 0;
-    for (int i = 0; i < 19; ++i) ran += g_forward_calls[i] ? 1 : 0;
-    o += std::snprintf(buf + o, o < cap ? cap - o : 0, "%d/19:", ran);
-    for (int i = 0; i < 19; ++i) o += std::snprintf(buf + (o < cap ? o : cap), o < cap ? cap - o : 0, " %s=%u", g_forward_names[i], g_forward_calls[i]);
+    for (int i = 0; i < 20; ++i) ran += g_forward_calls[i] ? 1 : 0;
+    o += std::snprintf(buf + o, o < cap ? cap - o : 0, "%d/20:", ran);
+    for (int i = 0; i < 20; ++i) o += std::snprintf(buf + (o < cap ? o : cap), o < cap ? cap - o : 0, " %s=%u", g_forward_names[i], g_forward_calls[i]);
     return ran;
 }
 
@@ -209,7 +209,8 @@ void kfusion::device::renderTangentColors(const Normals& normals, Image& image) 
     DF_CHK(dfusion_render_tangent_colors((const float*)normals.ptr(), normals.step(), normals.cols(), normals.rows(), (unsigned char*)image.ptr(),
                                          image.step(), 0));
 }
-void kfusion::device::cloud_to_depth(const Points&, Depth)                                                          // imgproc.cu:296
+void kfusion::device::cloud_to_depth(const Points& cloud, Depth depth)                                              // imgproc.cu:296
 {
-    kfusion::cuda::error("hip_bridge: device::cloud_to_depth is not part of the C-ABI", __FILE__, __LINE__, "");
+    DF_FORWARD(19);
+    DF_CHK(dfusion_cloud_to_depth((const float*)cloud.ptr(), cloud.step(), depth.ptr(), depth.step(), cloud.cols(), cloud.rows(), 0));
 }

@@ -15,7 +15,7 @@
 // called directly.  out.bin continues (W = cols, H = rows, h = half sizes):
 //   bilateral u16[H*W], truncated u16[H*W], pyramid u16[h*w], masked depth u16[H*W] + normals f32[H*W*4], points f32[H*W*4] + normals f32[H*W*4]
 //   (computePointNormals), resized depth u16[h*w] + normals f32[h*w*4], resized points f32[h*w*4] + normals f32[h*w*4], three images u8[H*W*4],
-//   psdf distances f32[H*W] + dists after u16[H*W], direct call: points f32[H*W*4] + dists after u16[H*W].
+//   psdf distances f32[H*W] + dists after u16[H*W], direct call: points f32[H*W*4] + dists after u16[H*W], cloudToDepth of the points u16[H*W].
 // The last stdout line reports which forwards ran (hip_bridge_forward_report).
 #include <cstdio>
 #include <cstdlib>
@@ -165,6 +165,10 @@ int main(int argc, char** argv)
         device::project_and_remove(view, (device::Points&)p4, proj);
         cuda::waitAllDefaultStream();
         put_f4(p4); put_u16(d3);
+        cuda::Depth c2d;
+        cuda::cloudToDepth(pc, c2d);                                                 // imgproc.cpp:98-103 -> device::cloud_to_depth (no caller in the reference)
+        cuda::waitAllDefaultStream();
+        put_u16(c2d);
         (void)hr; (void)hc;
     }
     std::fclose(out);

@@ -380,6 +380,38 @@ def test_cxx_zslab_collectives_with_more_than_one_rank(tmp_path, world, mode, ro
         assert planes.shape[0] == zn and np.array_equal(planes, vol[z0:z0 + zn])
 
 
+def test_cxx_warp_field_dqb_equals_reference_classes(tmp_path):
+    """WarpField::DQB / getWeightsAndUpdateKNN / weighting of the C++ mirror (round 6; warp_field.hpp:66-72): the k-NN comes from the GPU
+    (dfusion_knn), the weights and the blend are the reference's expressions on the host.  1000 points around 300 nodes with
+    non-trivial transforms and per-node dg_w: every blend equals WarpField::DQB of the REFERENCE's classes (nanoflann + warp_field.cpp
+    :203-241 through oracle/_ref) bit for bit; so do the weights and the neighbour lists against the oracle's k-NN."""
+    build.build_host()
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=300, k=8)
+    sc = Scene(cfg, n_frames=2)
+    rng = np.random.RandomState(5)
+    pts = (sc.pos[rng.randint(0, cfg.nodes, 1000)] + rng.normal(0, 0.05, (1000, 3))).astype(F32)
+    fin, fout = str(tmp_path / "dqb_in.bin"), str(tmp_path / "dqb_out.bin")
+    with open(fin, "wb") as f:
+        f.write(np.array([cfg.nodes, pts.shape[0], cfg.k], np.uint32).tobytes())
+        f.write(sc.pos.astype(F32).tobytes()); f.write(sc.dqs[1].astype(F32).tobytes()); f.write(sc.sigma.astype(F32).tobytes()); f.write(pts.tobytes())
+    r = subprocess.run([build.HOST_WARP_TESTS, "dqb", fin, fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "warp_tests dqb ok" in r.stdout, r.stdout + r.stderr
+    raw = np.fromfile(fout, np.uint8)
+    n, k = pts.shape[0], cfg.k
+    got = raw[:32 * n].view(F32).reshape(n, 8)
+    w = raw[32 * n:32 * n + 4 * n * k].view(F32).reshape(n, k)
+    ids = raw[32 * n + 4 * n * k:].view(np.uint32).reshape(n, k)
+    have_ref = O.have_ref()
+    want = O.dqb(sc.pos, sc.dqs[1], sc.sigma, pts, k, use_ref=have_ref)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%d of %d blends differ" % (int((got.view(np.uint32) != want.view(np.uint32)).any(1).sum()), n)
+    idx, d2 = O.knn(sc.pos, pts, k, use_ref=have_ref)
+    assert np.array_equal(ids.astype(np.int64), idx.astype(np.int64))
+    sg = sc.sigma[idx].astype(F32)
+    ww = np.exp((-d2.astype(F32) / (F32(2) * sg * sg)).astype(np.float64)).astype(F32)     # the argument in float, the exponential in double (warp_field.cpp:240)
+    assert np.array_equal(w.view(np.uint32), ww.view(np.uint32))
+    assert len(np.unique(got[:, 0])) > 100                                  # (not all the identity)
+
+
 def test_cxx_reference_warp_test_suites():
     """The reference's own solver tests (tests/ceres_warp_test.cpp, tests/warp_test.cpp) compiled against the C++ mirror: same
     WarpField calls and inputs, same 1e-3 bound (WarpAndReverseTest: the data term's least-squares optimum, see the source)."""

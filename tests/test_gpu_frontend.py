@@ -49,6 +49,14 @@ def test_front_end_images_match_oracle(cfg):
     # truncation (in place)
     t = frontend.depthTruncation(gd[0].clone(), 1.2)
     assert np.array_equal(download_u16(t), O.truncate_depth(cd[0], 1.2)) and (download_u16(t) == 0).sum() > (cd[0] == 0).sum()
+    # cloudToDepth (imgproc.cpp:98-103; round 6): the points image back to millimetres -- NaN points (no depth) give 0, values past the
+    # ushort range saturate, negative ones give 0 (the reference target's float -> ushort conversion)
+    c2d = frontend.cloudToDepth(gv[0])
+    assert np.array_equal(download_u16(c2d), O.cloud_to_depth(cv[0])) and (download_u16(c2d) > 0).sum() > 1000
+    edge = torch.tensor([[[0, 0, 70.0, 0], [0, 0, -1.0, 0], [0, 0, float("nan"), 0], [0, 0, 65.5349, 0], [0, 0, 0.0009999, 0], [0, 0, float("inf"), 0],
+                          [0, 0, 1.2345678, 0], [0, 0, 65.535, 0]]], dtype=torch.float32, device="cuda")
+    got_edge = download_u16(frontend.cloudToDepth(edge))
+    assert np.array_equal(got_edge, O.cloud_to_depth(edge.cpu().numpy())) and list(got_edge[0][:3]) == [65535, 0, 0] and got_edge[0][5] == 65535
     # USE_DEPTH build: normals + depth mask, resizeDepthNormals
     gm = gd[0].clone()
     gnm = frontend.computeNormalsAndMaskDepth(intr, gm)

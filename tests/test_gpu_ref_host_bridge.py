@@ -9,11 +9,11 @@ C-ABI of libdfusion_hip.so.  That is the patch a maintainer of the reference wou
   * GPU: the binary (built in the container, travelled with the snapshot) runs kfusion::cuda::TsdfVolume::{clear, integrate, raycast x2,
     compute_points, compute_normals} and cuda::computeDists of the reference on the MI355X, and every output equals the oracle's bit for
     bit (kfusion/src/tsdf_volume.cpp:89-174,184-220,312-324; kinfu.cpp:226,248,297,398-399);
-  * round 6: ALL 19 forwards of the bridge run -- the front-end through the reference's own imgproc.cpp wrappers
+  * round 6: ALL 20 forwards of the bridge run -- the front-end through the reference's own imgproc.cpp wrappers
     (depthBilateralFilter, depthTruncation, depthBuildPyramid, computeNormalsAndMaskDepth, computePointNormals, resizeDepthNormals,
-    resizePointsNormals, renderImage x 2, renderTangentColors) with NON-SQUARE intrinsics, TsdfVolume::psdf (tsdf_volume.cpp:266-292) ->
+    resizePointsNormals, renderImage x 2, renderTangentColors, cloudToDepth) with NON-SQUARE intrinsics, TsdfVolume::psdf (tsdf_volume.cpp:266-292) ->
     device::project_and_remove, and the overload nothing in the reference calls, directly -- each output equal to the oracle's bit for
-    bit; the binary reports which forwards ran and the test asserts 19 of 19."""
+    bit; the binary reports which forwards ran and the test asserts 20 of 20."""
 import os
 import subprocess
 import sys
@@ -72,7 +72,7 @@ def test_reference_tsdf_volume_class_on_the_gpu_matches_oracle(tmp_path):
     rep_line = [ln for ln in r.stdout.splitlines() if ln.startswith("hip_bridge forwards ")]
     assert rep_line, r.stdout
     print(rep_line[-1])
-    assert rep_line[-1].split()[2] == "19/19:", rep_line[-1]                 # every kfusion::device::* forward of the bridge ran
+    assert rep_line[-1].split()[2] == "20/20:", rep_line[-1]                 # every kfusion::device::* forward of the bridge ran
     assert "=0" not in rep_line[-1]
     raw = np.fromfile(fout, np.uint8)
     nv, npx = int(np.prod(cfg.dims)), cfg.rows * cfg.cols
@@ -96,6 +96,7 @@ def test_reference_tsdf_volume_class_on_the_gpu_matches_oracle(tmp_path):
     im1 = take(4 * npx, np.uint8, (H, W, 4)); im2 = take(4 * npx, np.uint8, (H, W, 4)); im3 = take(4 * npx, np.uint8, (H, W, 4))
     ro = take(4 * npx, F32, (npx,)); d2_after = take(2 * npx, np.uint16, (H, W))
     p4 = take(16 * npx, F32, (npx, 4)); d3_after = take(2 * npx, np.uint16, (H, W))
+    c2d = take(2 * npx, np.uint16, (H, W))
     assert o == len(raw)
 
     # the oracle on the same inputs, with the host arithmetic of the OpenCV stand-in (= the mirror's: cxx_inv / cxx_mul) for
@@ -149,5 +150,9 @@ def test_reference_tsdf_volume_class_on_the_gpu_matches_oracle(tmp_path):
     o_p4, o_after, o_ro, n_in = O.project_and_remove(dists2, w4, intr2)
     assert n_in > 1000
     assert np.array_equal(u(ro), u(o_ro)) and np.array_equal(d2_after, o_after) and (o_after != dists2).sum() > 1000
-    # ---- the non-const overload, called directly: the rewritten points and the same removal
-    assert np.array_equal(u(p4), u(o_p4)) and np.array_equal(d3_after, o_after)
+    # ---- the non-const overload, called directly on the cast's float4 image as it is (a miss is NaN in all four components and stays
+    # untouched; psdf above rebuilt its points with w = 0): the rewritten points and the same removal
+    o_p4, o_after3, _, _ = O.project_and_remove(dists2, pts.reshape(-1, 4), intr2)
+    assert np.array_equal(u(p4), u(o_p4)) and np.array_equal(d3_after, o_after3) and np.array_equal(o_after3, o_after)
+    # ---- cuda::cloudToDepth -> device::cloud_to_depth (round 6: the 20th forward)
+    assert np.array_equal(c2d, O.cloud_to_depth(o_pc)) and (c2d > 0).sum() > 1000 and (c2d == 0).any()

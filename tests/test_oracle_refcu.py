@@ -134,6 +134,11 @@ def test_frontend_kernels_equal_reference():
     t = d0.copy()
     R.refcu_truncate_depth(t, rows, cols, 1.3)                                                 # imgproc.cu:66-85
     assert np.array_equal(t, O.truncate_depth(d0, 1.3)) and (t == 0).sum() > (d0 == 0).sum()
+    # cloud_to_depth (imgproc.cu:273-282): back-projected points of the frame (NaN where there is no depth) -> depth in mm
+    pc, _ = O.compute_point_normals(ob, np.array(cfg.intr, F32))
+    c2d = np.zeros((rows, cols), np.uint16)
+    R.refcu_cloud_to_depth(pc.reshape(-1), rows, cols, c2d)
+    assert np.array_equal(c2d, O.cloud_to_depth(pc)) and np.isnan(pc[..., 2]).any() and (c2d > 0).sum() > 1000 and not c2d[np.isnan(pc[..., 2])].any()
     pyr = np.zeros((rows // 2, cols // 2), np.uint16)
     R.refcu_depth_pyramid(ob, rows, cols, 0.04, pyr)                                           # imgproc.cu:94-136
     assert np.array_equal(pyr, O.depth_pyramid(ob, 0.04))
