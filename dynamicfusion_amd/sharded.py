@@ -273,6 +273,77 @@ def slab_bounds(Z, world, halo=0, weights=None):
     return b
 
 
+def slab_costs(bounds, weights, halo=0):
+    """What each rank sweeps under halo RECOMPUTE (bench.py's default): the weights of its own planes AND of the `halo` planes it
+    integrates either side of them (clipped to the volume)."""
+    w = np.asarray(weights, np.float64).reshape(-1)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    Z = w.size
+    return [float(cum[min(Z, bounds[r + 1] + halo)] - cum[max(0, bounds[r] - halo)]) for r in range(len(bounds) - 1)]
+
+
+def slab_bounds_minmax(Z, world, halo, weights, count_halo=True):
+    """Boundaries that minimise the LARGEST per-rank cost (slab_costs: own planes + the halo planes the rank integrates itself) instead of
+    equalising the own planes' shares (slab_bounds): interior ranks carry two halos, the outer ones one, and at 8 ranks the 16 halo planes are
+    a quarter of a 64-plane slab -- equal own shares left max / mean = 1.21 on the headline scene (profiles/r05_scale_model_512_measured.txt).
+    Exact for the given granularity (multiples of 8 planes): a binary search on the bound T with a greedy left-to-right packing -- rank r
+    takes planes until one more step would put its cost above T."""
+    w = np.asarray(weights, np.float64).reshape(-1)
+    assert w.size == Z and (w >= 0).all()
+    step = 8 if Z % 8 == 0 else 1
+    min_planes = (max(int(halo), step) + step - 1) // step * step
+    H = int(halo) if count_halo else 0
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+
+    def cost(z0, z1):
+        return cum[min(Z, z1 + H)] - cum[max(0, z0 - H)]
+
+    def pack(T):
+        b = [0]
+        for r in range(world - 1):
+            z0 = b[-1]
+            hi = Z - (world - 1 - r) * min_planes               # every later rank keeps its minimum
+            z1 = z0 + min_planes
+            if z1 > hi:
+                return None
+            while z1 + step <= hi and cost(z0, z1 + step) <= T:
+                z1 += step
+            if cost(z0, z1) > T and z1 > z0 + min_planes:       # (cannot happen: the loop only grows while under T)
+                return None
+            b.append(z1)
+        b.append(Z)
+        return b if cost(b[-2], Z) <= T and all(cost(b[r], b[r + 1]) <= T for r in range(world)) else None
+
+    lo, hi = 0.0, float(cum[-1]) + 1.0
+    best = pack(hi)
+    if best is None:                                        # (the minimum slab thickness alone does not fit: equal shares)
+        return slab_bounds(Z, world, halo, weights)
+    for _ in range(48):
+        mid = 0.5 * (lo + hi)
+        b = pack(mid)
+        if b is None:
+            lo = mid
+        else:
+            hi, best = mid, b
+    return best
+
+
+def reweight_from_times(bounds, weights, halo, times_ms, fixed_ms=0.0):
+    """Second re-cut (round 6): per-plane weights corrected by what the ranks MEASURED.  Rank r swept cost_r = slab_costs(...)[r] of the
+    current weights in times_ms[r] (HIP events around its integrate, a few frames' mean); of that, fixed_ms is launch-sized work that
+    does not move with the slab.  The planes a rank owns are rescaled by (t_r - fixed) / cost_r -- what a unit of the a-priori weight
+    really costs there (far slabs hold more coded, denser blocks; a slab cut through a layer pays the whole layer's verdicts) -- and
+    the boundaries are then made again from the corrected weights.  One step of a fixed-point iteration; bench.py takes one."""
+    w = np.asarray(weights, np.float64).reshape(-1).copy()
+    costs = slab_costs(bounds, w, halo)
+    t = np.maximum(np.asarray(times_ms, np.float64) - float(fixed_ms), 1e-6)
+    rate = np.array([t[r] / max(costs[r], 1e-12) for r in range(len(costs))])
+    rate /= rate.mean()
+    for r in range(len(costs)):
+        w[bounds[r]:bounds[r + 1]] *= rate[r]
+    return w
+
+
 def layer_weights_to_planes(w_layer, Z):
     """per-8-plane-layer work (e.g. alive block counts, WarpField.alive_blocks_per_layer summed over the ranks) -> one weight per plane
     for slab_bounds, with the same small floor frustum_plane_weights gives culled planes (plan kernels are not free)."""

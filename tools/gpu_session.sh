@@ -2,13 +2,13 @@
 # Measurement session of a round: tests, bench, rocprofv3 kernel trace, PMC passes, probes.  Everything lands in gpurun_out/ under
 # names prefixed with the round tag (default r03); copy what is to be judged into profiles/.
 set -u
-T=${1:-r05}
+T=${1:-r06}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${T}_pytest_gpu.txt | tail -3
 echo "== rocprof kernel trace of the bench command"
 rm -rf gpurun_out/prof gpurun_out/pmc gpurun_out/pmc_rigid
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kinfu > $R/gpurun_out/rocprof.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kinfu --no-other-configs > $R/gpurun_out/rocprof.log 2>&1)
 tail -1 gpurun_out/rocprof.log | cut -c1-200
 cp $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_kernel_stats.csv
 python tools/frame_trace.py $(find gpurun_out/prof -name "*kernel_trace.csv" | head -1) > gpurun_out/${T}_frame_trace.txt 2>&1; head -3 gpurun_out/${T}_frame_trace.txt
@@ -21,6 +21,12 @@ done
 python tools/pmc_summary.py gpurun_out/pmc --last 20 --json gpurun_out/pmc_latest.json --config 512 --tag "round ${T#r0}" > gpurun_out/${T}_pmc_512.txt 2>&1; tail -3 gpurun_out/${T}_pmc_512.txt
 cp gpurun_out/pmc_latest.json profiles/pmc_latest.json      # bench.py reads roofline.traffic from here (this run's counters, stamped with the source's sha256)
 echo "== bench 512 (the driver's command)"; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/${T}_bench_512.json; cut -c1-400 gpurun_out/${T}_bench_512.json
+echo "== A/B against round 5's library (build/libdfusion_hip_r05.so: git archive f5aaea7 | hipcc), same box, interleaved"
+if [ -f build/libdfusion_hip_r05.so ]; then
+  (timeout 300 python tools/ab_rounds.py 512 r05 2>&1 | grep -v amdgpu.ids) | tee gpurun_out/${T}_ab_r05_512.txt
+  (timeout 300 python tools/ab_rounds.py 512 --nodes 8000 r05 2>&1 | grep -v amdgpu.ids) | tee gpurun_out/${T}_ab_r05_512_nodes8000.txt
+  (timeout 600 python tools/ab_rounds.py 1024 r05 2>&1 | grep -v amdgpu.ids) | tee gpurun_out/${T}_ab_r05_1024.txt
+fi
 echo "== A/B: look-ahead builds on / off, same box"; bash tools/ab_bench.sh ${T} "" "--no-prefetch" 2 > /dev/null; cat gpurun_out/${T}_ab_bench.txt
 echo "== bench 256"; timeout 300 python bench.py --steps 40 --warmup 5 --config 256 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/${T}_bench_256.json; cut -c1-300 gpurun_out/${T}_bench_256.json
 echo "== bench 1024 (the 8-GPU stress config on ONE GPU)"; timeout 900 python bench.py --steps 10 --warmup 2 --config 1024 --no-kinfu 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/${T}_bench_1024.json; cut -c1-300 gpurun_out/${T}_bench_1024.json

@@ -70,9 +70,12 @@ def main():
         torch.cuda.empty_cache()
     rows = []
     for n in (1, 2, 4, 8):
+      # `measured` (round 6): boundaries that minimise the largest rank's cost, halos included (slab_bounds_minmax), then ONE more
+      # re-cut from the per-rank integrate times this loop has just measured (sharded.reweight_from_times) -- what bench.py's ranks do
+      bounds = (sharded.slab_bounds_minmax(Z, n, halo, wts) if kind == "measured" else sharded.slab_bounds(Z, n, halo, wts if kind == "balanced" else None)) if n > 1 else [0, Z]
+      for attempt in range(2 if (kind == "measured" and n > 1) else 1):
         worst = {"integrate": 0.0, "march": 0.0, "shade": 0.0, "sum": 0.0}
         per_rank = []
-        bounds = sharded.slab_bounds(Z, n, halo, wts if (kind in ("balanced", "measured") and n > 1) else None)
         for r in range(n):
             z0, zn = bounds[r], bounds[r + 1] - bounds[r]
             vol = TsdfVolume(cfg.dims, slab=(z0, zn, halo if n > 1 else 0))
@@ -94,13 +97,22 @@ def main():
                 worst = {"integrate": t_i, "march": t_m, "shade": t_s, "sum": t_i + t_m + t_s}
             del wf, vol, vint
             torch.cuda.empty_cache()
+        if attempt == 0 and kind == "measured" and n > 1:
+            t_ms = [1e3 * p[0] for p in per_rank]
+            first = {"bounds": bounds, "per_rank_integrate_ms": t_ms}
+            b2 = sharded.slab_bounds_minmax(Z, n, halo, sharded.reweight_from_times(bounds, wts, halo, t_ms, 0.045))
+            if b2 == bounds or max(t_ms) <= 1.08 * float(np.mean(t_ms)):
+                break
+            bounds = b2
+      if True:
         comm = {k: collective(k, sizes[k], n) for k in sizes}
         t_frame = worst["sum"] + sum(comm.values())
         comm["all_to_all"] = collective("all_to_all", sizes["reduce"], n)      # round 5: the direct form of the second collective (bench.py --merge a2a)
         t_frame_a2a = t_frame - comm["reduce"] + comm["all_to_all"]
         rows.append({"n": n, "halo": halo if n > 1 else 0, "slabs": kind, "bounds": bounds, "kernels_ms": {k: 1e3 * v for k, v in worst.items()},
                      "collectives_ms": {k: 1e3 * v for k, v in comm.items()}, "frame_ms": 1e3 * t_frame, "frames_per_s": 1.0 / t_frame, "frame_ms_a2a": 1e3 * t_frame_a2a,
-                     "per_rank_integrate_ms": [1e3 * p[0] for p in per_rank]})
+                     "per_rank_integrate_ms": [1e3 * p[0] for p in per_rank],
+                     "first_cut": first if (kind == "measured" and n > 1) else None})
     base = rows[0]["frames_per_s"]
     print("| N | planes swept by the slowest rank's kernels: integrate / march / shade (ms, measured on one GPU) | broadcast / all_reduce(MIN) / reduce(SUM) (ms, model) | frame (ms) | frames/s | speed-up |")
     print("|---|---|---|---|---|---|")
