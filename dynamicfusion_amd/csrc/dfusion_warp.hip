@@ -19,7 +19,9 @@
 #include "dfusion_internal.h"
 #include "dfusion_pyramid.h"
 #include <atomic>
+#include <mutex>
 #include <utility>
+#include <vector>
 #include <stdlib.h>
 #include <stdio.h>
 #include <math.h>
@@ -1840,6 +1842,21 @@ __device__ __forceinline__ DfBlendSums dqb_sums_codes(const DfTabRaw<8>& r, unsi
     return S;
 }
 
+// the lane's number in its wave, made where it is used (two mbcnt instructions) instead of living in a register
+__device__ __forceinline__ unsigned df_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// ... and in a form the optimiser cannot hoist out of a loop and keep (or spill) for the loop's whole life: two instructions per use
+__device__ __forceinline__ unsigned df_lane_id_here()
+{
+    unsigned r;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(r));
+    return r;
+}
+// buffer descriptor of one volume plane (raw: stride 0, num_records in bytes; out-of-range lanes read 0 / store nothing)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t df_plane_rsrc(uint32_t* plane_ptr, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)df_wave_uniform(plane_ptr), (short)0, (int)bytes, 0x00020000);
+}
+
 // The launch plan of the pipelined sweep.  One wave per strip item: lane = (patch p = lane / 16, layer l = lane % 16) judges the
 // 8 x 8 x 8 voxels of its patch and layer (the verdict costs ~200 instructions; in the sweep itself it held a workgroup's LDS while
 // it ran); the ballot is the item's mask, its population count w the item's work.  Alive items go into bin w (bins[w * n_items ...],
@@ -1920,31 +1937,37 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? DF_EXP
     extern __shared__ __attribute__((aligned(16))) float4 s_lds[];      // LDSN: [2M] rot_j, node_t_j interleaved; else [waves][8][16][2] union copies
     constexpr bool CODES = !LDSN && K == 8;
     static_assert(!CODES || U == 1, "a coded batch lies in one half layer");
-    constexpr unsigned SPW = WGT >= 256 ? WGT / 256 : 1;                   // strip items per workgroup
-    // entry e of the plan = the e-th item counting the bins from the fullest down: lane j holds the count of bin 64 - j and the
-    // running total up to and including it
-    const unsigned bin_cnt = a.plan_cnt[DF_PLAN_BINS - 1 - (threadIdx.x & 63)];
-    unsigned bin_end = bin_cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(bin_end, o, 64); if ((int)(threadIdx.x & 63) >= o) bin_end += t; }
-    const unsigned n_alive = (unsigned)__builtin_amdgcn_readlane((int)bin_end, 63);
-    if (blockIdx.x * SPW >= n_alive) return;                               // past the end of the plan (the grid is sized for every strip)
-#ifdef DF_TRACE_WG
-    const unsigned long long t_start = wall_clock64();
-#endif
+    constexpr unsigned SPW = WGT >= 256 ? WGT / 256 : 1;                   // strip items per group of NW waves
+    constexpr unsigned NW = WGT / 64;
+    // ---- what a wave works on: plan entries (strip items, fullest bins first) are taken SPW at a time -- a GROUP, one per workgroup -- and a
+    // group's alive cells are dealt out over the workgroup's NW waves in equal SHARES (see below).
+    // (Round 6 measured the alternative -- a RESIDENT grid whose waves each take (group, share) units from an atomic cursor, no workgroup
+    // launches after the first fill: 0.623 against 0.582 ms, same box, profiles/r06_ab_resident.txt.  A wave's time for a unit is set by how
+    // many waves share its SIMD; workgroups put one equal share on each of a CU's four SIMDs, free-running waves do not, and the launch
+    // ended on a 200 us tail of overloaded SIMDs.  What the timeline's unfilled slots were -- ~14 % -- is not the dispatcher but every
+    // unit's start: five dependent trips to memory, plan to bins to masks to union lists to node records, before the first blend.)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // in an SGPR: what follows from it stays scalar
+    const unsigned group = blockIdx.x, share = (unsigned)wave;
     if ((unsigned)(size_t)(df_lds_cf4*)s_lds != 0u) __builtin_trap();    // the blend addresses the LDS from address 0
     if constexpr (LDSN) {
         for (int j = threadIdx.x; j < W.M; j += WGT) { s_lds[2 * j] = W.rot[j]; s_lds[2 * j + 1] = W.node_t[j]; }
         __syncthreads();
     }
     const df_global_ptr<const char> rt_g = (df_global_ptr<const char>)df_wave_uniform(reinterpret_cast<const char*>(W.rt));
-
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), ln = threadIdx.x & 63;    // in an SGPR: what follows from it stays scalar
     const size_t plane = (size_t)a.X * a.Y;
     const int own1 = min(a.z_own0 + a.z_own_n, a.Z);
     const unsigned pitch24 = (unsigned)a.P.pitch;                          // rows, pitch < 2^24 (checked by the launcher): 24-bit multiply
     unsigned int wave_upd = 0;                                             // (a wave-level count: ballots, no lane register)
+    // entry e of the plan = the e-th item counting the bins from the fullest down: lane j holds the count of bin 64 - j and the
+    // running total up to and including it
+    const unsigned bin_cnt = a.plan_cnt[DF_PLAN_BINS - 1 - df_lane_id_here()];
+    unsigned bin_end = bin_cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(bin_end, o, 64); if ((int)df_lane_id() >= o) bin_end += t; }
+    const unsigned n_alive = (unsigned)__builtin_amdgcn_readlane((int)bin_end, 63);
+    if (group * SPW >= n_alive) return;                                    // past the end of the plan (the grid is sized for every strip; no barrier follows)
 #ifdef DF_TRACE_WG
+    const unsigned long long t_start = wall_clock64();
     unsigned n_layers = 0;
 #endif
     // ---- the workgroup's work, dealt out evenly (round 4).  A workgroup takes SPW strip items = 4 SPW patches x <= 16 layers of alive
@@ -1953,13 +1976,12 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? DF_EXP
     // the workgroup's patches form ONE sequence (item, patch, layer, half-layer of 4 planes) and wave w takes the w-th of WGT / 64
     // equal shares of it: a run of layers of one patch, or the tail of one patch and the head of the next -- SEGMENTS, each walked by
     // the pipelined loop below as before.  Which voxel is updated by which wave changes; what is computed for it does not.
-    constexpr unsigned NW = WGT / 64;
     unsigned items_s[SPW]; unsigned long long masks_s[SPW];
     unsigned long long cmask_s[SPW];
     unsigned total2 = 0;
 #pragma unroll
     for (unsigned s_ = 0; s_ < SPW; ++s_) {
-        const unsigned sidx = blockIdx.x * SPW + s_;
+        const unsigned sidx = group * SPW + s_;
         items_s[s_] = 0u; masks_s[s_] = 0ull;
         cmask_s[s_] = 0ull;
         if (sidx < n_alive) {
@@ -1977,7 +1999,7 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? DF_EXP
             }
         }
     }
-    const unsigned c0 = total2 * (unsigned)wave / NW, c1 = total2 * ((unsigned)wave + 1u) / NW;      // this wave's half-layer cells [c0, c1)
+    const unsigned c0 = total2 * share / NW, c1 = total2 * (share + 1u) / NW;      // this unit's half-layer cells [c0, c1)
     unsigned pre = 0;
 #pragma unroll 1
     for (unsigned q = 0; q < SPW * 4u; ++q) {
@@ -2010,8 +2032,9 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? DF_EXP
     const unsigned tcol = item >> 1;
     const int tx = (int)(tcol % (unsigned)tiles_x), ty = (int)((tcol / (unsigned)tiles_x) % (unsigned)a.plan_tiles_y);
     const int wv = (int)(item & 1u) * 4 + wave_patch;
-    const int x = tx * DF_ROW_TX + (wv & 3) * 8 + (ln & 7);
-    const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (ln >> 3);
+    const int lnq = (int)df_lane_id_here();                               // (per segment: nothing of the lane's number is kept across segments)
+    const int x = tx * DF_ROW_TX + (wv & 3) * 8 + (lnq & 7);
+    const int y = ty * DF_LDS_TY + (wv >> 2) * 8 + (lnq >> 3);
     const bool in_xy = x < a.X && y < a.Y;
     const int xc = min(x, a.X - 1), yc = min(y, a.Y - 1);                 // clamped: out-of-volume lanes read valid entries, write nothing
     const float fxv = (float)x * a.vsx, fyv = (float)y * a.vsy;
@@ -2036,9 +2059,12 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? DF_EXP
         // table address = (workgroup-uniform record index: tile column + tile layer + plane in tile) + (loop-invariant 32-bit lane
         // offset inside the tile plane): the uniform part stays in SGPRs and the loads take the saddr + voffset form instead of
         // a 64-bit VALU address per load
-        // (the lane's BYTE offset in a volume plane, 32 bits: scalar plane base + zero-extended lane offset is then the load's / store's
-        // saddr form -- an element index would be scaled after the extension, a 64-bit VALU address per access and a register pair)
+        // (the lane's BYTE offset in a volume plane, 32 bits.  The voxel word is read and written through a BUFFER descriptor of its plane
+        // -- four scalar registers made from the plane's address -- with this offset in one VGPR: the global_load / _store forms of the same
+        // access took a 64-bit VALU address per access and a register pair for the zero-extended offset, because the extension is hoisted
+        // out of the loop and instruction selection then no longer sees scalar base + 32-bit offset.)
         const unsigned lane_vox4 = (unsigned)(yc * a.X + xc) * 4u;
+        const unsigned plane_bytes = (unsigned)plane * 4u;                // (< 2^32: dims[0] * dims[1] < 2^30, checked by the launcher)
         const unsigned lane_tab = df_tab_in_plane(xc, yc);
         const size_t tile_col = (size_t)(yc / DF_TAB_TY) * a.tab_ntx + (size_t)(xc / DF_TAB_TX);      // == (ty, tx) of the workgroup: uniform
         const size_t tile_col_u = (size_t)__builtin_amdgcn_readfirstlane((int)tile_col);
@@ -2063,7 +2089,7 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? DF_EXP
         const unsigned coded_alive = CODES ? (alive & cbits) : 0u;
         // (the block of the wave's patch in layer l, from scalars: tile column, patch number)
         const unsigned blk_x = (unsigned)tx * (DF_ROW_TX / 8) + ((unsigned)wv & 3u), blk_y = (unsigned)ty * (DF_LDS_TY / 8) + ((unsigned)wv >> 2);
-        auto lane_id = [&]() -> unsigned { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };   // (recomputed where used: no register held across the loop)
+        auto lane_id = [&]() -> unsigned { return df_lane_id(); };       // (recomputed where used: no register held across the loop)
         auto ids_load = [&](int l) -> unsigned {
             const size_t blk = ((size_t)(unsigned)(lt0 + l - a.tab_z0 / DF_ROW_TZ) * (unsigned)a.bm_nby + blk_y) * (unsigned)a.bm_nbx + blk_x;
             return *((df_global_ptr<const uint32_t>)(a.bm_ids + blk * 64) + lane_id());
@@ -2110,10 +2136,8 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? DF_EXP
                 const float sdf = Dp - pend.vn[u];                                            // :89
                 const bool upd = pend.ok[u] & (Dp != 0.f) & (sdf >= -a.P.trunc);              // :86, :91
                 wave_upd += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(upd));
-                if (upd) {
-                    df_global_ptr<char> vp = (df_global_ptr<char>)df_wave_uniform(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane) + lane_vox4;
-                    *(df_global_ptr<uint32_t>)vp = tsdf_fuse(pend.vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight);   // :93
-                }
+                if (upd) __builtin_amdgcn_raw_buffer_store_b32(tsdf_fuse(pend.vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight),       // :93
+                                                               df_plane_rsrc(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane, plane_bytes), lane_vox4, 0, 0);
             }
         };
         // one batch: consumes S (tables of batch (l, z0)), then refills S with the tables of batch (l2, z2)
@@ -2185,7 +2209,7 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? DF_EXP
                 // the voxel word is only needed if the voxel projects into the image (the finish is a batch away: time enough), and
                 // whole 32-byte runs of lanes that do not are not fetched at all
                 uint32_t vw = 0u;
-                if (ok[u]) vw = *(df_global_ptr<const uint32_t>)((df_global_ptr<const char>)df_wave_uniform(a.vol + (size_t)(zv[u] - a.z_store0) * plane) + lane_vox4);   // uniform plane base + lane offset
+                if (ok[u]) vw = __builtin_amdgcn_raw_buffer_load_b32(df_plane_rsrc(a.vol + (size_t)(zv[u] - a.z_store0) * plane, plane_bytes), lane_vox4, 0, 0);
                 pend.vn[u] = vn; pend.dpb[u] = dpb[u]; pend.vox[u] = vw; pend.z[u] = zv[u]; pend.ok[u] = ok[u];
             }
         };
@@ -2205,18 +2229,18 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? DF_EXP
 #ifdef DF_TRACE_WG
     n_layers += __popc(alive);
 #endif
-    }                                                                       // (the next segment of this wave)
+    }                                                                       // (the next segment of this unit)
 #ifdef DF_TRACE_WG
     {
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        if (ln == 0) {
-            unsigned long long* t = a.trace + ((size_t)blockIdx.x * (WGT / 64) + (threadIdx.x >> 6)) * 4;
+        if (df_lane_id_here() == 0u) {
+            unsigned long long* t = a.trace + ((size_t)group * NW + share) * 4;
             t[0] = t_start; t[1] = wall_clock64(); t[2] = ((unsigned long long)xcc << 32) | hw; t[3] = (unsigned long long)n_layers;
         }
     }
 #endif
-    if (a.n_upd && ln == 0 && wave_upd) atomicAdd(a.n_upd, (unsigned long long)wave_upd);
+    if (a.n_upd && df_lane_id_here() == 0u && wave_upd) atomicAdd(a.n_upd, (unsigned long long)wave_upd);
 }
 
 // max dists value over the image (for the cull's depth test); `out` zeroed on the stream first.
@@ -2603,7 +2627,7 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
     const bool no_lds = (flags & DF_WARP_NO_LDS) != 0;
     const bool lds_fits = (size_t)wf->M * 32 <= lds_limit;
     const bool pipe_form_ok = use_w && !(flags & DF_WARP_NO_PIPELINE) && pitch < (1u << 24) && rows < (1 << 24) &&
-                              (unsigned long long)rows * pitch < (1ull << 32);
+                              (unsigned long long)rows * pitch < (1ull << 32) && (unsigned long long)v.dims[0] * v.dims[1] < (1ull << 30);
     const bool pipe_sweep = use_tab && !no_lds && pipe_form_ok && (k == 8 || k == 4);
 
     if (!(flags & DF_WARP_NO_CULL) && proj[0] > 0.f && proj[1] > 0.f) {
@@ -2663,7 +2687,10 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
         // LDS of a launch: the node table (32 B a node) for the kernels that keep one -- k = 4's pipelined sweep where it fits, the batched
         // kernel of the other k --, 4 KiB of union copies per wave for k = 8's, nothing for k = 4 without a table
         const bool k4_table = pipe_ok && k == 4 && lds_fits;
-        const size_t lds = !pipe_ok || k4_table ? (size_t)wf->M * 32 : k == 8 ? (size_t)(DF_PIPE_WGT / 64) * 4096 : 0;
+        size_t lds = !pipe_ok || k4_table ? (size_t)wf->M * 32 : k == 8 ? (size_t)(DF_PIPE_WGT / 64) * 4096 : 0;
+#ifdef DF_EXP_LDS_KB
+        if (pipe_ok && !k4_table) lds = (size_t)DF_EXP_LDS_KB * 1024;       // (measurement: fewer workgroups per CU)
+#endif
         typedef void (*lds_kernel_t)(const DfWarpedArgs, const DfWarpView, int);
         lds_kernel_t kern = nullptr;
         // tile layers per workgroup: long walks amortise the LDS fill and the pipeline ramp, short ones even out the last round of
@@ -2748,10 +2775,11 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
             // this plan's sweep: its number, and what it will read
             wf->plan_reader[wf->pphase] = wf->node_reader[wf->nphase] = ++wf->seq;
             const unsigned spw = wg_threads >= 256u ? wg_threads / 256u : 1u;
-            grid = dim3((n_items + spw - 1) / spw, 1);
+            const unsigned groups = (n_items + spw - 1) / spw;
+            grid = dim3(groups, 1);
 #ifdef DF_TRACE_WG
             static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;
-            const size_t trace_n = (size_t)grid.x * (wg_threads / 64u) * 4;
+            const size_t trace_n = (size_t)groups * (wg_threads / 64u) * 4;
             if (trace_n > trace_cap) { (void)hipFree(trace_dev); DF_HIP(hipMalloc((void**)&trace_dev, trace_n * 8)); trace_cap = trace_n; }
             DF_HIP(hipMemsetAsync(trace_dev, 0, trace_n * 8, st));
             a.trace = trace_dev;
@@ -2761,7 +2789,7 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
                 unsigned long long* h = (unsigned long long*)malloc(trace_n * 8);
                 DF_HIP(hipMemcpy(h, trace_dev, trace_n * 8, hipMemcpyDeviceToHost));
                 FILE* f = fopen(getenv("DF_TRACE_FILE"), "wb");
-                if (f) { unsigned long long hdr[4] = {grid.x, 1, (unsigned long long)(wg_threads / 64u), 0}; fwrite(hdr, 8, 4, f); fwrite(h, 8, trace_n, f); fclose(f); }
+                if (f) { unsigned long long hdr[4] = {groups, 1, (unsigned long long)(wg_threads / 64u), 0}; fwrite(hdr, 8, 4, f); fwrite(h, 8, trace_n, f); fclose(f); }
                 free(h);
             }
             DF_LAUNCH_CHECK();
