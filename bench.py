@@ -380,6 +380,39 @@ def kinfu_frame_ms(cfg, frames=12):
                     "2x WarpField::warp, psdf, fusion, extract, ray-cast, resize (device-resident data flow)"}
 
 
+def cxx_headline_ms(cfg, prime, warmup, steps, depths_np, cam_poses, pos, sigma):
+    """The headline frame through the C++ mirror (the north star's host is C++): dynamicfusion_amd/host/headless_frame `bench`
+    runs the same poses, depth images and node transforms -- prime + warmup untimed, `steps` timed, everything resident on the device before
+    its clock starts -- through kfusion::WarpField::setTransformsDevice + cuda::computeDists + cuda::TsdfVolume::integrateAsync(..., warp) +
+    raycast(Points), wall clock between two device synchronises."""
+    import re
+    import subprocess
+    import tempfile
+    from dynamicfusion_amd import build
+    build.build_host()
+    n = prime + warmup + steps
+    with tempfile.TemporaryDirectory() as td:
+        fin = os.path.join(td, "in.bin")
+        with open(fin, "wb") as f:
+            f.write(synth.aff12(cfg.volume_pose).tobytes())
+            f.write(np.asarray(cfg.intr, np.float32).tobytes())
+            for i in range(n):
+                f.write(np.ascontiguousarray(depths_np[i], np.uint16).tobytes())
+                f.write(synth.aff12(cam_poses[i]).tobytes())
+            f.write(np.ascontiguousarray(pos, np.float32).tobytes())
+            for i in range(n):
+                f.write(np.ascontiguousarray(synth.node_transforms(cfg, i), np.float32).tobytes())
+            f.write(np.ascontiguousarray(sigma, np.float32).tobytes())
+        r = subprocess.run([build.HOST_APP, "bench", str(cfg.dims[0]), str(cfg.size), str(cfg.cols), str(cfg.rows), str(n), str(cfg.nodes), str(cfg.k),
+                            str(prime), str(warmup), fin], capture_output=True, text=True, timeout=600)
+    m = re.search(r"cxx_host_ms_per_frame ([0-9.]+) over (\d+) frames", r.stdout)
+    if r.returncode != 0 or not m:
+        raise RuntimeError((r.stdout + r.stderr)[-300:])
+    return {"cxx_host_ms_per_frame": float(m.group(1)), "frames": int(m.group(2)),
+            "what": "the same %d timed poses through the C++ mirror (libkfusion_hip.so over the C-ABI): WarpField::setTransformsDevice + computeDists + "
+                    "TsdfVolume::integrateAsync(dists, pose, intr, warp) + raycast(Points), wall clock; compare with ms_per_step (Python mirror + ctypes)" % int(m.group(2))}
+
+
 def _imports():
     global torch, dist, Intr, TsdfVolume, WarpField, capi, compute_dists, sharded, synth, upload_u16
     import torch
@@ -939,6 +972,13 @@ def main():
             del lean
         except Exception as e:
             extra["frame_nodes_changed_ms"] = {"error": repr(e)[:200]}
+        # the headline frame itself through the C++ mirror
+        if not args.no_kinfu and cfg.dims[0] == cfg.dims[1] == cfg.dims[2]:
+            try:
+                extra["cxx_host"] = cxx_headline_ms(cfg, N_PRIME, args.warmup, args.steps, depths_np, cam_poses, pos, sigma)
+                extra["cxx_host"]["python_over_cxx"] = (1e3 * elapsed / args.steps) / extra["cxx_host"]["cxx_host_ms_per_frame"]
+            except Exception as e:      # the extras never fail the bench line
+                extra["cxx_host"] = {"error": str(e)[:200]}
         # one whole KinFu::operator() frame (front-end, ICP, dynamicfusion, ray-cast) through the C++ mirror, for context
         if not args.no_kinfu:
             try:

@@ -396,12 +396,8 @@ __device__ __forceinline__ void df_rigid_batches(const DfRigidArgs& a, f3& vc, f
 // for every column of the patch inside the volume, whatever the verdict will be (the sweep reads 1.26 x the words it writes), and
 // (b) batch b + 1 is projected and its four requests issued BEFORE batch b is decided, fused and stored: 2 U voxels in flight per
 // wave instead of U, and one wait per batch instead of two dependent ones.
-#ifndef DF_RIGID_STARTS
-#define DF_RIGID_STARTS 1       // chunk starts made once per column by the plan kernel (0: every chunk replays the additions from plane 0)
-#endif
-#ifndef DF_RIGID_LOOKAHEAD
-#define DF_RIGID_LOOKAHEAD 1
-#endif
+// (Chunk starts are made once per column by the plan kernel -- every chunk replaying the additions from plane 0 was the first form --
+// and the run is software-pipelined one batch ahead; both used to be compile-time switches.)
 template <int U> struct DfRigidPend { float Dp[U], d2[U], s[U]; uint32_t v[U]; bool ok[U]; };
 template <int U>
 __device__ __forceinline__ void df_rigid_issue(const DfRigidArgs& a, f3& vc, f3 zstep, const uint32_t* p, size_t plane, bool active, DfRigidPend<U>& P)
@@ -464,7 +460,6 @@ template <int U, bool COUNT>
 __device__ __forceinline__ void df_rigid_run_pipe(const DfRigidArgs& a, f3& vc, f3 zstep, uint32_t*& p, size_t plane, int n, bool active, unsigned int& my_upd)
 {
     const float sat_t = df_sat_threshold(a.P.trunc);
-#if DF_RIGID_LOOKAHEAD
     DfRigidPend<U> A, B;
     df_rigid_issue<U>(a, vc, zstep, p, plane, active, A);
     for (int z = U; z < n; z += 2 * U) {
@@ -479,60 +474,21 @@ __device__ __forceinline__ void df_rigid_run_pipe(const DfRigidArgs& a, f3& vc, 
     }
     df_rigid_finish<U, COUNT>(a, p, plane, A, sat_t, my_upd);
     p += (size_t)U * plane;
-#else
-    for (int z = 0; z < n; z += U) {
-        DfRigidPend<U> A;
-        df_rigid_issue<U>(a, vc, zstep, p, plane, active, A);
-        df_rigid_finish<U, COUNT>(a, p, plane, A, sat_t, my_upd);
-        p += (size_t)U * plane;
-    }
-#endif
 }
 
-#ifndef DF_RIGID_PX
 #define DF_RIGID_PX 32           // columns of a wave's patch along x (a power of two <= 64); 64 / DF_RIGID_PX rows
-#endif
 #define DF_RIGID_PY (64 / DF_RIGID_PX)
-#ifndef DF_RIGID_SUB
 #define DF_RIGID_SUB 8
-#endif
-#ifndef DF_RIGID_U
 #define DF_RIGID_U 2
-#endif
-#ifndef DF_RIGID_U_GENERIC
 #define DF_RIGID_U_GENERIC 2
-#endif
-#ifndef DF_RIGID_WAVES
 #define DF_RIGID_WAVES 8
-#endif
 #define DF_RIGID_MAX_SUBS 8      // sub-chunks per chunk (the plan's masks are bytes)
-#ifndef DF_RIGID_STRIP
 #define DF_RIGID_STRIP 1         // patches (waves) side by side in x per plan item: 1, 2 or 4 (a sweep workgroup = 4 waves = 4 / STRIP items)
-#endif
-#ifndef DF_RIGID_ZC
 #define DF_RIGID_ZC 32           // planes per chunk wanted (a multiple of DF_RIGID_SUB, <= DF_RIGID_SUB * DF_RIGID_MAX_SUBS)
-#endif
 #define DF_RIGID_BINS (DF_RIGID_STRIP * DF_RIGID_MAX_SUBS + 1)
-// Round 5: PAIRS.  Two x-adjacent 32 x 2 patches whose alive sub-chunks (nearly) coincide in a chunk are walked as two 64 x 1 ROWS instead:
-// the same voxels, but a wave then read-modify-writes ONE run of 256 contiguous bytes per plane instead of two of 128 -- the access
-// pattern tools/rmw_probe.hip measures at 6.3-6.6 TB/s against 4.4.  (Whole 64 x 1 patches everywhere were tried in round 3: a 64-wide
-// strip cuts the frustum's side planes more often, swept / updated 1.60 instead of 1.37, and the launch got slower.  Here the verdicts
-// stay those of the 32 x 2 patches; only pairs that would be swept together anyway change shape.)  A row item walks the UNION of the two
-// patches' masks; DF_RIGID_ROW_SLACK bounds what that may add: popc(a | b) * 2 - popc(a) - popc(b) half-patch sub-chunks.
-// MEASURED (round 5, same box, interleaved, volumes bit-identical; profiles/r05_ab_rigid_pairs.txt): 0.1123 ms with pairs against 0.1121
-// without, 0.1125 with slack 0, 0.1136 / 0.1143 with slack 2 / 4 -- the 256-byte runs buy nothing here, so the sweep is not bound by how
-// wide its row runs are after all (the probe's waves do nothing but read-modify-write; these wait for a dists gather per plane as
-// well).  Kept as a compile-time option, not the default.
-#ifndef DF_RIGID_PAIR
-#define DF_RIGID_PAIR 0
-#endif
-#ifndef DF_RIGID_ROW_SLACK
-#define DF_RIGID_ROW_SLACK 1
-#endif
-#define DF_RIGID_ROW_FLAG 0x100u
-#if DF_RIGID_PAIR && (DF_RIGID_STRIP != 1 || DF_RIGID_PX != 32 || !DF_RIGID_STARTS)
-#error "DF_RIGID_PAIR needs 32 x 2 patches, one patch per plan item and chunk starts from the plan kernel"
-#endif
+// (Round 5 built PAIRS -- two x-adjacent 32 x 2 patches whose alive sub-chunks coincide walked as two 64 x 1 rows, one 256-byte run per
+// plane instead of two of 128: 0.1123 ms against 0.1121 without, same box, volumes identical, profiles/r05_ab_rigid_pairs.txt.  The sweep
+// is not bound by how wide its row runs are; the variant is gone from the source.)
 // Conservative, result-identical rejection of ALL the voxels of a 32 x 2 column patch on planes [zs, zs + n): the same two tests as
 // df_rigid_culled, on the box the patch's voxels span (its 8 corners; positions by multiplication, within the tests' margin of the
 // running sums the sweep carries): (a) all corners outside the same frustum side plane, (b) the box's least distance from the camera
@@ -580,7 +536,7 @@ __device__ __forceinline__ bool df_rigid_box_culled(const DfRigidArgs& a, const 
 // HBM -- independent waves, each read-modify-writing 64 (16 x 4 patch) or 128 (32 x 2) contiguous bytes per voxel row at places
 // unrelated to what every other wave was touching: tools/rmw_probe.hip measures 2.6 / 4.4 TB/s for exactly that traffic, and
 // 6.3-6.6 TB/s as soon as >= 256 contiguous bytes of a row are touched together.
-// With DF_RIGID_STARTS the same wave then makes the CHUNK STARTS of its patch: a chunk at plane zb needs the running position after zb
+// The same wave then makes the CHUNK STARTS of its patch: a chunk at plane zb needs the running position after zb
 // additions `vc += zstep` (tsdf_volume.cu:75) -- the sequence cannot be shortcut, its roundings are the result.  Lane l walks column l
 // of the patch ONCE, up to the last alive chunk, and leaves the position at every alive chunk's first plane in `starts`.
 template <bool DEPTH>
@@ -619,21 +575,13 @@ __global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a
         const unsigned wg0 = blockIdx.x * 16u + (unsigned)(DF_RIGID_STRIP * q);      // the strip's first wave
         const int scg = (int)(wg0 / (unsigned)a.tiles), strip = (int)(wg0 % (unsigned)a.tiles) / DF_RIGID_STRIP;
         item = (unsigned)(scg * cpw + c) * (unsigned)(a.tiles / DF_RIGID_STRIP) + (unsigned)strip;
-#if DF_RIGID_PAIR
-        // the x-neighbour of the pair (a.tiles_x is even and a workgroup's first tile too: q ^ 1 is in this workgroup and in the same row)
-        const unsigned mb = (unsigned)(s_alive[q ^ 1] >> (c * subs)) & smask;
-        if (m && mb && 2 * __popc(m | mb) - __popc(m) - __popc(mb) <= DF_RIGID_ROW_SLACK) m = (m | mb) | DF_RIGID_ROW_FLAG;   // both threads of the pair decide alike
-        w = (unsigned)__popc(m & 0xffu);
-#else
         w = (unsigned)__popc(m);
-#endif
         if (m) slot = atomicAdd(&s_cnt[w], 1u);
     }
     __syncthreads();
     if (threadIdx.x < DF_RIGID_BINS && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cnt[threadIdx.x], s_cnt[threadIdx.x]);
     __syncthreads();
     if ((int)threadIdx.x < n_local && m) { bins[(size_t)w * n_items + s_base[w] + slot] = item; mask_out[item] = m; }
-#if DF_RIGID_STARTS
     if (alive) {                                                           // wave-uniform: the chunk starts of the patch's columns
         const int x = tx * DF_RIGID_PX + (lane & (DF_RIGID_PX - 1)), y = ty * DF_RIGID_PY + (lane / DF_RIGID_PX);
         const f3 zstep = scale3(mk3(a.vol2cam.R[2], a.vol2cam.R[5], a.vol2cam.R[8]), a.vsz);  // tsdf_volume.cu:69 (three separate multiplies)
@@ -651,7 +599,6 @@ __global__ __launch_bounds__(1024) void df_rigid_plan_kernel(const DfRigidArgs a
                 starts[((size_t)(cg * cpw + c) * a.tiles + tile) * 64 + lane] = make_float4(vc.x, vc.y, vc.z, 0.f);
         }
     }
-#endif
 }
 
 // The sweep: wave e of the launch takes plan entry e (bins from the fullest down), replays `vc += zstep` up to its chunk, and walks
@@ -675,25 +622,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
     const int j = __ffsll((unsigned long long)__ballot(lane < DF_RIGID_BINS - 1 && e < bin_end)) - 1;
     const unsigned r = e - ((unsigned)__builtin_amdgcn_readlane((int)bin_end, j) - (unsigned)__builtin_amdgcn_readlane((int)bin_cnt, j));
     const unsigned sitem = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_bins[(size_t)(DF_RIGID_BINS - 1 - j) * a.plan_items + r]);
-#if DF_RIGID_PAIR
-    const unsigned mword = (unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_mask[sitem]);
-    const unsigned mask = mword & 0xffu;
-    const bool row = (mword & DF_RIGID_ROW_FLAG) != 0u;                    // wave-uniform: this wave walks one 64 x 1 row of the pair
-#else
     const unsigned mask = ((unsigned)__builtin_amdgcn_readfirstlane((int)a.plan_mask[sitem]) >> (8 * (wave % DF_RIGID_STRIP))) & 0xffu;
-#endif
     if (mask == 0u) return;                                                // nothing alive in this wave's patch
     const int strips = a.tiles / DF_RIGID_STRIP;
     const int chunk = (int)(sitem / (unsigned)strips), tile = (int)(sitem % (unsigned)strips) * DF_RIGID_STRIP + (wave % DF_RIGID_STRIP);
     const unsigned item = (unsigned)chunk * (unsigned)a.tiles + (unsigned)tile;     // (patch item: indexes plan_starts)
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-#if DF_RIGID_PAIR
-    // row item of patch tx: row (tx & 1) of the pair's two patches, lane l = column l of the 64
-    const int x = row ? (tx & ~1) * DF_RIGID_PX + lane : tx * DF_RIGID_PX + (lane & (DF_RIGID_PX - 1));
-    const int y = row ? ty * DF_RIGID_PY + (tx & 1) : ty * DF_RIGID_PY + (lane / DF_RIGID_PX);
-#else
     const int x = tx * DF_RIGID_PX + (lane & (DF_RIGID_PX - 1)), y = ty * DF_RIGID_PY + (lane / DF_RIGID_PX);
-#endif
     const bool active = x < a.X && y < a.Y;
     unsigned int my_upd = 0, my_swept = 0;
     const int zb = a.z_own0 + chunk * a.zc;
@@ -701,19 +636,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DF_RIGID_WA
     const f3 zstep = scale3(mk3(a.vol2cam.R[2], a.vol2cam.R[5], a.vol2cam.R[8]), a.vsz);      // tsdf_volume.cu:69 (three separate multiplies)
     // the column's running position at plane zb: vol2cam * (x, y, 0) + zb additions of zstep (:71-75), made once per column by
     // the plan kernel
-#if DF_RIGID_STARTS
-#if DF_RIGID_PAIR
-    // (a row's columns are lanes 32 r ... 32 r + 31 of the two patches' start records: both patches are alive in this chunk, so both were written)
-    const float4 st4 = row ? a.plan_starts[((size_t)(item & ~1u) + (unsigned)(lane >> 5)) * 64 + (unsigned)((lane & 31) + 32 * (tx & 1))]
-                           : a.plan_starts[(size_t)item * 64 + lane];
-#else
     const float4 st4 = a.plan_starts[(size_t)item * 64 + lane];
-#endif
     f3 vc = mk3(st4.x, st4.y, st4.z);
-#else
-    f3 vc = aff_mul(a.vol2cam, mk3((float)x * a.vsx, (float)y * a.vsy, 0.f));                  // :71-72
-    for (int z = 0; z < zb; ++z) vc = add3(vc, zstep);              // replay of `vc += zstep` (:75) for planes [0, zb)
-#endif
     const size_t plane = (size_t)a.X * a.Y;
     uint32_t* p = a.vol + (size_t)(zb - a.z_store0) * plane + (size_t)(active ? y : 0) * a.X + (active ? x : 0);
     int sb = 0;
@@ -910,7 +834,7 @@ extern "C" int dfusion_integrate_ex(const uint16_t* dists, size_t pitch, int col
         }
     }
     // column patches (one per wave), 4 side by side per strip (one per workgroup): the patch grid's x extent is padded to whole strips
-    constexpr int tx_pad = DF_RIGID_PAIR ? 2 : DF_RIGID_STRIP;             // (pairs: an even number of patches per row)
+    constexpr int tx_pad = DF_RIGID_STRIP;
     const int tiles_x = ((a.X + DF_RIGID_PX - 1) / DF_RIGID_PX + tx_pad - 1) / tx_pad * tx_pad;
     const int tiles = tiles_x * ((a.Y + DF_RIGID_PY - 1) / DF_RIGID_PY);
     // Z chunking: chunks of DF_RIGID_ZC planes -- 1, 2, 4 or 8 sub-chunks.  Short enough that the longest wave is a fraction of the
@@ -931,7 +855,7 @@ extern "C" int dfusion_integrate_ex(const uint16_t* dists, size_t pitch, int col
     const size_t off_cnt = 0, off_bins = 256, off_mask = off_bins + (size_t)DF_RIGID_BINS * n_items * 4;
     const size_t off_pyr = (off_mask + (size_t)n_items * 4 + 15) / 16 * 16;
     const size_t off_starts = (off_pyr + pyr_elems * sizeof(uint16_t) + 255) / 256 * 256;
-    const size_t bytes = off_starts + (DF_RIGID_STARTS ? (size_t)n_pitems * 64 * sizeof(float4) : 0);
+    const size_t bytes = off_starts + (size_t)n_pitems * 64 * sizeof(float4);
     // One scratch buffer per (device, stream), grown on demand and kept: calls on a stream are ordered, so the next call's kernels
     // cannot start before this call's have finished with it.  (Round 3 tried the runtime's stream-ordered allocator here,
     // hipMallocAsync / hipFreeAsync per call: in a process that also allocates and frees with hipMalloc / hipFree between the calls --

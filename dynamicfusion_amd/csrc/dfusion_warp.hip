@@ -1542,13 +1542,11 @@ __global__ __launch_bounds__(256) void df_warp_brick_kernel(const DfWarpedArgs a
 // ---- geometry of the pipelined sweep.  (Rounds 4-5 measured, and dropped, a series of compile-time variants of it -- 32 x 2 patches, an
 // f32-division normalisation, a short fuse division, split LDS node arrays, patch-major tables, both-loads code records: profiles/NOTES.md
 // and profiles/r05_ab_warp_variants.txt hold the numbers; the source keeps only what runs.)
-#ifndef DF_PIPE_WGT
 #define DF_PIPE_WGT 256           // threads of a k = 8 sweep workgroup: 4 waves dealing out ONE strip item; <= 80 VGPRs: 6 workgroups per CU = 6 waves / SIMD.
                                   // (Rounds 4-5 ran 768: the 64 KiB LDS node table left room for two workgroups per CU, so each had to bring 12 waves.
                                   // Without the table the size is free, and a CU refills 4 wave slots as soon as a SMALL workgroup ends instead of
                                   // waiting for the last of 12 waves: a per-wave timeline showed ~4100 of 6144 slots filled at 768 threads.  Same
-                                  // box, interleaved: 256 threads 0.577 ms, 512 0.580, 768 0.594 (profiles/r06_ab_wgsize.txt); 128: see there.)
-#endif
+                                  // box, interleaved: 256 threads 0.577 ms, 512 0.580, 768 0.594, 128 0.622 (profiles/r06_ab_wgsize.txt).)
 #define DF_ROW_TX 32
 #define DF_ROW_TY 8
 #define DF_ROW_TZ 8
@@ -1929,10 +1927,9 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
 //     from 2560 nodes on, no room for the union copies -- so no codes -- from 4864, no pipelined sweep at all from 5120.)
 //   LDSN = true (k = 4, M <= 5120): rot / node_t of all nodes in LDS, gathers by ds_read_b128 (k = 4 has no codes: measured +2 %, NOTES r5).
 template <int K, int U, int WGT, bool V2W_IDENTITY, bool LDSN>
-#ifndef DF_EXP_WPE
-#define DF_EXP_WPE 6
-#endif
-__global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? DF_EXP_WPE : 5)) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
+// (waves per SIMD asked of the compiler: 6 for k = 8 -- 78 VGPRs, no scratch; 7 waves at 72 VGPRs spill 48 bytes a lane and lose 5 %,
+// and holding a CU to 5 workgroups changes nothing: profiles/r06_ab_wgsize.txt, r06_ab_occupancy.txt -- the sweep is VALU-bound from 5 waves on)
+__global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? 6 : 5)) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_lds[];      // LDSN: [2M] rot_j, node_t_j interleaved; else [waves][8][16][2] union copies
     constexpr bool CODES = !LDSN && K == 8;
@@ -2687,10 +2684,7 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
         // LDS of a launch: the node table (32 B a node) for the kernels that keep one -- k = 4's pipelined sweep where it fits, the batched
         // kernel of the other k --, 4 KiB of union copies per wave for k = 8's, nothing for k = 4 without a table
         const bool k4_table = pipe_ok && k == 4 && lds_fits;
-        size_t lds = !pipe_ok || k4_table ? (size_t)wf->M * 32 : k == 8 ? (size_t)(DF_PIPE_WGT / 64) * 4096 : 0;
-#ifdef DF_EXP_LDS_KB
-        if (pipe_ok && !k4_table) lds = (size_t)DF_EXP_LDS_KB * 1024;       // (measurement: fewer workgroups per CU)
-#endif
+        const size_t lds = !pipe_ok || k4_table ? (size_t)wf->M * 32 : k == 8 ? (size_t)(DF_PIPE_WGT / 64) * 4096 : 0;
         typedef void (*lds_kernel_t)(const DfWarpedArgs, const DfWarpView, int);
         lds_kernel_t kern = nullptr;
         // tile layers per workgroup: long walks amortise the LDS fill and the pipeline ramp, short ones even out the last round of
@@ -2698,9 +2692,6 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
         const long long cols_layers = (long long)tiles_x * tiles_y * (zt_hi - zt_lo + 1);
         const bool pipe = pipe_sweep;                           // df_warp_rows_lds_kernel always walks DF_LDS_ZT layers per workgroup
         a.zt = !pipe ? DF_LDS_ZT : cols_layers <= 8192 ? 4 : cols_layers <= 65536 ? 8 : 16;
-#ifdef DF_EXP_ZT
-        if (pipe) a.zt = DF_EXP_ZT;
-#endif
         dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((zt_hi - zt_lo + 1 + a.zt - 1) / a.zt));
         const bool wide = k4_table && lds > 80 * 1024;          // one workgroup per CU either way: make it 1024 threads
         const bool vi = a.v2w_identity != 0;

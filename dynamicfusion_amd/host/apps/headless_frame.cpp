@@ -9,8 +9,10 @@
 //          With the trailing `surface_fusion` argument the body of KinFu::dynamicfusion (kinfu.cpp:344-391, minus the solver)
 //          then runs on the last frame: ray-cast points -> canonical -> WarpField::warp -> TsdfVolume::surface_fusion, and
 //          out.bin continues with: warped f32[rows*cols*3], depth after removal u16[rows*cols], volume u32[dims^3].
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <kfusion/cuda/tsdf_volume.hpp>
 #include <kfusion/cuda/imgproc.hpp>
@@ -25,8 +27,76 @@ static Affine3f read_affine(FILE* f)
     return aff12_to_affine(a);
 }
 
+// `headless_frame bench <dims> <size_m> <cols> <rows> <frames> <nodes> <k> <prime> <warmup> <in.bin>` (round 6): the
+// HEADLINE frame -- set_transforms + computeDists + TsdfVolume::integrate(..., warp) + raycast(Points) -- timed through the C++ mirror
+// with every input resident on the device before the clock starts, exactly the sequence bench.py times through the Python mirror:
+// `prime` untimed frames (first tables / models), the volume cleared, `warmup` untimed frames, then frames - prime - warmup timed ones
+// between two device synchronises, one new pose per frame.  in.bin as above (depth + pose per frame, then node positions, per-frame
+// transforms, dg_w).  Prints "cxx_host_ms_per_frame <ms> over <n> frames".
+static int bench_mode(int argc, char** argv)
+{
+    if (argc != 12) { std::fprintf(stderr, "usage: %s bench dims size cols rows frames nodes k prime warmup in.bin\n", argv[0]); return 2; }
+    const int dims = std::atoi(argv[2]); const float size = (float)std::atof(argv[3]);
+    const int cols = std::atoi(argv[4]), rows = std::atoi(argv[5]), frames = std::atoi(argv[6]), M = std::atoi(argv[7]), k = std::atoi(argv[8]);
+    const int prime = std::atoi(argv[9]), warmup = std::atoi(argv[10]);
+    FILE* in = std::fopen(argv[11], "rb");
+    if (!in || M <= 0 || frames <= prime + warmup) { std::fprintf(stderr, "bench: bad arguments\n"); return 2; }
+    const Affine3f volume_pose = read_affine(in);
+    float intr_v[4];
+    if (std::fread(intr_v, 4, 4, in) != 4) return 2;
+    const Intr intr(intr_v[0], intr_v[1], intr_v[2], intr_v[3]);
+    cuda::TsdfVolume volume(Vec3i(dims, dims, dims));
+    volume.setSize(Vec3f::all(size)); volume.setTruncDist(0.04f); volume.setMaxWeight(64); volume.setPose(volume_pose);
+    volume.setRaycastStepFactor(0.75f); volume.setGradientDeltaFactor(0.5f);
+    std::vector<cuda::Depth> depth_dev(frames);
+    std::vector<Affine3f> cam(frames);
+    {
+        std::vector<unsigned short> d((size_t)rows * cols);
+        for (int f = 0; f < frames; ++f) {
+            if (std::fread(d.data(), 2, d.size(), in) != d.size()) return 2;
+            cam[f] = read_affine(in);
+            depth_dev[f].upload(d.data(), (size_t)cols * 2, rows, cols);
+        }
+    }
+    WarpField warp(k);
+    std::vector<cuda::DeviceArray<float> > dq_dev(frames);
+    {
+        std::vector<float> pos((size_t)M * 3), sigma(M), dq((size_t)M * 8);
+        if (std::fread(pos.data(), 4, pos.size(), in) != pos.size()) return 2;
+        for (int f = 0; f < frames; ++f) { if (std::fread(dq.data(), 4, dq.size(), in) != dq.size()) return 2; dq_dev[f].upload(dq); }
+        if (std::fread(sigma.data(), 4, sigma.size(), in) != sigma.size()) return 2;
+        std::vector<Vec3f> pts(M);
+        for (int i = 0; i < M; ++i) pts[i] = Vec3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+        warp.init(pts);
+        for (int i = 0; i < M; ++i) (*warp.getNodes())[i].weight = sigma[i];
+        warp.commit(true);
+    }
+    std::fclose(in);
+    cuda::Dists dists;
+    cuda::Cloud points; cuda::Normals normals;
+    points.create(rows, cols); normals.create(rows, cols);
+    auto frame = [&](int f) {
+        warp.setTransformsDevice(dq_dev[f]);                                         // the solver's output, already on the device
+        cuda::computeDists(depth_dev[f], dists, intr);                               // kinfu.cpp:226
+        volume.integrateAsync(dists, cam[f], intr, warp);                            // the north-star fusion
+        volume.raycast(cam[f], intr, points, normals);                               // kinfu.cpp:297
+    };
+    for (int f = 0; f < prime; ++f) frame(f);
+    volume.clear();
+    for (int f = prime; f < prime + warmup; ++f) frame(f);
+    cuda::waitAllDefaultStream();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int f = prime + warmup; f < frames; ++f) frame(f);
+    cuda::waitAllDefaultStream();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const int n = frames - prime - warmup;
+    std::printf("cxx_host_ms_per_frame %.6f over %d frames (%d nodes, k = %d, %d^3)\n", ms / n, n, M, k, dims);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 2 && !std::strcmp(argv[1], "bench")) return bench_mode(argc, argv);
     if (argc != 10 && argc != 11) { std::fprintf(stderr, "usage: %s dims size cols rows frames nodes k in.bin out.bin\n", argv[0]); return 2; }
     const int dims = std::atoi(argv[1]); const float size = (float)std::atof(argv[2]);
     const int cols = std::atoi(argv[3]), rows = std::atoi(argv[4]), frames = std::atoi(argv[5]), M = std::atoi(argv[6]), k = std::atoi(argv[7]);

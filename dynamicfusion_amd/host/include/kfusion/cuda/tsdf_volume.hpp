@@ -74,6 +74,9 @@ public:
     // ---- fusion
     virtual void integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr);                        // rigid, tsdf_volume.cpp:110-122
     virtual void integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr, const WarpField& warp);  // per-voxel DQB warp first
+    // ... the same, enqueued only (the reference's integrate ends with a device synchronise, tsdf_volume.cu:160, and so do the two above;
+    // a host that keeps frames in flight -- apps/headless_frame bench -- synchronises once per batch of frames instead)
+    void integrateAsync(const Dists& dists, const Affine3f& camera_pose, const Intr& intr, const WarpField& warp);
     // tsdf_volume.cpp:228-255: depth pixels explained by a warped model point are zeroed, the rest is fused rigidly.  The per-point
     // weights loop of the reference (:241-254) has no effect there (its update lines are commented out) and is not run; psdf is
     // handed dists computed from `depth` (the reference binds the millimetre image as half, :235/:281 -- fixed).

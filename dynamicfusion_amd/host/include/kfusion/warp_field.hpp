@@ -60,6 +60,9 @@ namespace kfusion
         size_t nodeCount() const { return nodes_.size(); }
         /// push host-side node edits (positions or transforms) to the device; `positions_changed` invalidates the k-NN index
         void commit(bool positions_changed);
+        /// node transforms that are ALREADY on the device (8 floats a node: rotation_, translation_ -- what a device-side solver leaves):
+        /// no host round trip, nothing synchronises; the host node store follows on its next access (getNodes)
+        void setTransformsDevice(const cuda::DeviceArray<float>& dq8);
 
         /// warp_field.cpp:180-195, on the GPU; vectors are modified in place
         void warp(std::vector<Vec3f>& points, std::vector<Vec3f>& normals) const;

@@ -231,7 +231,7 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, cons
     KF_HIP(hipDeviceSynchronize());                     // device::integrate ends with cudaDeviceSynchronize (tsdf_volume.cu:160)
 }
 
-void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr, const WarpField& warp)
+void TsdfVolume::integrateAsync(const Dists& dists, const Affine3f& camera_pose, const Intr& intr, const WarpField& warp)
 {
     warp.ensureIndex(*this);
     float v2w[12], w2c[12];
@@ -240,6 +240,10 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, cons
     const float proj[4] = {intr.fx, intr.fy, intr.cx, intr.cy};
     KF_DF(dfusion_integrate_warped(dists.ptr(), dists.step(), dists.cols(), dists.rows(), c_volume(*this), c_slab_integrate(*this).ptr(), v2w, w2c, proj,
                                    warp.handle(), warp.k(), 0u, nullptr, nullptr));
+}
+void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_pose, const Intr& intr, const WarpField& warp)
+{
+    integrateAsync(dists, camera_pose, intr, warp);
     KF_HIP(hipDeviceSynchronize());
 }
 
@@ -497,6 +501,16 @@ void WarpField::commit(bool positions_changed)
         KF_DF(dfusion_warp_set_transforms(handle_, d_dq.ptr(), nullptr));
     }
     KF_HIP(hipDeviceSynchronize());                       // the temporaries above are freed on return
+}
+
+void WarpField::setTransformsDevice(const cuda::DeviceArray<float>& dq8)
+{
+    const size_t M = nodes_.size();
+    if (!M || dq8.size() != M * 8) error("WarpField::setTransformsDevice: 8 floats per node expected", __FILE__, __LINE__, "");
+    KF_DF(dfusion_warp_set_transforms(handle_, dq8.ptr(), nullptr));
+    solve_dq_.create(M * 8);                                 // what the host node store is refreshed from when it is next looked at
+    KF_HIP(hipMemcpyAsync(solve_dq_.ptr(), dq8.ptr(), M * 8 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+    nodes_stale_ = true;
 }
 
 void WarpField::energy_data(const cuda::DeviceArray<float>& canonical_vertices, const cuda::DeviceArray<float>& live_vertices, int n)
