@@ -1167,6 +1167,7 @@ struct DfWarpedArgs {
     uint16_t* knn_tab; float* w_tab; int tab_z0; size_t tab_nvox; int tab_ntx, tab_nty;
     int zt;                        // pipelined sweep: tile layers per workgroup (1..16)
     int v2w_identity;              // vol2world.R is exactly the identity (set by the launcher)
+    int sat_ok;                    // trunc inside the domain of the saturated-sample shortcut (df_sat_trunc_ok; set by the launcher)
     // pipelined sweep: the launch plan.  A STRIP item is half a 32 x 16 tile column (4 patches of 8 x 8 columns side by side: the
     // waves that share the 128-byte lines of the voxel rows) over one block of zt tile layers; item = ((zb * tiles_y + ty) * tiles_x
     // + tx) * 2 + half.  plan_mask[item] holds its 4 x 16 verdict bits (bit 16 p + l: patch p, layer l alive); the items with w > 0
@@ -2123,18 +2124,41 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? 6 : 5)
         // The end of a batch's sample (:85-93: compare with the dists value, fuse, store) is carried into the NEXT batch: the dists
         // gather is the last thing a voxel's chain issues, so finishing the batch at once waits for it with nothing left to do in the
         // wave; a batch later it has long arrived.  `pend` is what the finish needs (6 VGPRs); an empty one (ok = false) stores nothing.
-        struct { float vn[U]; uint16_t dpb[U]; uint32_t vox[U]; int z[U]; bool ok[U]; } pend;
+        // (round 6) The finish is the rigid sweep's two-stage sample (dfusion_device.h, tsdf_sample_pre / _finish -- proven and selftested
+        // there): with s = v_sqrt_f32(|vc|^2), one ulp, and sdf_a = Dp - s, a voxel with sdf_a >= T = df_sat_threshold(trunc) has tsdf = 1.f
+        // EXACTLY, one with sdf_a <= -T does not update, whatever the last bits of |vc| are (|vc| < 64 m, 2^-10 <= trunc <= 2^10).  Most
+        // batches lie in observed free space or behind the surface: when every voxel the wave is about to decide is decided that way, the
+        // exact square root (9 instructions) is never made, and where the stored values are 1.0 or still cleared the fuse is a weight
+        // increment (tsdf_fuse_one: (w + 1) / (w + 1) = 1 without the division).  A wave with a voxel within T of the surface takes :89-93
+        // as written.  `pend` is what either form needs.
+        struct { float d2[U]; uint16_t dpb[U]; uint32_t vox[U]; int z[U]; bool ok[U]; } pend;
 #pragma unroll
-        for (int u = 0; u < U; ++u) { pend.vn[u] = 0.f; pend.dpb[u] = 0; pend.vox[u] = 0u; pend.z[u] = a.z_store0; pend.ok[u] = false; }
+        for (int u = 0; u < U; ++u) { pend.d2[u] = 1.f; pend.dpb[u] = 0; pend.vox[u] = 0u; pend.z[u] = a.z_store0; pend.ok[u] = false; }
+        const float sat_t = df_sat_threshold(a.P.trunc);
         auto finish_pending = [&]() {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float Dp = h2f_bits(pend.dpb[u]);
-                const float sdf = Dp - pend.vn[u];                                            // :89
-                const bool upd = pend.ok[u] & (Dp != 0.f) & (sdf >= -a.P.trunc);              // :86, :91
+                const float d2 = pend.d2[u];
+                const bool live = pend.ok[u] & (Dp != 0.f);                                   // :82, :86
+                const float sdf_a = Dp - __builtin_amdgcn_sqrtf(d2);
+                // decided: far enough from the surface on either side, inside the domain of the error bound (|vc| <= 32 m; a NaN fails)
+                const bool decided = (fabsf(sdf_a) >= sat_t) & (d2 <= 1024.f);
+                bool upd; uint32_t out;
+                if (a.sat_ok && df_wave_all(!live | decided)) {
+                    upd = live & (sdf_a >= sat_t);
+                    if (df_wave_all(!upd | tsdf_fuse_one_ok(pend.vox[u]))) out = tsdf_fuse_one(pend.vox[u], a.P.max_weight);
+                    else out = tsdf_fuse(pend.vox[u], 1.f, a.P.max_weight);                   // :93 with tsdf = fminf(1.f, .) = 1.f
+                } else {
+                    float vn;
+                    if (__builtin_expect(df_wave_all(df_sqrt_short_ok(d2)), 1)) vn = df_sqrt_short(d2);
+                    else vn = sqrtf(d2);                                                      // (NaN positions of zero-weight voxels come here)
+                    const float sdf = Dp - vn;                                                // :89
+                    upd = live & (sdf >= -a.P.trunc);                                         // :91
+                    out = tsdf_fuse(pend.vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight);   // :93
+                }
                 wave_upd += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(upd));
-                if (upd) __builtin_amdgcn_raw_buffer_store_b32(tsdf_fuse(pend.vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight),       // :93
-                                                               df_plane_rsrc(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane, plane_bytes), lane_vox4, 0, 0);
+                if (upd) __builtin_amdgcn_raw_buffer_store_b32(out, df_plane_rsrc(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane, plane_bytes), lane_vox4, 0, 0);
             }
         };
         // one batch: consumes S (tables of batch (l, z0)), then refills S with the tables of batch (l2, z2)
@@ -2196,18 +2220,14 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? 6 : 5)
             // would make the compiler assume the loads may not have been issued and wait for most of the prefetch.
             load_batch(S, l2 >= 0 ? l2 : l, l2 >= 0 ? z2 : z0);
             __builtin_amdgcn_sched_barrier(0);
-            // (4) |vc| of this batch (:89); the rest of the sample waits in `pend`
+            // (4) |vc|^2 of this batch (:89); the rest of the sample waits in `pend`
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float v2 = dot3(vc[u], vc[u]);
-                float vn;
-                if (__builtin_expect(df_wave_all(df_sqrt_short_ok(v2)), 1)) vn = df_sqrt_short(v2);
-                else vn = sqrtf(v2);                                                         // (NaN positions of zero-weight voxels come here)
                 // the voxel word is only needed if the voxel projects into the image (the finish is a batch away: time enough), and
                 // whole 32-byte runs of lanes that do not are not fetched at all
                 uint32_t vw = 0u;
                 if (ok[u]) vw = __builtin_amdgcn_raw_buffer_load_b32(df_plane_rsrc(a.vol + (size_t)(zv[u] - a.z_store0) * plane, plane_bytes), lane_vox4, 0, 0);
-                pend.vn[u] = vn; pend.dpb[u] = dpb[u]; pend.vox[u] = vw; pend.z[u] = zv[u]; pend.ok[u] = ok[u];
+                pend.d2[u] = dot3(vc[u], vc[u]); pend.dpb[u] = dpb[u]; pend.vox[u] = vw; pend.z[u] = zv[u]; pend.ok[u] = ok[u];
             }
         };
         for (;;) {
@@ -2603,6 +2623,7 @@ static int df_integrate_warped_impl(const uint16_t* dists, size_t pitch, int col
     a.P.dists = dists; a.P.pitch = pitch; a.P.cols = cols; a.P.rows = rows;
     a.P.fx = proj[0]; a.P.fy = proj[1]; a.P.cx = proj[2]; a.P.cy = proj[3];
     a.P.trunc = v.trunc_dist; a.P.trunc_inv = 1.f / v.trunc_dist; a.P.max_weight = v.max_weight;
+    a.sat_ok = df_sat_trunc_ok(v.trunc_dist) ? 1 : 0;
     a.n_upd = n_updated;
     a.n_swept = wf->dbg_swept;
     a.kf = (float)k; a.cam_scale = 1.f; a.origin_cam = -1.f;
