@@ -70,6 +70,14 @@ def parse(argv=None):
                          "collective model puts it at 0.026 ms against 0.093 for the ring at N = 8); `rows` (round 4's default): the same bands by "
                          "reduce_scatter (1/N of the bytes lands on a rank); `root`: reduce(SUM) to rank 0, which makes "
                          "the whole image.  N>1 runs time the other forms as variants after the timed region (scaling_detail.variants)")
+    ap.add_argument("--key-merge", choices=["direct", "ring"], default="direct",
+                    help="N>1: the ray-cast's FIRST collective, the per-pixel MIN of the 64-bit keys -- `direct` (default since round 6): all-to-all of "
+                         "the keys' row bands + local minimum (dfusion_raycast_min_pieces) + all-gather of the merged bands: two exchanges of one step "
+                         "each over the pairwise xGMI links (stated model at N = 8: 0.046 ms); `ring`: one ncclAllReduce(MIN) (2 (N - 1) ring steps: "
+                         "0.128 ms in the same model).  Same bits; the other form is timed as a variant")
+    ap.add_argument("--bcast", choices=["direct", "ring"], default="direct",
+                    help="N>1: how the frame's inputs (depth + node transforms, one 0.68 MB bundle) leave rank 0 -- `direct` (default since round 6): "
+                         "N - 1 point-to-point sends in one group, each on its own link; `ring`: ncclBroadcast")
     ap.add_argument("--no-variants", action="store_true", help="N>1: skip the untimed variant passes (the other merges, the halo exchange)")
     ap.add_argument("--long-frames", type=int, default=200,
                     help="frame_stats.long_sweep: the sweep goes on (untimed by the wall clock, HIP events per frame) until this many consecutive frames "
@@ -204,6 +212,9 @@ def dry_run(args, rank, world):
             pad = torch.zeros((world * per, cfg.cols, 4), dtype=torch.float32)
             sharded.coll_reduce_scatter_rows(pad.view(torch.int32), torch.empty((per, cfg.cols, 4), dtype=torch.int32))
             sharded.coll_all_to_all_rows(pad.view(torch.int32), torch.empty((world, per, cfg.cols, 4), dtype=torch.int32))
+            sharded.coll_broadcast_direct(bundle, 0)              # round 6: the direct forms of the first two collectives
+            sharded.coll_all_reduce_min_direct(torch.full((world * per, cfg.cols), sharded.KEY_NONE, dtype=torch.int64),
+                                               torch.empty((world, per, cfg.cols), dtype=torch.int64), torch.empty((per, cfg.cols), dtype=torch.int64))
     if dist.is_initialized():
         dist.all_reduce(alive, op=dist.ReduceOp.SUM)       # the re-balance's per-plane alive counts
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
@@ -531,7 +542,10 @@ def main():
 
     dists = torch.empty((cfg.rows, cfg.cols), dtype=torch.int16, device=dev)
     dists2 = [dists, torch.empty_like(dists)]
-    keys = torch.empty((cfg.rows, cfg.cols), dtype=torch.int64, device=dev) if dist_on else None
+    # the key image lives in the first rows of a buffer of world * per rows (whole row bands for the direct key merge; the rows past the image
+    # stay KEY_NONE)
+    keys_pad = torch.full((world * sharded.row_bands(cfg.rows, world)[0], cfg.cols), sharded.KEY_NONE, dtype=torch.int64, device=dev) if dist_on else None
+    keys = keys_pad[:cfg.rows] if dist_on else None
     out2 = torch.empty((2, cfg.rows, cfg.cols, 4), dtype=torch.float32, device=dev)
     pts, nrm = out2[0], out2[1]
     rows_merge = dist_on          # (the band buffers exist whenever the frame is sharded: the variant passes use them too)
@@ -541,6 +555,8 @@ def main():
         nrm_band = torch.empty((per_rows, cfg.cols, 4), dtype=torch.float32, device=dev)
         pts_band = torch.empty((per_rows, cfg.cols, 4), dtype=torch.float32, device=dev)
         a2a_recv = torch.empty((world, per_rows, cfg.cols, 4), dtype=torch.float32, device=dev)     # the direct merge's N pieces of this rank's band
+        keys_recv = torch.empty((world, per_rows, cfg.cols), dtype=torch.int64, device=dev)         # the direct key merge's N pieces of this rank's band
+        keys_band = torch.empty((per_rows, cfg.cols), dtype=torch.int64, device=dev)
     # frame inputs travel as ONE byte bundle (depth image + node transforms): one ncclBroadcast per frame
     n_depth = cfg.rows * cfg.cols * 2
     bundle = torch.empty(n_depth + cfg.nodes * 32, dtype=torch.uint8, device=dev)
@@ -562,18 +578,22 @@ def main():
         s_prep.wait_stream(s_main)
         ev_sweep[0].record(s_main); ev_sweep[1].record(s_main)
 
-    def step(i, ev=None, timer=None, merge=None, halo_mode=None):
+    def step(i, ev=None, timer=None, merge=None, halo_mode=None, key_merge=None, bcast=None):
         """one frame.  timer: a sharded.StageTimer (the stages of this frame are marked); merge / halo_mode: a variant of the frame's
         second collective / of how the halo planes are made (default: the command line's)."""
         f = i % F
         merge = args.merge if merge is None else merge
+        key_merge = args.key_merge if key_merge is None else key_merge
+        bcast = args.bcast if bcast is None else bcast
+        km = dict(key_merge=key_merge, keys_pad=keys_pad, keys_recv=keys_recv, keys_band=keys_band) if dist_on else {}
         halo_mode = halo_main if halo_mode is None else halo_mode
         mark = timer.mark if timer is not None else (lambda name: None)
         if timer is not None: timer.start()
         if dist_on:                                    # rank 0 owns the sensor frame and the solver output
             if rank == 0:
                 depth_in.copy_(depths[f]); dq_in.copy_(dqs[f])
-            sharded.coll_broadcast(bundle, 0)
+            if bcast == "direct": sharded.coll_broadcast_direct(bundle, 0)
+            else: sharded.coll_broadcast(bundle, 0)
             mark("broadcast")
             d_in, q_in = depth_in, dq_in
         else:
@@ -617,12 +637,12 @@ def main():
                 return nrm_pad
             out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, rank), shade_padded,
                                           lambda mk, nb, r0, nr: vol.raycast_points_of_keys(cam_poses[f], intr, mk, nb, pts_band[:nr], r0, nr),
-                                          rank, world, collectives=True, merge=merge, band_out=nrm_band, a2a_recv=a2a_recv, timer=timer)
+                                          rank, world, collectives=True, merge=merge, band_out=nrm_band, a2a_recv=a2a_recv, timer=timer, **km)
         elif dist_on:
             out = sharded.raycast_sharded(lambda: vol.raycast_march(cam_poses[f], intr, keys, rank),
                                           lambda mk: vol.raycast_shade(cam_poses[f], intr, mk, None, nrm)[1],
                                           lambda mk, n: vol.raycast_points_of_keys(cam_poses[f], intr, mk, n, pts),
-                                          rank, world, collectives=True, timer=timer)
+                                          rank, world, collectives=True, timer=timer, **km)
         else:
             vol.raycast(cam_poses[f], intr, pts, nrm)
             mark("raycast")
@@ -835,18 +855,21 @@ def main():
         scaling_detail["devices"] = gather("%s:%d" % (torch.cuda.get_device_name(dev), dev.index))
         px = cfg.rows * cfg.cols
         sizes = {"broadcast": px * 2 + cfg.nodes * 32, "all_reduce_min": px * 8, "reduce_scatter": px * 16, "all_to_all": px * 16, "reduce": px * 16,
-                 "halo_exchange": halo * X * Y * 4}
-        kinds = {"broadcast": "broadcast", "all_reduce_min": "all_reduce", "reduce_scatter": "reduce_scatter", "all_to_all": "all_to_all",
-                 "reduce": "reduce", "halo_exchange": "halo"}
+                 "halo_exchange": halo * X * Y * 4, "broadcast(ring)": px * 2 + cfg.nodes * 32, "all_reduce_min(ring)": px * 8}
+        kinds = {"broadcast": "broadcast_direct" if args.bcast == "direct" else "broadcast",
+                 "all_reduce_min": "all_reduce_direct" if args.key_merge == "direct" else "all_reduce", "reduce_scatter": "reduce_scatter",
+                 "all_to_all": "all_to_all", "reduce": "reduce", "halo_exchange": "halo", "broadcast(ring)": "broadcast", "all_reduce_min(ring)": "all_reduce"}
         scaling_detail["predicted_collective_ms"] = {k: 1e3 * sharded.collective_model_s(kinds[k], sizes[k], world) for k in sizes}
         scaling_detail["predicted_how"] = ("tools/scale_model.py's stated model: %.0f us per call + %.0f us per ring step + bytes on the busiest link / %.0f GB/s "
-                                           "(rings: N - 1 steps, all_reduce 2 (N - 1); all_to_all and the halo exchange: one step)"
+                                           "(rings: N - 1 steps, all_reduce 2 (N - 1); all_to_all, the halo exchange and the direct forms of broadcast / key merge: one step per exchange)"
                                            % (sharded.T_LAUNCH * 1e6, sharded.T_HOP * 1e6, sharded.LINK_GBPS))
         if world > 1 and not args.no_variants:
             variants = {}
             n_var = max(4, min(10, args.steps))
             base = i0 + args.steps                       # (the poses right after the timed ones, every variant the same ones)
             todo = [("merge=%s" % m, dict(merge=m)) for m in ("rows", "a2a", "root")] + [("halo=exchange", dict(halo_mode="exchange"))]
+            todo += [("key_merge=%s" % ("ring" if args.key_merge == "direct" else "direct"), dict(key_merge="ring" if args.key_merge == "direct" else "direct")),
+                     ("bcast=%s" % ("ring" if args.bcast == "direct" else "direct"), dict(bcast="ring" if args.bcast == "direct" else "direct"))]
             for name, kw in todo:
                 tm = sharded.StageTimer()
                 for i in range(2):
@@ -863,8 +886,8 @@ def main():
                                   "per_rank_ms": {k: [float(r.get(k, float("nan"))) for r in pr] for k in pr[0].keys()}}
             scaling_detail["variants"] = variants
             scaling_detail["variants_how"] = ("after the timed region, %d frames each (poses %d..%d, every variant the same; wall clock between barriers, "
-                                              "max over ranks, incl. the stage events): the headline's form is merge=%s, halo=%s"
-                                              % (n_var, base, base + n_var - 1, args.merge, halo_main))
+                                              "max over ranks, incl. the stage events): the headline's form is merge=%s, halo=%s, key_merge=%s, bcast=%s"
+                                              % (n_var, base, base + n_var - 1, args.merge, halo_main, args.key_merge, args.bcast))
 
     # ---- the launch plan's cull, verified on the timed frames themselves: the same frames from the same start volume with the cull
     # switched off (every voxel goes through the reference's own tests, tsdf_volume.cu:77-93) must leave the same bits
@@ -1066,6 +1089,11 @@ def main():
                                          ("all_reduce(MIN) of the keys + one direct all-to-all of the normals' row bands (fixed-size pieces, no counts) + a local "
                                           "sum: every rank finishes its band of %d rows" % sharded.row_bands(cfg.rows, world)[0]) if args.merge == "a2a" else
                                          "all_reduce(MIN) of the keys + reduce(SUM) of the normals to rank 0") if dist_on else None,
+                       "key_merge": (("direct: all-to-all of the keys' row bands + local minimum + all-gather (two one-step exchanges instead of a ring "
+                                      "all_reduce; the `all_reduce(MIN)` named in raycast_merge is made this way)") if args.key_merge == "direct" else
+                                     "ring: ncclAllReduce(MIN)") if dist_on else None,
+                       "inputs": (("rank 0 sends depth + node transforms to every rank point-to-point, one group (each copy on its own xGMI link)"
+                                   if args.bcast == "direct" else "ncclBroadcast of depth + node transforms from rank 0") if dist_on else None),
                        "frame": "set_transforms + compute_dists + integrate_warped + raycast_points" +
                                 (" (frames pipelined over two streams: the volume-free half of frame f + 1 runs beside the sweep and ray-cast of frame f)" if pipeline else "")},
             "kernel_ms": {"integrate_warped": ms_int, "raycast(+merge)": ms_ray, "index_build_once_s": t_index,

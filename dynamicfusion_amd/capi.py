@@ -58,7 +58,7 @@ SYMBOLS = [
     "dfusion_bilateral_filter", "dfusion_truncate_depth", "dfusion_depth_pyramid", "dfusion_compute_normals_mask_depth",
     "dfusion_compute_point_normals", "dfusion_resize_depth_normals", "dfusion_resize_points_normals",
     "dfusion_icp_workspace_floats", "dfusion_icp_sums_points", "dfusion_icp_sums_depth", "dfusion_transform_points", "dfusion_warp_solve_data_term", "dfusion_warp_index_info", "dfusion_icp_estimate", "dfusion_release_scratch", "dfusion_raycast_points_of_keys",
-    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_integrate_ex", "dfusion_warp_debug_counters", "dfusion_warp_alive_blocks", "dfusion_warp_coded_blocks", "dfusion_raycast_points_of_keys_rows", "dfusion_raycast_sum_pieces", "dfusion_integrate_warped_prepare", "dfusion_integrate_warped_sweep",
+    "dfusion_selftest_exact_forms", "dfusion_warp_set_point_tiling", "dfusion_integrate_ex", "dfusion_warp_debug_counters", "dfusion_warp_alive_blocks", "dfusion_warp_coded_blocks", "dfusion_raycast_points_of_keys_rows", "dfusion_raycast_sum_pieces", "dfusion_raycast_min_pieces", "dfusion_integrate_warped_prepare", "dfusion_integrate_warped_sweep",
     "dfusion_render_image_points", "dfusion_render_image_depth", "dfusion_render_tangent_colors", "dfusion_cloud_to_depth",
 ]
 
@@ -143,6 +143,7 @@ def load(path, strict=True):
     L.dfusion_warp_index_info.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint), C.POINTER(C.c_int)]
     L.dfusion_selftest_exact_forms.argtypes = [C.c_ulonglong, vp, vp]
     L.dfusion_raycast_sum_pieces.argtypes = [vp, C.c_int, C.c_ulonglong, vp, vp]
+    L.dfusion_raycast_min_pieces.argtypes = [vp, C.c_int, C.c_ulonglong, vp, vp]
     L.dfusion_integrate_warped_prepare.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, DfVolume, C.POINTER(DfSlab), fp, fp, fp, vp, C.c_int, C.c_uint, vp]
     L.dfusion_integrate_warped_sweep.argtypes = [DfVolume, C.POINTER(DfSlab), vp, vp, vp]
     L.dfusion_warp_set_point_tiling.argtypes = [vp, C.c_int]

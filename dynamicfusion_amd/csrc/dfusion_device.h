@@ -96,7 +96,8 @@ __device__ __forceinline__ f3 dq_transform(quat rot, quat dual, f3 p)
 //
 // sqrtf for finite x >= 2^-96: the compiler's own expansion (v_sqrt_f32, then step to the neighbour below / above when
 // the residual says so) without its input scaling for tiny x and its zero / inf / NaN pass-through.
-__device__ __forceinline__ bool df_sqrt_short_ok(float x) { return (x >= 0x1p-96f) & (x < __builtin_inff()); }
+// (2^-96 <= x < inf as ONE unsigned compare of the bits: negative floats and NaNs have bits above every positive finite float's)
+__device__ __forceinline__ bool df_sqrt_short_ok(float x) { return (__float_as_uint(x) - 0x0f800000u) < 0x70000000u; }
 __device__ __forceinline__ float df_sqrt_short(float x)
 {
     const float s = __builtin_amdgcn_sqrtf(x);

@@ -786,3 +786,32 @@ extern "C" int dfusion_raycast_sum_pieces(const uint32_t* pieces, int n_pieces, 
     DF_LAUNCH_CHECK();
     return DF_OK;
 }
+
+// ---- the direct form of the sharded cast's FIRST collective (include/dfusion.h dfusion_raycast_min_pieces): out = the per-key minimum of n_pieces
+// pieces of n keys (non-negative int64 merge keys: the unsigned order is the signed one)
+__global__ __launch_bounds__(256) void df_min_pieces_kernel(const unsigned long long* __restrict__ pieces, int n_pieces, unsigned long long n, unsigned long long* __restrict__ out)
+{
+    for (unsigned long long i = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 2; i < n; i += (unsigned long long)gridDim.x * 512) {
+        if (i + 2 <= n) {
+            ulonglong2 a = *reinterpret_cast<const ulonglong2*>(pieces + i);
+            for (int p = 1; p < n_pieces; ++p) {
+                const ulonglong2 b = *reinterpret_cast<const ulonglong2*>(pieces + (unsigned long long)p * n + i);
+                a.x = b.x < a.x ? b.x : a.x; a.y = b.y < a.y ? b.y : a.y;
+            }
+            *reinterpret_cast<ulonglong2*>(out + i) = a;
+        } else {
+            unsigned long long a = pieces[i];
+            for (int p = 1; p < n_pieces; ++p) { const unsigned long long b = pieces[(unsigned long long)p * n + i]; a = b < a ? b : a; }
+            out[i] = a;
+        }
+    }
+}
+extern "C" int dfusion_raycast_min_pieces(const unsigned long long* pieces, int n_pieces, unsigned long long n_keys, unsigned long long* out, dfStream stream)
+{
+    if (!pieces || !out || n_pieces < 1 || ((size_t)pieces & 15) || ((size_t)out & 15) || (n_pieces > 1 && (n_keys & 1ull))) return DF_E_INVALID;   // (16-byte accesses: pieces start on even keys)
+    if (n_keys == 0) return DF_OK;
+    const unsigned long long want = ((n_keys + 1) / 2 + 255) / 256;
+    hipLaunchKernelGGL(df_min_pieces_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, pieces, n_pieces, n_keys, out);
+    DF_LAUNCH_CHECK();
+    return DF_OK;
+}

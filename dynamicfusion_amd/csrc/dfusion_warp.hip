@@ -2131,33 +2131,38 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? 6 : 5)
         // exact square root (9 instructions) is never made, and where the stored values are 1.0 or still cleared the fuse is a weight
         // increment (tsdf_fuse_one: (w + 1) / (w + 1) = 1 without the division).  A wave with a voxel within T of the surface takes :89-93
         // as written.  `pend` is what either form needs.
-        struct { float d2[U]; uint16_t dpb[U]; uint32_t vox[U]; int z[U]; bool ok[U]; } pend;
+        // (a voxel that does not project into the image waits with dists bits 0: `no measurement`, :86 -- one flag less to carry)
+        struct { float d2[U]; uint16_t dpb[U]; uint32_t vox[U]; int z[U]; } pend;
 #pragma unroll
-        for (int u = 0; u < U; ++u) { pend.d2[u] = 1.f; pend.dpb[u] = 0; pend.vox[u] = 0u; pend.z[u] = a.z_store0; pend.ok[u] = false; }
+        for (int u = 0; u < U; ++u) { pend.d2[u] = 1.f; pend.dpb[u] = 0; pend.vox[u] = 0u; pend.z[u] = a.z_store0; }
         const float sat_t = df_sat_threshold(a.P.trunc);
         auto finish_pending = [&]() {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float Dp = h2f_bits(pend.dpb[u]);
                 const float d2 = pend.d2[u];
-                const bool live = pend.ok[u] & (Dp != 0.f);                                   // :82, :86
                 const float sdf_a = Dp - __builtin_amdgcn_sqrtf(d2);
+                // Wave-wide decisions as algebra on the compares' lane masks (a ballot of a compound bool costs two more VALU instructions)
+                const unsigned long long live_m = __builtin_amdgcn_ballot_w64(Dp != 0.f);                  // :82, :86
                 // decided: far enough from the surface on either side, inside the domain of the error bound (|vc| <= 32 m; a NaN fails)
-                const bool decided = (fabsf(sdf_a) >= sat_t) & (d2 <= 1024.f);
+                const unsigned long long decided_m = __builtin_amdgcn_ballot_w64(fabsf(sdf_a) >= sat_t) & __builtin_amdgcn_ballot_w64(d2 <= 1024.f);
                 bool upd; uint32_t out;
-                if (a.sat_ok && df_wave_all(!live | decided)) {
-                    upd = live & (sdf_a >= sat_t);
-                    if (df_wave_all(!upd | tsdf_fuse_one_ok(pend.vox[u]))) out = tsdf_fuse_one(pend.vox[u], a.P.max_weight);
+                if (a.sat_ok && (live_m & ~decided_m) == 0ull) {
+                    const unsigned long long upd_m = live_m & __builtin_amdgcn_ballot_w64(sdf_a >= sat_t);
+                    upd = (Dp != 0.f) & (sdf_a >= sat_t);
+                    const unsigned long long one_m = __builtin_amdgcn_ballot_w64(pend.vox[u] == 0u) | __builtin_amdgcn_ballot_w64((pend.vox[u] & 0xffffu) == 0x3c00u);   // tsdf_fuse_one_ok
+                    if ((upd_m & ~one_m) == 0ull) out = tsdf_fuse_one(pend.vox[u], a.P.max_weight);
                     else out = tsdf_fuse(pend.vox[u], 1.f, a.P.max_weight);                   // :93 with tsdf = fminf(1.f, .) = 1.f
+                    wave_upd += (unsigned)__popcll(upd_m);
                 } else {
                     float vn;
                     if (__builtin_expect(df_wave_all(df_sqrt_short_ok(d2)), 1)) vn = df_sqrt_short(d2);
                     else vn = sqrtf(d2);                                                      // (NaN positions of zero-weight voxels come here)
                     const float sdf = Dp - vn;                                                // :89
-                    upd = live & (sdf >= -a.P.trunc);                                         // :91
+                    upd = (Dp != 0.f) & (sdf >= -a.P.trunc);                                  // :91
                     out = tsdf_fuse(pend.vox[u], fminf(1.f, sdf * a.P.trunc_inv), a.P.max_weight);   // :93
+                    wave_upd += (unsigned)__popcll(live_m & __builtin_amdgcn_ballot_w64(sdf >= -a.P.trunc));
                 }
-                wave_upd += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(upd));
                 if (upd) __builtin_amdgcn_raw_buffer_store_b32(out, df_plane_rsrc(a.vol + (size_t)(pend.z[u] - a.z_store0) * plane, plane_bytes), lane_vox4, 0, 0);
             }
         };
@@ -2227,7 +2232,7 @@ __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? 6 : 5)
                 // whole 32-byte runs of lanes that do not are not fetched at all
                 uint32_t vw = 0u;
                 if (ok[u]) vw = __builtin_amdgcn_raw_buffer_load_b32(df_plane_rsrc(a.vol + (size_t)(zv[u] - a.z_store0) * plane, plane_bytes), lane_vox4, 0, 0);
-                pend.d2[u] = dot3(vc[u], vc[u]); pend.dpb[u] = dpb[u]; pend.vox[u] = vw; pend.z[u] = zv[u]; pend.ok[u] = ok[u];
+                pend.d2[u] = dot3(vc[u], vc[u]); pend.dpb[u] = ok[u] ? dpb[u] : (uint16_t)0; pend.vox[u] = vw; pend.z[u] = zv[u];
             }
         };
         for (;;) {

@@ -2,7 +2,7 @@
 //
 // No counterpart in the reference (single GPU).  One process per GPU; rank g holds the planes ZSlabComm::slabRange gives it as a
 // TsdfVolume::setSlab shard.  What crosses GPUs per frame (BASELINE.json north star):
-//   broadcast()      the frame inputs from rank 0 (depth image, node transforms) -- one ncclBroadcast of bytes each
+//   broadcast()      the frame inputs from rank 0 (depth image, node transforms) -- N - 1 point-to-point copies in one group (or one ncclBroadcast)
 //   exchangeHalos()  after the integrate: the H boundary planes to / from both Z neighbours, paired ncclSend / ncclRecv in one
 //                    group (ring neighbours only: two of the seven xGMI links).  Not needed when every rank integrates its halo
 //                    planes itself -- TsdfVolume::setSlab(z0, n, H, /*integrate_halo=*/true): the integrate is a pure function of
@@ -81,6 +81,16 @@ public:
     enum RowMerge { REDUCE_SCATTER = 0, ALL_TO_ALL = 1 };
     void setRowMerge(RowMerge m) { row_merge_ = m; }
     RowMerge rowMerge() const { return row_merge_; }
+    /// How the casts merge the keys (round 6).  KEYS_RING: one ncclAllReduce(MIN) -- 2 (N - 1) ring steps.  KEYS_DIRECT (default): every rank
+    /// sends each other rank ITS band of the key image (one ncclSend / ncclRecv group), takes the per-key minimum of the N pieces of its own
+    /// band (dfusion_raycast_min_pieces) and one ncclAllGather hands every rank the merged image: two exchanges of one step each over the
+    /// pairwise xGMI links.  Same bits.  DFUSION_ZSLAB_KEY_MERGE=ring selects the ring.
+    enum KeyMerge { KEYS_RING = 0, KEYS_DIRECT = 1 };
+    void setKeyMerge(KeyMerge m) { key_merge_ = m; }
+    KeyMerge keyMerge() const { return key_merge_; }
+    /// broadcast() as N - 1 point-to-point copies in one group, each on its own link (default), or one ncclBroadcast
+    /// (DFUSION_ZSLAB_BCAST=ring)
+    void setBroadcastDirect(bool on) { bcast_direct_ = on; }
     int bandRowsPerRank(int rows) const { return (rows + world_ - 1) / world_; }
     int bandRow0(int rows) const { return std::min(rows, rank_ * bandRowsPerRank(rows)); }
     int bandRows(int rows) const { return std::max(0, std::min(rows, (rank_ + 1) * bandRowsPerRank(rows)) - bandRow0(rows)); }
@@ -104,6 +114,12 @@ private:
     DeviceArray<int> token_;
     RowMerge row_merge_;
     DeviceArray<Point> pieces_;  // ALL_TO_ALL: the world pieces of this rank's band
+    KeyMerge key_merge_;
+    bool bcast_direct_;
+    bool keyImage(int cols, int rows);
+    bool mergeKeys(int cols, int rows);
+    DeviceArray<unsigned long long> keys_pad_;     // the key image + padding to whole row bands (keys64_ is a view of its first cols * rows keys)
+    DeviceArray<unsigned long long> key_pieces_;   // KEYS_DIRECT: the world pieces of this rank's band, then the merged band
 };
 
 } }

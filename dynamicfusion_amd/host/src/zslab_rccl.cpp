@@ -45,6 +45,8 @@ ZSlabComm::ZSlabComm(int rank, int world, const std::string& id_path, Backend ba
     if (world < 1 || world > 128 || rank < 0 || rank >= world) { fail("ZSlabComm: rank " + std::to_string(rank) + " of " + std::to_string(world) + " (1..128 ranks: the merge key carries the rank in 7 bits)"); return; }
     if (backend_ == FROM_ENV) { const char* b = std::getenv("DFUSION_ZSLAB_BACKEND"); backend_ = (b && !std::strcmp(b, "host")) ? HOST_STAGED : RCCL; }
     { const char* m = std::getenv("DFUSION_ZSLAB_MERGE"); row_merge_ = (m && !std::strcmp(m, "a2a")) ? ALL_TO_ALL : REDUCE_SCATTER; }
+    { const char* m = std::getenv("DFUSION_ZSLAB_KEY_MERGE"); key_merge_ = (m && !std::strcmp(m, "ring")) ? KEYS_RING : KEYS_DIRECT; }
+    { const char* m = std::getenv("DFUSION_ZSLAB_BCAST"); bcast_direct_ = !(m && !std::strcmp(m, "ring")); }
     if (backend_ == HOST_STAGED) initHost(id_path); else initRccl(id_path);
 }
 
@@ -229,7 +231,65 @@ bool ZSlabComm::broadcast(void* device_ptr, size_t bytes, int root)
         if (rank_ != root) ZS_HIP(hipMemcpy(device_ptr, hostSlot(root), bytes, hipMemcpyHostToDevice));
         return hostBarrier();
     }
+    if (bcast_direct_) {
+        // round 6: N - 1 point-to-point copies in one group, each on its own xGMI link -- one step instead of a ring's N - 1
+        ncclComm_t c = (ncclComm_t)comm_; hipStream_t st = (hipStream_t)stream_;
+        ZS_NCCL(ncclGroupStart());
+        bool sent = true;
+        if (rank_ == root) { for (int r = 0; r < world_ && sent; ++r) if (r != root) sent = ncclSend(device_ptr, bytes, ncclUint8, r, c, st) == ncclSuccess; }
+        else sent = ncclRecv(device_ptr, bytes, ncclUint8, root, c, st) == ncclSuccess;
+        const bool closed = ncclGroupEnd() == ncclSuccess;
+        if (!sent || !closed) return fail("ZSlabComm: ncclSend / ncclRecv of the frame inputs");
+        return true;
+    }
     ZS_NCCL(ncclBroadcast(device_ptr, device_ptr, bytes, ncclUint8, root, (ncclComm_t)comm_, (hipStream_t)stream_));
+    return true;
+}
+
+// The per-pixel MIN of the keys over the ranks -- the first event along every ray, its owner and its Ts (dfusion.h) -- in keys64_[0 .. px).
+// KEYS_RING: one ncclAllReduce(MIN).  KEYS_DIRECT (round 6): all-to-all of the keys' row bands, per-key minimum of the N pieces
+// (dfusion_raycast_min_pieces), all-gather of the merged bands: two exchanges of one step each over the pairwise links.  keys64_ is a view
+// of keys_pad_ (keyImage): whole row bands for every rank.
+// keys64_ = a view of the first cols * rows keys of keys_pad_, which holds whole row bands for every rank (world * per * cols keys; the keys
+// past the image are all-ones: larger than every key, never read as pixels)
+bool ZSlabComm::keyImage(int cols, int rows)
+{
+    const size_t px = (size_t)cols * rows, pad = (size_t)bandRowsPerRank(rows) * cols * (size_t)world_;
+    keys_pad_.create(pad);
+    if (pad > px) ZS_HIP(hipMemsetAsync(keys_pad_.ptr() + px, 0xff, (pad - px) * 8, (hipStream_t)stream_));
+    keys64_ = DeviceArray<unsigned long long>(keys_pad_.ptr(), px);
+    return true;
+}
+
+bool ZSlabComm::mergeKeys(int cols, int rows)
+{
+    if (world_ == 1) return true;
+    ncclComm_t c = (ncclComm_t)comm_; hipStream_t st = (hipStream_t)stream_;
+    const size_t px = (size_t)cols * rows;
+    if (backend_ == HOST_STAGED) {
+        if (px * 8 > slot_bytes_) return fail("ZSlabComm(host): image larger than a slot (DFUSION_ZSLAB_HOST_SLOT_MB)");
+        ZS_HIP(hipMemcpy(hostSlot(rank_), keys64_.ptr(), px * 8, hipMemcpyDeviceToHost));
+        if (!hostBarrier()) return false;
+        std::vector<long long> m((const long long*)hostSlot(0), (const long long*)hostSlot(0) + px);
+        for (int r = 1; r < world_; ++r) { const long long* o = (const long long*)hostSlot(r); for (size_t i = 0; i < px; ++i) m[i] = std::min(m[i], o[i]); }
+        if (!hostBarrier()) return false;                           // (everybody has read every slot before anyone reuses its own)
+        ZS_HIP(hipMemcpy(keys64_.ptr(), m.data(), px * 8, hipMemcpyHostToDevice));
+        return true;
+    }
+    if (key_merge_ == KEYS_RING) { ZS_NCCL(ncclAllReduce(keys64_.ptr(), keys64_.ptr(), px, ncclInt64, ncclMin, c, st)); return true; }
+    const size_t band_k = (size_t)bandRowsPerRank(rows) * cols;     // keys per band
+    key_pieces_.create(band_k * (size_t)world_ + band_k);           // the world pieces of my band, then the merged band
+    ZS_NCCL(ncclGroupStart());
+    bool sent = true;
+    for (int r = 0; r < world_ && sent; ++r)
+        sent = ncclSend(keys_pad_.ptr() + (size_t)r * band_k, band_k, ncclInt64, r, c, st) == ncclSuccess &&
+               ncclRecv(key_pieces_.ptr() + (size_t)r * band_k, band_k, ncclInt64, r, c, st) == ncclSuccess;
+    const bool closed = ncclGroupEnd() == ncclSuccess;
+    if (!sent || !closed) return fail("ZSlabComm: ncclSend / ncclRecv of the key bands");
+    unsigned long long* merged = key_pieces_.ptr() + band_k * (size_t)world_;
+    const int rc = dfusion_raycast_min_pieces(key_pieces_.ptr(), world_, (unsigned long long)band_k, merged, stream_);
+    if (rc != 0) return fail(std::string("dfusion_raycast_min_pieces: ") + dfusion_error_string(rc));
+    ZS_NCCL(ncclAllGather(merged, keys_pad_.ptr(), band_k, ncclInt64, c, st));
     return true;
 }
 
@@ -281,17 +341,9 @@ bool ZSlabComm::raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Int
     if (!ok_) return false;
     ncclComm_t c = (ncclComm_t)comm_; hipStream_t st = (hipStream_t)stream_;
     const size_t px = (size_t)cols * rows;
+    if (!keyImage(cols, rows)) return false;
     slab.raycastMarch(camera_pose, intr, cols, rows, (unsigned)rank_, keys64_);
-    // ONE merge collective: the per-pixel MIN of the keys is the first event along every ray, its owner and its Ts (dfusion.h)
-    if (world_ > 1 && backend_ == HOST_STAGED) {
-        if (px * 16 > slot_bytes_) return fail("ZSlabComm(host): image larger than a slot (DFUSION_ZSLAB_HOST_SLOT_MB)");
-        ZS_HIP(hipMemcpy(hostSlot(rank_), keys64_.ptr(), px * 8, hipMemcpyDeviceToHost));
-        if (!hostBarrier()) return false;
-        std::vector<long long> m((const long long*)hostSlot(0), (const long long*)hostSlot(0) + px);
-        for (int r = 1; r < world_; ++r) { const long long* o = (const long long*)hostSlot(r); for (size_t i = 0; i < px; ++i) m[i] = std::min(m[i], o[i]); }
-        if (!hostBarrier()) return false;                           // (everybody has read every slot before anyone reuses its own)
-        ZS_HIP(hipMemcpy(keys64_.ptr(), m.data(), px * 8, hipMemcpyHostToDevice));
-    } else if (world_ > 1) ZS_NCCL(ncclAllReduce(keys64_.ptr(), keys64_.ptr(), px, ncclInt64, ncclMin, c, st));
+    if (!mergeKeys(cols, rows)) return false;
     out_.create(2 * px);                                            // normals (what the reduce sums), then the points
     normals = Normals(rows, cols, out_.ptr(), (size_t)cols * sizeof(Normal));
     points = Cloud(rows, cols, out_.ptr() + px, (size_t)cols * sizeof(Point));
@@ -318,16 +370,9 @@ bool ZSlabComm::raycastRowBands(TsdfVolume& slab, const Affine3f& camera_pose, c
     const size_t px = (size_t)cols * rows;
     const int per = bandRowsPerRank(rows), row0 = bandRow0(rows), nrows = bandRows(rows);
     const size_t band_px = (size_t)per * cols, pad_px = band_px * (size_t)world_;
+    if (!keyImage(cols, rows)) return false;
     slab.raycastMarch(camera_pose, intr, cols, rows, (unsigned)rank_, keys64_);
-    if (world_ > 1 && backend_ == HOST_STAGED) {
-        if (px * 8 > slot_bytes_ || pad_px * 16 > slot_bytes_) return fail("ZSlabComm(host): image larger than a slot (DFUSION_ZSLAB_HOST_SLOT_MB)");
-        ZS_HIP(hipMemcpy(hostSlot(rank_), keys64_.ptr(), px * 8, hipMemcpyDeviceToHost));
-        if (!hostBarrier()) return false;
-        std::vector<long long> m((const long long*)hostSlot(0), (const long long*)hostSlot(0) + px);
-        for (int r = 1; r < world_; ++r) { const long long* o = (const long long*)hostSlot(r); for (size_t i = 0; i < px; ++i) m[i] = std::min(m[i], o[i]); }
-        if (!hostBarrier()) return false;
-        ZS_HIP(hipMemcpy(keys64_.ptr(), m.data(), px * 8, hipMemcpyHostToDevice));
-    } else if (world_ > 1) ZS_NCCL(ncclAllReduce(keys64_.ptr(), keys64_.ptr(), px, ncclInt64, ncclMin, c, st));
+    if (!mergeKeys(cols, rows)) return false;
     // out_: the padded normals every rank shades into (world * per rows; the rows past the image stay zero), this rank's band of
     // the summed normals, this rank's band of points
     out_.create(pad_px + 2 * band_px);

@@ -110,6 +110,50 @@ def coll_all_to_all_rows(full, recv, group=None):
     recv.copy_(dst.view(recv.shape))
 
 
+def coll_all_reduce_min_direct(keys_pad, recv, band, group=None):
+    """keys_pad[world * per, cols] int64 <- the per-key MIN over the ranks, WITHOUT a ring (round 6): ncclAllReduce on a ring is 2 (N - 1)
+    sequential steps; the GPUs of an xGMI node are linked pairwise, so the same result is two exchanges of ONE step each --
+      (1) all-to-all of the row bands: rank r receives every rank's copy of band r (recv [world, per, cols]; fixed-size pieces),
+      (2) r takes the per-key minimum of its N pieces (dfusion_raycast_min_pieces on the GPU) into band [per, cols],
+      (3) all-gather of the merged bands back into keys_pad on every rank.
+    Rows past the image must hold KEY_NONE (or any value: they are never read back as pixels)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = band.shape[0]
+    assert keys_pad.dtype == torch.int64 and keys_pad.shape[0] == world * per and recv.shape[0] == world and recv.shape[1] == per
+    coll_all_to_all_rows(keys_pad, recv, group=group)
+    if recv.is_cuda:
+        from . import capi
+        capi.check(capi.lib().dfusion_raycast_min_pieces(recv.data_ptr(), world, recv[0].numel(), band.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "dfusion_raycast_min_pieces")
+    else:
+        torch.amin(recv, dim=0, out=band)
+    if dist.get_backend(group) == "nccl" and not _staged(keys_pad):
+        dist.all_gather_into_tensor(keys_pad, band, group=group)
+    else:
+        pieces = [torch.empty(band.shape, dtype=band.dtype) for _ in range(world)]
+        dist.all_gather(pieces, band.cpu() if band.is_cuda else band.contiguous(), group=group)
+        keys_pad.copy_(torch.cat(pieces, dim=0))
+
+
+def coll_broadcast_direct(t, src=0, group=None):
+    """rank `src`'s tensor to every rank as N - 1 point-to-point sends in ONE group (RCCL: ncclGroupStart / ncclSend x (N - 1) / ncclGroupEnd):
+    each copy crosses its own xGMI link, all links of `src` at once -- one step instead of the N - 1 of a ring broadcast; what the frame
+    inputs (0.68 MB) want.  gloo / host-staged: the same sends on CPU copies."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return
+    staged = _staged(t) or dist.get_backend(group) != "nccl"
+    buf = (t.cpu() if t.is_cuda else t) if staged else t
+    if rank == src:
+        ops = [dist.P2POp(dist.isend, buf, r, group) for r in range(world) if r != src]
+    else:
+        ops = [dist.P2POp(dist.irecv, buf, src, group)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    if staged and rank != src and buf is not t:
+        t.copy_(buf)
+
+
 # ---- the collective model of tools/scale_model.py (DESIGN.md section 5), here so that bench.py can print the PREDICTED time of every
 # collective next to the one it measures: t = launches * T_LAUNCH + steps * T_HOP + bytes on the busiest link / LINK_GBPS
 T_LAUNCH, T_HOP, LINK_GBPS = 15e-6, 5e-6, 100.0
@@ -117,7 +161,8 @@ T_LAUNCH, T_HOP, LINK_GBPS = 15e-6, 5e-6, 100.0
 
 def collective_model_s(kind, size, n):
     """kind: broadcast | all_reduce | reduce | reduce_scatter (rings: N - 1 or 2 (N - 1) steps) | all_to_all (direct: one step, size / N
-    per link, all links of a rank in parallel) | halo (one paired send / receive of `size` bytes per side)."""
+    per link, all links of a rank in parallel) | all_reduce_direct | broadcast_direct (round 6: the same results as direct exchanges) |
+    halo (one paired send / receive of `size` bytes per side)."""
     if n == 1:
         return 0.0
     if kind == "broadcast":
@@ -128,6 +173,10 @@ def collective_model_s(kind, size, n):
         steps, b = n - 1, (n - 1.0) / n * size
     elif kind == "all_to_all":
         steps, b = 1, size / n
+    elif kind == "all_reduce_direct":          # all-to-all of the bands + all-gather of the merged bands: two launches of one step, size / N per link each
+        return 2 * (T_LAUNCH + T_HOP + (size / n) / (LINK_GBPS * 1e9))
+    elif kind == "broadcast_direct":           # N - 1 sends from one rank, each on its own link
+        steps, b = 1, size
     elif kind == "halo":
         steps, b = 1, size
     else:
@@ -431,7 +480,7 @@ def exchange_halos(vol_tensor, z_store0, z_own0, z_own_n, Z, halo, rank, world, 
 
 
 def raycast_sharded(march_fn, shade_fn, points_fn, rank, world, dst=0, group=None, collectives=None, merge="root", band_out=None,
-                    a2a_recv=None, timer=None):
+                    a2a_recv=None, timer=None, key_merge="ring", keys_pad=None, keys_recv=None, keys_band=None):
     """Sharded ray-cast (include/dfusion.h: dfusion_raycast_march / _shade / _points_of_keys).
 
     march_fn()                  -> keys64 int64 [rows, cols]: the merge keys of this slab (first event | rank | Ts bits)
@@ -453,13 +502,24 @@ def raycast_sharded(march_fn, shade_fn, points_fn, rank, world, dst=0, group=Non
     the seven links of a rank in parallel: N - 1 times fewer sequential steps than the ring behind reduce_scatter, the same bytes per
     link -- and the receiver adds the N pieces of its band (integer adds; every summand but one is zero, so the sum is the owner's bits).
     No counts are exchanged: the pieces have a fixed size.  a2a_recv: [world, per, cols, 4] float buffer for the pieces.
+    key_merge = "direct" (round 6): the FIRST collective without a ring as well (coll_all_reduce_min_direct): march_fn must return the
+    first `rows` rows of keys_pad [world * per, cols] int64 (or anything, which is then copied there); keys_recv [world, per, cols] and
+    keys_band [per, cols] are its buffers.  The stage is marked "all_reduce_min" either way.
     collectives: None = only when world > 1; True = also with one rank (an RCCL dry run of the dtypes and ops).
     timer: a StageTimer; the stages march / all_reduce_min / shade / reduce_scatter | all_to_all | reduce / points are marked."""
     on = world > 1 if collectives is None else collectives
     mark = timer.mark if timer is not None else (lambda name: None)
     keys64 = march_fn()
     mark("march")
-    if on:
+    if on and key_merge == "direct":
+        rows_img = keys64.shape[0]
+        assert keys_pad is not None and keys_recv is not None and keys_band is not None and keys_pad.shape[0] >= rows_img
+        if keys64.data_ptr() != keys_pad.data_ptr():
+            keys_pad[:rows_img].copy_(keys64)
+        coll_all_reduce_min_direct(keys_pad, keys_recv, keys_band, group=group)
+        keys64 = keys_pad[:rows_img]
+        mark("all_reduce_min")
+    elif on:
         coll_all_reduce(keys64, dist.ReduceOp.MIN, group=group)
         mark("all_reduce_min")
     normals = shade_fn(keys64)

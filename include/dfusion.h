@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DFUSION_ABI_VERSION 6   /* 6: dfusion_cloud_to_depth; the planned warped sweep takes every node count (no LDS node table: DF_WARP_NO_LDS now only selects the plain gather kernel), a prepared plan is also voided by set_nodes / build_index / a second set_transforms; 5: dfusion_integrate_warped_prepare / _sweep (the frame's integrate in two calls, for cross-frame overlap), dfusion_raycast_sum_pieces (direct row-band merge), DF_WARP_STEADY_PREFETCH, dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation), DF_WARP_NO_CODES + dfusion_warp_coded_blocks (4-bit neighbour codes of modelled blocks); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
+#define DFUSION_ABI_VERSION 7   /* 7: dfusion_raycast_min_pieces (the sharded cast's key merge as direct exchanges: all-to-all of row bands, local MIN, all-gather); 6: dfusion_cloud_to_depth; the planned warped sweep takes every node count (no LDS node table: DF_WARP_NO_LDS now only selects the plain gather kernel), a prepared plan is also voided by set_nodes / build_index / a second set_transforms; 5: dfusion_integrate_warped_prepare / _sweep (the frame's integrate in two calls, for cross-frame overlap), dfusion_raycast_sum_pieces (direct row-band merge), DF_WARP_STEADY_PREFETCH, dfusion_selftest_exact_forms takes TEN counters ([8], [9]: the f32-division form of the blend's first normalisation), DF_WARP_NO_CODES + dfusion_warp_coded_blocks (4-bit neighbour codes of modelled blocks); 4: no process-wide state left: dfusion_integrate_ex (validation flags + swept counter per call) replaces dfusion_debug_rigid / dfusion_debug_rigid_counters, dfusion_warp_debug_counters (per handle) replaces dfusion_debug_warp_counters; dfusion_warp_alive_blocks; dfusion_raycast_points_of_keys_rows; DF_WARP_NO_PREFETCH; 3: dfusion_raycast_points_of_keys (dfusion_raycast_shade's points nullable), dfusion_release_scratch, DF_INDEX_TABLES_ON_DEMAND, DF_WARP_*_BLOCK_MODEL flags; 2: sharded cast merges on one key (no vertex exchange), dfusion_debug_rigid_counters, selftest counts[6] */
 
 typedef void *dfStream; /* hipStream_t */
 
@@ -241,6 +241,14 @@ int dfusion_raycast_points_of_keys_rows(const float cam2vol[12], const float Rin
  * them: out[i] = sum over p < n_pieces of pieces[p * n_words + i], 32-bit integer adds on the bit patterns (all summands but one are zero, so
  * the sum IS the owner's bits -- the same arithmetic a reduce_scatter(SUM) on the int32 view performs).  n_words: 32-bit words per piece.   */
 int dfusion_raycast_sum_pieces(const uint32_t *pieces_dev, int n_pieces, unsigned long long n_words, uint32_t *out_dev, dfStream stream);
+
+/* The local step of the DIRECT form of the sharded cast's FIRST collective (ABI 7).  ncclAllReduce(MIN) of the key image walks a ring of
+ * 2 (N - 1) sequential steps; xGMI links every pair of GPUs of a node directly, so the same result takes two exchanges of ONE step each:
+ * every rank sends rank r its copy of r's band of pixel rows (one all-to-all of fixed-size pieces, as for the normals), r takes the per-key
+ * minimum of the N pieces -- this call -- and one all-gather hands every rank the merged image.  out[i] = min over p < n_pieces of
+ * pieces[p * n_keys + i]; keys are the non-negative int64 merge keys above (DF_RC_KEY_NONE in padding rows).  n_keys even unless
+ * n_pieces == 1; pieces_dev / out_dev 16-byte aligned.                                                                                */
+int dfusion_raycast_min_pieces(const unsigned long long *pieces_dev, int n_pieces, unsigned long long n_keys, unsigned long long *out_dev, dfStream stream);
 
 /* ---- surface extraction -------------------------------------------------------
  * device::extractCloud (internal.hpp:142; tsdf_volume.cu:511-710,798-817): zero crossings between every voxel and its

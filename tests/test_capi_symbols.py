@@ -27,7 +27,7 @@ def test_library_builds_for_gfx950_and_exports_every_symbol():
     L = C.CDLL(path)
     for name in declared_functions():
         assert hasattr(L, name), name
-    assert capi.lib().dfusion_abi_version() == 6                      # DFUSION_ABI_VERSION
+    assert capi.lib().dfusion_abi_version() == 7                      # DFUSION_ABI_VERSION
 
 
 def test_struct_layout_matches_header():

@@ -112,7 +112,7 @@ def test_argument_validation():
     assert L.dfusion_warp_set_nodes(wf.handle, d.data_ptr(), d.data_ptr(), d.data_ptr(), 70000, None) == DF_E_INVALID   # ids are 16-bit
     assert L.dfusion_warp_solve_data_term(wf.handle, 4, d.data_ptr(), d.data_ptr(), 0, 10, 0.0, None, None, None) == DF_E_INVALID
     assert L.dfusion_icp_estimate(None, 1, 0, Intr(1, 1, 0, 0).as_proj(), 0.01, 0.9, d.data_ptr(), d.data_ptr(), None) == DF_E_INVALID
-    assert L.dfusion_error_string(DF_E_INVALID) and L.dfusion_error_string(100002) and L.dfusion_abi_version() == 6
+    assert L.dfusion_error_string(DF_E_INVALID) and L.dfusion_error_string(100002) and L.dfusion_abi_version() == 7
 
 
 @pytest.mark.parametrize("k", [1, 2, 3, 5, 6, 7])

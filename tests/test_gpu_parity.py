@@ -60,7 +60,7 @@ def assert_volume_parity(gpu_u32, ref_u32, exact=True):
 
 
 def test_library_is_the_hip_build():
-    assert capi.lib().dfusion_abi_version() == 6
+    assert capi.lib().dfusion_abi_version() == 7
     assert torch.cuda.is_available()
 
 

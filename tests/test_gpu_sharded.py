@@ -43,6 +43,22 @@ def run_sharded(sc, world, frames, k=None, recompute_halo=False):
         v.raycast_march(sc.cam_poses[f], intr, k64, rank=r)
         k64s.append(k64)
     merged = torch.stack(k64s).min(0).values.contiguous()
+    # the DIRECT key merge (round 6, --key-merge direct): rank r receives every rank's copy of band r of the padded key image and takes the per-key
+    # minimum on the device (dfusion_raycast_min_pieces); the bands, gathered, are what all_reduce(MIN) computes
+    from dynamicfusion_amd import capi
+    per_k, bands_k = sharded.row_bands(cfg.rows, world)
+    pads = torch.full((world, world * per_k, cfg.cols), sharded.KEY_NONE, dtype=torch.int64, device="cuda")
+    for s_, k64 in enumerate(k64s):
+        pads[s_, :cfg.rows] = k64
+    gathered = torch.empty((world * per_k, cfg.cols), dtype=torch.int64, device="cuda")
+    for r in range(world):
+        pieces_k = pads[:, r * per_k:(r + 1) * per_k].contiguous()
+        capi.check(capi.lib().dfusion_raycast_min_pieces(pieces_k.data_ptr(), world, pieces_k[0].numel(), gathered[r * per_k:(r + 1) * per_k].data_ptr(), None),
+                   "dfusion_raycast_min_pieces")
+    assert torch.equal(gathered[:cfg.rows], merged) and bool((gathered[cfg.rows:] == sharded.KEY_NONE).all())
+    one = torch.empty((4,), dtype=torch.int64, device="cuda")                      # (an odd count is fine with a single piece; not with several)
+    assert capi.lib().dfusion_raycast_min_pieces(merged.data_ptr(), 1, 3, one.data_ptr(), None) == 0 and torch.equal(one[:3], merged.view(-1)[:3])
+    assert capi.lib().dfusion_raycast_min_pieces(merged.data_ptr(), 2, 3, one.data_ptr(), None) != 0
     best = torch.where(merged == sharded.KEY_NONE, torch.full_like(merged, 0xFFFFFFFF), (merged >> 39) & 0xFFFFFF)
     acc = torch.zeros((2, cfg.rows, cfg.cols, 4), dtype=torch.int32, device="cuda")
     for v in vols:                                      # stage 2 + what reduce(SUM) of the bit patterns computes
@@ -65,7 +81,6 @@ def run_sharded(sc, world, frames, k=None, recompute_halo=False):
             assert torch.equal(pb.view(torch.int32), acc[0][r0:r0 + nr])
     # the DIRECT row-band merge (round 5, --merge a2a): rank r receives every rank's piece of ITS band of the padded normals image and adds
     # them on the device (dfusion_raycast_sum_pieces) -- the band of the summed normals, bit for bit
-    from dynamicfusion_amd import capi
     shaded = torch.zeros((world, world * per, cfg.cols, 4), dtype=torch.float32, device="cuda")       # [source rank][padded image]
     for s_, v in enumerate(vols):
         v.raycast_shade(sc.cam_poses[f], intr, merged, None, shaded[s_, :cfg.rows])
@@ -172,7 +187,9 @@ def test_bench_gpus_n_launches_its_own_ranks():
         assert sd["rccl_ranks_seen"] == n and len(sd["devices"]) == n
         for st in ("broadcast", "integrate_warped", "march", "all_reduce_min", "shade", "points"):
             assert st in sd["stages"] and len(sd["per_rank_ms"][st]) == n and all(v > 0 for v in sd["per_rank_ms"][st]), st
-        assert set(sd["variants"]) == {"merge=rows", "merge=a2a", "merge=root", "halo=exchange"}
+        assert set(sd["variants"]) == {"merge=rows", "merge=a2a", "merge=root", "halo=exchange", "key_merge=ring", "bcast=ring"}
+        assert d["config"]["key_merge"].startswith("direct") and "point-to-point" in d["config"]["inputs"]
+        assert sd["predicted_collective_ms"]["all_reduce_min"] < sd["predicted_collective_ms"]["all_reduce_min(ring)"] + 0.02
         assert "all_to_all" in sd["variants"]["merge=a2a"]["per_rank_ms"] and "halo_exchange" in sd["variants"]["halo=exchange"]["per_rank_ms"]
         assert all(v["ms_per_frame"] > 0 for v in sd["variants"].values())
         assert sd["predicted_collective_ms"]["all_to_all"] > 0 and sd["predicted_collective_ms"]["all_reduce_min"] > sd["predicted_collective_ms"]["broadcast"]

@@ -39,7 +39,7 @@ def _unsharded(sc):
     return vol, p, n
 
 
-def _worker(rank, world, port, recompute_halo, balanced=False, merge="root"):
+def _worker(rank, world, port, recompute_halo, balanced=False, merge="root", direct=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -71,8 +71,12 @@ def _worker(rank, world, port, recompute_halo, balanced=False, merge="root"):
         for f in range(FRAMES):
             depth = torch.from_numpy(sc.depths[f].view(np.int16).copy()) if rank == 0 else torch.empty((CFG.rows, CFG.cols), dtype=torch.int16)
             dq = torch.from_numpy(sc.dqs[f].copy()) if rank == 0 else torch.empty((CFG.nodes, 8), dtype=torch.float32)
-            sharded.broadcast_bytes(depth, 0)                                   # rank 0 owns the sensor frame ...
-            sharded.broadcast_bytes(dq, 0)                                      # ... and the solver's node transforms
+            if direct:                                                          # (round 6: N - 1 point-to-point sends in one group)
+                sharded.coll_broadcast_direct(depth, 0)
+                sharded.coll_broadcast_direct(dq, 0)
+            else:
+                sharded.broadcast_bytes(depth, 0)                               # rank 0 owns the sensor frame ...
+                sharded.broadcast_bytes(dq, 0)                                  # ... and the solver's node transforms
             dists = O.compute_dists(depth.numpy().view(np.uint16), sc.intr)
             O.integrate_warped(dists, vol, sc.ovol(vol), synth.aff12(sc.pose), synth.aff12(sc.world2cam(f)), sc.intr,
                                sc.pos, dq.numpy(), sc.sigma, CFG.k, slab=slab_int)
@@ -113,7 +117,10 @@ def _worker(rank, world, port, recompute_halo, balanced=False, merge="root"):
                 pts, nrm, (r0, nr) = sharded.raycast_sharded(march, shade_padded, points_band, rank, world, merge=merge,
                                                              band_out=torch.empty((per, CFG.cols, 4), dtype=torch.float32),
                                                              a2a_recv=torch.empty((world, per, CFG.cols, 4), dtype=torch.float32) if merge == "a2a" else None,
-                                                             timer=timer)
+                                                             timer=timer, key_merge="direct" if direct else "ring",
+                                                             keys_pad=torch.full((world * per, CFG.cols), sharded.KEY_NONE, dtype=torch.int64) if direct else None,
+                                                             keys_recv=torch.empty((world, per, CFG.cols), dtype=torch.int64) if direct else None,
+                                                             keys_band=torch.empty((per, CFG.cols), dtype=torch.int64) if direct else None)
                 timer.end()
                 stages = list(timer.means())
                 assert stages == ["march", "all_reduce_min", "shade", "all_to_all" if merge == "a2a" else "reduce_scatter", "points"], stages
@@ -170,6 +177,29 @@ def test_zslab_pipeline_direct_all_to_all_merge(world):
     mp.spawn(_worker, args=(world, _free_port(), True, False, "a2a"), nprocs=world, join=True)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_zslab_pipeline_with_every_collective_direct(world):
+    """Round 6: no ring left in the frame -- the inputs go out as N - 1 point-to-point sends, the key merge is an all-to-all of row bands +
+    local MIN + all-gather (coll_all_reduce_min_direct), the normals the round-5 all-to-all.  Same bits as the unsharded frame."""
+    mp.spawn(_worker, args=(world, _free_port(), True, False, "a2a", True), nprocs=world, join=True)
+
+
+def test_direct_key_merge_equals_all_reduce_min_on_ragged_bands():
+    """One process, three emulated ranks, an image whose rows do not divide by the world: the band-wise minimum of the pieces, gathered, is
+    the elementwise minimum of the images; padding rows never reach the image."""
+    world, rows, cols = 3, 7, 5
+    per, bands = sharded.row_bands(rows, world)
+    g = torch.Generator().manual_seed(5)
+    imgs = [torch.randint(0, 1 << 40, (rows, cols), generator=g, dtype=torch.int64) for _ in range(world)]
+    imgs[1][2, 3] = sharded.KEY_NONE
+    pads = [torch.full((world * per, cols), sharded.KEY_NONE, dtype=torch.int64) for _ in range(world)]
+    for p, im in zip(pads, imgs):
+        p[:rows] = im
+    merged = torch.cat([torch.amin(torch.stack([pads[s][r * per:(r + 1) * per] for s in range(world)]), dim=0) for r in range(world)])
+    assert torch.equal(merged[:rows], torch.amin(torch.stack(imgs), dim=0))
+    assert (merged[rows:] == sharded.KEY_NONE).all()
+
+
 def test_collective_model_orders_the_merges():
     # the stated model (tools/scale_model.py): the direct all-to-all beats the ring reduce_scatter from 4 ranks on, both beat reduce-to-root
     px16 = 640 * 480 * 16
@@ -177,6 +207,10 @@ def test_collective_model_orders_the_merges():
         a, rs, rd = (sharded.collective_model_s(k, px16, n) for k in ("all_to_all", "reduce_scatter", "reduce"))
         assert a < rs < rd
     assert sharded.collective_model_s("all_reduce", 1 << 20, 1) == 0.0
+    for n in (2, 4, 8):                                    # the direct forms never lose to the rings they replace
+        assert sharded.collective_model_s("all_reduce_direct", 640 * 480 * 8, n) <= sharded.collective_model_s("all_reduce", 640 * 480 * 8, n) + 16e-6
+        assert sharded.collective_model_s("broadcast_direct", 680000, n) <= sharded.collective_model_s("broadcast", 680000, n)
+    assert sharded.collective_model_s("all_reduce_direct", 640 * 480 * 8, 8) < 0.5 * sharded.collective_model_s("all_reduce", 640 * 480 * 8, 8)
 
 
 def test_zslab_pipeline_over_gloo_with_work_balanced_slabs():

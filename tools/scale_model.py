@@ -9,8 +9,8 @@ checkable way:
     t(collective) = launches * T_LAUNCH + steps * T_HOP + bytes_on_the_busiest_link / LINK_GBPS
 with xGMI ~153 GB/s per link and direction pair (guide), of which a ring step sustains LINK_GBPS = 100; T_HOP = 5 us per ring step
 (RCCL's LL/LL128 protocols for messages of a few MB), T_LAUNCH = 15 us per collective call (host enqueue + kernel start):
-    broadcast  (depth + transforms, 0.68 MB):  N - 1 ring steps, bytes = size
-    all_reduce MIN of the int64 keys (2.46 MB): 2 (N - 1) steps, bytes = 2 (N - 1) / N * size
+    broadcast  (depth + transforms, 0.68 MB):  N - 1 ring steps, bytes = size          [direct, round 6: one step, bytes = size]
+    all_reduce MIN of the int64 keys (2.46 MB): 2 (N - 1) steps, bytes = 2 (N - 1) / N * size   [direct: 2 launches x (1 step, size / N)]
     reduce SUM of the normals to rank 0 (4.92 MB; the points follow from the merged keys): N - 1 steps, bytes = size
 Usage:  python tools/scale_model.py [CONFIG] [balanced|uniform]     (prints a markdown table, writes gpurun_out/scale_model_<cfg>_<kind>.json)
 `measured` (bench.py's default, round 4): slab boundaries re-cut from the verdict pass's alive-block counts per 8-plane layer after three
@@ -109,8 +109,13 @@ def main():
         t_frame = worst["sum"] + sum(comm.values())
         comm["all_to_all"] = collective("all_to_all", sizes["reduce"], n)      # round 5: the direct form of the second collective (bench.py --merge a2a)
         t_frame_a2a = t_frame - comm["reduce"] + comm["all_to_all"]
+        # round 6: no ring left -- the inputs as N - 1 point-to-point sends, the key merge as all-to-all of row bands + local MIN + all-gather
+        # (bench.py's defaults: --bcast direct --key-merge direct --merge a2a)
+        comm["broadcast_direct"] = collective("broadcast_direct", sizes["broadcast"], n)
+        comm["all_reduce_direct"] = collective("all_reduce_direct", sizes["all_reduce"], n)
+        t_frame_direct = worst["sum"] + comm["broadcast_direct"] + comm["all_reduce_direct"] + comm["all_to_all"]
         rows.append({"n": n, "halo": halo if n > 1 else 0, "slabs": kind, "bounds": bounds, "kernels_ms": {k: 1e3 * v for k, v in worst.items()},
-                     "collectives_ms": {k: 1e3 * v for k, v in comm.items()}, "frame_ms": 1e3 * t_frame, "frames_per_s": 1.0 / t_frame, "frame_ms_a2a": 1e3 * t_frame_a2a,
+                     "collectives_ms": {k: 1e3 * v for k, v in comm.items()}, "frame_ms": 1e3 * t_frame, "frames_per_s": 1.0 / t_frame, "frame_ms_a2a": 1e3 * t_frame_a2a, "frame_ms_direct": 1e3 * t_frame_direct,
                      "per_rank_integrate_ms": [1e3 * p[0] for p in per_rank],
                      "first_cut": first if (kind == "measured" and n > 1) else None})
     base = rows[0]["frames_per_s"]
@@ -123,6 +128,9 @@ def main():
             r["frames_per_s"] / base))
     print("second collective as ONE direct all-to-all of the row bands (--merge a2a): " +
           ", ".join("N = %d: %.3f ms -> frame %.3f ms (%.2fx)" % (r["n"], r["collectives_ms"]["all_to_all"], r["frame_ms_a2a"], rows[0]["frame_ms"] / r["frame_ms_a2a"]) for r in rows))
+    print("every collective direct (bench.py's defaults since round 6: --bcast direct --key-merge direct --merge a2a): " +
+          ", ".join("N = %d: %.3f + %.3f + %.3f ms -> frame %.3f ms (%.2fx)" % (r["n"], r["collectives_ms"]["broadcast_direct"], r["collectives_ms"]["all_reduce_direct"],
+                                                                              r["collectives_ms"]["all_to_all"], r["frame_ms_direct"], rows[0]["frame_ms"] / r["frame_ms_direct"]) for r in rows))
     for r in rows:
         print("N = %d (%s slabs %s) integrate per rank (ms):" % (r["n"], kind, r["bounds"]), " ".join("%.3f" % v for v in r["per_rank_integrate_ms"]))
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
