@@ -1010,12 +1010,12 @@ def main():
                 extra["kinfu_frame"] = {"error": str(e)[:200]}
 
     # kernel that ran + its per-voxel cache footprint; PMC traffic comes from the committed rocprofv3 --pmc passes
-    # (dfusion_warp.hip, df_integrate_warped_impl: k = 8 runs the union-copy sweep at every node count, 768 threads, one plane per batch;
+    # (dfusion_warp.hip, df_integrate_warped_impl: k = 8 runs the union-copy sweep at every node count, 256 threads, one plane per batch;
     # k = 4 keeps the LDS node table where it fits -- 1024 threads past 80 KiB --, and gathers from the L2 otherwise)
     lds_ok = cfg.nodes * 32 <= 160 * 1024
     axis_aligned = bool(np.array_equal(np.asarray(cfg.volume_pose, np.float32).reshape(4, 4)[:3, :3], np.eye(3, dtype=np.float32)))
     if cfg.k == 8:
-        kernel_name = "df_warp_rows_pipe_kernel<8, 1, 768, %s, false>" % ("true" if axis_aligned else "false")
+        kernel_name = "df_warp_rows_pipe_kernel<8, 1, 256, %s, false>" % ("true" if axis_aligned else "false")
     elif cfg.k == 4:
         wide = lds_ok and cfg.nodes * 32 > 80 * 1024
         kernel_name = "df_warp_rows_pipe_kernel<4, 2, %d, %s, %s>" % (1024 if wide else 512, "true" if axis_aligned else "false", "true" if lds_ok else "false")
