@@ -116,6 +116,8 @@ private:
     DeviceArray<Point> pieces_;  // ALL_TO_ALL: the world pieces of this rank's band
     KeyMerge key_merge_;
     bool bcast_direct_;
+    bool force_ = false;         // DFUSION_ZSLAB_FORCE_COLLECTIVES: the RCCL calls are issued with one rank too
+    bool on() const { return world_ > 1 || force_; }
     bool keyImage(int cols, int rows);
     bool mergeKeys(int cols, int rows);
     DeviceArray<unsigned long long> keys_pad_;     // the key image + padding to whole row bands (keys64_ is a view of its first cols * rows keys)

@@ -47,6 +47,9 @@ ZSlabComm::ZSlabComm(int rank, int world, const std::string& id_path, Backend ba
     { const char* m = std::getenv("DFUSION_ZSLAB_MERGE"); row_merge_ = (m && !std::strcmp(m, "a2a")) ? ALL_TO_ALL : REDUCE_SCATTER; }
     { const char* m = std::getenv("DFUSION_ZSLAB_KEY_MERGE"); key_merge_ = (m && !std::strcmp(m, "ring")) ? KEYS_RING : KEYS_DIRECT; }
     { const char* m = std::getenv("DFUSION_ZSLAB_BCAST"); bcast_direct_ = !(m && !std::strcmp(m, "ring")); }
+    // DFUSION_ZSLAB_FORCE_COLLECTIVES=1: issue the RCCL calls of the casts and the broadcast with ONE rank too (every one of them is the
+    // identity there: an all-reduce over one rank, a send to oneself) -- a dry run of the calls' types, counts and grouping on a one-GPU box
+    { const char* m = std::getenv("DFUSION_ZSLAB_FORCE_COLLECTIVES"); force_ = m && m[0] == '1' && backend_ != HOST_STAGED; }
     if (backend_ == HOST_STAGED) initHost(id_path); else initRccl(id_path);
 }
 
@@ -223,7 +226,7 @@ bool ZSlabComm::partitionOk(int Z, int world, int halo, std::string* why)
 bool ZSlabComm::broadcast(void* device_ptr, size_t bytes, int root)
 {
     if (!ok_) return false;
-    if (world_ == 1 || !bytes) return true;
+    if (!on() || !bytes) return true;
     if (backend_ == HOST_STAGED) {
         if (bytes > slot_bytes_) return fail("ZSlabComm(host): broadcast larger than a slot (DFUSION_ZSLAB_HOST_SLOT_MB)");
         if (rank_ == root) ZS_HIP(hipMemcpy(hostSlot(root), device_ptr, bytes, hipMemcpyDeviceToHost));
@@ -236,7 +239,7 @@ bool ZSlabComm::broadcast(void* device_ptr, size_t bytes, int root)
         ncclComm_t c = (ncclComm_t)comm_; hipStream_t st = (hipStream_t)stream_;
         ZS_NCCL(ncclGroupStart());
         bool sent = true;
-        if (rank_ == root) { for (int r = 0; r < world_ && sent; ++r) if (r != root) sent = ncclSend(device_ptr, bytes, ncclUint8, r, c, st) == ncclSuccess; }
+        if (rank_ == root) { for (int r = 0; r < world_ && sent; ++r) if (r != root) sent = ncclSend(device_ptr, bytes, ncclUint8, r, c, st) == ncclSuccess; }   // (one rank: an empty group)
         else sent = ncclRecv(device_ptr, bytes, ncclUint8, root, c, st) == ncclSuccess;
         const bool closed = ncclGroupEnd() == ncclSuccess;
         if (!sent || !closed) return fail("ZSlabComm: ncclSend / ncclRecv of the frame inputs");
@@ -263,7 +266,7 @@ bool ZSlabComm::keyImage(int cols, int rows)
 
 bool ZSlabComm::mergeKeys(int cols, int rows)
 {
-    if (world_ == 1) return true;
+    if (!on()) return true;
     ncclComm_t c = (ncclComm_t)comm_; hipStream_t st = (hipStream_t)stream_;
     const size_t px = (size_t)cols * rows;
     if (backend_ == HOST_STAGED) {
@@ -349,7 +352,7 @@ bool ZSlabComm::raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Int
     points = Cloud(rows, cols, out_.ptr() + px, (size_t)cols * sizeof(Point));
     slab.raycastShadeNormals(camera_pose, intr, keys64_, normals);
     // only the normals cross GPUs (4.9 MB at 640 x 480; every summand but one is integer zero): the points follow from the merged keys
-    if (world_ > 1 && backend_ == HOST_STAGED) {
+    if (on() && backend_ == HOST_STAGED) {
         ZS_HIP(hipMemcpy(hostSlot(rank_), out_.ptr(), px * 16, hipMemcpyDeviceToHost));
         if (!hostBarrier()) return false;
         if (rank_ == dst) {
@@ -358,7 +361,7 @@ bool ZSlabComm::raycast(TsdfVolume& slab, const Affine3f& camera_pose, const Int
             ZS_HIP(hipMemcpy(out_.ptr(), sum.data(), px * 16, hipMemcpyHostToDevice));
         }
         if (!hostBarrier()) return false;
-    } else if (world_ > 1) ZS_NCCL(ncclReduce(out_.ptr(), out_.ptr(), px * 4, ncclInt32, ncclSum, dst, c, st));
+    } else if (on()) ZS_NCCL(ncclReduce(out_.ptr(), out_.ptr(), px * 4, ncclInt32, ncclSum, dst, c, st));
     if (rank_ == dst) slab.raycastPointsOfKeys(camera_pose, intr, keys64_, normals, points);
     return true;
 }
@@ -380,7 +383,7 @@ bool ZSlabComm::raycastRowBands(TsdfVolume& slab, const Affine3f& camera_pose, c
     if (pad_px > px) ZS_HIP(hipMemsetAsync(out_.ptr() + px, 0, (pad_px - px) * sizeof(Point), st));
     slab.raycastShadeNormals(camera_pose, intr, keys64_, shaded);
     Point* band_n = out_.ptr() + pad_px; Point* band_p = band_n + band_px;
-    if (world_ > 1 && row_merge_ == ALL_TO_ALL) {
+    if (on() && row_merge_ == ALL_TO_ALL) {
         // the direct form: piece r of pieces_ = rank r's shading of MY band; then the pieces are added on the device
         pieces_.create(pad_px);
         if (backend_ == HOST_STAGED) {
@@ -401,14 +404,14 @@ bool ZSlabComm::raycastRowBands(TsdfVolume& slab, const Affine3f& camera_pose, c
         }
         const int rc = dfusion_raycast_sum_pieces((const uint32_t*)pieces_.ptr(), world_, (unsigned long long)band_px * 4, (uint32_t*)band_n, stream_);
         if (rc != 0) return fail(std::string("dfusion_raycast_sum_pieces: ") + dfusion_error_string(rc));
-    } else if (world_ > 1 && backend_ == HOST_STAGED) {
+    } else if (on() && backend_ == HOST_STAGED) {
         ZS_HIP(hipMemcpy(hostSlot(rank_), out_.ptr(), pad_px * 16, hipMemcpyDeviceToHost));
         if (!hostBarrier()) return false;
         std::vector<int> sum(band_px * 4, 0);
         for (int r = 0; r < world_; ++r) { const int* o = (const int*)hostSlot(r) + (size_t)rank_ * band_px * 4; for (size_t i = 0; i < band_px * 4; ++i) sum[i] = (int)((unsigned)sum[i] + (unsigned)o[i]); }
         if (!hostBarrier()) return false;
         ZS_HIP(hipMemcpy(band_n, sum.data(), band_px * 16, hipMemcpyHostToDevice));
-    } else if (world_ > 1) {
+    } else if (on()) {
         ZS_NCCL(ncclReduceScatter(out_.ptr(), band_n, band_px * 4, ncclInt32, ncclSum, c, st));
     } else {
         ZS_HIP(hipMemcpyAsync(band_n, out_.ptr(), band_px * 16, hipMemcpyDeviceToDevice, st));
@@ -423,7 +426,7 @@ bool ZSlabComm::barrier()
 {
     if (!ok_) return false;
     if (backend_ == HOST_STAGED) { ZS_HIP(hipDeviceSynchronize()); return world_ > 1 ? hostBarrier() : true; }
-    if (world_ > 1) ZS_NCCL(ncclAllReduce(token_.ptr(), token_.ptr(), 1, ncclInt32, ncclSum, (ncclComm_t)comm_, (hipStream_t)stream_));
+    if (on()) ZS_NCCL(ncclAllReduce(token_.ptr(), token_.ptr(), 1, ncclInt32, ncclSum, (ncclComm_t)comm_, (hipStream_t)stream_));
     ZS_HIP(hipDeviceSynchronize());
     return true;
 }

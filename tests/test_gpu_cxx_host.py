@@ -326,6 +326,39 @@ def test_cxx_zslab_rccl_path(tmp_path, with_nodes):
         assert planes.shape[0] == hi - lo and np.array_equal(planes, vol[lo:hi])
 
 
+@pytest.mark.parametrize("key_merge", ["direct", "ring"])
+@pytest.mark.parametrize("rows", [False, "rs", "a2a"], ids=["root", "rows-rs", "rows-a2a"])
+def test_cxx_zslab_rccl_calls_issued_with_one_rank(tmp_path, rows, key_merge):
+    """Round 6: every RCCL call of ZSlabComm's casts REALLY issued on this one-GPU box (DFUSION_ZSLAB_FORCE_COLLECTIVES=1: with one rank each
+    is the identity -- ncclAllReduce / ncclReduce / ncclReduceScatter over one rank, ncclSend / ncclRecv to oneself in a group,
+    ncclAllGather of one piece): the ring key merge and the direct one (send / recv group -> dfusion_raycast_min_pieces -> ncclAllGather),
+    the normals to the root, reduce-scattered by rows, and as the direct all-to-all -- types, counts, grouping and buffer sizes of the
+    calls N > 1 ranks make, and the unsharded harness's bytes at the end."""
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=100, k=8)
+    frames = 2
+    sc = Scene(cfg, n_frames=frames)
+    vol, pts, nrm, _, _ = run_harness(tmp_path, cfg, sc, frames, True)
+    build.build_host()
+    fin, fout, idf = str(tmp_path / "in.bin"), str(tmp_path / "zf.bin"), str(tmp_path / "idf")
+    cmd = [build.HOST_ZSLAB_APP, str(cfg.dims[0]), str(cfg.size), str(cfg.cols), str(cfg.rows), str(frames), str(cfg.nodes), str(cfg.k), fin, fout, idf, "recompute"]
+    if rows: cmd.append("rows")
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", DFUSION_ZSLAB_FORCE_COLLECTIVES="1", DFUSION_ZSLAB_KEY_MERGE=key_merge,
+               DFUSION_ZSLAB_MERGE="a2a" if rows == "a2a" else "rs", DFUSION_ZSLAB_BCAST="ring" if key_merge == "ring" else "direct")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "zslab_frame ok: rank 0 of 1" in r.stdout, r.stdout + r.stderr
+    npx = cfg.rows * cfg.cols
+    raw = np.fromfile(fout, np.uint8)
+    if rows:
+        b = np.fromfile(fout + ".band0", np.uint8)
+        r0, nr = [int(v) for v in b[:8].view(np.int32)]
+        assert (r0, nr) == (0, cfg.rows)
+        img = b[8:].view(np.float32).reshape(2, nr, cfg.cols, 4)
+    else:
+        img = raw[:2 * npx * 16].view(np.float32).reshape(2, cfg.rows, cfg.cols, 4)
+    assert np.array_equal(img[0].view(np.uint32), pts.view(np.uint32)) and np.array_equal(img[1].view(np.uint32), nrm.view(np.uint32))
+    assert np.array_equal(raw[2 * npx * 16:].view(np.uint32).reshape(cfg.dims[2], cfg.dims[1], cfg.dims[0]), vol)
+
+
 @pytest.mark.parametrize("world,mode,rows", [(2, "exchange", False), (2, "recompute", False), (3, "recompute", False), (2, "recompute", True), (7, "recompute", True),
                                              (3, "recompute", "a2a"), (7, "recompute", "a2a")])
 def test_cxx_zslab_collectives_with_more_than_one_rank(tmp_path, world, mode, rows):
