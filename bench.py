@@ -560,6 +560,7 @@ def main():
     # frame inputs travel as ONE byte bundle (depth image + node transforms): one ncclBroadcast per frame
     n_depth = cfg.rows * cfg.cols * 2
     bundle = torch.empty(n_depth + cfg.nodes * 32, dtype=torch.uint8, device=dev)
+    bcast_scratch = torch.empty(world * bundle.numel(), dtype=torch.uint8, device=dev) if (dist_on and rank == 0) else None     # the N copies rank 0's direct send reads
     depth_in = bundle[:n_depth].view(torch.int16).view(cfg.rows, cfg.cols)
     dq_in = bundle[n_depth:].view(torch.float32).view(cfg.nodes, 8)
 
@@ -592,7 +593,7 @@ def main():
         if dist_on:                                    # rank 0 owns the sensor frame and the solver output
             if rank == 0:
                 depth_in.copy_(depths[f]); dq_in.copy_(dqs[f])
-            if bcast == "direct": sharded.coll_broadcast_direct(bundle, 0)
+            if bcast == "direct": sharded.coll_broadcast_direct(bundle, 0, scratch=bcast_scratch)
             else: sharded.coll_broadcast(bundle, 0)
             mark("broadcast")
             d_in, q_in = depth_in, dq_in

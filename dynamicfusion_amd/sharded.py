@@ -135,22 +135,34 @@ def coll_all_reduce_min_direct(keys_pad, recv, band, group=None):
         keys_pad.copy_(torch.cat(pieces, dim=0))
 
 
-def coll_broadcast_direct(t, src=0, group=None):
-    """rank `src`'s tensor to every rank as N - 1 point-to-point sends in ONE group (RCCL: ncclGroupStart / ncclSend x (N - 1) / ncclGroupEnd):
-    each copy crosses its own xGMI link, all links of `src` at once -- one step instead of the N - 1 of a ring broadcast; what the frame
-    inputs (0.68 MB) want.  gloo / host-staged: the same sends on CPU copies."""
+def coll_broadcast_direct(t, src=0, group=None, scratch=None):
+    """rank `src`'s tensor to every rank as N - 1 point-to-point copies in ONE group, each on its own xGMI link, all links of `src` at once --
+    one step instead of the N - 1 of a ring broadcast; what the frame inputs (0.68 MB) want.  RCCL: one all_to_all_single with uneven
+    splits (the grouped ncclSend / ncclRecv the other direct exchanges use, on the group's own communicator): `src` sends the whole tensor
+    to every rank, everybody else sends nothing; `scratch` (optional, N * t.numel() elements on `src`) holds the N copies the call reads.
+    gloo / host-staged: the same as isend / irecv pairs on CPU copies."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if dist.get_backend(group) == "nccl" and not _staged(t):
+        flat = t.view(-1)
+        n = flat.numel()
+        if rank == src:
+            rep = scratch.view(-1)[:world * n] if scratch is not None else torch.empty(world * n, dtype=t.dtype, device=t.device)
+            rep.view(world, n).copy_(flat.unsqueeze(0).expand(world, n))
+            out = torch.empty(n, dtype=t.dtype, device=t.device)               # (its own copy comes back: the input is not also an output)
+            dist.all_to_all_single(out, rep, output_split_sizes=[n if r == src else 0 for r in range(world)], input_split_sizes=[n] * world, group=group)
+        else:
+            dist.all_to_all_single(flat, flat[:0], output_split_sizes=[n if r == src else 0 for r in range(world)], input_split_sizes=[0] * world, group=group)
+        return
     if world == 1:
         return
-    staged = _staged(t) or dist.get_backend(group) != "nccl"
-    buf = (t.cpu() if t.is_cuda else t) if staged else t
+    buf = t.cpu() if t.is_cuda else t
     if rank == src:
         ops = [dist.P2POp(dist.isend, buf, r, group) for r in range(world) if r != src]
     else:
         ops = [dist.P2POp(dist.irecv, buf, src, group)]
     for w in dist.batch_isend_irecv(ops):
         w.wait()
-    if staged and rank != src and buf is not t:
+    if rank != src and buf is not t:
         t.copy_(buf)
 
 
