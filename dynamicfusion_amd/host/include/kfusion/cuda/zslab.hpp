@@ -9,8 +9,9 @@
 //                    the broadcast inputs, the own range stays the non-overlapping one -- the harness offers both
 //   raycast()        two stages, because the zero-crossing refinement can move a vertex into ANOTHER rank's slab
 //                    (tsdf_volume.cu:389): march on the global step lattice (each rank evaluates only the steps whose sample lies
-//                    in a plane it owns) -> ONE ncclAllReduce(MIN) of the int64 merge keys [step | hit | rank | Ts bits]
-//                    (include/dfusion.h): first event along every ray, its owner, and its refined ray parameter Ts, from which
+//                    in a plane it owns) -> the per-pixel MIN of the int64 merge keys [step | hit | rank | Ts bits]
+//                    (include/dfusion.h; as direct exchanges -- row bands all-to-all, local minimum, all-gather: setKeyMerge -- or
+//                    one ncclAllReduce): first event along every ray, its owner, and its refined ray parameter Ts, from which
 //                    every rank recomputes the vertex -> the owner of the vertex' plane computes the normal -> ONE ncclReduce(SUM) of the
 //                    int32 view of the NORMALS to rank `dst` (every summand but one is integer zero) -> rank `dst` makes the points
 //                    from the merged keys (vertex = origin + direction * Ts; a hit stands iff its normal does): bit-identical with the
