@@ -1929,7 +1929,8 @@ __global__ __launch_bounds__(DF_PLAN_WG) void df_sweep_plan_kernel(const DfWarpe
 //   LDSN = true (k = 4, M <= 5120): rot / node_t of all nodes in LDS, gathers by ds_read_b128 (k = 4 has no codes: measured +2 %, NOTES r5).
 template <int K, int U, int WGT, bool V2W_IDENTITY, bool LDSN>
 // (waves per SIMD asked of the compiler: 6 for k = 8 -- 78 VGPRs, no scratch; 7 waves at 72 VGPRs spill 48 bytes a lane and lose 5 %,
-// and holding a CU to 5 workgroups changes nothing: profiles/r06_ab_wgsize.txt, r06_ab_occupancy.txt -- the sweep is VALU-bound from 5 waves on)
+// and holding a CU to 5 workgroups changes nothing: profiles/r06_ab_wgsize.txt, r06_ab_occupancy.txt -- waves buy nothing from 5 on; neither do fewer instructions or a third table
+// set in flight: the launch sits 8-15 % above two floors a few per cent apart, its arithmetic alone and its memory accesses alone -- DESIGN 4.1)
 __global__ __launch_bounds__(WGT, LDSN ? (WGT == 512 ? 4 : 1) : (K == 8 ? 6 : 5)) void df_warp_rows_pipe_kernel(const DfWarpedArgs a, const DfWarpView W, int tiles_x)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_lds[];      // LDSN: [2M] rot_j, node_t_j interleaved; else [waves][8][16][2] union copies
