@@ -28,10 +28,11 @@ static Affine3f to_affine(const float a[12])
 
 int main(int argc, char** argv)
 {
-    if (argc == 5 && !std::strcmp(argv[1], "bounds")) {     // zslab_frame bounds <world> <halo> <weights.f64>: ZSlabComm::slabBounds of the file's planes
+    if (argc == 5 && (!std::strcmp(argv[1], "bounds") || !std::strcmp(argv[1], "bounds-minmax"))) {     // zslab_frame bounds[-minmax] <world> <halo> <weights.f64>: ZSlabComm::slabBounds[MinMax] of the file's planes
         std::vector<double> w;
         if (FILE* f = std::fopen(argv[4], "rb")) { double v; while (std::fread(&v, 8, 1, f) == 1) w.push_back(v); std::fclose(f); }
-        const std::vector<int> b = cuda::ZSlabComm::slabBounds((int)w.size(), std::atoi(argv[2]), std::atoi(argv[3]), w);
+        const std::vector<int> b = !std::strcmp(argv[1], "bounds") ? cuda::ZSlabComm::slabBounds((int)w.size(), std::atoi(argv[2]), std::atoi(argv[3]), w)
+                                                                   : cuda::ZSlabComm::slabBoundsMinMax((int)w.size(), std::atoi(argv[2]), std::atoi(argv[3]), w);
         for (size_t i = 0; i < b.size(); ++i) std::printf("%s%d", i ? "," : "", b[i]);
         std::printf("\n");
         return 0;

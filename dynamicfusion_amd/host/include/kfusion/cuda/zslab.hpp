@@ -54,6 +54,11 @@ public:
     /// multiples of 8 where Z allows, every slab at least max(halo, 8) planes, about the same weight per rank.  Equal plane counts
     /// leave the far ranks several times the near ranks' work (a frustum's cross-section grows with the square of the depth).
     static std::vector<int> slabBounds(int Z, int world, int halo, const std::vector<double>& weights);
+    /// boundaries that minimise the LARGEST rank's cost instead (round 6; sharded.slab_bounds_minmax, the same bisection): a rank's cost
+    /// is the weight of its own planes plus -- count_halo -- of the halo planes it integrates itself (setSlab(..., integrate_halo = true));
+    /// interior ranks carry two halos, and at 8 ranks 16 halo planes are a quarter of a slab.  What to cut with after the first frames'
+    /// WarpField::aliveBlocksPerLayer, summed over the ranks, has said where the work is.
+    static std::vector<int> slabBoundsMinMax(int Z, int world, int halo, const std::vector<double>& weights, bool count_halo = true);
     /// planes of the neighbour a slab must hold for the ray-cast: the march's `next` sample is one time_step beyond `curr`
     /// (tsdf_volume.cu:378-380), trilinear taps read g+1 (:236-243), gradient probes reach +-gradient_delta (:413-423)
     static int haloPlanes(float trunc_dist, float step_factor, float delta_factor, float voxel_z);

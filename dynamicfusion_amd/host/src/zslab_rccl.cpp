@@ -208,6 +208,40 @@ std::vector<int> ZSlabComm::slabBounds(int Z, int world, int halo, const std::ve
     return b;
 }
 
+// dynamicfusion_amd/sharded.py slab_bounds_minmax, step for step (the same 48 bisections on the same doubles): boundaries that minimise
+// the LARGEST rank's cost -- its own planes plus the halo planes it integrates itself
+std::vector<int> ZSlabComm::slabBoundsMinMax(int Z, int world, int halo, const std::vector<double>& weights, bool count_halo)
+{
+    if ((int)weights.size() != Z || world < 1) return slabBounds(Z, world, halo, weights);
+    const int step = (Z % 8 == 0) ? 8 : 1;
+    const int min_planes = (std::max(halo, step) + step - 1) / step * step;
+    const int H = count_halo ? halo : 0;
+    std::vector<double> cum((size_t)Z + 1, 0.0);
+    for (int z = 0; z < Z; ++z) cum[z + 1] = cum[z] + weights[z];
+    auto cost = [&](int z0, int z1) { return cum[std::min(Z, z1 + H)] - cum[std::max(0, z0 - H)]; };
+    auto pack = [&](double T, std::vector<int>& b) -> bool {
+        b.assign(1, 0);
+        for (int r = 0; r < world - 1; ++r) {
+            const int z0 = b.back(), hi = Z - (world - 1 - r) * min_planes;      // every later rank keeps its minimum
+            int z1 = z0 + min_planes;
+            if (z1 > hi) return false;
+            while (z1 + step <= hi && cost(z0, z1 + step) <= T) z1 += step;
+            b.push_back(z1);
+        }
+        b.push_back(Z);
+        for (int r = 0; r < world; ++r) if (!(cost(b[r], b[r + 1]) <= T)) return false;
+        return true;
+    };
+    double lo = 0.0, hi = cum[Z] + 1.0;
+    std::vector<int> best, b;
+    if (!pack(hi, best)) return slabBounds(Z, world, halo, weights);            // (the minimum slab thickness alone does not fit: equal shares)
+    for (int it = 0; it < 48; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (pack(mid, b)) { hi = mid; best = b; } else lo = mid;
+    }
+    return best;
+}
+
 int ZSlabComm::haloPlanes(float trunc_dist, float step_factor, float delta_factor, float voxel_z)
 {
     return (int)std::ceil((double)trunc_dist * step_factor / voxel_z + delta_factor) + 2;

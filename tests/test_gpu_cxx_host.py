@@ -314,6 +314,14 @@ def test_cxx_zslab_rccl_path(tmp_path, with_nodes):
         want = sharded.slab_bounds(cfg.dims[2], world, halo, w)
         r = subprocess.run([build.HOST_ZSLAB_APP, "bounds", str(world), str(halo), wf_], capture_output=True, text=True, timeout=60)
         assert r.returncode == 0 and [int(x) for x in r.stdout.strip().split(",")] == want, (r.stdout, want)
+    # ... and the min-max boundaries of round 6 (halo planes counted), on this profile and on random ones
+    rng_b = np.random.RandomState(17)
+    for world, prof in [(2, w), (4, w), (3, rng_b.rand(cfg.dims[2]) ** 3 + 0.02), (4, np.concatenate([np.full(24, 0.02), np.linspace(0.05, 1.0, cfg.dims[2] - 24)]))]:
+        wf2 = str(tmp_path / "weights_mm.f64")
+        np.asarray(prof, np.float64).tofile(wf2)
+        want = sharded.slab_bounds_minmax(cfg.dims[2], world, halo, prof)
+        r = subprocess.run([build.HOST_ZSLAB_APP, "bounds-minmax", str(world), str(halo), wf2], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and [int(x) for x in r.stdout.strip().split(",")] == want, (r.stdout, want)
     bounds = sharded.slab_bounds(cfg.dims[2], 4, halo, w)
     assert bounds != sharded.slab_bounds(cfg.dims[2], 4)
     for r_ in range(4):

@@ -252,3 +252,93 @@ def test_validate_slabs_rejects_unworkable_partitions():
         sharded.validate_slabs(64, 8, 13)          # 8 planes per rank < 13 halo planes
     with pytest.raises(ValueError):
         sharded.validate_slabs(4096, 129, 1)       # rank does not fit the 7-bit tag
+
+
+def _brute_minmax(Z, world, halo, w, step=8):
+    """every partition of Z planes into `world` slabs of multiples of `step` planes, each >= max(halo, step): the smallest largest cost"""
+    import itertools
+    mn = (max(halo, step) + step - 1) // step * step
+    best, arg = None, None
+    cuts = range(step, Z, step)
+    for c in itertools.combinations(cuts, world - 1):
+        b = [0] + list(c) + [Z]
+        if any(b[i + 1] - b[i] < mn for i in range(world)):
+            continue
+        m = max(sharded.slab_costs(b, w, halo))
+        if best is None or m < best - 1e-12:
+            best, arg = m, b
+    return best, arg
+
+
+def test_minmax_slab_bounds_are_optimal_on_small_volumes_and_valid_on_large_ones():
+    """sharded.slab_bounds_minmax (round 6; what bench.py's ranks and tools/scale_model.py cut the volume with): against a brute force over every
+    8-aligned partition on small volumes -- the largest rank's cost, halos included, is the minimum --, and on headline-sized ones the
+    boundaries pass validate_bounds and never cost more than the equal-shares cut they replace."""
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        Z = int(rng.choice([64, 96, 128])); world = int(rng.integers(2, 5)); halo = int(rng.choice([0, 3, 8]))
+        w = rng.random(Z) ** 3 + 0.02
+        if rng.random() < 0.3:
+            w[: Z // 3] = 0.02                                                   # (a cheap near third, like the frustum's)
+        want, arg = _brute_minmax(Z, world, halo, w)
+        if want is None:
+            continue
+        b = sharded.slab_bounds_minmax(Z, world, halo, w)
+        sharded.validate_bounds(b, Z, halo)
+        got = max(sharded.slab_costs(b, w, halo))
+        assert got <= want * (1 + 1e-9) + 1e-12, (Z, world, halo, b, arg, got, want)
+    for world in (2, 4, 8):
+        Z, halo = 512, 8
+        w = np.concatenate([np.full(160, 0.02), np.linspace(0.05, 1.0, 352) ** 2]) * (1 + 0.1 * rng.random(Z))
+        b = sharded.slab_bounds_minmax(Z, world, halo, w)
+        sharded.validate_bounds(b, Z, halo)
+        assert b[0] == 0 and b[-1] == Z and all(x % 8 == 0 for x in b)
+        assert max(sharded.slab_costs(b, w, halo)) <= max(sharded.slab_costs(sharded.slab_bounds(Z, world, halo, w), w, halo)) * (1 + 1e-9)
+    # a world that cannot be served (more minimum-thickness slabs than planes) falls back to slab_bounds' answer instead of failing
+    assert sharded.slab_bounds_minmax(64, 8, 8, np.ones(64)) == sharded.slab_bounds(64, 8, 8, np.ones(64))
+
+
+def test_reweight_from_times_is_a_fixed_point_for_consistent_times_and_moves_work_off_the_slow_rank():
+    """sharded.reweight_from_times (round 6): times proportional to the swept cost (+ the fixed part) leave the weights' PROFILE alone -- the
+    boundaries made from them do not move; a rank that measured twice its share gets its planes made dearer, and the re-cut takes planes
+    away from it."""
+    rng = np.random.default_rng(3)
+    Z, world, halo = 256, 4, 8
+    w = np.linspace(0.1, 1.0, Z) * (1 + 0.05 * rng.random(Z))
+    b = sharded.slab_bounds_minmax(Z, world, halo, w)
+    costs = np.array(sharded.slab_costs(b, w, halo))
+    w2 = sharded.reweight_from_times(b, w, halo, 0.045 + 0.01 * costs, 0.045)
+    assert np.allclose(w2 / w, (w2 / w)[0]) and np.isfinite(w2).all() and (w2 > 0).all()
+    assert sharded.slab_bounds_minmax(Z, world, halo, w2) == b
+    t = 0.045 + 0.01 * costs
+    t[2] = 0.045 + 0.02 * costs[2]                                               # rank 2 took twice as long as its cost says
+    w3 = sharded.reweight_from_times(b, w, halo, t, 0.045)
+    assert (w3[b[2]:b[3]] / w[b[2]:b[3]]).min() > (w3[b[0]:b[1]] / w[b[0]:b[1]]).max()
+    b3 = sharded.slab_bounds_minmax(Z, world, halo, w3)
+    sharded.validate_bounds(b3, Z, halo)
+    assert b3[3] - b3[2] < b[3] - b[2]                                           # fewer planes for the slow rank
+    # degenerate inputs: a time below the fixed part, a zero-cost slab
+    w4 = sharded.reweight_from_times(b, w, halo, [0.01, 0.2, 0.2, 0.2], 0.045)
+    assert np.isfinite(w4).all() and (w4 > 0).all()
+
+
+def test_cxx_slab_bounds_equal_the_python_ones():
+    """kfusion::cuda::ZSlabComm::slabBounds / slabBoundsMinMax (what a C++ host cuts the volume with) against sharded.slab_bounds /
+    slab_bounds_minmax on random work profiles, worlds 1..8, several halos: the same boundaries, plane for plane.  (`zslab_frame bounds`
+    touches no GPU; the binary is one of build()'s host-side products.)"""
+    import subprocess
+    from dynamicfusion_amd import build
+    if not os.path.exists(build.HOST_ZSLAB_APP):
+        pytest.skip("host apps not built (python -c 'import __graft_entry__ as g; g.build()')")
+    import tempfile
+    rng = np.random.default_rng(2)
+    with tempfile.TemporaryDirectory() as d:
+        for t in range(40):
+            Z = int(rng.choice([64, 96, 128, 512, 1000])); world = int(rng.integers(1, 9)); halo = int(rng.choice([0, 3, 8, 11]))
+            w = rng.random(Z) ** 3 + 0.02
+            path = os.path.join(d, "w.f64")
+            w.astype(np.float64).tofile(path)
+            for mode, fn in (("bounds", sharded.slab_bounds), ("bounds-minmax", sharded.slab_bounds_minmax)):
+                r = subprocess.run([build.HOST_ZSLAB_APP, mode, str(world), str(halo), path], capture_output=True, text=True, timeout=60)
+                assert r.returncode == 0, r.stderr
+                assert [int(x) for x in r.stdout.strip().split(",")] == fn(Z, world, halo, w), (mode, Z, world, halo)
