@@ -32,10 +32,11 @@ static Affine3f read_affine(FILE* f)
 // with every input resident on the device before the clock starts, exactly the sequence bench.py times through the Python mirror:
 // `prime` untimed frames (first tables / models), the volume cleared, `warmup` untimed frames, then frames - prime - warmup timed ones
 // between two device synchronises, one new pose per frame.  in.bin as above (depth + pose per frame, then node positions, per-frame
-// transforms, dg_w).  Prints "cxx_host_ms_per_frame <ms> over <n> frames".
+// transforms, dg_w).  Prints "cxx_host_ms_per_frame <ms> over <n> frames"; with an out.bin, writes the final volume and the last frame's
+// points and normals behind it.
 static int bench_mode(int argc, char** argv)
 {
-    if (argc != 12) { std::fprintf(stderr, "usage: %s bench dims size cols rows frames nodes k prime warmup in.bin\n", argv[0]); return 2; }
+    if (argc != 12 && argc != 13) { std::fprintf(stderr, "usage: %s bench dims size cols rows frames nodes k prime warmup in.bin [out.bin]\n", argv[0]); return 2; }
     const int dims = std::atoi(argv[2]); const float size = (float)std::atof(argv[3]);
     const int cols = std::atoi(argv[4]), rows = std::atoi(argv[5]), frames = std::atoi(argv[6]), M = std::atoi(argv[7]), k = std::atoi(argv[8]);
     const int prime = std::atoi(argv[9]), warmup = std::atoi(argv[10]);
@@ -91,6 +92,21 @@ static int bench_mode(int argc, char** argv)
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     const int n = frames - prime - warmup;
     std::printf("cxx_host_ms_per_frame %.6f over %d frames (%d nodes, k = %d, %d^3)\n", ms / n, n, M, k, dims);
+    if (argc == 13) {
+        // what the asynchronous sequence left behind, for a parity check (tests/test_gpu_cxx_host.py): the volume, then the last frame's
+        // points and normals
+        FILE* out = std::fopen(argv[12], "wb");
+        if (!out) { std::perror("out"); return 2; }
+        std::vector<unsigned int> vol((size_t)dims * dims * dims);
+        volume.data().download(vol.data());
+        std::fwrite(vol.data(), 4, vol.size(), out);
+        std::vector<float> p((size_t)rows * cols * 4), nn((size_t)rows * cols * 4);
+        points.download(p.data(), (size_t)cols * 16);
+        normals.download(nn.data(), (size_t)cols * 16);
+        std::fwrite(p.data(), 4, p.size(), out);
+        std::fwrite(nn.data(), 4, nn.size(), out);
+        std::fclose(out);
+    }
     return 0;
 }
 

@@ -421,6 +421,53 @@ def test_cxx_zslab_collectives_with_more_than_one_rank(tmp_path, world, mode, ro
         assert planes.shape[0] == zn and np.array_equal(planes, vol[z0:z0 + zn])
 
 
+def test_cxx_headline_sequence_equals_the_python_mirror(tmp_path):
+    """`headless_frame bench` (round 6: what bench.py reports as cxx_host) is the headline frame through the C++ mirror with nothing waiting
+    for anything: WarpField::setTransformsDevice (node transforms already on the device) + computeDists + TsdfVolume::integrateAsync(...,
+    warp) + raycast, `prime` frames, clear, the rest.  Its final volume and last ray-cast must be the Python mirror's over the same
+    sequence, bit for bit -- the timing it prints is then a timing of the same work."""
+    import torch
+    from dynamicfusion_amd import Intr, TsdfVolume, WarpField, compute_dists, upload_u16
+    build.build_host()
+    cfg = synth.Config(64, 1.0, cols=160, rows=120, nodes=100, k=8)
+    frames, prime, warmup = 6, 2, 1
+    pos, sigma = synth.make_nodes(cfg)
+    fin, fout = str(tmp_path / "hb_in.bin"), str(tmp_path / "hb_out.bin")
+    with open(fin, "wb") as f:
+        f.write(synth.aff12(cfg.volume_pose).tobytes()); f.write(np.asarray(cfg.intr, F32).tobytes())
+        for i in range(frames):
+            f.write(np.ascontiguousarray(synth.depth_frame(cfg, i), np.uint16).tobytes()); f.write(synth.aff12(synth.camera_pose(cfg, i)).tobytes())
+        f.write(np.ascontiguousarray(pos, F32).tobytes())
+        for i in range(frames):
+            f.write(np.ascontiguousarray(synth.node_transforms(cfg, i), F32).tobytes())
+        f.write(np.ascontiguousarray(sigma, F32).tobytes())
+    r = subprocess.run([build.HOST_APP, "bench", str(cfg.dims[0]), str(cfg.size), str(cfg.cols), str(cfg.rows), str(frames), str(cfg.nodes), str(cfg.k),
+                        str(prime), str(warmup), fin, fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "cxx_host_ms_per_frame" in r.stdout, r.stdout + r.stderr
+    # the same sequence through the Python mirror
+    assert (cfg.trunc_dist, cfg.max_weight, cfg.raycast_step_factor, cfg.gradient_delta_factor) == (0.04, 64, 0.75, 0.5)     # (what the app sets)
+    intr = Intr(*cfg.intr)
+    vol = TsdfVolume(cfg.dims); vol.setSize([cfg.size] * 3); vol.setTruncDist(cfg.trunc_dist); vol.setMaxWeight(cfg.max_weight); vol.setPose(cfg.volume_pose)
+    vol.setRaycastStepFactor(cfg.raycast_step_factor); vol.setGradientDeltaFactor(cfg.gradient_delta_factor)
+    wf = WarpField(k=cfg.k); wf.init(pos, sigma=sigma, transforms=synth.node_transforms(cfg, 0))
+    pts = torch.empty((cfg.rows, cfg.cols, 4), dtype=torch.float32, device="cuda"); nrm = torch.empty_like(pts)
+    for i in range(frames):
+        if i == prime: vol.clear()
+        wf.set_transforms(torch.from_numpy(synth.node_transforms(cfg, i)).cuda())
+        vol.integrate_warped(compute_dists(upload_u16(synth.depth_frame(cfg, i)), intr), synth.camera_pose(cfg, i), intr, wf)
+        vol.raycast(synth.camera_pose(cfg, i), intr, pts, nrm)
+    torch.cuda.synchronize()
+    raw = np.fromfile(fout, np.uint8)
+    nv, npx = int(np.prod(cfg.dims)), cfg.rows * cfg.cols
+    assert raw.size == nv * 4 + 2 * npx * 16
+    got_vol = raw[:nv * 4].view(np.uint32).reshape(cfg.dims[2], cfg.dims[1], cfg.dims[0])
+    got = raw[nv * 4:].view(np.uint32).reshape(2, cfg.rows, cfg.cols, 4)
+    want_vol = vol.download()
+    assert (want_vol >> 16).any() and np.array_equal(got_vol, want_vol)
+    assert np.array_equal(got[0], pts.cpu().numpy().view(np.uint32)) and np.array_equal(got[1], nrm.cpu().numpy().view(np.uint32))
+    assert np.isfinite(pts.cpu().numpy()[..., 0]).mean() > 0.2
+
+
 def test_cxx_warp_field_dqb_equals_reference_classes(tmp_path):
     """WarpField::DQB / getWeightsAndUpdateKNN / weighting of the C++ mirror (round 6; warp_field.hpp:66-72): the k-NN comes from the GPU
     (dfusion_knn), the weights and the blend are the reference's expressions on the host.  1000 points around 300 nodes with
